@@ -1,0 +1,1250 @@
+/*
+ * dg_oracle.c -- CPU ORACLE for the DG compressible-flow hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the checker, never the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may
+ * build, load or call it.  Nothing under quinoa_amd/ links or imports it.
+ *
+ * It is a plain-C restatement (own code, own names, no containers) of the
+ * algorithm of Quinoa/Inciter's DG path, keeping the reference's loop
+ * structure (face loop with scatter to left/right element, element loops for
+ * volume/source terms), its AoS `tk::Fields` indexing
+ *      U[e*nprop + c*rdof + k],   R/L[e*nprop + c*ndof + k]
+ * and its arithmetic association, so that it can be pinned against the
+ * reference's committed regression baselines (tests/golden/, see
+ * tests/test_oracle_golden.py).  Each function cites the reference file:line
+ * it follows (paths relative to the reference repository root).
+ *
+ * Parity status: PINNED -- reproduces the reference's golden ExodusII fields
+ * and diagnostics tables for Sod DG-P0, Sedov DG-P1+Superbee+CFL,
+ * VorticalFlow P0/P1 (HLLC and Lax-Friedrichs), TaylorGreen DG-P2 (dt and
+ * CFL variants); tolerances are written in the tests.
+ */
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+/* ------------------------------------------------------------------ config */
+
+enum { ORC_FLUX_HLLC = 0, ORC_FLUX_LAXFRIEDRICHS = 1 };
+enum { ORC_LIM_NONE = 0, ORC_LIM_WENOP1 = 1, ORC_LIM_SUPERBEEP1 = 2 };
+enum { ORC_PROB_USER = 0, ORC_PROB_SOD = 1, ORC_PROB_SEDOV = 2,
+       ORC_PROB_VORTICAL = 3, ORC_PROB_TAYLOR_GREEN = 4 };
+
+typedef struct {
+  int64_t ndof, rdof;    /* src/Control/Inciter/InputDeck/Grammar.hpp:378-406 */
+  int32_t flux;          /* default HLLC, InputDeck.hpp:206 */
+  int32_t limiter;       /* default none, InputDeck.hpp:209 */
+  int32_t problem;
+  int32_t pad_;
+  double cweight;        /* InputDeck.hpp:210 */
+  double gamma, pstiff, cv; /* Grammar.hpp:154-175 (pstiff 0, cv 717.5) */
+  double alpha, beta, p0;   /* vortical_flow parameters */
+} orc_cfg;
+
+/* boundary-condition description: side sets of the mesh + configured lists */
+typedef struct {
+  int64_t nset;              /* number of side sets in bface map */
+  const int64_t* set_id;     /* [nset] side set ids (ascending: std::map) */
+  const int64_t* set_off;    /* [nset+1] offsets into set_face */
+  const int64_t* set_face;   /* boundary face ids per set */
+  int64_t ndir, nsym, nextrap;
+  const int64_t* dir;        /* configured side set ids, bc_dirichlet */
+  const int64_t* sym;        /* bc_sym */
+  const int64_t* extrap;     /* bc_extrapolate */
+} orc_bc;
+
+#define NCOMP 5
+
+/* src/Mesh/DerivedData.hpp:36 -- local face -> local nodes, outward normal */
+static const int LPOFA[4][3] = { {1, 2, 3}, {2, 0, 3}, {3, 0, 1}, {0, 2, 1} };
+
+/* --------------------------------------------- quadrature (Quadrature.hpp) */
+
+/* src/PDE/Integrate/Quadrature.hpp:25-60 */
+static int ng_vol(int64_t ndof)  { return ndof == 1 ? 1 : ndof == 4 ? 5 : 11; }
+static int ng_fa(int64_t ndof)   { return ndof == 1 ? 1 : ndof == 4 ? 3 : 6; }
+static int ng_diag(int64_t ndof) { return ndof == 1 ? 1 : ndof == 4 ? 4 : 14; }
+static int ng_init(int64_t ndof) { return ndof == 1 ? 1 : 14; }
+
+/* src/PDE/Integrate/Quadrature.cpp:16-259 -- tetrahedron rules */
+static void quad_tet(int ng, double c[3][14], double* w)
+{
+  int i;
+  switch (ng) {
+  case 1:
+    c[0][0] = c[1][0] = c[2][0] = 0.25; w[0] = 1.0;
+    break;
+  case 4: {
+    const double a1 = 0.5854101966249685, a2 = 0.1381966011250105;
+    for (i = 0; i < 4; ++i) { c[0][i] = c[1][i] = c[2][i] = a2; w[i] = 0.25; }
+    c[0][1] = a1; c[1][2] = a1; c[2][3] = a1;
+    break; }
+  case 5:
+    c[0][0] = c[1][0] = c[2][0] = 0.25; w[0] = -12.0 / 15.0;
+    for (i = 1; i < 5; ++i) {
+      c[0][i] = c[1][i] = c[2][i] = 1.0 / 6.0; w[i] = 9.0 / 20.0;
+    }
+    c[0][2] = 0.5; c[1][3] = 0.5; c[2][4] = 0.5;
+    break;
+  case 11: {
+    const double c1 = 0.3994035761667992, c2 = 0.1005964238332008;
+    const double c3 = 343.0 / 7500.0, c4 = 56.0 / 375.0;
+    c[0][0] = c[1][0] = c[2][0] = 0.25; w[0] = -148.0 / 1875.0;
+    for (i = 1; i < 5; ++i) {
+      c[0][i] = c[1][i] = c[2][i] = 1.0 / 14.0; w[i] = c3;
+    }
+    c[0][1] = 11.0 / 14.0; c[1][2] = 11.0 / 14.0; c[2][3] = 11.0 / 14.0;
+    { /* six permutations of (c1,c1,c2)/(c1,c2,c2) in the reference order */
+      const double t[6][3] = { {c1, c1, c2}, {c1, c2, c1}, {c1, c2, c2},
+                               {c2, c1, c1}, {c2, c1, c2}, {c2, c2, c1} };
+      for (i = 0; i < 6; ++i) {
+        c[0][5 + i] = t[i][0]; c[1][5 + i] = t[i][1]; c[2][5 + i] = t[i][2];
+        w[5 + i] = c4;
+      }
+    }
+    break; }
+  case 14: {
+    const double a = 0.0673422422100983, b = 0.3108859192633005;
+    const double cc = 0.7217942490673264, d = 0.0927352503108912;
+    const double e = 0.4544962958743506, f = 0.0455037041256494;
+    const double p = 0.1126879257180162, q = 0.0734930431163619;
+    const double r = 0.0425460207770812;
+    const double t[14][4] = {
+      {a, b, b, p}, {b, a, b, p}, {b, b, a, p}, {b, b, b, p},
+      {cc, d, d, q}, {d, cc, d, q}, {d, d, cc, q}, {d, d, d, q},
+      {e, e, f, r}, {e, f, e, r}, {e, f, f, r},
+      {f, e, e, r}, {f, e, f, r}, {f, f, e, r} };
+    for (i = 0; i < 14; ++i) {
+      c[0][i] = t[i][0]; c[1][i] = t[i][1]; c[2][i] = t[i][2]; w[i] = t[i][3];
+    }
+    break; }
+  default: abort();
+  }
+}
+
+/* src/PDE/Integrate/Quadrature.cpp:261-339 -- triangle rules */
+static void quad_tri(int ng, double c[2][6], double* w)
+{
+  switch (ng) {
+  case 1:
+    c[0][0] = 1.0 / 3.0; c[1][0] = 1.0 / 3.0; w[0] = 1.0;
+    break;
+  case 3:
+    c[0][0] = 2.0 / 3.0; c[1][0] = 1.0 / 6.0; w[0] = 1.0 / 3.0;
+    c[0][1] = 1.0 / 6.0; c[1][1] = 2.0 / 3.0; w[1] = 1.0 / 3.0;
+    c[0][2] = 1.0 / 6.0; c[1][2] = 1.0 / 6.0; w[2] = 1.0 / 3.0;
+    break;
+  case 4:
+    c[0][0] = 1.0 / 3.0; c[1][0] = 1.0 / 3.0; w[0] = -27.0 / 48.0;
+    c[0][1] = 1.0 / 5.0; c[1][1] = 1.0 / 5.0; w[1] = 25.0 / 48.0;
+    c[0][2] = 3.0 / 5.0; c[1][2] = 1.0 / 5.0; w[2] = 25.0 / 48.0;
+    c[0][3] = 1.0 / 5.0; c[1][3] = 3.0 / 5.0; w[3] = 25.0 / 48.0;
+    break;
+  case 6: {
+    const double c1 = 0.816847572980459, c2 = 0.091576213509771;
+    const double c3 = 0.091576213509771, c4 = 0.108103018168070;
+    const double c5 = 0.445948490915965, c6 = 0.445948490915965;
+    const double w1 = 0.054975870996713638 * 2.0;
+    const double w2 = 0.1116907969117165 * 2.0;
+    c[0][0] = c1; c[1][0] = c2; w[0] = w1;
+    c[0][1] = c2; c[1][1] = c3; w[1] = w1;
+    c[0][2] = c3; c[1][2] = c1; w[2] = w1;
+    c[0][3] = c4; c[1][3] = c5; w[3] = w2;
+    c[0][4] = c5; c[1][4] = c6; w[4] = w2;
+    c[0][5] = c6; c[1][5] = c4; w[5] = w2;
+    break; }
+  default: abort();
+  }
+}
+
+/* exported for unit tests (ng points; arrays sized >= ng) */
+void orc_quad_tet(int ng, double* cx, double* cy, double* cz, double* w)
+{
+  double c[3][14], ww[14]; int i;
+  quad_tet(ng, c, ww);
+  for (i = 0; i < ng; ++i) { cx[i] = c[0][i]; cy[i] = c[1][i]; cz[i] = c[2][i]; w[i] = ww[i]; }
+}
+void orc_quad_tri(int ng, double* cx, double* cy, double* w)
+{
+  double c[2][6], ww[6]; int i;
+  quad_tri(ng, c, ww);
+  for (i = 0; i < ng; ++i) { cx[i] = c[0][i]; cy[i] = c[1][i]; w[i] = ww[i]; }
+}
+
+/* ------------------------------------------------- geometry (Vector.cpp) */
+
+/* src/Base/Vector.cpp:133-153 : det of the tet map, triple(ba,ca,da) */
+static double jacobian(const double* a, const double* b, const double* c,
+                       const double* d)
+{
+  const double ba[3] = { b[0] - a[0], b[1] - a[1], b[2] - a[2] };
+  const double ca[3] = { c[0] - a[0], c[1] - a[1], c[2] - a[2] };
+  const double da[3] = { d[0] - a[0], d[1] - a[1], d[2] - a[2] };
+  /* tk::triple = dot(v1, cross(v2,v3)) -- src/Base/Vector.hpp */
+  const double cx = ca[1] * da[2] - ca[2] * da[1];
+  const double cy = ca[2] * da[0] - ca[0] * da[2];
+  const double cz = ca[0] * da[1] - ca[1] * da[0];
+  return ba[0] * cx + ba[1] * cy + ba[2] * cz;
+}
+double orc_jacobian(const double* a, const double* b, const double* c, const double* d)
+{ return jacobian(a, b, c, d); }
+
+/* src/Base/Vector.cpp:155-197 */
+static void inverse_jacobian(const double* v1, const double* v2,
+                             const double* v3, const double* v4, double ji[3][3])
+{
+  const double detJ = jacobian(v1, v2, v3, v4);
+  ji[0][0] =  ((v3[1]-v1[1])*(v4[2]-v1[2]) - (v4[1]-v1[1])*(v3[2]-v1[2])) / detJ;
+  ji[1][0] = -((v2[1]-v1[1])*(v4[2]-v1[2]) - (v4[1]-v1[1])*(v2[2]-v1[2])) / detJ;
+  ji[2][0] =  ((v2[1]-v1[1])*(v3[2]-v1[2]) - (v3[1]-v1[1])*(v2[2]-v1[2])) / detJ;
+  ji[0][1] = -((v3[0]-v1[0])*(v4[2]-v1[2]) - (v4[0]-v1[0])*(v3[2]-v1[2])) / detJ;
+  ji[1][1] =  ((v2[0]-v1[0])*(v4[2]-v1[2]) - (v4[0]-v1[0])*(v2[2]-v1[2])) / detJ;
+  ji[2][1] = -((v2[0]-v1[0])*(v3[2]-v1[2]) - (v3[0]-v1[0])*(v2[2]-v1[2])) / detJ;
+  ji[0][2] =  ((v3[0]-v1[0])*(v4[1]-v1[1]) - (v4[0]-v1[0])*(v3[1]-v1[1])) / detJ;
+  ji[1][2] = -((v2[0]-v1[0])*(v4[1]-v1[1]) - (v4[0]-v1[0])*(v2[1]-v1[1])) / detJ;
+  ji[2][2] =  ((v2[0]-v1[0])*(v3[1]-v1[1]) - (v3[0]-v1[0])*(v2[1]-v1[1])) / detJ;
+}
+void orc_inverse_jacobian(const double* a, const double* b, const double* c,
+                          const double* d, double* out9)
+{
+  double ji[3][3]; int i, j;
+  inverse_jacobian(a, b, c, d, ji);
+  for (i = 0; i < 3; ++i) for (j = 0; j < 3; ++j) out9[3 * i + j] = ji[i][j];
+}
+
+/* ------------------------------------------------------- basis (Basis.cpp) */
+
+/* src/PDE/Integrate/Basis.cpp:267-307 : Dubiner basis on the reference tet */
+static void eval_basis(int64_t ndof, double xi, double eta, double zeta, double* B)
+{
+  B[0] = 1.0;
+  if (ndof > 1) {
+    B[1] = 2.0 * xi + eta + zeta - 1.0;
+    B[2] = 3.0 * eta + zeta - 1.0;
+    B[3] = 4.0 * zeta - 1.0;
+    if (ndof > 4) {
+      B[4] = 6.0 * xi * xi + eta * eta + zeta * zeta
+           + 6.0 * xi * eta + 6.0 * xi * zeta + 2.0 * eta * zeta
+           - 6.0 * xi - 2.0 * eta - 2.0 * zeta + 1.0;
+      B[5] = 5.0 * eta * eta + zeta * zeta
+           + 10.0 * xi * eta + 2.0 * xi * zeta + 6.0 * eta * zeta
+           - 2.0 * xi - 6.0 * eta - 2.0 * zeta + 1.0;
+      B[6] = 6.0 * zeta * zeta + 12.0 * xi * zeta + 6.0 * eta * zeta - 2.0 * xi
+           - eta - 7.0 * zeta + 1.0;
+      B[7] = 10.0 * eta * eta + zeta * zeta + 8.0 * eta * zeta
+           - 8.0 * eta - 2.0 * zeta + 1.0;
+      B[8] = 6.0 * zeta * zeta + 18.0 * eta * zeta - 3.0 * eta - 7.0 * zeta + 1.0;
+      B[9] = 15.0 * zeta * zeta - 10.0 * zeta + 1.0;
+    }
+  }
+}
+void orc_eval_basis(int64_t ndof, double xi, double eta, double zeta, double* B)
+{ eval_basis(ndof, xi, eta, zeta, B); }
+
+/* src/PDE/Integrate/Basis.cpp:77-149 : dB/dx for the linear modes
+ * dBdx[d][k] = sum_j dB_k/dxi_j * jacInv[j][d] */
+static void eval_dBdx_p1(const double ji[3][3], double dBdx[3][10])
+{
+  static const double dxi[3][3] = { {2.0, 1.0, 1.0}, {0.0, 3.0, 1.0}, {0.0, 0.0, 4.0} };
+  int d, k;
+  for (d = 0; d < 3; ++d) {
+    dBdx[d][0] = 0.0;
+    for (k = 1; k < 4; ++k)
+      dBdx[d][k] = dxi[k-1][0] * ji[0][d] + dxi[k-1][1] * ji[1][d] + dxi[k-1][2] * ji[2][d];
+  }
+}
+
+/* src/PDE/Integrate/Basis.cpp:151-265 : dB/dx for the quadratic modes */
+static void eval_dBdx_p2(double xi, double eta, double zeta,
+                         const double ji[3][3], double dBdx[3][10])
+{
+  double g[6][3]; int d, k;
+  g[0][0] = 12.0 * xi + 6.0 * eta + 6.0 * zeta - 6.0;
+  g[0][1] = 6.0 * xi + 2.0 * eta + 2.0 * zeta - 2.0;
+  g[0][2] = 6.0 * xi + 2.0 * eta + 2.0 * zeta - 2.0;
+  g[1][0] = 10.0 * eta + 2.0 * zeta - 2.0;
+  g[1][1] = 10.0 * xi + 10.0 * eta + 6.0 * zeta - 6.0;
+  g[1][2] = 2.0 * xi + 6.0 * eta + 2.0 * zeta - 2.0;
+  g[2][0] = 12.0 * zeta - 2.0;
+  g[2][1] = 6.0 * zeta - 1.0;
+  g[2][2] = 12.0 * xi + 6.0 * eta + 12.0 * zeta - 7.0;
+  g[3][0] = 0;
+  g[3][1] = 20.0 * eta + 8.0 * zeta - 8.0;
+  g[3][2] = 8.0 * eta + 2.0 * zeta - 2.0;
+  g[4][0] = 0;
+  g[4][1] = 18.0 * zeta - 3.0;
+  g[4][2] = 18.0 * eta + 12.0 * zeta - 7.0;
+  g[5][0] = 0;
+  g[5][1] = 0;
+  g[5][2] = 30.0 * zeta - 10.0;
+  for (k = 0; k < 6; ++k)
+    for (d = 0; d < 3; ++d)
+      dBdx[d][4 + k] = g[k][0] * ji[0][d] + g[k][1] * ji[1][d] + g[k][2] * ji[2][d];
+}
+
+/* src/PDE/Integrate/Basis.cpp:309-358 : state at a point from the DOFs.
+ * `stride` is the per-component DOF stride used to index U (rdof; volInt
+ * passes ndof, Volume.cpp:100), `dof_el` the number of modes summed. */
+static void eval_state(int64_t nprop, int64_t stride, int64_t dof_el, int64_t e,
+                       const double* U, const double* B, double* s)
+{
+  int c;
+  const double* u = U + e * nprop;
+  for (c = 0; c < NCOMP; ++c) {
+    const int64_t m = c * stride;
+    s[c] = u[m];
+    if (dof_el > 1)
+      s[c] += u[m+1] * B[1] + u[m+2] * B[2] + u[m+3] * B[3];
+    if (dof_el > 4)
+      s[c] += u[m+4] * B[4] + u[m+5] * B[5] + u[m+6] * B[6]
+            + u[m+7] * B[7] + u[m+8] * B[8] + u[m+9] * B[9];
+  }
+}
+
+/* ----------------------------------------------------- EoS (EoS/EoS.hpp) */
+
+/* src/PDE/EoS/EoS.hpp:66-84 */
+static double eos_pressure(const orc_cfg* k, double rho, double u, double v,
+                           double w, double rhoE)
+{
+  return (rhoE - 0.5 * rho * (u * u + v * v + w * w) - k->pstiff)
+         * (k->gamma - 1.0) - k->pstiff;
+}
+/* src/PDE/EoS/EoS.hpp:95-108 */
+static double eos_soundspeed(const orc_cfg* k, double rho, double pr)
+{
+  return sqrt(k->gamma * (pr + k->pstiff) / rho);
+}
+/* src/PDE/EoS/EoS.hpp:123-140 */
+static double eos_totalenergy(const orc_cfg* k, double rho, double u, double v,
+                              double w, double pr)
+{
+  return (pr + k->pstiff) / (k->gamma - 1.0)
+         + 0.5 * rho * (u * u + v * v + w * w) + k->pstiff;
+}
+
+/* --------------------------------------------------- Riemann solvers */
+
+/* src/PDE/Integrate/Riemann/HLLC.hpp:36-125 */
+static void flux_hllc(const orc_cfg* k, const double* fn, const double* ul_,
+                      const double* ur_, double* flx)
+{
+  const double rhol = ul_[0], rhor = ur_[0];
+  const double ul = ul_[1] / rhol, vl = ul_[2] / rhol, wl = ul_[3] / rhol;
+  const double ur = ur_[1] / rhor, vr = ur_[2] / rhor, wr = ur_[3] / rhor;
+  const double pl = eos_pressure(k, rhol, ul, vl, wl, ul_[4]);
+  const double pr = eos_pressure(k, rhor, ur, vr, wr, ur_[4]);
+  const double al = eos_soundspeed(k, rhol, pl);
+  const double ar = eos_soundspeed(k, rhor, pr);
+  const double vnl = ul * fn[0] + vl * fn[1] + wl * fn[2];
+  const double vnr = ur * fn[0] + vr * fn[1] + wr * fn[2];
+  const double rlr = sqrt(rhor / rhol);
+  const double rlr1 = 1.0 + rlr;
+  const double vnroe = (vnr * rlr + vnl) / rlr1;
+  const double aroe = (ar * rlr + al) / rlr1;
+  const double Sl = fmin(vnl - al, vnroe - aroe);
+  const double Sr = fmax(vnr + ar, vnroe + aroe);
+  const double Sm = (rhor * vnr * (Sr - vnr) - rhol * vnl * (Sl - vnl) + pl - pr)
+                  / (rhor * (Sr - vnr) - rhol * (Sl - vnl));
+  const double pStar = rhol * (vnl - Sl) * (vnl - Sm) + pl;
+  double us[5];
+  if (Sl > 0.0) {
+    flx[0] = ul_[0] * vnl;
+    flx[1] = ul_[1] * vnl + pl * fn[0];
+    flx[2] = ul_[2] * vnl + pl * fn[1];
+    flx[3] = ul_[3] * vnl + pl * fn[2];
+    flx[4] = (ul_[4] + pl) * vnl;
+  } else if (Sl <= 0.0 && Sm > 0.0) {
+    us[0] = (Sl - vnl) * rhol / (Sl - Sm);
+    us[1] = ((Sl - vnl) * ul_[1] + (pStar - pl) * fn[0]) / (Sl - Sm);
+    us[2] = ((Sl - vnl) * ul_[2] + (pStar - pl) * fn[1]) / (Sl - Sm);
+    us[3] = ((Sl - vnl) * ul_[3] + (pStar - pl) * fn[2]) / (Sl - Sm);
+    us[4] = ((Sl - vnl) * ul_[4] - pl * vnl + pStar * Sm) / (Sl - Sm);
+    flx[0] = us[0] * Sm;
+    flx[1] = us[1] * Sm + pStar * fn[0];
+    flx[2] = us[2] * Sm + pStar * fn[1];
+    flx[3] = us[3] * Sm + pStar * fn[2];
+    flx[4] = (us[4] + pStar) * Sm;
+  } else if (Sm <= 0.0 && Sr >= 0.0) {
+    us[0] = (Sr - vnr) * rhor / (Sr - Sm);
+    us[1] = ((Sr - vnr) * ur_[1] + (pStar - pr) * fn[0]) / (Sr - Sm);
+    us[2] = ((Sr - vnr) * ur_[2] + (pStar - pr) * fn[1]) / (Sr - Sm);
+    us[3] = ((Sr - vnr) * ur_[3] + (pStar - pr) * fn[2]) / (Sr - Sm);
+    us[4] = ((Sr - vnr) * ur_[4] - pr * vnr + pStar * Sm) / (Sr - Sm);
+    flx[0] = us[0] * Sm;
+    flx[1] = us[1] * Sm + pStar * fn[0];
+    flx[2] = us[2] * Sm + pStar * fn[1];
+    flx[3] = us[3] * Sm + pStar * fn[2];
+    flx[4] = (us[4] + pStar) * Sm;
+  } else {
+    flx[0] = ur_[0] * vnr;
+    flx[1] = ur_[1] * vnr + pr * fn[0];
+    flx[2] = ur_[2] * vnr + pr * fn[1];
+    flx[3] = ur_[3] * vnr + pr * fn[2];
+    flx[4] = (ur_[4] + pr) * vnr;
+  }
+}
+
+/* src/PDE/Integrate/Riemann/LaxFriedrichs.hpp:34-88 */
+static void flux_laxfriedrichs(const orc_cfg* k, const double* fn,
+                               const double* ul_, const double* ur_, double* flx)
+{
+  const double rhol = ul_[0], rhor = ur_[0];
+  const double ul = ul_[1] / rhol, vl = ul_[2] / rhol, wl = ul_[3] / rhol;
+  const double ur = ur_[1] / rhor, vr = ur_[2] / rhor, wr = ur_[3] / rhor;
+  const double pl = eos_pressure(k, rhol, ul, vl, wl, ul_[4]);
+  const double pr = eos_pressure(k, rhor, ur, vr, wr, ur_[4]);
+  const double al = eos_soundspeed(k, rhol, pl);
+  const double ar = eos_soundspeed(k, rhor, pr);
+  const double vnl = ul * fn[0] + vl * fn[1] + wl * fn[2];
+  const double vnr = ur * fn[0] + vr * fn[1] + wr * fn[2];
+  double fl[5], fr[5], lambda; int c;
+  fl[0] = ul_[0] * vnl;
+  fl[1] = ul_[1] * vnl + pl * fn[0];
+  fl[2] = ul_[2] * vnl + pl * fn[1];
+  fl[3] = ul_[3] * vnl + pl * fn[2];
+  fl[4] = (ul_[4] + pl) * vnl;
+  fr[0] = ur_[0] * vnr;
+  fr[1] = ur_[1] * vnr + pr * fn[0];
+  fr[2] = ur_[2] * vnr + pr * fn[1];
+  fr[3] = ur_[3] * vnr + pr * fn[2];
+  fr[4] = (ur_[4] + pr) * vnr;
+  lambda = fmax(al, ar) + fmax(fabs(vnl), fabs(vnr));
+  for (c = 0; c < 5; ++c)
+    flx[c] = 0.5 * (fl[c] + fr[c] - lambda * (ur_[c] - ul_[c]));
+}
+
+static void riemann(const orc_cfg* k, const double* fn, const double* ul,
+                    const double* ur, double* flx)
+{
+  if (k->flux == ORC_FLUX_LAXFRIEDRICHS) flux_laxfriedrichs(k, fn, ul, ur, flx);
+  else flux_hllc(k, fn, ul, ur, flx);
+}
+void orc_riemann(const orc_cfg* k, const double* fn, const double* ul,
+                 const double* ur, double* flx)
+{ riemann(k, fn, ul, ur, flx); }
+
+/* src/PDE/CompFlow/DGCompFlow.hpp:599-635 : Euler flux F[c][d] */
+static void euler_flux(const orc_cfg* k, const double* s, double F[5][3])
+{
+  const double u = s[1] / s[0], v = s[2] / s[0], w = s[3] / s[0];
+  const double p = eos_pressure(k, s[0], u, v, w, s[4]);
+  F[0][0] = s[1];         F[1][0] = s[1] * u + p; F[2][0] = s[1] * v;
+  F[3][0] = s[1] * w;     F[4][0] = u * (s[4] + p);
+  F[0][1] = s[2];         F[1][1] = s[2] * u;     F[2][1] = s[2] * v + p;
+  F[3][1] = s[2] * w;     F[4][1] = v * (s[4] + p);
+  F[0][2] = s[3];         F[1][2] = s[3] * u;     F[2][2] = s[3] * v;
+  F[3][2] = s[3] * w + p; F[4][2] = w * (s[4] + p);
+}
+
+/* ------------------------------------------------ Problem policies (a22) */
+
+/* Problem::solution -- src/PDE/CompFlow/Problem/SodShocktube.cpp:28-78,
+ * SedovBlastwave.cpp:28-75, VorticalFlow.cpp:28-64, TaylorGreen.cpp:28-62 */
+static void prob_solution(const orc_cfg* k, double x, double y, double z,
+                          double t, double* s)
+{
+  (void)t;
+  switch (k->problem) {
+  case ORC_PROB_SOD: {
+    double r, p;
+    if (x < 0.5) { r = 1.0; p = 1.0; } else { r = 0.125; p = 0.1; }
+    s[0] = r; s[1] = r * 0.0; s[2] = r * 0.0; s[3] = r * 0.0;
+    s[4] = eos_totalenergy(k, r, 0.0, 0.0, 0.0, p);
+    break; }
+  case ORC_PROB_SEDOV: {
+    double r = 1.0, p;
+    if ((x < 0.05) && (y < 0.05)) p = 783.4112; else p = 1.0e-6;
+    s[0] = r; s[1] = r * 0.0; s[2] = r * 0.0; s[3] = r * 0.0;
+    s[4] = eos_totalenergy(k, r, 0.0, 0.0, 0.0, p);
+    break; }
+  case ORC_PROB_VORTICAL: {
+    const double a = k->alpha, b = k->beta, p0 = k->p0, g = k->gamma;
+    const double ru = a * x - b * y;
+    const double rv = b * x + a * y;
+    const double rw = -2.0 * a * z;
+    const double rE = (ru * ru + rv * rv + rw * rw) / 2.0
+                    + (p0 - 2.0 * a * a * z * z) / (g - 1.0);
+    s[0] = 1.0; s[1] = ru; s[2] = rv; s[3] = rw; s[4] = rE;
+    break; }
+  case ORC_PROB_TAYLOR_GREEN: {
+    const double r = 1.0;
+    const double p = 10.0 + r / 4.0 * (cos(2.0 * M_PI * x) + cos(2.0 * M_PI * y));
+    const double u = sin(M_PI * x) * cos(M_PI * y);
+    const double v = -cos(M_PI * x) * sin(M_PI * y);
+    const double w = 0.0;
+    s[0] = r; s[1] = r * u; s[2] = r * v; s[3] = r * w;
+    s[4] = eos_totalenergy(k, r, u, v, w, p);
+    break; }
+  default:
+    s[0] = s[1] = s[2] = s[3] = s[4] = 0.0;
+  }
+}
+void orc_solution(const orc_cfg* k, double x, double y, double z, double t, double* s)
+{ prob_solution(k, x, y, z, t, s); }
+
+/* Problem::src -- SodShocktube.cpp:106-115, SedovBlastwave.cpp:104-113,
+ * VorticalFlow.cpp:80-115, TaylorGreen.cpp:77-90 */
+static void prob_src(const orc_cfg* k, double x, double y, double z, double t,
+                     double* r)
+{
+  (void)t;
+  switch (k->problem) {
+  case ORC_PROB_VORTICAL: {
+    const double a = k->alpha, b = k->beta, g = k->gamma;
+    double s[5];
+    prob_solution(k, x, y, z, 0.0, s);
+    r[0] = 0.0;
+    r[1] = a * s[1] / s[0] - b * s[2] / s[0];
+    r[2] = b * s[1] / s[0] + a * s[2] / s[0];
+    r[3] = 0.0;
+    r[4] = (r[1] * s[1] + r[2] * s[2]) / s[0] + 8.0 * a * a * a * z * z / (g - 1.0);
+    break; }
+  case ORC_PROB_TAYLOR_GREEN:
+    r[0] = r[1] = r[2] = r[3] = 0.0;
+    r[4] = 3.0 * M_PI / 8.0 * (cos(3.0 * M_PI * x) * cos(M_PI * y)
+                               - cos(3.0 * M_PI * y) * cos(M_PI * x));
+    break;
+  default:
+    r[0] = r[1] = r[2] = r[3] = r[4] = 0.0;
+  }
+}
+
+/* BC state functions -- src/PDE/CompFlow/DGCompFlow.hpp:649-701 */
+enum { BC_DIRICHLET = 0, BC_SYMMETRY = 1, BC_EXTRAPOLATE = 2 };
+static void bc_state(const orc_cfg* k, int type, const double* ul, double x,
+                     double y, double z, double t, const double* fn, double* ur)
+{
+  if (type == BC_DIRICHLET) {
+    prob_solution(k, x, y, z, t, ur);
+  } else if (type == BC_SYMMETRY) {
+    const double v1l = ul[1] / ul[0], v2l = ul[2] / ul[0], v3l = ul[3] / ul[0];
+    const double vnl = v1l * fn[0] + v2l * fn[1] + v3l * fn[2];
+    const double v1r = v1l - 2.0 * vnl * fn[0];
+    const double v2r = v2l - 2.0 * vnl * fn[1];
+    const double v3r = v3l - 2.0 * vnl * fn[2];
+    ur[0] = ul[0];
+    ur[1] = ur[0] * v1r; ur[2] = ur[0] * v2r; ur[3] = ur[0] * v3r;
+    ur[4] = ul[4];
+  } else {
+    memcpy(ur, ul, 5 * sizeof(double));
+  }
+}
+
+/* ------------------------------------------ derived mesh data (DerivedData) */
+
+/* src/Mesh/DerivedData.cpp:45-127 : elements surrounding points (linked
+ * lists esup1[esup2[p]+1 .. esup2[p+1]]).  esup1 has 4*nelem+1 entries. */
+void orc_gen_esup(const int64_t* inpoel, int64_t nelem, int64_t npoin,
+                  int64_t* esup1, int64_t* esup2)
+{
+  int64_t i, n4 = 4 * nelem;
+  for (i = 0; i <= npoin; ++i) esup2[i] = 0;
+  for (i = 0; i < n4; ++i) ++esup2[inpoel[i] + 1];
+  for (i = 1; i <= npoin; ++i) esup2[i] += esup2[i - 1];
+  for (i = 0; i < n4; ++i) {
+    const int64_t n = inpoel[i];
+    const int64_t j = esup2[n] + 1;
+    esup2[n] = j;
+    esup1[j] = i / 4;
+  }
+  for (i = npoin; i > 0; --i) esup2[i] = esup2[i - 1];
+  esup2[0] = 0;
+}
+
+/* src/Mesh/DerivedData.cpp:937-1051 : elements surrounding elements, -1 on
+ * the boundary; esuel[4*e+f] is the neighbour across local face LPOFA[f] */
+void orc_gen_esuel(const int64_t* inpoel, int64_t nelem, int64_t npoin,
+                   const int64_t* esup1, const int64_t* esup2, int32_t* esuel)
+{
+  int64_t e, j; int fe, fj, m;
+  unsigned char* lpoin = (unsigned char*)calloc((size_t)npoin, 1);
+  for (e = 0; e < 4 * nelem; ++e) esuel[e] = -1;
+  for (e = 0; e < nelem; ++e) {
+    for (fe = 0; fe < 4; ++fe) {
+      const int64_t p0 = inpoel[4 * e + LPOFA[fe][0]];
+      const int64_t p1 = inpoel[4 * e + LPOFA[fe][1]];
+      const int64_t p2 = inpoel[4 * e + LPOFA[fe][2]];
+      lpoin[p0] = lpoin[p1] = lpoin[p2] = 1;
+      for (j = esup2[p0] + 1; j <= esup2[p0 + 1]; ++j) {
+        const int64_t je = esup1[j];
+        if (je == e) continue;
+        for (fj = 0; fj < 4; ++fj) {
+          int cnt = 0;
+          for (m = 0; m < 3; ++m)
+            if (lpoin[inpoel[4 * je + LPOFA[fj][m]]] == 1) ++cnt;
+          if (cnt == 3) {
+            esuel[4 * e + fe] = (int32_t)je;
+            esuel[4 * je + fj] = (int32_t)e;
+          }
+        }
+      }
+      lpoin[p0] = lpoin[p1] = lpoin[p2] = 0;
+    }
+  }
+  free(lpoin);
+}
+
+/* src/Mesh/DerivedData.cpp:1053-1093 */
+int64_t orc_gen_nipfac(int64_t nbfac, const int32_t* esuel, int64_t nelem)
+{
+  int64_t e, n = 0; int f;
+  for (e = 0; e < nelem; ++e)
+    for (f = 0; f < 4; ++f)
+      if (esuel[4 * e + f] != -1 && e < (int64_t)esuel[4 * e + f]) ++n;
+  return n + nbfac;
+}
+
+/* src/Mesh/DerivedData.cpp:1153-1218 : face-node connectivity; boundary faces
+ * [0,nbfac) copy triinpoel, interior faces enumerated by ascending element,
+ * local face, kept when e < neighbour */
+void orc_gen_inpofa(int64_t nbfac, const int64_t* inpoel, int64_t nelem,
+                    const int64_t* triinpoel, const int32_t* esuel,
+                    int64_t* inpofa)
+{
+  int64_t e, ic = 3 * nbfac; int f;
+  for (e = 0; e < nelem; ++e)
+    for (f = 0; f < 4; ++f) {
+      const int32_t je = esuel[4 * e + f];
+      if (je != -1 && e < (int64_t)je) {
+        inpofa[ic]     = inpoel[4 * e + LPOFA[f][0]];
+        inpofa[ic + 1] = inpoel[4 * e + LPOFA[f][1]];
+        inpofa[ic + 2] = inpoel[4 * e + LPOFA[f][2]];
+        ic += 3;
+      }
+    }
+  for (e = 0; e < 3 * nbfac; ++e) inpofa[e] = triinpoel[e];
+}
+
+/* src/Mesh/DerivedData.cpp:1220-1290 : host element of each boundary face =
+ * the element appearing 3 times in the union of its nodes' element lists */
+void orc_gen_belem(int64_t nbfac, const int64_t* inpofa, const int64_t* esup1,
+                   const int64_t* esup2, int64_t* belem)
+{
+  int64_t f, i, j, cap = 64, *cl = (int64_t*)malloc((size_t)cap * sizeof(int64_t));
+  for (f = 0; f < nbfac; ++f) {
+    int64_t n = 0; int lp;
+    belem[f] = 0;
+    for (lp = 0; lp < 3; ++lp) {
+      const int64_t gp = inpofa[3 * f + lp];
+      for (i = esup2[gp] + 1; i <= esup2[gp + 1]; ++i) {
+        if (n == cap) { cap *= 2; cl = (int64_t*)realloc(cl, (size_t)cap * sizeof(int64_t)); }
+        cl[n++] = esup1[i];
+      }
+    }
+    for (i = 0; i < n; ++i) {
+      int tag = 1;
+      for (j = 0; j < n; ++j) if (i != j && cl[j] == cl[i]) ++tag;
+      if (tag == 3) { belem[f] = cl[i]; break; }
+    }
+  }
+  free(cl);
+}
+
+/* src/Mesh/DerivedData.cpp:1095-1151 : left/right element of each face;
+ * left id < right id for interior faces, right = -1 on the boundary */
+void orc_gen_esuf(int64_t nbfac, const int64_t* belem, const int32_t* esuel,
+                  int64_t nelem, int32_t* esuf)
+{
+  int64_t e, ic = 2 * nbfac; int f;
+  for (e = 0; e < nelem; ++e)
+    for (f = 0; f < 4; ++f) {
+      const int32_t je = esuel[4 * e + f];
+      if (je != -1 && e < (int64_t)je) {
+        esuf[ic] = (int32_t)e; esuf[ic + 1] = je; ic += 2;
+      }
+    }
+  for (e = 0; e < nbfac; ++e) { esuf[2 * e] = (int32_t)belem[e]; esuf[2 * e + 1] = -1; }
+}
+
+/* src/Mesh/DerivedData.cpp:1292-1434 : geoFace[f*7+{area,nx,ny,nz,cx,cy,cz}],
+ * area by Heron's formula, unit normal of (p1-p0)x(p2-p0) */
+void orc_gen_geoface(int64_t nfac, const int64_t* inpofa, const double* x,
+                     const double* y, const double* z, double* geoFace)
+{
+  int64_t f;
+  for (f = 0; f < nfac; ++f) {
+    const int64_t a = inpofa[3 * f], b = inpofa[3 * f + 1], c = inpofa[3 * f + 2];
+    const double X[3] = { x[a], x[b], x[c] }, Y[3] = { y[a], y[b], y[c] },
+                 Z[3] = { z[a], z[b], z[c] };
+    const double sa = sqrt((X[1]-X[0])*(X[1]-X[0]) + (Y[1]-Y[0])*(Y[1]-Y[0]) + (Z[1]-Z[0])*(Z[1]-Z[0]));
+    const double sb = sqrt((X[2]-X[1])*(X[2]-X[1]) + (Y[2]-Y[1])*(Y[2]-Y[1]) + (Z[2]-Z[1])*(Z[2]-Z[1]));
+    const double sc = sqrt((X[0]-X[2])*(X[0]-X[2]) + (Y[0]-Y[2])*(Y[0]-Y[2]) + (Z[0]-Z[2])*(Z[0]-Z[2]));
+    const double sp = 0.5 * (sa + sb + sc);
+    const double ax = X[1]-X[0], ay = Y[1]-Y[0], az = Z[1]-Z[0];
+    const double bx = X[2]-X[0], by = Y[2]-Y[0], bz = Z[2]-Z[0];
+    const double nx = ay * bz - az * by;
+    const double ny = -(ax * bz - az * bx);
+    const double nz = ax * by - ay * bx;
+    const double fa = sqrt(nx * nx + ny * ny + nz * nz);
+    double* g = geoFace + 7 * f;
+    g[0] = sqrt(sp * (sp - sa) * (sp - sb) * (sp - sc));
+    g[1] = nx / fa; g[2] = ny / fa; g[3] = nz / fa;
+    g[4] = (X[0] + X[1] + X[2]) / 3.0;
+    g[5] = (Y[0] + Y[1] + Y[2]) / 3.0;
+    g[6] = (Z[0] + Z[1] + Z[2]) / 3.0;
+  }
+}
+
+/* src/Mesh/DerivedData.cpp:1436-1491 : geoElem[e*4+{vol,cx,cy,cz}] */
+void orc_gen_geoelem(const int64_t* inpoel, int64_t nelem, const double* x,
+                     const double* y, const double* z, double* geoElem)
+{
+  int64_t e;
+  for (e = 0; e < nelem; ++e) {
+    const int64_t A = inpoel[4*e], B = inpoel[4*e+1], C = inpoel[4*e+2], D = inpoel[4*e+3];
+    const double pa[3] = { x[A], y[A], z[A] }, pb[3] = { x[B], y[B], z[B] };
+    const double pc[3] = { x[C], y[C], z[C] }, pd[3] = { x[D], y[D], z[D] };
+    geoElem[4*e]   = jacobian(pa, pb, pc, pd) / 6.0;
+    geoElem[4*e+1] = (x[A] + x[B] + x[C] + x[D]) / 4.0;
+    geoElem[4*e+2] = (y[A] + y[B] + y[C] + y[D]) / 4.0;
+    geoElem[4*e+3] = (z[A] + z[B] + z[C] + z[D]) / 4.0;
+  }
+}
+
+/* ---------------------------------------------------------- integrators */
+
+static void elem_coords(const int64_t* inpoel, int64_t e, const double* x,
+                        const double* y, const double* z, double p[4][3])
+{
+  int i;
+  for (i = 0; i < 4; ++i) {
+    const int64_t n = inpoel[4 * e + i];
+    p[i][0] = x[n]; p[i][1] = y[n]; p[i][2] = z[n];
+  }
+}
+
+/* src/PDE/Integrate/Basis.cpp:50-75 : physical coords of a tet Gauss point */
+static void gp_tet(double p[4][3], double xi, double eta, double zeta, double* gp)
+{
+  const double s1 = 1.0 - xi - eta - zeta, s2 = xi, s3 = eta, s4 = zeta;
+  int d;
+  for (d = 0; d < 3; ++d)
+    gp[d] = p[0][d] * s1 + p[1][d] * s2 + p[2][d] * s3 + p[3][d] * s4;
+}
+/* src/PDE/Integrate/Basis.cpp:24-48 : physical coords of a face Gauss point */
+static void gp_tri(double p[3][3], double a, double b, double* gp)
+{
+  const double s1 = 1.0 - a - b, s2 = a, s3 = b;
+  int d;
+  for (d = 0; d < 3; ++d)
+    gp[d] = p[0][d] * s1 + p[1][d] * s2 + p[2][d] * s3;
+}
+
+/* reference coordinates of physical point gp in tet p (Surface.cpp:128-166) */
+static void ref_coords(double p[4][3], double detT, const double* gp,
+                       double* xi, double* eta, double* zeta)
+{
+  *xi   = jacobian(p[0], gp, p[2], p[3]) / detT;
+  *eta  = jacobian(p[0], p[1], gp, p[3]) / detT;
+  *zeta = jacobian(p[0], p[1], p[2], gp) / detT;
+}
+
+/* src/PDE/Integrate/Mass.cpp:25-73 : diagonal mass matrix */
+void orc_mass(const orc_cfg* k, const double* geoElem, int64_t nunk, double* L)
+{
+  static const double f[10] = { 1.0, 1.0/10.0, 3.0/10.0, 3.0/5.0, 1.0/35.0,
+                                1.0/21.0, 1.0/14.0, 1.0/7.0, 3.0/14.0, 3.0/7.0 };
+  const int64_t ndof = k->ndof, nprop = NCOMP * ndof;
+  int64_t e; int c;
+  (void)f;
+  for (e = 0; e < nunk; ++e) {
+    const double vol = geoElem[4 * e];
+    for (c = 0; c < NCOMP; ++c) {
+      double* l = L + e * nprop + c * ndof;
+      l[0] = vol;
+      if (ndof > 1) { l[1] = vol / 10.0; l[2] = vol * 3.0 / 10.0; l[3] = vol * 3.0 / 5.0; }
+      if (ndof > 4) {
+        l[4] = vol / 35.0; l[5] = vol / 21.0; l[6] = vol / 14.0;
+        l[7] = vol / 7.0;  l[8] = vol * 3.0 / 14.0; l[9] = vol * 3.0 / 7.0;
+      }
+    }
+  }
+}
+
+/* src/PDE/Integrate/Initialize.cpp:29-201 : L2 projection of the IC onto the
+ * basis over interior elements [0,nielem); U indexed with ndof stride as the
+ * reference does (unk(e, c*ndof+k)) */
+void orc_initialize(const orc_cfg* k, const double* L, const int64_t* inpoel,
+                    const double* x, const double* y, const double* z,
+                    double* U, double t, int64_t nielem)
+{
+  const int64_t ndof = k->ndof, nprop_l = NCOMP * ndof, nprop_u = NCOMP * k->rdof;
+  const int ng = ng_init(ndof);
+  double cg[3][14], wg[14], p[4][3], R[50], B[10], gp[3], s[5];
+  int64_t e; int ig, c, j;
+  quad_tet(ng, cg, wg);
+  for (e = 0; e < nielem; ++e) {
+    const double vole = L[e * nprop_l];
+    elem_coords(inpoel, e, x, y, z, p);
+    for (j = 0; j < 50; ++j) R[j] = 0.0;
+    for (ig = 0; ig < ng; ++ig) {
+      double wt;
+      gp_tet(p, cg[0][ig], cg[1][ig], cg[2][ig], gp);
+      eval_basis(ndof, cg[0][ig], cg[1][ig], cg[2][ig], B);
+      prob_solution(k, gp[0], gp[1], gp[2], t, s);
+      wt = wg[ig] * vole;
+      for (c = 0; c < NCOMP; ++c) {
+        const int64_t m = c * ndof;
+        R[m] += wt * s[c];
+        for (j = 1; j < ndof; ++j) R[m + j] += wt * s[c] * B[j];
+      }
+    }
+    /* NOTE: the reference indexes unk with the ndof stride too
+     * (Initialize.cpp:159-201); identical to rdof stride when rdof==ndof */
+    for (c = 0; c < NCOMP; ++c)
+      for (j = 0; j < ndof; ++j)
+        U[e * nprop_u + c * ndof + j] = R[c * ndof + j] / L[e * nprop_l + c * ndof + j];
+  }
+}
+
+/* src/PDE/Integrate/Surface.cpp:22-291 : interior-face Riemann flux integral */
+static void surf_int(const orc_cfg* k, int64_t nbfac, int64_t nfac,
+                     const int32_t* esuf, const int64_t* inpofa,
+                     const int64_t* inpoel, const double* x, const double* y,
+                     const double* z, const double* geoFace, const double* U,
+                     double* R)
+{
+  const int64_t ndof = k->ndof, rdof = k->rdof;
+  const int64_t npu = NCOMP * rdof, npr = NCOMP * ndof;
+  const int ng = ng_fa(ndof);
+  const int64_t dof_e = (rdof > ndof) ? rdof : ndof;
+  double cg[2][6], wg[6];
+  int64_t f;
+  quad_tri(ng, cg, wg);
+  for (f = nbfac; f < nfac; ++f) {
+    const int64_t el = esuf[2 * f], er = esuf[2 * f + 1];
+    double pl[4][3], pr[4][3], pf[3][3], detl, detr, fn[3];
+    int ig, c, i; int64_t j;
+    elem_coords(inpoel, el, x, y, z, pl);
+    elem_coords(inpoel, er, x, y, z, pr);
+    detl = jacobian(pl[0], pl[1], pl[2], pl[3]);
+    detr = jacobian(pr[0], pr[1], pr[2], pr[3]);
+    for (i = 0; i < 3; ++i) {
+      const int64_t n = inpofa[3 * f + i];
+      pf[i][0] = x[n]; pf[i][1] = y[n]; pf[i][2] = z[n];
+    }
+    fn[0] = geoFace[7 * f + 1]; fn[1] = geoFace[7 * f + 2]; fn[2] = geoFace[7 * f + 3];
+    for (ig = 0; ig < ng; ++ig) {
+      double gp[3], xi, eta, zeta, Bl[10], Br[10], sl[5], sr[5], fl[5], wt;
+      gp_tri(pf, cg[0][ig], cg[1][ig], gp);
+      ref_coords(pl, detl, gp, &xi, &eta, &zeta);
+      eval_basis(dof_e, xi, eta, zeta, Bl);
+      ref_coords(pr, detr, gp, &xi, &eta, &zeta);
+      eval_basis(dof_e, xi, eta, zeta, Br);
+      wt = wg[ig] * geoFace[7 * f];
+      eval_state(npu, rdof, dof_e, el, U, Bl, sl);
+      eval_state(npu, rdof, dof_e, er, U, Br, sr);
+      riemann(k, fn, sl, sr, fl);
+      /* update_rhs_fa, Surface.cpp:192-271 */
+      for (c = 0; c < NCOMP; ++c) {
+        double* rl = R + el * npr + c * ndof;
+        double* rr = R + er * npr + c * ndof;
+        rl[0] -= wt * fl[c];
+        rr[0] += wt * fl[c];
+        for (j = 1; j < ndof; ++j) rl[j] -= wt * fl[c] * Bl[j];
+        for (j = 1; j < ndof; ++j) rr[j] += wt * fl[c] * Br[j];
+      }
+    }
+  }
+}
+
+/* src/PDE/Integrate/Source.cpp:21-141 */
+static void src_int(const orc_cfg* k, double t, const int64_t* inpoel,
+                    const double* x, const double* y, const double* z,
+                    const double* geoElem, int64_t nunk, double* R)
+{
+  const int64_t ndof = k->ndof, npr = NCOMP * ndof;
+  const int ng = ng_vol(ndof);
+  double cg[3][14], wg[14];
+  int64_t e;
+  quad_tet(ng, cg, wg);
+  for (e = 0; e < nunk; ++e) {
+    double p[4][3]; int ig, c; int64_t j;
+    elem_coords(inpoel, e, x, y, z, p);
+    for (ig = 0; ig < ng; ++ig) {
+      double gp[3], B[10], s[5], wt;
+      gp_tet(p, cg[0][ig], cg[1][ig], cg[2][ig], gp);
+      eval_basis(ndof, cg[0][ig], cg[1][ig], cg[2][ig], B);
+      prob_src(k, gp[0], gp[1], gp[2], t, s);
+      wt = wg[ig] * geoElem[4 * e];
+      for (c = 0; c < NCOMP; ++c) {
+        double* r = R + e * npr + c * ndof;
+        r[0] += wt * s[c];
+        for (j = 1; j < ndof; ++j) r[j] += wt * s[c] * B[j];
+      }
+    }
+  }
+}
+
+/* src/PDE/Integrate/Volume.cpp:20-168 */
+static void vol_int(const orc_cfg* k, const int64_t* inpoel, const double* x,
+                    const double* y, const double* z, const double* geoElem,
+                    int64_t nunk, const double* U, double* R)
+{
+  const int64_t ndof = k->ndof, npu = NCOMP * k->rdof, npr = NCOMP * ndof;
+  const int ng = ng_vol(ndof);
+  double cg[3][14], wg[14];
+  int64_t e;
+  quad_tet(ng, cg, wg);
+  for (e = 0; e < nunk; ++e) {
+    double p[4][3], ji[3][3], dBdx[3][10]; int ig, c; int64_t j;
+    elem_coords(inpoel, e, x, y, z, p);
+    inverse_jacobian(p[0], p[1], p[2], p[3], ji);
+    eval_dBdx_p1(ji, dBdx);
+    for (ig = 0; ig < ng; ++ig) {
+      double B[10], s[5], F[5][3], wt;
+      if (ndof > 4) eval_dBdx_p2(cg[0][ig], cg[1][ig], cg[2][ig], ji, dBdx);
+      eval_basis(ndof, cg[0][ig], cg[1][ig], cg[2][ig], B);
+      wt = wg[ig] * geoElem[4 * e];
+      /* reference passes ndof as the U stride here (Volume.cpp:100) */
+      eval_state(npu, ndof, ndof, e, U, B, s);
+      euler_flux(k, s, F);
+      for (c = 0; c < NCOMP; ++c) {
+        double* r = R + e * npr + c * ndof;
+        for (j = 1; j < ndof; ++j)
+          r[j] += wt * (F[c][0] * dBdx[0][j] + F[c][1] * dBdx[1][j] + F[c][2] * dBdx[2][j]);
+      }
+    }
+  }
+}
+
+/* src/PDE/Integrate/Boundary.cpp:23-243 : one BC type over its configured
+ * side sets */
+static void bnd_surf_int(const orc_cfg* k, const orc_bc* bc, int type,
+                         const int64_t* conf, int64_t nconf, double t,
+                         const int32_t* esuf, const int64_t* inpofa,
+                         const int64_t* inpoel, const double* x,
+                         const double* y, const double* z,
+                         const double* geoFace, const double* U, double* R)
+{
+  const int64_t ndof = k->ndof, rdof = k->rdof;
+  const int64_t npu = NCOMP * rdof, npr = NCOMP * ndof;
+  const int ng = ng_fa(ndof);
+  const int64_t dof_e = (rdof > ndof) ? rdof : ndof;
+  double cg[2][6], wg[6];
+  int64_t ic, is, q;
+  quad_tri(ng, cg, wg);
+  for (ic = 0; ic < nconf; ++ic) {
+    for (is = 0; is < bc->nset; ++is) {
+      if (bc->set_id[is] != conf[ic]) continue;
+      for (q = bc->set_off[is]; q < bc->set_off[is + 1]; ++q) {
+        const int64_t f = bc->set_face[q];
+        const int64_t el = esuf[2 * f];
+        double pl[4][3], pf[3][3], detl, fn[3];
+        int ig, c, i; int64_t j;
+        elem_coords(inpoel, el, x, y, z, pl);
+        detl = jacobian(pl[0], pl[1], pl[2], pl[3]);
+        for (i = 0; i < 3; ++i) {
+          const int64_t n = inpofa[3 * f + i];
+          pf[i][0] = x[n]; pf[i][1] = y[n]; pf[i][2] = z[n];
+        }
+        fn[0] = geoFace[7 * f + 1]; fn[1] = geoFace[7 * f + 2]; fn[2] = geoFace[7 * f + 3];
+        for (ig = 0; ig < ng; ++ig) {
+          double gp[3], xi, eta, zeta, Bl[10], ul[5], ur[5], fl[5], wt;
+          gp_tri(pf, cg[0][ig], cg[1][ig], gp);
+          ref_coords(pl, detl, gp, &xi, &eta, &zeta);
+          eval_basis(dof_e, xi, eta, zeta, Bl);
+          wt = wg[ig] * geoFace[7 * f];
+          eval_state(npu, rdof, dof_e, el, U, Bl, ul);
+          bc_state(k, type, ul, gp[0], gp[1], gp[2], t, fn, ur);
+          riemann(k, fn, ul, ur, fl);
+          for (c = 0; c < NCOMP; ++c) {
+            double* rl = R + el * npr + c * ndof;
+            rl[0] -= wt * fl[c];
+            for (j = 1; j < ndof; ++j) rl[j] -= wt * fl[c] * Bl[j];
+          }
+        }
+      }
+    }
+  }
+}
+
+/* src/PDE/CompFlow/DGCompFlow.hpp:130-195 : R = 0; surfInt; srcInt; volInt
+ * (ndof>1); bndSurfInt for Dirichlet, Symmetry, Extrapolate in that order */
+void orc_rhs(const orc_cfg* k, const orc_bc* bc, double t, int64_t nunk,
+             int64_t nbfac, int64_t nfac, const int32_t* esuf,
+             const int64_t* inpofa, const int64_t* inpoel, const double* x,
+             const double* y, const double* z, const double* geoFace,
+             const double* geoElem, const double* U, double* R)
+{
+  memset(R, 0, (size_t)(nunk * NCOMP * k->ndof) * sizeof(double));
+  surf_int(k, nbfac, nfac, esuf, inpofa, inpoel, x, y, z, geoFace, U, R);
+  src_int(k, t, inpoel, x, y, z, geoElem, nunk, R);
+  if (k->ndof > 1) vol_int(k, inpoel, x, y, z, geoElem, nunk, U, R);
+  bnd_surf_int(k, bc, BC_DIRICHLET, bc->dir, bc->ndir, t, esuf, inpofa, inpoel, x, y, z, geoFace, U, R);
+  bnd_surf_int(k, bc, BC_SYMMETRY, bc->sym, bc->nsym, t, esuf, inpofa, inpoel, x, y, z, geoFace, U, R);
+  bnd_surf_int(k, bc, BC_EXTRAPOLATE, bc->extrap, bc->nextrap, t, esuf, inpofa, inpoel, x, y, z, geoFace, U, R);
+}
+
+/* src/PDE/CompFlow/DGCompFlow.hpp:206-406 : CFL time step.  Note the
+ * reference ASSIGNS dSV = wt*(|vn|+a) per Gauss point and adds
+ * max(dSV_l,dSV_r) to delt[] inside the Gauss loop; the minimum runs over
+ * all nunk elements (ghosts included). */
+double orc_dt(const orc_cfg* k, int64_t nunk, int64_t nfac, const int32_t* esuf,
+              const int64_t* inpofa, const int64_t* inpoel, const double* x,
+              const double* y, const double* z, const double* geoFace,
+              const double* geoElem, const double* U)
+{
+  const int64_t ndof = k->ndof, rdof = k->rdof, npu = NCOMP * rdof;
+  const int ng = ng_fa(ndof);
+  double cg[2][6], wg[6], mindt = DBL_MAX;
+  double* delt = (double*)calloc((size_t)nunk, sizeof(double));
+  int64_t f, e;
+  quad_tri(ng, cg, wg);
+  for (f = 0; f < nfac; ++f) {
+    const int64_t el = esuf[2 * f];
+    const int32_t er = esuf[2 * f + 1];
+    double pl[4][3], pr[4][3], pf[3][3], detl, detr = 0.0, dSV_l = 0.0, dSV_r = 0.0;
+    int ig, i;
+    elem_coords(inpoel, el, x, y, z, pl);
+    detl = jacobian(pl[0], pl[1], pl[2], pl[3]);
+    if (er > -1) {
+      elem_coords(inpoel, er, x, y, z, pr);
+      detr = jacobian(pr[0], pr[1], pr[2], pr[3]);
+    }
+    for (i = 0; i < 3; ++i) {
+      const int64_t n = inpofa[3 * f + i];
+      pf[i][0] = x[n]; pf[i][1] = y[n]; pf[i][2] = z[n];
+    }
+    for (ig = 0; ig < ng; ++ig) {
+      double gp[3], xi, eta, zeta, B[10], s[5], rho, u, v, w, p, a, vn, wt;
+      gp_tri(pf, cg[0][ig], cg[1][ig], gp);
+      ref_coords(pl, detl, gp, &xi, &eta, &zeta);
+      eval_basis(ndof, xi, eta, zeta, B);
+      wt = wg[ig] * geoFace[7 * f];
+      eval_state(npu, rdof, ndof, el, U, B, s);
+      rho = s[0]; u = s[1] / rho; v = s[2] / rho; w = s[3] / rho;
+      p = eos_pressure(k, rho, u, v, w, s[4]);
+      a = eos_soundspeed(k, rho, p);
+      vn = u * geoFace[7*f+1] + v * geoFace[7*f+2] + w * geoFace[7*f+3];
+      dSV_l = wt * (fabs(vn) + a);
+      if (er > -1) {
+        ref_coords(pr, detr, gp, &xi, &eta, &zeta);
+        eval_basis(ndof, xi, eta, zeta, B);
+        eval_state(npu, rdof, ndof, er, U, B, s);
+        rho = s[0]; u = s[1] / rho; v = s[2] / rho; w = s[3] / rho;
+        p = eos_pressure(k, rho, u, v, w, s[4]);
+        a = eos_soundspeed(k, rho, p);
+        vn = u * geoFace[7*f+1] + v * geoFace[7*f+2] + w * geoFace[7*f+3];
+        dSV_r = wt * (fabs(vn) + a);
+        delt[er] += (dSV_l > dSV_r ? dSV_l : dSV_r);
+      }
+      delt[el] += (dSV_l > dSV_r ? dSV_l : dSV_r);
+    }
+  }
+  for (e = 0; e < nunk; ++e) {
+    const double d = geoElem[4 * e] / delt[e];
+    if (d < mindt) mindt = d;
+  }
+  free(delt);
+  return mindt;
+}
+
+/* ------------------------------------------------------------ limiters */
+
+/* src/PDE/Limiter.cpp:29-153 : WENO for the P1 modes, per component, Jacobi
+ * (all elements computed from the unlimited field, then written back) */
+void orc_weno_p1(const orc_cfg* k, const int32_t* esuel, int64_t nielem,
+                 double* U)
+{
+  const int64_t rdof = k->rdof, npu = NCOMP * rdof;
+  double* lim = (double*)malloc((size_t)(3 * nielem) * sizeof(double));
+  int c; int64_t e;
+  for (c = 0; c < NCOMP; ++c) {
+    const int64_t m = c * rdof;
+    for (e = 0; e < nielem; ++e) {
+      double g[5][3], wst[5], osc[5], wd[5], wtot = 0.0; int is, d;
+      g[0][0] = U[e * npu + m + 1]; g[0][1] = U[e * npu + m + 2]; g[0][2] = U[e * npu + m + 3];
+      wst[0] = k->cweight;
+      for (is = 1; is < 5; ++is) {
+        const int32_t n = esuel[4 * e + (is - 1)];
+        if (n == -1) { g[is][0] = g[is][1] = g[is][2] = 0.0; wst[is] = 0.0; continue; }
+        g[is][0] = U[(int64_t)n * npu + m + 1];
+        g[is][1] = U[(int64_t)n * npu + m + 2];
+        g[is][2] = U[(int64_t)n * npu + m + 3];
+        wst[is] = 1.0;
+      }
+      for (is = 0; is < 5; ++is)
+        osc[is] = sqrt(g[is][0] * g[is][0] + g[is][1] * g[is][1] + g[is][2] * g[is][2]);
+      for (is = 0; is < 5; ++is) {
+        wd[is] = wst[is] * pow(1.0e-8 + osc[is], -2);
+        wtot += wd[is];
+      }
+      for (is = 0; is < 5; ++is) wd[is] = wd[is] / wtot;
+      for (d = 0; d < 3; ++d) {
+        double a = 0.0;
+        for (is = 0; is < 5; ++is) a += wd[is] * g[is][d];
+        lim[3 * e + d] = a;
+      }
+    }
+    for (e = 0; e < nielem; ++e) {
+      U[e * npu + m + 1] = lim[3 * e];
+      U[e * npu + m + 2] = lim[3 * e + 1];
+      U[e * npu + m + 3] = lim[3 * e + 2];
+    }
+  }
+  free(lim);
+}
+
+/* src/PDE/Limiter.cpp:155-316 : Superbee for the P1 modes */
+void orc_superbee_p1(const orc_cfg* k, const int32_t* esuel, int64_t nielem,
+                     const int64_t* inpoel, const double* x, const double* y,
+                     const double* z, double* U)
+{
+  const int64_t rdof = k->rdof, npu = NCOMP * rdof;
+  const int64_t dof_el = k->ndof;
+  const double beta_lim = 2.0;
+  const int ng = ng_fa(rdof);
+  double cg[2][6], wg[6];
+  int64_t e;
+  if (dof_el <= 1) return;
+  quad_tri(ng, cg, wg);
+  for (e = 0; e < nielem; ++e) {
+    double uMin[5], uMax[5], phi[5], p[4][3], detT; int c, is, lf, ig, i;
+    for (c = 0; c < NCOMP; ++c) uMin[c] = uMax[c] = U[e * npu + c * rdof];
+    for (is = 0; is < 4; ++is) {
+      const int32_t n = esuel[4 * e + is];
+      if (n == -1) continue;
+      for (c = 0; c < NCOMP; ++c) {
+        const double v = U[(int64_t)n * npu + c * rdof];
+        if (v < uMin[c]) uMin[c] = v;
+        if (v > uMax[c]) uMax[c] = v;
+      }
+    }
+    elem_coords(inpoel, e, x, y, z, p);
+    detT = jacobian(p[0], p[1], p[2], p[3]);
+    for (c = 0; c < NCOMP; ++c) phi[c] = 1.0;
+    for (lf = 0; lf < 4; ++lf) {
+      double pf[3][3];
+      for (i = 0; i < 3; ++i) {
+        const int64_t n = inpoel[4 * e + LPOFA[lf][i]];
+        pf[i][0] = x[n]; pf[i][1] = y[n]; pf[i][2] = z[n];
+      }
+      for (ig = 0; ig < ng; ++ig) {
+        double gp[3], xi, eta, zeta, B[10], s[5];
+        gp_tri(pf, cg[0][ig], cg[1][ig], gp);
+        ref_coords(p, detT, gp, &xi, &eta, &zeta);
+        eval_basis(rdof, xi, eta, zeta, B);
+        eval_state(npu, rdof, dof_el, e, U, B, s);
+        for (c = 0; c < NCOMP; ++c) {
+          const double u0 = U[e * npu + c * rdof];
+          const double uNeg = s[c] - u0;
+          double pg = 1.0, t1, t2;
+          if (uNeg > 1.0e-14)       pg = fmin(1.0, (uMax[c] - u0) / (2.0 * uNeg));
+          else if (uNeg < -1.0e-14) pg = fmin(1.0, (uMin[c] - u0) / (2.0 * uNeg));
+          else                      pg = 1.0;
+          t1 = fmin(beta_lim * pg, 1.0);
+          t2 = fmin(pg, beta_lim);
+          pg = fmax(0.0, fmax(t1, t2));
+          phi[c] = fmin(phi[c], pg);
+        }
+      }
+    }
+    for (c = 0; c < NCOMP; ++c) {
+      double* u = U + e * npu + c * rdof;
+      u[1] = phi[c] * u[1]; u[2] = phi[c] * u[2]; u[3] = phi[c] * u[3];
+    }
+  }
+}
+
+/* src/Inciter/DG.cpp:1229-1260 : limiter dispatch (rdof>1 only) */
+void orc_limit(const orc_cfg* k, const int32_t* esuel, int64_t nielem,
+               const int64_t* inpoel, const double* x, const double* y,
+               const double* z, double* U)
+{
+  if (k->rdof <= 1) return;
+  if (k->limiter == ORC_LIM_WENOP1) orc_weno_p1(k, esuel, nielem, U);
+  else if (k->limiter == ORC_LIM_SUPERBEEP1)
+    orc_superbee_p1(k, esuel, nielem, inpoel, x, y, z, U);
+}
+
+/* src/Inciter/DG.cpp:39-40,1478-1488 : SSP-RK3 stage update over all nunk */
+void orc_rk_update(const orc_cfg* k, int stage, double dt, const double* Un,
+                   const double* R, const double* L, double* U, int64_t nunk)
+{
+  static const double rk[2][3] = { { 0.0, 3.0 / 4.0, 1.0 / 3.0 },
+                                   { 1.0, 1.0 / 4.0, 2.0 / 3.0 } };
+  const int64_t ndof = k->ndof, rdof = k->rdof;
+  const int64_t npu = NCOMP * rdof, npr = NCOMP * ndof;
+  int64_t e, j; int c;
+  for (e = 0; e < nunk; ++e)
+    for (c = 0; c < NCOMP; ++c)
+      for (j = 0; j < ndof; ++j) {
+        const int64_t rm = e * npu + c * rdof + j, m = e * npr + c * ndof + j;
+        U[rm] = rk[0][stage] * Un[rm] + rk[1][stage] * (U[rm] + dt * R[m] / L[m]);
+      }
+}
+
+/* src/Inciter/ElemDiagnostics.cpp:116-215 : per-component sums over interior
+ * elements; out[0..4]=sum wt*u^2, out[5..9]=sum wt*(u-s)^2, out[10..14]=max|u-s|
+ * (final sqrt(./V) is Transporter.cpp:901-916) */
+void orc_diag(const orc_cfg* k, double t_new, const int64_t* inpoel,
+              const double* x, const double* y, const double* z,
+              const double* geoElem, const double* U, int64_t nielem,
+              double* out)
+{
+  const int64_t ndof = k->ndof, rdof = k->rdof, npu = NCOMP * rdof;
+  const int ng = ng_diag(ndof);
+  double cg[3][14], wg[14];
+  int64_t e; int i;
+  quad_tet(ng, cg, wg);
+  for (i = 0; i < 15; ++i) out[i] = 0.0;
+  for (e = 0; e < nielem; ++e) {
+    double p[4][3]; int ig, c;
+    elem_coords(inpoel, e, x, y, z, p);
+    for (ig = 0; ig < ng; ++ig) {
+      double gp[3], B[10], s[5], u[5], wt;
+      gp_tet(p, cg[0][ig], cg[1][ig], cg[2][ig], gp);
+      eval_basis(ndof, cg[0][ig], cg[1][ig], cg[2][ig], B);
+      wt = wg[ig] * geoElem[4 * e];
+      prob_solution(k, gp[0], gp[1], gp[2], t_new, s);
+      eval_state(npu, rdof, ndof, e, U, B, u);
+      for (c = 0; c < NCOMP; ++c) {
+        const double err = fabs(u[c] - s[c]);
+        out[c] += wt * u[c] * u[c];
+        out[5 + c] += wt * (u[c] - s[c]) * (u[c] - s[c]);
+        if (err > out[10 + c]) out[10 + c] = err;
+      }
+    }
+  }
+}
+
+/* One full SSP-RK3 time step in the reference's stage order
+ * (limit -> [stage 0: dt, Un=U] -> rhs -> update; src/Inciter/DG.cpp:1229-1260,
+ * 1360-1430, 1432-1488; CFL scaling DG.cpp:1404-1418).  Single partition:
+ * nunk == nielem, no ghosts.  If fixed_dt > 0 it is used, else dt from CFL.
+ * `tleft` caps dt (Discretization.cpp:476-487).  Returns the dt taken.
+ * Work arrays Un, R are caller-provided (nunk*nprop each). */
+double orc_step(const orc_cfg* k, const orc_bc* bc, double t, double fixed_dt,
+                double cfl, double tleft, int64_t nunk, int64_t nbfac,
+                int64_t nfac, const int32_t* esuel, const int32_t* esuf,
+                const int64_t* inpofa, const int64_t* inpoel, const double* x,
+                const double* y, const double* z, const double* geoFace,
+                const double* geoElem, const double* L, double* U, double* Un,
+                double* R)
+{
+  double dt = fixed_dt; int stage;
+  for (stage = 0; stage < 3; ++stage) {
+    orc_limit(k, esuel, nunk, inpoel, x, y, z, U);
+    if (stage == 0) {
+      if (!(fixed_dt > 0.0)) {
+        const double dgp = (k->ndof == 4) ? 1.0 : (k->ndof == 10) ? 2.0 : 0.0;
+        dt = orc_dt(k, nunk, nfac, esuf, inpofa, inpoel, x, y, z, geoFace, geoElem, U);
+        dt *= cfl / (2.0 * dgp + 1.0);
+      }
+      if (dt > tleft) dt = tleft;
+      memcpy(Un, U, (size_t)(nunk * NCOMP * k->rdof) * sizeof(double));
+    }
+    orc_rhs(k, bc, t, nunk, nbfac, nfac, esuf, inpofa, inpoel, x, y, z, geoFace, geoElem, U, R);
+    orc_rk_update(k, stage, dt, Un, R, L, U, nunk);
+  }
+  return dt;
+}

@@ -1,0 +1,313 @@
+"""ctypes front-end of the CPU oracle (oracle/dg_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, by __graft_entry__.smoke() and by
+bench.py's `cpu_baseline` leg.  Nothing under quinoa_amd/ imports this module.
+
+It assembles, with the oracle's own restatements, everything a serial
+reference run holds for one mesh chunk (the `FaceData` arrays, geoFace,
+geoElem, the regenerated boundary faces) and drives the reference's time loop
+(limit -> dt -> rhs -> RK3 update).  Reference citations are in dg_oracle.c.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+FLUX = {"hllc": 0, "laxfriedrichs": 1}
+LIMITER = {"nolimiter": 0, "wenop1": 1, "superbeep1": 2}
+PROBLEM = {"user_defined": 0, "sod_shocktube": 1, "sedov_blastwave": 2,
+           "vortical_flow": 3, "taylor_green": 4}
+
+c_i64p = C.POINTER(C.c_int64)
+c_i32p = C.POINTER(C.c_int32)
+c_f64p = C.POINTER(C.c_double)
+
+
+class Cfg(C.Structure):
+    _fields_ = [("ndof", C.c_int64), ("rdof", C.c_int64), ("flux", C.c_int32),
+                ("limiter", C.c_int32), ("problem", C.c_int32),
+                ("pad_", C.c_int32), ("cweight", C.c_double),
+                ("gamma", C.c_double), ("pstiff", C.c_double),
+                ("cv", C.c_double), ("alpha", C.c_double),
+                ("beta", C.c_double), ("p0", C.c_double)]
+
+
+class Bc(C.Structure):
+    _fields_ = [("nset", C.c_int64), ("set_id", c_i64p), ("set_off", c_i64p),
+                ("set_face", c_i64p), ("ndir", C.c_int64), ("nsym", C.c_int64),
+                ("nextrap", C.c_int64), ("dir", c_i64p), ("sym", c_i64p),
+                ("extrap", c_i64p)]
+
+
+def build(force=False):
+    """Compile oracle/libdgoracle.so (and oracle/_ref when the reference is
+    present, i.e. in the development container only)."""
+    so = os.path.join(_HERE, "libdgoracle.so")
+    src = os.path.join(_HERE, "dg_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
+    if os.path.isdir("/root/reference/src"):
+        ref = os.path.join(_HERE, "_ref", "libquinoa_ref.so")
+        if force or not os.path.exists(ref):
+            subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.orc_dt.restype = C.c_double
+        _LIB.orc_step.restype = C.c_double
+        _LIB.orc_jacobian.restype = C.c_double
+        _LIB.orc_gen_nipfac.restype = C.c_int64
+    return _LIB
+
+
+def ref_lib():
+    """The reference's own Vector.cpp/Quadrature.cpp build, or None."""
+    p = os.path.join(_HERE, "_ref", "libquinoa_ref.so")
+    if not os.path.exists(p):
+        return None
+    L = C.CDLL(p)
+    L.ref_jacobian.restype = C.c_double
+    return L
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+def make_cfg(ndof, rdof=None, flux="hllc", limiter="nolimiter",
+             problem="sod_shocktube", gamma=1.4, pstiff=0.0, cv=717.5,
+             cweight=1.0, alpha=0.0, beta=0.0, p0=0.0):
+    return Cfg(ndof=ndof, rdof=rdof or ndof, flux=FLUX[flux],
+               limiter=LIMITER[limiter], problem=PROBLEM[problem], pad_=0,
+               cweight=cweight, gamma=gamma, pstiff=pstiff, cv=cv,
+               alpha=alpha, beta=beta, p0=p0)
+
+
+def regen_boundary_faces(inpoel, sidesets):
+    """Boundary-face regeneration of the reference's mesh loader
+    (src/Inciter/Partitioner.cpp:357-393): the file's side-set triangles are
+    only order-independent keys; for each tet in input order its faces
+    {0,2,1},{0,1,3},{0,3,2},{1,2,3} that match a side-set triangle are
+    appended (in that node order) to that side set.  Boundary faces are then
+    numbered side set by side set in ascending id (std::map<int,..> order of
+    FaceData::m_bface, src/Inciter/FaceData.hpp).
+
+    Returns (bface: {id: face ids}, triinpoel[nb,3])."""
+    key = {}
+    for sid in sorted(sidesets):
+        for t in np.asarray(sidesets[sid]):
+            key[tuple(sorted(int(v) for v in t))] = sid
+    per = {sid: [] for sid in sorted(sidesets)}
+    loc = ((0, 2, 1), (0, 1, 3), (0, 3, 2), (1, 2, 3))
+    for t in np.asarray(inpoel):
+        for f in loc:
+            tri = (int(t[f[0]]), int(t[f[1]]), int(t[f[2]]))
+            sid = key.get(tuple(sorted(tri)))
+            if sid is not None:
+                per[sid].append(tri)
+    bface, tri_all, n = {}, [], 0
+    for sid in sorted(per):
+        m = len(per[sid])
+        bface[sid] = np.arange(n, n + m, dtype=np.int64)
+        tri_all.extend(per[sid])
+        n += m
+    triinpoel = np.array(tri_all, dtype=np.int64).reshape(-1, 3)
+    return bface, triinpoel
+
+
+class OracleMesh:
+    """Serial (single-chunk) mesh with the reference's derived data."""
+
+    def __init__(self, coord, inpoel, sidesets=None, bface=None, triinpoel=None):
+        L = lib()
+        self.coord = np.ascontiguousarray(coord, dtype=np.float64)
+        self.x = np.ascontiguousarray(self.coord[:, 0])
+        self.y = np.ascontiguousarray(self.coord[:, 1])
+        self.z = np.ascontiguousarray(self.coord[:, 2])
+        self.inpoel = np.ascontiguousarray(inpoel, dtype=np.int64).reshape(-1, 4)
+        ne = self.nelem = self.inpoel.shape[0]
+        npoin = self.npoin = self.coord.shape[0]
+        if bface is None:
+            bface, triinpoel = regen_boundary_faces(self.inpoel, sidesets or {})
+        self.bface = {int(k): np.asarray(v, dtype=np.int64) for k, v in bface.items()}
+        self.triinpoel = np.ascontiguousarray(triinpoel, dtype=np.int64).reshape(-1, 3)
+        nb = self.nbfac = self.triinpoel.shape[0]
+        inp = self.inpoel.reshape(-1)
+        esup1 = np.zeros(4 * ne + 1, dtype=np.int64)
+        esup2 = np.zeros(npoin + 1, dtype=np.int64)
+        L.orc_gen_esup(_p(inp, c_i64p), C.c_int64(ne), C.c_int64(npoin),
+                       _p(esup1, c_i64p), _p(esup2, c_i64p))
+        self.esup1, self.esup2 = esup1, esup2
+        self.esuel = np.zeros(4 * ne, dtype=np.int32)
+        L.orc_gen_esuel(_p(inp, c_i64p), C.c_int64(ne), C.c_int64(npoin),
+                        _p(esup1, c_i64p), _p(esup2, c_i64p), _p(self.esuel, c_i32p))
+        nf = self.nfac = int(L.orc_gen_nipfac(C.c_int64(nb), _p(self.esuel, c_i32p), C.c_int64(ne)))
+        self.inpofa = np.zeros(3 * nf, dtype=np.int64)
+        tri = np.ascontiguousarray(self.triinpoel.reshape(-1))
+        L.orc_gen_inpofa(C.c_int64(nb), _p(inp, c_i64p), C.c_int64(ne),
+                         _p(tri, c_i64p), _p(self.esuel, c_i32p), _p(self.inpofa, c_i64p))
+        self.belem = np.zeros(max(nb, 1), dtype=np.int64)
+        L.orc_gen_belem(C.c_int64(nb), _p(self.inpofa, c_i64p), _p(esup1, c_i64p),
+                        _p(esup2, c_i64p), _p(self.belem, c_i64p))
+        self.belem = self.belem[:nb]
+        self.esuf = np.zeros(2 * nf, dtype=np.int32)
+        L.orc_gen_esuf(C.c_int64(nb), _p(self.belem, c_i64p), _p(self.esuel, c_i32p),
+                       C.c_int64(ne), _p(self.esuf, c_i32p))
+        self.geoFace = np.zeros(7 * nf)
+        L.orc_gen_geoface(C.c_int64(nf), _p(self.inpofa, c_i64p), _p(self.x, c_f64p),
+                          _p(self.y, c_f64p), _p(self.z, c_f64p), _p(self.geoFace, c_f64p))
+        self.geoElem = np.zeros(4 * ne)
+        L.orc_gen_geoelem(_p(inp, c_i64p), C.c_int64(ne), _p(self.x, c_f64p),
+                          _p(self.y, c_f64p), _p(self.z, c_f64p), _p(self.geoElem, c_f64p))
+        self.meshvol = float(self.geoElem[0::4].sum())
+        # flattened bface map
+        ids = sorted(self.bface)
+        self._set_id = np.array(ids, dtype=np.int64)
+        self._set_off = np.zeros(len(ids) + 1, dtype=np.int64)
+        faces = []
+        for i, s in enumerate(ids):
+            faces.append(self.bface[s])
+            self._set_off[i + 1] = self._set_off[i] + len(self.bface[s])
+        self._set_face = (np.concatenate(faces) if faces else np.zeros(0, np.int64)).astype(np.int64)
+        if self._set_face.size == 0:
+            self._set_face = np.zeros(1, dtype=np.int64)
+
+
+class Oracle:
+    """Reference time loop on one mesh chunk (CPU, AoS fields)."""
+
+    def __init__(self, mesh, cfg, bc_dirichlet=(), bc_sym=(), bc_extrapolate=()):
+        self.m, self.cfg, self.L_ = mesh, cfg, lib()
+        self._dir = np.array(list(bc_dirichlet) or [0], dtype=np.int64)
+        self._sym = np.array(list(bc_sym) or [0], dtype=np.int64)
+        self._ext = np.array(list(bc_extrapolate) or [0], dtype=np.int64)
+        self.bc = Bc(nset=len(mesh._set_id), set_id=_p(mesh._set_id, c_i64p),
+                     set_off=_p(mesh._set_off, c_i64p), set_face=_p(mesh._set_face, c_i64p),
+                     ndir=len(bc_dirichlet), nsym=len(bc_sym), nextrap=len(bc_extrapolate),
+                     dir=_p(self._dir, c_i64p), sym=_p(self._sym, c_i64p),
+                     extrap=_p(self._ext, c_i64p))
+        self.nprop = 5 * cfg.rdof
+        self.npropr = 5 * cfg.ndof
+
+    # --- single operators -------------------------------------------------
+    def lhs(self):
+        m = self.m
+        Lm = np.zeros(m.nelem * self.npropr)
+        self.L_.orc_mass(C.byref(self.cfg), _p(m.geoElem, c_f64p), C.c_int64(m.nelem), _p(Lm, c_f64p))
+        return Lm
+
+    def initialize(self, Lm, t=0.0):
+        m = self.m
+        U = np.zeros(m.nelem * self.nprop)
+        self.L_.orc_initialize(C.byref(self.cfg), _p(Lm, c_f64p), _p(m.inpoel.reshape(-1), c_i64p),
+                               _p(m.x, c_f64p), _p(m.y, c_f64p), _p(m.z, c_f64p),
+                               _p(U, c_f64p), C.c_double(t), C.c_int64(m.nelem))
+        return U
+
+    def rhs(self, t, U):
+        m = self.m
+        R = np.zeros(m.nelem * self.npropr)
+        self.L_.orc_rhs(C.byref(self.cfg), C.byref(self.bc), C.c_double(t), C.c_int64(m.nelem),
+                        C.c_int64(m.nbfac), C.c_int64(m.nfac), _p(m.esuf, c_i32p),
+                        _p(m.inpofa, c_i64p), _p(m.inpoel.reshape(-1), c_i64p),
+                        _p(m.x, c_f64p), _p(m.y, c_f64p), _p(m.z, c_f64p),
+                        _p(m.geoFace, c_f64p), _p(m.geoElem, c_f64p), _p(U, c_f64p), _p(R, c_f64p))
+        return R
+
+    def dt(self, U):
+        m = self.m
+        return float(self.L_.orc_dt(C.byref(self.cfg), C.c_int64(m.nelem), C.c_int64(m.nfac),
+                                    _p(m.esuf, c_i32p), _p(m.inpofa, c_i64p),
+                                    _p(m.inpoel.reshape(-1), c_i64p), _p(m.x, c_f64p),
+                                    _p(m.y, c_f64p), _p(m.z, c_f64p), _p(m.geoFace, c_f64p),
+                                    _p(m.geoElem, c_f64p), _p(U, c_f64p)))
+
+    def limit(self, U):
+        """In place, like the reference (src/Inciter/DG.cpp:1251-1260)."""
+        m = self.m
+        self.L_.orc_limit(C.byref(self.cfg), _p(m.esuel, c_i32p), C.c_int64(m.nelem),
+                          _p(m.inpoel.reshape(-1), c_i64p), _p(m.x, c_f64p), _p(m.y, c_f64p),
+                          _p(m.z, c_f64p), _p(U, c_f64p))
+        return U
+
+    def rk_update(self, stage, dt, Un, R, Lm, U):
+        self.L_.orc_rk_update(C.byref(self.cfg), C.c_int(stage), C.c_double(dt), _p(Un, c_f64p),
+                              _p(R, c_f64p), _p(Lm, c_f64p), _p(U, c_f64p), C.c_int64(self.m.nelem))
+        return U
+
+    def diag(self, t_new, U):
+        """Row of the reference's diag file after sqrt(./V): L2(u_c) x5,
+        L2(u_c - analytic) x5 (Transporter.cpp:901-916)."""
+        m = self.m
+        out = np.zeros(15)
+        self.L_.orc_diag(C.byref(self.cfg), C.c_double(t_new), _p(m.inpoel.reshape(-1), c_i64p),
+                         _p(m.x, c_f64p), _p(m.y, c_f64p), _p(m.z, c_f64p),
+                         _p(m.geoElem, c_f64p), _p(U, c_f64p), C.c_int64(m.nelem), _p(out, c_f64p))
+        return np.sqrt(out[:10] / m.meshvol), out[10:]
+
+    def step(self, t, U, Lm, fixed_dt=0.0, cfl=0.0, tleft=1e300, work=None):
+        m = self.m
+        if work is None:
+            work = (np.zeros_like(U), np.zeros(m.nelem * self.npropr))
+        Un, R = work
+        dt = self.L_.orc_step(C.byref(self.cfg), C.byref(self.bc), C.c_double(t),
+                              C.c_double(fixed_dt), C.c_double(cfl), C.c_double(tleft),
+                              C.c_int64(m.nelem), C.c_int64(m.nbfac), C.c_int64(m.nfac),
+                              _p(m.esuel, c_i32p), _p(m.esuf, c_i32p), _p(m.inpofa, c_i64p),
+                              _p(m.inpoel.reshape(-1), c_i64p), _p(m.x, c_f64p), _p(m.y, c_f64p),
+                              _p(m.z, c_f64p), _p(m.geoFace, c_f64p), _p(m.geoElem, c_f64p),
+                              _p(Lm, c_f64p), _p(U, c_f64p), _p(Un, c_f64p), _p(R, c_f64p))
+        return float(dt)
+
+    # --- field output (cell means), Problem::fieldOutput ------------------
+    def field_output(self, U):
+        """density, x/y/z velocity, specific total energy, pressure from cell
+        means (src/PDE/CompFlow/Problem/SodShocktube.cpp:160-215)."""
+        rd = self.cfg.rdof
+        Um = U.reshape(self.m.nelem, self.nprop)
+        r, ru, rv, rw, re = (Um[:, c * rd] for c in range(5))
+        u, v, w = ru / r, rv / r, rw / r
+        g, pc = self.cfg.gamma, self.cfg.pstiff
+        p = (re - 0.5 * r * (u * u + v * v + w * w) - pc) * (g - 1.0) - pc
+        return np.stack([r, u, v, w, re / r, p])
+
+
+def run_case(case, fix, nstep=None, on_step=None):
+    """Run one tests/golden case with the oracle.  Returns dict with the diag
+    rows and the field output at every plot time (incl. t=0 and last step)."""
+    mesh = OracleMesh(fix["coord"], fix["inpoel"],
+                      {int(s): fix["ss_tri_%d" % s] for s in fix["ss_ids"]})
+    cfg = make_cfg(case["ndof"], flux=case["flux"], limiter=case["limiter"],
+                   problem=case["problem"], gamma=case["gamma"],
+                   alpha=case.get("alpha", 0.0), beta=case.get("beta", 0.0),
+                   p0=case.get("p0", 0.0))
+    orc = Oracle(mesh, cfg, case["bc_dirichlet"], case["bc_sym"], case["bc_extrapolate"])
+    Lm = orc.lhs()
+    U = orc.initialize(Lm, 0.0)
+    t, it = 0.0, 0
+    nstep = nstep or case["nstep"]
+    diag_rows, fields, times = [], [orc.field_output(U)], [0.0]
+    work = (np.zeros_like(U), np.zeros(mesh.nelem * orc.npropr))
+    while it < nstep:
+        dt = orc.step(t, U, Lm, fixed_dt=case["dt"], cfl=case["cfl"], work=work)
+        if (it + 1) % case["diag_interval"] == 0:
+            l2, _ = orc.diag(t + dt, U)
+            diag_rows.append(np.concatenate([[it + 1, t + dt, dt], l2]))
+        t += dt
+        it += 1
+        if it % case["plot_interval"] == 0 or it == nstep:
+            fields.append(orc.field_output(U))
+            times.append(t)
+        if on_step:
+            on_step(it, t, dt, U)
+    return {"mesh": mesh, "oracle": orc, "U": U, "L": Lm, "t": t,
+            "diag": np.array(diag_rows), "fields": np.array(fields),
+            "times": np.array(times)}

@@ -1,0 +1,131 @@
+#!/usr/bin/env python3
+"""Convert the reference's own DG regression fixtures into small .npz vectors.
+
+Runs ONLY in the development container (needs /root/reference). It reads
+*data files* held by the reference's regression tests -- ExodusII meshes
+(NetCDF CDF-2, readable with scipy), the committed golden ExodusII outputs
+(`*.std.exo`) and the committed golden diagnostics tables (`diag*.std`) -- and
+stores them as compressed numpy archives under tests/golden/.  No reference
+source code is read, executed or copied by this script.
+
+Source directory: tests/regression/inciter/compflow/Euler/** (see CASES).
+Control-file parameters of each case (scheme, dt/cfl, nstep, flux, limiter,
+BC side sets, material gamma, problem constants) are transcribed in
+tests/golden/cases.json from the `.q` files named there.
+
+Usage:  python tests/golden/make_fixtures.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+from scipy.io import netcdf_file
+
+REF = "/root/reference/tests/regression/inciter"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _str(chararr):
+    return b"".join(chararr).decode().strip("\x00 ").strip()
+
+
+def read_mesh(path):
+    """ExodusII input mesh -> coord[nnode,3], inpoel[ne,4] (0-based),
+    side sets as {id: triangles[n,3]} (node ids, order-independent keys)."""
+    f = netcdf_file(path, "r", mmap=False)
+    v = f.variables
+    coord = np.stack([v["coordx"][:], v["coordy"][:], v["coordz"][:]], axis=1)
+    coord = np.ascontiguousarray(coord, dtype=np.float64)
+    tri = None
+    tet = None
+    tri_first_id = None
+    eid = 1
+    nblk = f.dimensions["num_el_blk"]
+    for b in range(1, nblk + 1):
+        c = v["connect%d" % b]
+        et = c.elem_type.decode().upper()
+        arr = np.array(c[:], dtype=np.int64) - 1
+        if et.startswith("TRI"):
+            tri = arr
+            tri_first_id = eid
+        elif et.startswith("TET"):
+            tet = arr
+        eid += arr.shape[0]
+    assert tet is not None
+    ss = {}
+    if "ss_prop1" in v:
+        ids = np.array(v["ss_prop1"][:], dtype=np.int64)
+        for k, sid in enumerate(ids, start=1):
+            el = np.array(v["elem_ss%d" % k][:], dtype=np.int64)
+            # every side set of the CompFlow fixtures references TRI-block
+            # elements (file ids tri_first_id .. tri_first_id+ntri-1)
+            loc = el - tri_first_id
+            assert tri is not None and loc.min() >= 0 and loc.max() < len(tri)
+            ss[int(sid)] = tri[loc]
+    f.close()
+    return coord, tet, ss
+
+
+def read_golden_exo(path, ntet):
+    """Golden ExodusII output -> times[nt], names[nv], vals[nt,nv,ne] for the
+    TETRA block, plus the output mesh (to verify ordering is the input's)."""
+    f = netcdf_file(path, "r", mmap=False)
+    v = f.variables
+    times = np.array(v["time_whole"][:], dtype=np.float64)
+    names = [_str(r) for r in v["name_elem_var"][:]]
+    blk = None
+    for b in range(1, f.dimensions["num_el_blk"] + 1):
+        if v["connect%d" % b].elem_type.decode().upper().startswith("TET"):
+            blk = b
+    conn = np.array(v["connect%d" % blk][:], dtype=np.int64) - 1
+    assert conn.shape[0] == ntet
+    vals = np.zeros((len(times), len(names), ntet))
+    for i in range(len(names)):
+        vals[:, i, :] = v["vals_elem_var%deb%d" % (i + 1, blk)][:]
+    coord = np.stack([v["coordx"][:], v["coordy"][:], v["coordz"][:]], axis=1)
+    f.close()
+    return times, names, vals, conn, np.array(coord, dtype=np.float64)
+
+
+def read_diag(path):
+    rows = []
+    with open(path) as fh:
+        for line in fh:
+            if line.lstrip().startswith("#") or not line.strip():
+                continue
+            rows.append([float(x) for x in line.split()])
+    return np.array(rows)
+
+
+def main():
+    with open(os.path.join(HERE, "cases.json")) as fh:
+        cases = json.load(fh)
+    for name, c in cases.items():
+        d = os.path.join(REF, c["dir"])
+        coord, inpoel, ss = read_mesh(os.path.join(d, c["mesh"]))
+        out = {"coord": coord, "inpoel": inpoel.astype(np.int64),
+               "ss_ids": np.array(sorted(ss), dtype=np.int64)}
+        for sid in ss:
+            out["ss_tri_%d" % sid] = ss[sid].astype(np.int64)
+        if c.get("golden_exo"):
+            t, names, vals, conn, gcoord = read_golden_exo(
+                os.path.join(d, c["golden_exo"]), inpoel.shape[0])
+            # serial runs keep the input ordering of tets and nodes
+            assert np.array_equal(conn, inpoel), name
+            assert np.abs(gcoord - coord).max() < 1e-14, name
+            keep = [i for i, n in enumerate(names) if n.endswith("_numerical")]
+            out["exo_times"] = t
+            out["exo_names"] = np.array([names[i] for i in keep])
+            out["exo_vals"] = vals[:, keep, :]
+        if c.get("golden_diag"):
+            out["diag"] = read_diag(os.path.join(d, c["golden_diag"]))
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **out)
+        print("%-28s ne=%6d nnode=%5d ss=%s -> %s (%.0f kB)" % (
+            name, inpoel.shape[0], coord.shape[0], sorted(ss),
+            os.path.basename(path), os.path.getsize(path) / 1e3))
+
+
+if __name__ == "__main__":
+    sys.exit(main())

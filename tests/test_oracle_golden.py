@@ -1,0 +1,78 @@
+"""Pin the CPU oracle against the reference's own committed regression
+baselines (tests/golden/*.npz made by tests/golden/make_fixtures.py from
+tests/regression/inciter/compflow/Euler/** of the reference).
+
+The reference's harness accepts rel 1e-7 (exodiff_dg.cfg / *_diag.ndiff.cfg);
+the oracle is held to much tighter bounds on the ExodusII fields (stored as
+full doubles) and to the 7 printed digits of the diag tables.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from conftest import load_fixture
+
+# absolute tolerance on golden ExodusII element fields (full-precision f64)
+FIELD_ATOL = {"sod_dg": 1e-13, "sedov_dgp1": 5e-12, "vortical_flow_dg": 1e-12,
+              "vortical_flow_dg_lf": 1e-12, "vortical_flow_dgp1": 1e-12,
+              "vortical_flow_dgp1_lf": 1e-12, "taylor_green_dgp2": 1e-12,
+              "taylor_green_dgp2_cfl": 1e-12}
+# the diag files print 7 significant digits
+DIAG_RTOL = 6e-7
+
+
+@pytest.mark.parametrize("name", sorted(FIELD_ATOL))
+def test_oracle_reproduces_reference_golden(name, cases):
+    case, fix = cases[name], load_fixture(name)
+    r = O.run_case(case, fix)
+    # --- ExodusII element fields at every output time ---
+    assert np.allclose(r["times"], fix["exo_times"], rtol=0, atol=1e-15)
+    nvar = 6
+    if case["problem"] == "vortical_flow":
+        # VorticalFlow::fieldOutput overwrites u,v,w with the analytic values
+        # before evaluating "pressure_numerical"
+        # (src/PDE/CompFlow/Problem/VorticalFlow.cpp:208-240): an output quirk
+        # outside the hot path, so only the 5 state-derived fields are pinned.
+        nvar = 5
+    err = np.abs(r["fields"][:, :nvar] - fix["exo_vals"][:, :nvar]).max()
+    assert err <= FIELD_ATOL[name], (name, err)
+    # --- diagnostics table: it, t, dt, L2(u_c) x5, L2(u_c - analytic) x5 ---
+    gold = {int(row[0]): row for row in fix["diag"]}
+    assert len(r["diag"]) == len(gold)
+    for row in r["diag"]:
+        g = gold[int(row[0])]
+        for a, b in zip(row[1:13], g[1:13]):
+            assert abs(a - b) <= DIAG_RTOL * abs(b) + 1e-13, (name, int(row[0]), a, b)
+
+
+def test_oracle_matches_reference_build_jacobian_and_quadrature():
+    """Where the reference's own sources compile as they lie (Vector.cpp,
+    Quadrature.cpp -> oracle/_ref), the restatement must be bit-identical."""
+    R = O.ref_lib()
+    if R is None:
+        pytest.skip("oracle/_ref not built (reference absent on this box)")
+    import ctypes as C
+    L = O.lib()
+    rng = np.random.default_rng(7)
+    f64p = C.POINTER(C.c_double)
+    for _ in range(200):
+        p = rng.normal(size=(4, 3))
+        args = [p[i].ctypes.data_as(f64p) for i in range(4)]
+        assert L.orc_jacobian(*args) == R.ref_jacobian(*args)
+        a, b = np.zeros(9), np.zeros(9)
+        L.orc_inverse_jacobian(*args, a.ctypes.data_as(f64p))
+        R.ref_inverse_jacobian(*args, b.ctypes.data_as(f64p))
+        assert np.array_equal(a, b)
+    for ng in (1, 4, 5, 11, 14):
+        a, b = np.zeros((4, ng)), np.zeros((4, ng))
+        L.orc_quad_tet(ng, *[a[i].ctypes.data_as(f64p) for i in range(4)])
+        R.ref_quad_tet(ng, *[b[i].ctypes.data_as(f64p) for i in range(4)])
+        assert np.array_equal(a, b)
+        assert abs(a[3].sum() - 1.0) < 1e-14
+    for ng in (1, 3, 4, 6):
+        a, b = np.zeros((3, ng)), np.zeros((3, ng))
+        L.orc_quad_tri(ng, *[a[i].ctypes.data_as(f64p) for i in range(3)])
+        R.ref_quad_tri(ng, *[b[i].ctypes.data_as(f64p) for i in range(3)])
+        assert np.array_equal(a, b)
+    for nd, (v, f, d, i) in {1: (1, 1, 1, 1), 4: (5, 3, 4, 14), 10: (11, 6, 14, 14)}.items():
+        assert (R.ref_ngvol(nd), R.ref_ngfa(nd), R.ref_ngdiag(nd), R.ref_nginit(nd)) == (v, f, d, i)
