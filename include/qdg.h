@@ -1,0 +1,189 @@
+/*
+ * qdg.h -- C ABI of the MI355X-native DG compressible-flow path for
+ *          Quinoa/Inciter.
+ *
+ * Drop-in boundary: everything Inciter's `DG` chare reaches
+ * through `inciter::DGPDE` for the CompFlow DG scheme, plus the two free
+ * limiter functions and the SSP-RK3 update that `DG` runs itself.  Paths are
+ * relative to the reference repository root.
+ *
+ *   entry point            replaces (reference interface)
+ *   ---------------------  ------------------------------------------------
+ *   qdg_ctx_create         dg::CompFlow ctor + the g_inputdeck values it reads
+ *                          (src/PDE/CompFlow/DGCompFlow.hpp:80-93,
+ *                           src/Control/Inciter/InputDeck/InputDeck.hpp:191-238)
+ *   qdg_mesh_upload        the per-chare mesh arguments of every DGPDE call:
+ *                          inpoel, coord, FaceData, geoFace, geoElem
+ *                          (src/PDE/DGPDE.hpp:93-114, src/Inciter/FaceData.hpp:41-106)
+ *   qdg_lhs                DGPDE::lhs        (DGPDE.hpp:89-90  -> Integrate/Mass.cpp:25-73)
+ *   qdg_initialize         DGPDE::initialize (DGPDE.hpp:80-86  -> Integrate/Initialize.cpp:29-201)
+ *   qdg_rhs                DGPDE::rhs        (DGPDE.hpp:93-104 -> DGCompFlow.hpp:130-195)
+ *   qdg_dt                 DGPDE::dt         (DGPDE.hpp:107-114 -> DGCompFlow.hpp:206-406)
+ *   qdg_limit              WENO_P1 / Superbee_P1 as called from DG::lim
+ *                          (src/Inciter/DG.cpp:1251-1260, src/PDE/Limiter.cpp:29-316)
+ *   qdg_state_* / qdg_stage / qdg_step
+ *                          the resident form of DG::lim/dt/solve for one RK
+ *                          stage / one time step (DG.cpp:1229-1282, 1360-1430,
+ *                          1432-1508): fields stay in HBM between stages
+ *   qdg_diag               ElemDiagnostics::compute_diag
+ *                          (src/Inciter/ElemDiagnostics.cpp:116-215)
+ *   qdg_halo_*             DG::next/comsol/lim/comlim/dt ghost plumbing
+ *                          (DG.cpp:1009-1086, 1262-1282, 1315-1380)
+ *   qdg_gen_* / qdg_bnd_faces
+ *                          host-side mirrors of inciter::FaceData's ctor and of
+ *                          the geometry generators (src/Inciter/FaceData.cpp:19-41,
+ *                          src/Mesh/DerivedData.cpp:937-1491) and of the
+ *                          boundary-face regeneration of the mesh loader
+ *                          (src/Inciter/Partitioner.cpp:357-393)
+ *
+ * Conventions
+ *  - every function returns 0 on success, non-zero on error; it never throws.
+ *    qdg_last_error() returns the message of the calling thread's last error.
+ *  - host field arrays use the reference's `tk::Fields` (UnkEqComp) layout:
+ *    U[e*nprop + c*rdof + k], R/L[e*(5*ndof) + c*ndof + k]
+ *    (src/Base/Data.hpp:462-471), c in {rho, rho*u, rho*v, rho*w, rho*E}.
+ *  - size_t arrays are the reference's std::vector<std::size_t>; int arrays its
+ *    std::vector<int> (esuel, esuf; -1 = physical boundary).
+ *  - the callee BORROWS every pointer for the duration of the call only.
+ *  - a handle may be used from one thread at a time; no hidden global state.
+ *  - all arithmetic is IEEE fp64 on the device.
+ *  - there is NO CPU fallback: without a HIP device qdg_ctx_create fails.
+ */
+#ifndef QDG_H
+#define QDG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct qdg_ctx qdg_ctx;
+typedef struct qdg_mesh qdg_mesh;
+
+/* discr::flux (src/Control/Inciter/Options/Flux.hpp) */
+enum { QDG_FLUX_HLLC = 0, QDG_FLUX_LAXFRIEDRICHS = 1 };
+/* discr::limiter (src/Control/Inciter/Options/Limiter.hpp) */
+enum { QDG_LIMITER_NONE = 0, QDG_LIMITER_WENOP1 = 1, QDG_LIMITER_SUPERBEEP1 = 2 };
+/* Problem policy (src/PDE/CompFlow/Problem.hpp:14-80) */
+enum { QDG_PROBLEM_USER_DEFINED = 0, QDG_PROBLEM_SOD_SHOCKTUBE = 1,
+       QDG_PROBLEM_SEDOV_BLASTWAVE = 2, QDG_PROBLEM_VORTICAL_FLOW = 3,
+       QDG_PROBLEM_TAYLOR_GREEN = 4 };
+/* BC state functions (src/PDE/CompFlow/DGCompFlow.hpp:649-701) */
+enum { QDG_BC_DIRICHLET = 1, QDG_BC_SYMMETRY = 2, QDG_BC_EXTRAPOLATE = 3 };
+
+typedef struct qdg_config {
+  int32_t struct_size;     /* = sizeof(qdg_config), ABI check */
+  int32_t device;          /* HIP device ordinal */
+  int32_t ndof, rdof;      /* 1/1 (dg), 4/4 (dgp1), 10/10 (dgp2) */
+  int32_t flux;            /* QDG_FLUX_* */
+  int32_t limiter;         /* QDG_LIMITER_* */
+  int32_t problem;         /* QDG_PROBLEM_* */
+  int32_t nbc;             /* number of (side set, type) pairs below */
+  const int32_t* bc_sideset; /* [nbc] side set ids (param::compflow::bc*) */
+  const int32_t* bc_type;    /* [nbc] QDG_BC_* */
+  double gamma, pstiff, cv;  /* param::compflow::gamma|pstiff|cv */
+  double cweight;            /* discr::cweight (WENO central weight) */
+  double alpha, beta, p0;    /* vortical_flow parameters */
+  double cfl;                /* discr::cfl; used when dt <= 0 */
+  double dt;                 /* discr::dt; > 0 selects constant time step */
+} qdg_config;
+
+/* flattened std::map<int, std::vector<std::size_t>> FaceData::m_bface */
+typedef struct qdg_bface {
+  size_t nset;
+  const int32_t* set_id;    /* [nset] */
+  const size_t* set_off;    /* [nset+1] offsets into face */
+  const size_t* face;       /* boundary face ids */
+} qdg_bface;
+
+const char* qdg_last_error(void);
+const char* qdg_version(void);
+
+int qdg_ctx_create(const qdg_config* cfg, qdg_ctx** out);
+int qdg_ctx_destroy(qdg_ctx* ctx);
+/* run all kernels of this context on an existing HIP stream (hipStream_t) */
+int qdg_ctx_set_stream(qdg_ctx* ctx, void* hip_stream);
+int qdg_ctx_synchronize(qdg_ctx* ctx);
+
+/* Upload one mesh chunk.  nielem interior tets, nunk >= nielem incl. ghosts
+ * (rows [nielem,nunk) of every field are ghosts filled by the halo exchange);
+ * inpoel has 4*nunk entries, esuel 4*nielem, esuf 2*nfac, inpofa 3*nfac,
+ * geoFace 7*nfac, geoElem 4*nunk; faces [0,nbfac) are physical-boundary
+ * faces.  Interior elements are renumbered on the device for locality; all
+ * host-facing arrays stay in the caller's numbering. */
+int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t nnode,
+                    const size_t* inpoel, const double* x, const double* y,
+                    const double* z, size_t nbfac, size_t nfac,
+                    const int* esuf, const int* esuel, const size_t* inpofa,
+                    const double* geoFace, const double* geoElem,
+                    const qdg_bface* bface, qdg_mesh** out);
+int qdg_mesh_destroy(qdg_mesh* mesh);
+
+/* -- stateless operators on host fields (the DGPDE-shaped calls) ---------- */
+int qdg_lhs(qdg_mesh* mesh, double* L_aos);                       /* nunk rows */
+int qdg_initialize(qdg_mesh* mesh, double t, double* U_aos);      /* rows [0,nielem) */
+int qdg_rhs(qdg_mesh* mesh, double t, const double* U_aos, double* R_aos);
+int qdg_dt(qdg_mesh* mesh, const double* U_aos, double* mindt);   /* unscaled min(vol/delt) */
+int qdg_limit(qdg_mesh* mesh, double* U_aos);                     /* in place */
+
+/* -- device-resident fast path ------------------------------------------- */
+int qdg_state_upload(qdg_mesh* mesh, const double* U_aos);        /* nunk rows */
+int qdg_state_download(qdg_mesh* mesh, double* U_aos);            /* nunk rows */
+int qdg_state_initialize(qdg_mesh* mesh, double t);               /* IC projection on device */
+/* phases of one RK stage, in the reference's order; the caller exchanges
+ * ghosts (qdg_halo_*) between them exactly where DG::comsol / DG::comlim sit */
+int qdg_stage_limit(qdg_mesh* mesh);
+int qdg_stage_dt(qdg_mesh* mesh, double tleft); /* stage 0: local dt (CFL or constant, capped
+                                                  to tleft) -> device scalar */
+int qdg_stage_dt_get(qdg_mesh* mesh, double* dt_host);  /* sync + read local dt */
+int qdg_stage_dt_set(qdg_mesh* mesh, double dt);        /* reduced dt back */
+int qdg_stage_dt_device_ptr(qdg_mesh* mesh, void** dptr); /* for an in-place device min-reduction */
+int qdg_stage_rhs_update(qdg_mesh* mesh, int stage, double t);
+/* whole step on one chunk without ghosts: 3 x (limit, [dt], rhs, update);
+ * returns the dt taken (host sync only when dt_taken != NULL) */
+int qdg_step(qdg_mesh* mesh, double t, double tleft, double* dt_taken);
+/* sum_e sum_g wt*u^2, wt*(u-s)^2, max|u-s| per component (15 doubles) */
+int qdg_diag(qdg_mesh* mesh, double t_new, double* out15);
+/* device pointer/stride of the resident SoA state, for zero-copy plumbing */
+int qdg_state_device_ptr(qdg_mesh* mesh, void** dptr, size_t* stride);
+
+/* -- ghost halo ---------------------------------------------------------- */
+/* nnbr neighbours; send_elem lists local interior tets per neighbour (in the
+ * order the receiver stores its ghosts), recv ranges are contiguous ghost
+ * rows.  Buffers are device memory owned by the mesh handle, one contiguous
+ * slab per direction, element-major rows of nprop doubles (like the
+ * reference's comsol payload u[j] = m_u[tet]). */
+int qdg_halo_setup(qdg_mesh* mesh, size_t nnbr, const int32_t* nbr_rank,
+                   const size_t* send_off, const size_t* send_elem,
+                   const size_t* recv_off);
+int qdg_halo_buffers(qdg_mesh* mesh, void** send_dev, void** recv_dev,
+                     size_t* row_bytes);
+int qdg_halo_pack(qdg_mesh* mesh);     /* U[send list] -> send slab */
+int qdg_halo_unpack(qdg_mesh* mesh);   /* recv slab -> ghost rows of U */
+
+/* -- host-side mesh-derived data (mirror of FaceData / DerivedData) ------- */
+int qdg_gen_esuel(size_t nelem, const size_t* inpoel, int* esuel);
+size_t qdg_gen_nipfac(size_t nelem, size_t nbfac, const int* esuel);
+int qdg_gen_inpofa(size_t nelem, size_t nbfac, const size_t* inpoel,
+                   const size_t* triinpoel, const int* esuel, size_t* inpofa);
+int qdg_gen_belem(size_t nelem, size_t nbfac, const size_t* inpoel,
+                  const size_t* inpofa, size_t* belem);
+int qdg_gen_esuf(size_t nelem, size_t nbfac, const size_t* belem,
+                 const int* esuel, int* esuf);
+int qdg_gen_geoface(size_t nfac, const size_t* inpofa, const double* x,
+                    const double* y, const double* z, double* geoFace);
+int qdg_gen_geoelem(size_t nelem, const size_t* inpoel, const double* x,
+                    const double* y, const double* z, double* geoElem);
+/* boundary-face regeneration: ntri side-set triangles (3 node ids each, any
+ * order) tagged with tri_set[]; out arrays sized >= ntri.  Faces are returned
+ * grouped by ascending side set id, within a set in tet order. */
+int qdg_bnd_faces(size_t nelem, const size_t* inpoel, size_t ntri,
+                  const size_t* tri, const int32_t* tri_set, size_t* nbfac,
+                  size_t* triinpoel, int32_t* face_set);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QDG_H */

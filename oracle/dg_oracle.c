@@ -62,6 +62,11 @@ typedef struct {
 
 #define NCOMP 5
 
+/* std::max / std::min exactly as the C++ library defines them (matters only
+ * when an argument is NaN, e.g. a negative pressure at a Gauss point) */
+#define STDMAX(a, b) (((a) < (b)) ? (b) : (a))
+#define STDMIN(a, b) (((b) < (a)) ? (b) : (a))
+
 /* src/Mesh/DerivedData.hpp:36 -- local face -> local nodes, outward normal */
 static const int LPOFA[4][3] = { {1, 2, 3}, {2, 0, 3}, {3, 0, 1}, {0, 2, 1} };
 
@@ -1035,14 +1040,14 @@ double orc_dt(const orc_cfg* k, int64_t nunk, int64_t nfac, const int32_t* esuf,
         a = eos_soundspeed(k, rho, p);
         vn = u * geoFace[7*f+1] + v * geoFace[7*f+2] + w * geoFace[7*f+3];
         dSV_r = wt * (fabs(vn) + a);
-        delt[er] += (dSV_l > dSV_r ? dSV_l : dSV_r);
+        delt[er] += STDMAX(dSV_l, dSV_r);
       }
-      delt[el] += (dSV_l > dSV_r ? dSV_l : dSV_r);
+      delt[el] += STDMAX(dSV_l, dSV_r);
     }
   }
   for (e = 0; e < nunk; ++e) {
     const double d = geoElem[4 * e] / delt[e];
-    if (d < mindt) mindt = d;
+    mindt = STDMIN(mindt, d);
   }
   free(delt);
   return mindt;

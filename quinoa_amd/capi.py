@@ -1,0 +1,333 @@
+"""ctypes binding of the C ABI in include/qdg.h (quinoa_amd/lib/libqdg.so).
+
+This is plumbing for tests and bench.py: the product is the shared library.
+There is no fallback of any kind here -- if libqdg.so is missing or a call
+fails, an exception is raised.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libqdg.so")
+
+FLUX = {"hllc": 0, "laxfriedrichs": 1}
+LIMITER = {"nolimiter": 0, "wenop1": 1, "superbeep1": 2}
+PROBLEM = {"user_defined": 0, "sod_shocktube": 1, "sedov_blastwave": 2,
+           "vortical_flow": 3, "taylor_green": 4}
+BC_DIRICHLET, BC_SYMMETRY, BC_EXTRAPOLATE = 1, 2, 3
+
+c_szp = C.POINTER(C.c_size_t)
+c_i32p = C.POINTER(C.c_int32)
+c_f64p = C.POINTER(C.c_double)
+
+
+class QdgError(RuntimeError):
+    pass
+
+
+class qdg_config(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32),
+                ("ndof", C.c_int32), ("rdof", C.c_int32), ("flux", C.c_int32),
+                ("limiter", C.c_int32), ("problem", C.c_int32), ("nbc", C.c_int32),
+                ("bc_sideset", c_i32p), ("bc_type", c_i32p),
+                ("gamma", C.c_double), ("pstiff", C.c_double), ("cv", C.c_double),
+                ("cweight", C.c_double), ("alpha", C.c_double), ("beta", C.c_double),
+                ("p0", C.c_double), ("cfl", C.c_double), ("dt", C.c_double)]
+
+
+class qdg_bface(C.Structure):
+    _fields_ = [("nset", C.c_size_t), ("set_id", c_i32p), ("set_off", c_szp),
+                ("face", c_szp)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libqdg.so; fail loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise QdgError("HIP extension missing: %s (run `python -c 'import "
+                           "__graft_entry__ as g; g.build()'`); there is no CPU "
+                           "fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.qdg_last_error.restype = C.c_char_p
+        L.qdg_version.restype = C.c_char_p
+        L.qdg_gen_nipfac.restype = C.c_size_t
+        L.qdg_gen_nipfac.argtypes = [C.c_size_t, C.c_size_t, c_i32p]
+        _lib = L
+    return _lib
+
+
+def _chk(rc):
+    if rc != 0:
+        raise QdgError(lib().qdg_last_error().decode())
+
+
+def _sz(a):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return a, a.ctypes.data_as(c_szp)
+
+
+def _f64(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(c_f64p)
+
+
+def _i32(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(c_i32p)
+
+
+# ------------------------------------------------------------------ host mesh
+# mirrors of inciter::FaceData / DerivedData (no GPU needed)
+
+def bnd_faces(inpoel, sidesets):
+    """Boundary-face regeneration (Partitioner.cpp:357-393).  `sidesets` maps
+    side set id -> triangles[n,3].  Returns (bface {id: face ids}, triinpoel)."""
+    L = lib()
+    inp, pinp = _sz(np.asarray(inpoel).reshape(-1))
+    ids = sorted(sidesets)
+    tri = np.concatenate([np.asarray(sidesets[s]).reshape(-1, 3) for s in ids]) if ids \
+        else np.zeros((0, 3), np.uint64)
+    tset = np.concatenate([np.full(len(np.asarray(sidesets[s]).reshape(-1, 3)), s, np.int32)
+                           for s in ids]) if ids else np.zeros(0, np.int32)
+    ntri = tri.shape[0]
+    tri, ptri = _sz(tri.reshape(-1))
+    tset, ptset = _i32(tset)
+    out_tri = np.zeros(3 * max(ntri, 1), dtype=np.uint64)
+    out_set = np.zeros(max(ntri, 1), dtype=np.int32)
+    nb = C.c_size_t(0)
+    _chk(L.qdg_bnd_faces(C.c_size_t(len(inp) // 4), pinp, C.c_size_t(ntri), ptri, ptset,
+                         C.byref(nb), out_tri.ctypes.data_as(c_szp),
+                         out_set.ctypes.data_as(c_i32p)))
+    nb = nb.value
+    out_set = out_set[:nb]
+    bface = {int(s): np.nonzero(out_set == s)[0].astype(np.uint64) for s in ids}
+    return bface, out_tri[:3 * nb].reshape(-1, 3).copy()
+
+
+class FaceData:
+    """inciter::FaceData (src/Inciter/FaceData.hpp:41-106): same ctor arguments,
+    same members (esuel, nipfac, inpofa, belem, esuf), built by libqdg."""
+
+    def __init__(self, inpoel, bface, triinpoel):
+        L = lib()
+        self.inpoel, pinp = _sz(np.asarray(inpoel).reshape(-1))
+        ne = self.nelem = len(self.inpoel) // 4
+        self.bface = {int(k): np.ascontiguousarray(v, dtype=np.uint64) for k, v in bface.items()}
+        self.triinpoel, ptri = _sz(np.asarray(triinpoel).reshape(-1))
+        nb = self.nbfac = sum(len(v) for v in self.bface.values())
+        assert nb == len(self.triinpoel) // 3
+        self.esuel = np.zeros(4 * ne, dtype=np.int32)
+        _chk(L.qdg_gen_esuel(C.c_size_t(ne), pinp, self.esuel.ctypes.data_as(c_i32p)))
+        self.nipfac = int(L.qdg_gen_nipfac(C.c_size_t(ne), C.c_size_t(nb),
+                                           self.esuel.ctypes.data_as(c_i32p)))
+        self.inpofa = np.zeros(3 * self.nipfac, dtype=np.uint64)
+        _chk(L.qdg_gen_inpofa(C.c_size_t(ne), C.c_size_t(nb), pinp, ptri,
+                              self.esuel.ctypes.data_as(c_i32p), self.inpofa.ctypes.data_as(c_szp)))
+        self.belem = np.zeros(max(nb, 1), dtype=np.uint64)
+        _chk(L.qdg_gen_belem(C.c_size_t(ne), C.c_size_t(nb), pinp,
+                             self.inpofa.ctypes.data_as(c_szp), self.belem.ctypes.data_as(c_szp)))
+        self.esuf = np.zeros(2 * self.nipfac, dtype=np.int32)
+        _chk(L.qdg_gen_esuf(C.c_size_t(ne), C.c_size_t(nb), self.belem.ctypes.data_as(c_szp),
+                            self.esuel.ctypes.data_as(c_i32p), self.esuf.ctypes.data_as(c_i32p)))
+        self.belem = self.belem[:nb]
+
+
+def gen_geoface(nfac, inpofa, coord):
+    x, px = _f64(coord[:, 0]); y, py = _f64(coord[:, 1]); z, pz = _f64(coord[:, 2])
+    inpofa, pf = _sz(inpofa)
+    g = np.zeros(7 * nfac)
+    _chk(lib().qdg_gen_geoface(C.c_size_t(nfac), pf, px, py, pz, g.ctypes.data_as(c_f64p)))
+    return g
+
+
+def gen_geoelem(inpoel, coord):
+    x, px = _f64(coord[:, 0]); y, py = _f64(coord[:, 1]); z, pz = _f64(coord[:, 2])
+    inp, pinp = _sz(np.asarray(inpoel).reshape(-1))
+    g = np.zeros(len(inp))
+    _chk(lib().qdg_gen_geoelem(C.c_size_t(len(inp) // 4), pinp, px, py, pz,
+                               g.ctypes.data_as(c_f64p)))
+    return g
+
+
+# ------------------------------------------------------------------ device side
+
+class Context:
+    def __init__(self, ndof, flux="hllc", limiter="nolimiter", problem="sod_shocktube",
+                 gamma=1.4, pstiff=0.0, cv=717.5, cweight=1.0, alpha=0.0, beta=0.0, p0=0.0,
+                 cfl=0.0, dt=0.0, bc_dirichlet=(), bc_sym=(), bc_extrapolate=(), device=0):
+        L = lib()
+        ss = list(bc_dirichlet) + list(bc_sym) + list(bc_extrapolate)
+        ty = [BC_DIRICHLET] * len(bc_dirichlet) + [BC_SYMMETRY] * len(bc_sym) + \
+             [BC_EXTRAPOLATE] * len(bc_extrapolate)
+        self._ss, pss = _i32(np.array(ss or [0], dtype=np.int32))
+        self._ty, pty = _i32(np.array(ty or [1], dtype=np.int32))
+        self.cfg = qdg_config(struct_size=C.sizeof(qdg_config), device=device, ndof=ndof,
+                              rdof=ndof, flux=FLUX[flux], limiter=LIMITER[limiter],
+                              problem=PROBLEM[problem], nbc=len(ss), bc_sideset=pss, bc_type=pty,
+                              gamma=gamma, pstiff=pstiff, cv=cv, cweight=cweight, alpha=alpha,
+                              beta=beta, p0=p0, cfl=cfl, dt=dt)
+        self.h = C.c_void_p()
+        _chk(L.qdg_ctx_create(C.byref(self.cfg), C.byref(self.h)))
+        self.ndof = ndof
+        self.nprop = 5 * ndof
+
+    def set_stream(self, stream_ptr):
+        _chk(lib().qdg_ctx_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def synchronize(self):
+        _chk(lib().qdg_ctx_synchronize(self.h))
+
+    def close(self):
+        if self.h:
+            lib().qdg_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+class Mesh:
+    """One uploaded mesh chunk (qdg_mesh).  Arguments are the reference-shaped
+    arrays of one DG chare: inpoel[4*nunk], coord[nnode,3], FaceData members,
+    geoFace[7*nfac], geoElem[4*nunk], bface."""
+
+    def __init__(self, ctx, nielem, inpoel, coord, esuf, esuel, inpofa, geoFace, geoElem,
+                 bface, nbfac):
+        L = lib()
+        self.ctx = ctx
+        inp, pinp = _sz(np.asarray(inpoel).reshape(-1))
+        self.nunk = len(inp) // 4
+        self.nielem = int(nielem)
+        coord = np.asarray(coord, dtype=np.float64)
+        x, px = _f64(coord[:, 0]); y, py = _f64(coord[:, 1]); z, pz = _f64(coord[:, 2])
+        esuf, pesuf = _i32(esuf); esuel, pesuel = _i32(esuel)
+        inpofa, pinpofa = _sz(inpofa)
+        gf, pgf = _f64(geoFace); ge, pge = _f64(geoElem)
+        ids = sorted(bface)
+        set_id, pid = _i32(np.array(ids or [0], dtype=np.int32))
+        off = np.zeros(len(ids) + 1, dtype=np.uint64)
+        faces = []
+        for i, s_ in enumerate(ids):
+            faces.append(np.asarray(bface[s_], dtype=np.uint64))
+            off[i + 1] = off[i] + len(faces[-1])
+        face = np.concatenate(faces) if faces else np.zeros(1, np.uint64)
+        if face.size == 0:
+            face = np.zeros(1, np.uint64)
+        face, pface = _sz(face)
+        off, poff = _sz(off)
+        bf = qdg_bface(nset=len(ids), set_id=pid, set_off=poff, face=pface)
+        self.h = C.c_void_p()
+        _chk(L.qdg_mesh_upload(ctx.h, C.c_size_t(self.nielem), C.c_size_t(self.nunk),
+                               C.c_size_t(coord.shape[0]), pinp, px, py, pz, C.c_size_t(nbfac),
+                               C.c_size_t(len(esuf) // 2), pesuf, pesuel, pinpofa, pgf, pge,
+                               C.byref(bf), C.byref(self.h)))
+        self.nprop = ctx.nprop
+
+    # stateless DGPDE-shaped calls
+    def lhs(self):
+        Lm = np.zeros(self.nunk * self.nprop)
+        _chk(lib().qdg_lhs(self.h, Lm.ctypes.data_as(c_f64p)))
+        return Lm
+
+    def initialize(self, t=0.0):
+        U = np.zeros(self.nunk * self.nprop)
+        _chk(lib().qdg_initialize(self.h, C.c_double(t), U.ctypes.data_as(c_f64p)))
+        return U
+
+    def rhs(self, t, U):
+        U, pU = _f64(U)
+        R = np.zeros(self.nunk * self.nprop)
+        _chk(lib().qdg_rhs(self.h, C.c_double(t), pU, R.ctypes.data_as(c_f64p)))
+        return R
+
+    def dt(self, U):
+        U, pU = _f64(U)
+        v = C.c_double(0.0)
+        _chk(lib().qdg_dt(self.h, pU, C.byref(v)))
+        return v.value
+
+    def limit(self, U):
+        U = np.array(U, dtype=np.float64, copy=True)
+        _chk(lib().qdg_limit(self.h, U.ctypes.data_as(c_f64p)))
+        return U
+
+    # resident path
+    def state_upload(self, U):
+        U, pU = _f64(U)
+        _chk(lib().qdg_state_upload(self.h, pU))
+
+    def state_download(self):
+        U = np.zeros(self.nunk * self.nprop)
+        _chk(lib().qdg_state_download(self.h, U.ctypes.data_as(c_f64p)))
+        return U
+
+    def state_initialize(self, t=0.0):
+        _chk(lib().qdg_state_initialize(self.h, C.c_double(t)))
+
+    def stage_limit(self):
+        _chk(lib().qdg_stage_limit(self.h))
+
+    def stage_dt(self, tleft=1e300):
+        _chk(lib().qdg_stage_dt(self.h, C.c_double(tleft)))
+
+    def stage_dt_get(self):
+        v = C.c_double(0.0)
+        _chk(lib().qdg_stage_dt_get(self.h, C.byref(v)))
+        return v.value
+
+    def stage_dt_set(self, dt):
+        _chk(lib().qdg_stage_dt_set(self.h, C.c_double(dt)))
+
+    def stage_dt_device_ptr(self):
+        p = C.c_void_p()
+        _chk(lib().qdg_stage_dt_device_ptr(self.h, C.byref(p)))
+        return p.value
+
+    def stage_rhs_update(self, stage, t):
+        _chk(lib().qdg_stage_rhs_update(self.h, C.c_int(stage), C.c_double(t)))
+
+    def step(self, t, tleft=1e300, want_dt=True):
+        v = C.c_double(0.0)
+        _chk(lib().qdg_step(self.h, C.c_double(t), C.c_double(tleft),
+                            C.byref(v) if want_dt else None))
+        return v.value
+
+    def diag(self, t_new):
+        out = np.zeros(15)
+        _chk(lib().qdg_diag(self.h, C.c_double(t_new), out.ctypes.data_as(c_f64p)))
+        return out
+
+    # halo
+    def halo_setup(self, nbr_rank, send_lists, recv_counts):
+        nbr, pn = _i32(np.array(list(nbr_rank) or [0], dtype=np.int32))
+        soff = np.zeros(len(nbr_rank) + 1, dtype=np.uint64)
+        roff = np.zeros(len(nbr_rank) + 1, dtype=np.uint64)
+        for i, sl in enumerate(send_lists):
+            soff[i + 1] = soff[i] + len(sl)
+            roff[i + 1] = roff[i] + recv_counts[i]
+        se = np.concatenate([np.asarray(s_, dtype=np.uint64) for s_ in send_lists]) \
+            if len(send_lists) else np.zeros(1, np.uint64)
+        if se.size == 0:
+            se = np.zeros(1, np.uint64)
+        se, pse = _sz(se); soff, psoff = _sz(soff); roff, proff = _sz(roff)
+        _chk(lib().qdg_halo_setup(self.h, C.c_size_t(len(nbr_rank)), pn, psoff, pse, proff))
+        self.send_off, self.recv_off = soff.astype(np.int64), roff.astype(np.int64)
+
+    def halo_buffers(self):
+        a, b, r = C.c_void_p(), C.c_void_p(), C.c_size_t()
+        _chk(lib().qdg_halo_buffers(self.h, C.byref(a), C.byref(b), C.byref(r)))
+        return a.value, b.value, r.value
+
+    def halo_pack(self):
+        _chk(lib().qdg_halo_pack(self.h))
+
+    def halo_unpack(self):
+        _chk(lib().qdg_halo_unpack(self.h))
+
+    def close(self):
+        if self.h:
+            lib().qdg_mesh_destroy(self.h)
+            self.h = C.c_void_p()

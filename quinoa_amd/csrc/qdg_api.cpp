@@ -1,0 +1,777 @@
+// qdg_api.cpp -- host layer of libqdg: the C ABI of include/qdg.h on top of the
+// gfx950 kernels (qdg_kernels.hip).  Mesh upload builds the device layout
+// described in qdg_device.hpp; every operator is either stateless on host
+// `tk::Fields`-layout arrays (the DGPDE-shaped calls) or runs on the
+// device-resident state.  There is no CPU fallback in this library.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/qdg.h"
+#include "qdg_device.hpp"
+#include "qdg_host.hpp"
+#include "qdg_kernels.hpp"
+#include "qdg_tables.hpp"
+
+namespace qdg {
+
+static thread_local std::string g_err;
+void set_error(const std::string& m) { g_err = m; }
+int fail(const std::string& m) { g_err = m; return 1; }
+
+#define HIPCHK(call)                                                              \
+  do {                                                                            \
+    hipError_t e_ = (call);                                                       \
+    if (e_ != hipSuccess)                                                         \
+      return ::qdg::fail(std::string(#call) + ": " + hipGetErrorString(e_));      \
+  } while (0)
+
+// owning device buffer
+template <class T> struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t count)
+  {
+    if (p) { (void)hipFree(p); p = nullptr; }
+    n = count;
+    if (count == 0) return hipSuccess;
+    return hipMalloc((void**)&p, count * sizeof(T));
+  }
+  hipError_t upload(const std::vector<T>& h, hipStream_t s)
+  {
+    hipError_t e = alloc(h.size());
+    if (e != hipSuccess || h.empty()) return e;
+    e = hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return e;
+    return hipStreamSynchronize(s);   // h may be a temporary of the caller
+  }
+};
+
+}  // namespace qdg
+
+using namespace qdg;
+
+struct qdg_ctx {
+  qdg_config cfg;
+  std::vector<int32_t> bc_sideset, bc_type;
+  Phys ph;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+};
+
+struct qdg_mesh {
+  qdg_ctx* ctx = nullptr;
+  DevMesh dm{};
+  int ndof = 1, nprop = 5;
+  size_t nie = 0, ne = 0, stride = 0;
+  // mesh
+  DevBuf<int> inpoel, nbr, finfo, fid, d2h;
+  DevBuf<double> x, y, z, farea, fnx, fny, fnz, vol;
+  // fields (SoA planes [nprop][stride])
+  DevBuf<double> U, Un, R, W;     // W: scratch state (stateless ops, WENO ping-pong)
+  DevBuf<double> aos;             // [ne*nprop] staging in the caller's layout
+  DevBuf<double> blockmin, dtraw, dtdev, diagpart, diagout;
+  double* Ucur = nullptr;         // resident state (U or W after a WENO swap)
+  double* Ualt = nullptr;
+  // halo
+  size_t nnbr = 0, nsend = 0, nrecv = 0;
+  std::vector<int32_t> nbr_rank;
+  std::vector<size_t> send_off, recv_off;
+  DevBuf<int> send_elem;
+  DevBuf<double> send_slab, recv_slab;
+};
+
+// ---------------------------------------------------------------- misc
+
+extern "C" const char* qdg_last_error(void) { return g_err.c_str(); }
+extern "C" const char* qdg_version(void) { return "quinoa_amd/qdg 0.1 (gfx950)"; }
+
+static int check_cfg(const qdg_config* c)
+{
+  if (!c) return fail("qdg_ctx_create: null config");
+  if (c->struct_size != (int32_t)sizeof(qdg_config))
+    return fail("qdg_ctx_create: qdg_config.struct_size mismatch (ABI)");
+  if (!(c->ndof == 1 || c->ndof == 4 || c->ndof == 10))
+    return fail("qdg_ctx_create: ndof must be one of 1,4,10");
+  if (c->rdof != c->ndof)
+    return fail("qdg_ctx_create: rdof != ndof (P0P1 reconstruction) is not supported");
+  if (c->flux != QDG_FLUX_HLLC && c->flux != QDG_FLUX_LAXFRIEDRICHS)
+    return fail("qdg_ctx_create: unknown flux");
+  if (c->limiter < QDG_LIMITER_NONE || c->limiter > QDG_LIMITER_SUPERBEEP1)
+    return fail("qdg_ctx_create: unknown limiter");
+  if (c->problem < QDG_PROBLEM_USER_DEFINED || c->problem > QDG_PROBLEM_TAYLOR_GREEN)
+    return fail("qdg_ctx_create: unknown problem");
+  if (!(c->gamma > 1.0)) return fail("qdg_ctx_create: gamma must be > 1");
+  if (c->nbc < 0 || (c->nbc > 0 && (!c->bc_sideset || !c->bc_type)))
+    return fail("qdg_ctx_create: bad BC table");
+  for (int i = 0; i < c->nbc; ++i)
+    if (c->bc_type[i] < QDG_BC_DIRICHLET || c->bc_type[i] > QDG_BC_EXTRAPOLATE)
+      return fail("qdg_ctx_create: unknown BC type");
+  return 0;
+}
+
+extern "C" int qdg_ctx_create(const qdg_config* cfg, qdg_ctx** out)
+{
+  QDG_TRY
+  if (!out) return fail("qdg_ctx_create: null out");
+  *out = nullptr;
+  if (int rc = check_cfg(cfg)) return rc;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return fail("qdg_ctx_create: no HIP device available (this library has no CPU fallback)");
+  if (cfg->device < 0 || cfg->device >= ndev) return fail("qdg_ctx_create: bad device ordinal");
+  HIPCHK(hipSetDevice(cfg->device));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, cfg->device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !std::getenv("QDG_ALLOW_ANY_ARCH"))
+    return fail(std::string("qdg_ctx_create: device is ") + prop.gcnArchName +
+                ", this library is built for gfx950 (MI355X) only");
+  std::unique_ptr<qdg_ctx> c(new qdg_ctx);
+  c->cfg = *cfg;
+  c->bc_sideset.assign(cfg->bc_sideset, cfg->bc_sideset + cfg->nbc);
+  c->bc_type.assign(cfg->bc_type, cfg->bc_type + cfg->nbc);
+  c->cfg.bc_sideset = c->bc_sideset.data();
+  c->cfg.bc_type = c->bc_type.data();
+  c->device = cfg->device;
+  c->ph.gamma = cfg->gamma; c->ph.pstiff = cfg->pstiff; c->ph.cweight = cfg->cweight;
+  c->ph.alpha = cfg->alpha; c->ph.beta = cfg->beta; c->ph.p0 = cfg->p0;
+  c->ph.flux = cfg->flux; c->ph.problem = cfg->problem; c->ph.limiter = cfg->limiter;
+  HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  c->own_stream = true;
+  // constant tables (one copy per device/module)
+  {
+    auto t1 = std::make_unique<Tables<1>>();
+    auto t4 = std::make_unique<Tables<4>>();
+    auto t10 = std::make_unique<Tables<10>>();
+    fill_tables(*t1); fill_tables(*t4); fill_tables(*t10);
+    QuadTet qi[3], qd[3];
+    const int nd[3] = { 1, 4, 10 };
+    for (int i = 0; i < 3; ++i) { fill_quadtet(qi[i], nginit(nd[i])); fill_quadtet(qd[i], ngdiag(nd[i])); }
+    HIPCHK(upload_tables(*t1, *t4, *t10, qi, qd));
+  }
+  *out = c.release();
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_ctx_destroy(qdg_ctx* ctx)
+{
+  QDG_TRY
+  if (!ctx) return 0;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->own_stream && ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
+  delete ctx;
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_ctx_set_stream(qdg_ctx* ctx, void* s)
+{
+  QDG_TRY
+  if (!ctx) return fail("qdg_ctx_set_stream: null ctx");
+  HIPCHK(hipSetDevice(ctx->device));
+  if (ctx->own_stream && ctx->stream) { HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(hipStreamDestroy(ctx->stream)); }
+  ctx->stream = (hipStream_t)s;
+  ctx->own_stream = false;
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_ctx_synchronize(qdg_ctx* ctx)
+{
+  QDG_TRY
+  if (!ctx) return fail("qdg_ctx_synchronize: null ctx");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+  QDG_CATCH
+}
+
+// ---------------------------------------------------------------- upload
+
+static inline uint64_t spread21(uint64_t v)
+{
+  v &= 0x1fffff;
+  v = (v | v << 32) & 0x1f00000000ffffULL;
+  v = (v | v << 16) & 0x1f0000ff0000ffULL;
+  v = (v | v << 8) & 0x100f00f00f00f00fULL;
+  v = (v | v << 4) & 0x10c30c30c30c30c3ULL;
+  v = (v | v << 2) & 0x1249249249249249ULL;
+  return v;
+}
+
+extern "C" int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t nnode,
+                               const size_t* inpoel, const double* x, const double* y,
+                               const double* z, size_t nbfac, size_t nfac, const int* esuf,
+                               const int* esuel, const size_t* inpofa, const double* geoFace,
+                               const double* geoElem, const qdg_bface* bface, qdg_mesh** out)
+{
+  QDG_TRY
+  if (!ctx || !out) return fail("qdg_mesh_upload: null ctx/out");
+  *out = nullptr;
+  if (!inpoel || !x || !y || !z || !esuf || !esuel || !inpofa || !geoFace || !geoElem)
+    return fail("qdg_mesh_upload: null mesh array");
+  if (nielem == 0 || nunk < nielem) return fail("qdg_mesh_upload: need 0 < nielem <= nunk");
+  if (nunk > (size_t)(INT32_MAX - 64) / 4 || nnode > (size_t)INT32_MAX || nfac > (size_t)INT32_MAX)
+    return fail("qdg_mesh_upload: chunk too large for 32-bit device indices");
+  if (nbfac > nfac) return fail("qdg_mesh_upload: nbfac > nfac");
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t nie = nielem, ne = nunk;
+
+  // ---- validate connectivity before anything reaches a kernel -----------
+  for (size_t i = 0; i < 4 * ne; ++i)
+    if (inpoel[i] >= nnode) return fail("qdg_mesh_upload: inpoel entry out of range");
+  for (size_t i = 0; i < 4 * nie; ++i)
+    if (esuel[i] < -1 || (size_t)(esuel[i] + 1) > ne) return fail("qdg_mesh_upload: esuel entry out of range");
+  for (size_t e = 0; e < ne; ++e)
+    if (!(geoElem[4 * e] > 0.0)) return fail("qdg_mesh_upload: non-positive element volume");
+
+  // ---- device order of interior tets: Morton curve of the centroids ------
+  std::vector<int> d2h(ne), h2d(ne);
+  std::iota(d2h.begin(), d2h.end(), 0);
+  if (!std::getenv("QDG_NO_RENUMBER")) {
+    double lo[3] = { DBL_MAX, DBL_MAX, DBL_MAX }, hi[3] = { -DBL_MAX, -DBL_MAX, -DBL_MAX };
+    for (size_t e = 0; e < nie; ++e)
+      for (int d = 0; d < 3; ++d) {
+        lo[d] = std::min(lo[d], geoElem[4 * e + 1 + d]);
+        hi[d] = std::max(hi[d], geoElem[4 * e + 1 + d]);
+      }
+    const double ext = std::max({ hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2], 1e-300 });
+    std::vector<std::pair<uint64_t, int>> key(nie);
+    for (size_t e = 0; e < nie; ++e) {
+      uint64_t k = 0;
+      for (int d = 0; d < 3; ++d) {
+        const double t = (geoElem[4 * e + 1 + d] - lo[d]) / ext;
+        const uint64_t q = (uint64_t)std::min(2097151.0, std::max(0.0, t * 2097152.0));
+        k |= spread21(q) << d;
+      }
+      key[e] = { k, (int)e };
+    }
+    std::sort(key.begin(), key.end());
+    for (size_t d = 0; d < nie; ++d) d2h[d] = key[d].second;
+  }
+  for (size_t d = 0; d < ne; ++d) h2d[d2h[d]] = (int)d;
+
+  // ---- nodes renumbered by first touch in device order -------------------
+  std::vector<int> nnew(nnode, -1);
+  int ncount = 0;
+  for (size_t d = 0; d < ne; ++d)
+    for (int i = 0; i < 4; ++i) {
+      const size_t n = inpoel[4 * (size_t)d2h[d] + i];
+      if (nnew[n] < 0) nnew[n] = ncount++;
+    }
+  std::vector<double> hx(ncount), hy(ncount), hz(ncount);
+  for (size_t n = 0; n < nnode; ++n)
+    if (nnew[n] >= 0) { hx[nnew[n]] = x[n]; hy[nnew[n]] = y[n]; hz[nnew[n]] = z[n]; }
+
+  // ---- (host element, local face) -> reference face id --------------------
+  std::vector<int> rface(4 * nie, -1);
+  for (size_t f = 0; f < nfac; ++f) {
+    const int el = esuf[2 * f], er = esuf[2 * f + 1];
+    if (el < 0 || (size_t)el >= nie) return fail("qdg_mesh_upload: esuf left element is not an interior tet");
+    if (er < -1 || (er >= 0 && (size_t)er >= ne)) return fail("qdg_mesh_upload: esuf right element out of range");
+    if (er == -1) {
+      if (f >= nbfac) return fail("qdg_mesh_upload: boundary face beyond nbfac");
+      int found = -1;
+      for (int lf = 0; lf < 4 && found < 0; ++lf) {
+        int cnt = 0;
+        for (int j = 0; j < 3; ++j)
+          for (int k = 0; k < 3; ++k)
+            if (inpoel[4 * (size_t)el + LPOFA[lf][j]] == inpofa[3 * f + k]) ++cnt;
+        if (cnt == 3) found = lf;
+      }
+      if (found < 0) return fail("qdg_mesh_upload: boundary face nodes do not match its element");
+      if (esuel[4 * (size_t)el + found] != -1)
+        return fail("qdg_mesh_upload: boundary face on an element face that has a neighbour");
+      rface[4 * (size_t)el + found] = (int)f;
+    } else {
+      if (f < nbfac) return fail("qdg_mesh_upload: interior face inside the boundary-face range");
+      int a = -1, b = -1;
+      for (int lf = 0; lf < 4; ++lf) if (esuel[4 * (size_t)el + lf] == er) a = lf;
+      if (a < 0) return fail("qdg_mesh_upload: esuf/esuel mismatch (left)");
+      rface[4 * (size_t)el + a] = (int)f;
+      if ((size_t)er < nie) {
+        for (int lf = 0; lf < 4; ++lf) if (esuel[4 * (size_t)er + lf] == el) b = lf;
+        if (b < 0) return fail("qdg_mesh_upload: esuf/esuel mismatch (right)");
+        rface[4 * (size_t)er + b] = (int)f;
+      }
+    }
+  }
+  for (size_t i = 0; i < 4 * nie; ++i)
+    if (rface[i] < 0) return fail("qdg_mesh_upload: element face without an entry in esuf "
+                                  "(every boundary face must be listed in [0,nbfac))");
+
+  // ---- BC type of every boundary face -------------------------------------
+  // reference: bndSurfInt over the configured side sets of each BC type
+  // (src/PDE/Integrate/Boundary.cpp:84-90); faces of unconfigured sets get no flux
+  std::vector<int> bcface(nbfac, 0);
+  if (bface && bface->nset > 0) {
+    for (size_t s = 0; s < bface->nset; ++s) {
+      int type = 0;
+      for (size_t i = 0; i < ctx->bc_sideset.size(); ++i)
+        if (ctx->bc_sideset[i] == bface->set_id[s]) {
+          if (type != 0 && type != ctx->bc_type[i])
+            return fail("qdg_mesh_upload: a side set is configured with two different BC types");
+          type = ctx->bc_type[i];
+        }
+      if (type == 0) continue;
+      for (size_t q = bface->set_off[s]; q < bface->set_off[s + 1]; ++q) {
+        const size_t f = bface->face[q];
+        if (f >= nbfac) return fail("qdg_mesh_upload: bface entry out of range");
+        if (bcface[f] != 0) return fail("qdg_mesh_upload: a boundary face belongs to two configured side sets");
+        bcface[f] = type;
+      }
+    }
+  }
+
+  // ---- device arrays -------------------------------------------------------
+  const size_t stride = (ne + 63) / 64 * 64;
+  std::vector<int> h_inpoel(4 * stride, 0), h_nbr(4 * stride, -1), h_finfo(4 * stride, 0), h_fid(4 * stride, 0);
+  std::vector<double> h_vol(stride, 1.0);
+  std::vector<int> fmap(nfac, -1);
+  int nfd = 0;
+  for (size_t d = 0; d < ne; ++d) {
+    const size_t h = d2h[d];
+    for (int i = 0; i < 4; ++i) h_inpoel[i * stride + d] = nnew[inpoel[4 * h + i]];
+    h_vol[d] = geoElem[4 * h];
+    if (d >= nie) continue;
+    for (int lf = 0; lf < 4; ++lf) {
+      const int f = rface[4 * h + lf];
+      if (fmap[f] < 0) fmap[f] = nfd++;
+      h_fid[lf * stride + d] = fmap[f];
+      const int nb = esuel[4 * h + lf];
+      int info = ((size_t)esuf[2 * f] == h) ? (1 << 6) : 0;
+      if (nb < 0) {
+        h_nbr[lf * stride + d] = -(1 + bcface[f]);
+      } else {
+        h_nbr[lf * stride + d] = h2d[nb];
+        for (int j = 0; j < 3; ++j) {
+          const size_t g = inpoel[4 * h + LPOFA[lf][j]];
+          int m = -1;
+          for (int q = 0; q < 4; ++q) if (inpoel[4 * (size_t)nb + q] == g) m = q;
+          if (m < 0) return fail("qdg_mesh_upload: neighbour does not share the face nodes (bad esuel/inpoel)");
+          info |= m << (2 * j);
+        }
+      }
+      h_finfo[lf * stride + d] = info;
+    }
+  }
+  std::vector<double> h_area(std::max(nfd, 1)), h_nx(std::max(nfd, 1)), h_ny(std::max(nfd, 1)), h_nz(std::max(nfd, 1));
+  for (size_t f = 0; f < nfac; ++f)
+    if (fmap[f] >= 0) {
+      h_area[fmap[f]] = geoFace[7 * f];
+      h_nx[fmap[f]] = geoFace[7 * f + 1];
+      h_ny[fmap[f]] = geoFace[7 * f + 2];
+      h_nz[fmap[f]] = geoFace[7 * f + 3];
+    }
+
+  std::unique_ptr<qdg_mesh> m(new qdg_mesh);
+  m->ctx = ctx;
+  m->ndof = ctx->cfg.ndof;
+  m->nprop = NCOMP * m->ndof;
+  m->nie = nie; m->ne = ne; m->stride = stride;
+  hipStream_t s = ctx->stream;
+  HIPCHK(m->inpoel.upload(h_inpoel, s));
+  HIPCHK(m->nbr.upload(h_nbr, s));
+  HIPCHK(m->finfo.upload(h_finfo, s));
+  HIPCHK(m->fid.upload(h_fid, s));
+  HIPCHK(m->d2h.upload(d2h, s));
+  HIPCHK(m->x.upload(hx, s)); HIPCHK(m->y.upload(hy, s)); HIPCHK(m->z.upload(hz, s));
+  HIPCHK(m->farea.upload(h_area, s)); HIPCHK(m->fnx.upload(h_nx, s));
+  HIPCHK(m->fny.upload(h_ny, s)); HIPCHK(m->fnz.upload(h_nz, s));
+  HIPCHK(m->vol.upload(h_vol, s));
+  const size_t fsz = (size_t)m->nprop * stride;
+  HIPCHK(m->U.alloc(fsz)); HIPCHK(m->Un.alloc(fsz)); HIPCHK(m->R.alloc(fsz)); HIPCHK(m->W.alloc(fsz));
+  HIPCHK(m->aos.alloc(ne * (size_t)m->nprop));
+  HIPCHK(hipMemsetAsync(m->U.p, 0, fsz * sizeof(double), s));
+  HIPCHK(hipMemsetAsync(m->Un.p, 0, fsz * sizeof(double), s));
+  HIPCHK(hipMemsetAsync(m->R.p, 0, fsz * sizeof(double), s));
+  HIPCHK(hipMemsetAsync(m->W.p, 0, fsz * sizeof(double), s));
+  const size_t nblk = (nie + 255) / 256;
+  HIPCHK(m->blockmin.alloc(nblk)); HIPCHK(m->dtraw.alloc(1)); HIPCHK(m->dtdev.alloc(1));
+  HIPCHK(m->diagpart.alloc(nblk * 15)); HIPCHK(m->diagout.alloc(15));
+  m->Ucur = m->U.p; m->Ualt = m->W.p;
+
+  DevMesh& dm = m->dm;
+  dm.nie = (int)nie; dm.ne = (int)ne; dm.stride = (int)stride; dm.nnode = ncount; dm.nfac = nfd;
+  dm.inpoel = m->inpoel.p; dm.nbr = m->nbr.p; dm.finfo = m->finfo.p; dm.fid = m->fid.p;
+  dm.x = m->x.p; dm.y = m->y.p; dm.z = m->z.p;
+  dm.farea = m->farea.p; dm.fnx = m->fnx.p; dm.fny = m->fny.p; dm.fnz = m->fnz.p;
+  dm.vol = m->vol.p; dm.d2h = m->d2h.p;
+  HIPCHK(hipStreamSynchronize(s));
+  *out = m.release();
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_mesh_destroy(qdg_mesh* mesh)
+{
+  QDG_TRY
+  if (!mesh) return 0;
+  (void)hipSetDevice(mesh->ctx->device);
+  (void)hipStreamSynchronize(mesh->ctx->stream);
+  delete mesh;
+  return 0;
+  QDG_CATCH
+}
+
+// ---------------------------------------------------------------- helpers
+
+#define MESH_ENTER(name)                                         \
+  if (!mesh) return fail(name ": null mesh");                    \
+  qdg_ctx* ctx = mesh->ctx;                                      \
+  HIPCHK(hipSetDevice(ctx->device));                             \
+  hipStream_t s = ctx->stream;                                   \
+  (void)s
+
+// host AoS (all ne rows) -> SoA planes `dst`
+static int host_to_planes(qdg_mesh* mesh, const double* aos_host, double* dst)
+{
+  hipStream_t s = mesh->ctx->stream;
+  const size_t n = mesh->ne * (size_t)mesh->nprop;
+  HIPCHK(hipMemcpyAsync(mesh->aos.p, aos_host, n * sizeof(double), hipMemcpyHostToDevice, s));
+  launch_aos2soa(mesh->aos.p, mesh->nprop, mesh->d2h.p, 0, (int)mesh->ne, (int)mesh->stride, dst, s);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// SoA planes rows [0,nrows) -> host AoS; rows >= nrows of the host array are
+// written as `fill_rest_zero ? 0 : unchanged`
+static int planes_to_host(qdg_mesh* mesh, const double* src, size_t nrows, double* aos_host,
+                          bool zero_rest)
+{
+  hipStream_t s = mesh->ctx->stream;
+  const size_t n = mesh->ne * (size_t)mesh->nprop;
+  if (zero_rest && nrows < mesh->ne)
+    HIPCHK(hipMemsetAsync(mesh->aos.p, 0, n * sizeof(double), s));
+  launch_soa2aos(src, mesh->nprop, mesh->d2h.p, 0, (int)nrows, (int)mesh->stride, mesh->aos.p, s);
+  HIPCHK(hipGetLastError());
+  if (zero_rest || nrows == mesh->ne) {
+    HIPCHK(hipMemcpyAsync(aos_host, mesh->aos.p, n * sizeof(double), hipMemcpyDeviceToHost, s));
+  } else {
+    // interior rows are not contiguous in the caller's numbering only if the
+    // caller interleaves ghosts; by contract ghosts are rows [nie,ne)
+    HIPCHK(hipMemcpyAsync(aos_host, mesh->aos.p, nrows * (size_t)mesh->nprop * sizeof(double),
+                          hipMemcpyDeviceToHost, s));
+  }
+  HIPCHK(hipStreamSynchronize(s));
+  return 0;
+}
+
+static int run_limiter(qdg_mesh* mesh, double*& Ucur, double*& Ualt)
+{
+  qdg_ctx* ctx = mesh->ctx;
+  hipStream_t s = ctx->stream;
+  if (mesh->ndof == 1) return 0;          // DG.cpp:1251: rdof > 1 only
+  if (ctx->cfg.limiter == QDG_LIMITER_SUPERBEEP1) {
+    launch_superbee(mesh->ndof, mesh->dm, Ucur, s);
+  } else if (ctx->cfg.limiter == QDG_LIMITER_WENOP1) {
+    launch_copy_planes(Ucur, Ualt, mesh->nprop, (int)mesh->ne, (int)mesh->stride, s);
+    launch_weno(mesh->ndof, mesh->dm, ctx->ph.cweight, Ucur, Ualt, s);
+    std::swap(Ucur, Ualt);
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------- stateless
+
+extern "C" int qdg_lhs(qdg_mesh* mesh, double* L_aos)
+{
+  QDG_TRY
+  MESH_ENTER("qdg_lhs");
+  if (!L_aos) return fail("qdg_lhs: null L");
+  launch_mass(mesh->ndof, mesh->dm, mesh->R.p, s);
+  HIPCHK(hipGetLastError());
+  return planes_to_host(mesh, mesh->R.p, mesh->ne, L_aos, false);
+  QDG_CATCH
+}
+
+extern "C" int qdg_initialize(qdg_mesh* mesh, double t, double* U_aos)
+{
+  QDG_TRY
+  MESH_ENTER("qdg_initialize");
+  if (!U_aos) return fail("qdg_initialize: null U");
+  double* w = mesh->Ualt;
+  launch_init(mesh->ndof, mesh->dm, ctx->ph, t, w, s);
+  HIPCHK(hipGetLastError());
+  return planes_to_host(mesh, w, mesh->nie, U_aos, false);
+  QDG_CATCH
+}
+
+extern "C" int qdg_rhs(qdg_mesh* mesh, double t, const double* U_aos, double* R_aos)
+{
+  QDG_TRY
+  MESH_ENTER("qdg_rhs");
+  if (!U_aos || !R_aos) return fail("qdg_rhs: null U/R");
+  double* w = mesh->Ualt;
+  if (int rc = host_to_planes(mesh, U_aos, w)) return rc;
+  launch_rhs(mesh->ndof, mesh->dm, ctx->ph, t, w, mesh->R.p, s);
+  HIPCHK(hipGetLastError());
+  // ghost rows of R are returned as zero (the reference leaves partial sums
+  // there that DG::solve never reads back: ghosts are overwritten by comsol)
+  return planes_to_host(mesh, mesh->R.p, mesh->nie, R_aos, true);
+  QDG_CATCH
+}
+
+extern "C" int qdg_dt(qdg_mesh* mesh, const double* U_aos, double* mindt)
+{
+  QDG_TRY
+  MESH_ENTER("qdg_dt");
+  if (!U_aos || !mindt) return fail("qdg_dt: null argument");
+  double* w = mesh->Ualt;
+  if (int rc = host_to_planes(mesh, U_aos, w)) return rc;
+  launch_dt(mesh->ndof, mesh->dm, ctx->ph, w, mesh->blockmin.p, 1.0, DBL_MAX, mesh->dtraw.p,
+            mesh->diagout.p /*scratch*/, s);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(mindt, mesh->dtraw.p, sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_limit(qdg_mesh* mesh, double* U_aos)
+{
+  QDG_TRY
+  MESH_ENTER("qdg_limit");
+  if (!U_aos) return fail("qdg_limit: null U");
+  // scratch pair that does not alias the resident state
+  double* a = mesh->Ualt;
+  double* b = mesh->R.p;
+  if (int rc = host_to_planes(mesh, U_aos, a)) return rc;
+  if (int rc = run_limiter(mesh, a, b)) return rc;
+  return planes_to_host(mesh, a, mesh->ne, U_aos, false);
+  QDG_CATCH
+}
+
+// ---------------------------------------------------------------- resident
+
+extern "C" int qdg_state_upload(qdg_mesh* mesh, const double* U_aos)
+{
+  QDG_TRY
+  MESH_ENTER("qdg_state_upload");
+  if (!U_aos) return fail("qdg_state_upload: null U");
+  if (int rc = host_to_planes(mesh, U_aos, mesh->Ucur)) return rc;
+  HIPCHK(hipStreamSynchronize(s));
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_state_download(qdg_mesh* mesh, double* U_aos)
+{
+  QDG_TRY
+  MESH_ENTER("qdg_state_download");
+  if (!U_aos) return fail("qdg_state_download: null U");
+  return planes_to_host(mesh, mesh->Ucur, mesh->ne, U_aos, false);
+  QDG_CATCH
+}
+
+extern "C" int qdg_state_initialize(qdg_mesh* mesh, double t)
+{
+  QDG_TRY
+  MESH_ENTER("qdg_state_initialize");
+  launch_init(mesh->ndof, mesh->dm, ctx->ph, t, mesh->Ucur, s);
+  HIPCHK(hipGetLastError());
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_state_device_ptr(qdg_mesh* mesh, void** dptr, size_t* stride)
+{
+  QDG_TRY
+  if (!mesh || !dptr || !stride) return fail("qdg_state_device_ptr: null argument");
+  *dptr = mesh->Ucur; *stride = mesh->stride;
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_stage_limit(qdg_mesh* mesh)
+{
+  QDG_TRY
+  MESH_ENTER("qdg_stage_limit");
+  return run_limiter(mesh, mesh->Ucur, mesh->Ualt);
+  QDG_CATCH
+}
+
+extern "C" int qdg_stage_dt(qdg_mesh* mesh, double tleft)
+{
+  QDG_TRY
+  MESH_ENTER("qdg_stage_dt");
+  if (ctx->cfg.dt > 0.0) {
+    // constant dt configured (DG.cpp:1386-1393)
+    const double v = std::min(ctx->cfg.dt, tleft);
+    // zero blocks to reduce: the final kernel writes min(DBL_MAX*1, v) = v
+    DevMesh none{};
+    launch_dt(mesh->ndof, none, ctx->ph, nullptr, mesh->blockmin.p, 1.0, v, mesh->dtraw.p,
+              mesh->dtdev.p, s);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
+  const double p = (mesh->ndof == 4) ? 1.0 : (mesh->ndof == 10) ? 2.0 : 0.0;
+  const double scale = ctx->cfg.cfl / (2.0 * p + 1.0);     // DG.cpp:1404-1418
+  launch_dt(mesh->ndof, mesh->dm, ctx->ph, mesh->Ucur, mesh->blockmin.p, scale, tleft,
+            mesh->dtraw.p, mesh->dtdev.p, s);
+  HIPCHK(hipGetLastError());
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_stage_dt_get(qdg_mesh* mesh, double* dt_host)
+{
+  QDG_TRY
+  MESH_ENTER("qdg_stage_dt_get");
+  if (!dt_host) return fail("qdg_stage_dt_get: null argument");
+  HIPCHK(hipMemcpyAsync(dt_host, mesh->dtdev.p, sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_stage_dt_set(qdg_mesh* mesh, double dt)
+{
+  QDG_TRY
+  MESH_ENTER("qdg_stage_dt_set");
+  HIPCHK(hipMemcpyAsync(mesh->dtdev.p, &dt, sizeof(double), hipMemcpyHostToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_stage_dt_device_ptr(qdg_mesh* mesh, void** dptr)
+{
+  QDG_TRY
+  if (!mesh || !dptr) return fail("qdg_stage_dt_device_ptr: null argument");
+  *dptr = mesh->dtdev.p;
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_stage_rhs_update(qdg_mesh* mesh, int stage, double t)
+{
+  QDG_TRY
+  MESH_ENTER("qdg_stage_rhs_update");
+  if (stage < 0 || stage > 2) return fail("qdg_stage_rhs_update: stage must be 0,1,2");
+  static const double rk[2][3] = { { 0.0, 3.0 / 4.0, 1.0 / 3.0 }, { 1.0, 1.0 / 4.0, 2.0 / 3.0 } };
+  const size_t fsz = (size_t)mesh->nprop * mesh->stride * sizeof(double);
+  if (stage == 0)   // m_un = m_u, DG.cpp:1472
+    HIPCHK(hipMemcpyAsync(mesh->Un.p, mesh->Ucur, fsz, hipMemcpyDeviceToDevice, s));
+  launch_rhs(mesh->ndof, mesh->dm, ctx->ph, t, mesh->Ucur, mesh->R.p, s);
+  launch_rk(mesh->ndof, mesh->dm, rk[0][stage], rk[1][stage], mesh->dtdev.p, mesh->Un.p,
+            mesh->R.p, mesh->Ucur, s);
+  HIPCHK(hipGetLastError());
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_step(qdg_mesh* mesh, double t, double tleft, double* dt_taken)
+{
+  QDG_TRY
+  if (!mesh) return fail("qdg_step: null mesh");
+  if (mesh->nnbr != 0)
+    return fail("qdg_step: this chunk has halo neighbours; drive the stages and the exchange "
+                "explicitly (qdg_stage_* + qdg_halo_*)");
+  for (int stage = 0; stage < 3; ++stage) {
+    if (int rc = qdg_stage_limit(mesh)) return rc;
+    if (stage == 0) if (int rc = qdg_stage_dt(mesh, tleft)) return rc;
+    if (int rc = qdg_stage_rhs_update(mesh, stage, t)) return rc;
+  }
+  if (dt_taken) return qdg_stage_dt_get(mesh, dt_taken);
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_diag(qdg_mesh* mesh, double t_new, double* out15)
+{
+  QDG_TRY
+  MESH_ENTER("qdg_diag");
+  if (!out15) return fail("qdg_diag: null out");
+  launch_diag(mesh->ndof, mesh->dm, ctx->ph, t_new, mesh->Ucur, mesh->diagpart.p, mesh->diagout.p, s);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out15, mesh->diagout.p, 15 * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return 0;
+  QDG_CATCH
+}
+
+// ---------------------------------------------------------------- halo
+
+extern "C" int qdg_halo_setup(qdg_mesh* mesh, size_t nnbr, const int32_t* nbr_rank,
+                              const size_t* send_off, const size_t* send_elem,
+                              const size_t* recv_off)
+{
+  QDG_TRY
+  MESH_ENTER("qdg_halo_setup");
+  if (nnbr > 0 && (!nbr_rank || !send_off || !send_elem || !recv_off))
+    return fail("qdg_halo_setup: null argument");
+  mesh->nnbr = nnbr;
+  mesh->nbr_rank.assign(nbr_rank, nbr_rank + nnbr);
+  mesh->send_off.assign(send_off, send_off + nnbr + 1);
+  mesh->recv_off.assign(recv_off, recv_off + nnbr + 1);
+  mesh->nsend = nnbr ? send_off[nnbr] : 0;
+  mesh->nrecv = nnbr ? recv_off[nnbr] : 0;
+  if (nnbr && (send_off[0] != 0 || recv_off[0] != 0)) return fail("qdg_halo_setup: offsets must start at 0");
+  if (mesh->nrecv != mesh->ne - mesh->nie)
+    return fail("qdg_halo_setup: receive counts must add up to the number of ghost rows");
+  // host tet id -> device row of the send list
+  std::vector<int> d2h(mesh->ne), h2d(mesh->ne);
+  HIPCHK(hipMemcpy(d2h.data(), mesh->d2h.p, mesh->ne * sizeof(int), hipMemcpyDeviceToHost));
+  for (size_t d = 0; d < mesh->ne; ++d) h2d[d2h[d]] = (int)d;
+  std::vector<int> se(mesh->nsend);
+  for (size_t i = 0; i < mesh->nsend; ++i) {
+    if (send_elem[i] >= mesh->nie) return fail("qdg_halo_setup: send list entry is not an interior tet");
+    se[i] = h2d[send_elem[i]];
+  }
+  HIPCHK(mesh->send_elem.upload(se, s));
+  HIPCHK(mesh->send_slab.alloc(std::max<size_t>(1, mesh->nsend * mesh->nprop)));
+  HIPCHK(mesh->recv_slab.alloc(std::max<size_t>(1, mesh->nrecv * mesh->nprop)));
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_halo_buffers(qdg_mesh* mesh, void** send_dev, void** recv_dev, size_t* row_bytes)
+{
+  QDG_TRY
+  if (!mesh || !send_dev || !recv_dev || !row_bytes) return fail("qdg_halo_buffers: null argument");
+  *send_dev = mesh->send_slab.p; *recv_dev = mesh->recv_slab.p;
+  *row_bytes = (size_t)mesh->nprop * sizeof(double);
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_halo_pack(qdg_mesh* mesh)
+{
+  QDG_TRY
+  MESH_ENTER("qdg_halo_pack");
+  launch_halo_pack(mesh->Ucur, mesh->nprop, (int)mesh->stride, mesh->send_elem.p, (int)mesh->nsend,
+                   mesh->send_slab.p, s);
+  HIPCHK(hipGetLastError());
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_halo_unpack(qdg_mesh* mesh)
+{
+  QDG_TRY
+  MESH_ENTER("qdg_halo_unpack");
+  launch_halo_unpack(mesh->recv_slab.p, mesh->nprop, (int)mesh->stride, (int)mesh->nie,
+                     (int)mesh->nrecv, mesh->Ucur, s);
+  HIPCHK(hipGetLastError());
+  return 0;
+  QDG_CATCH
+}

@@ -1,0 +1,84 @@
+// qdg_device.hpp -- data structures shared by the host layer and the gfx950
+// kernels of the DG compressible-flow path (MI355X / CDNA4 only).
+//
+// HBM layout (all fp64 fields are struct-of-arrays by DOF, one "plane" per
+// (component, mode) pair, so that a wavefront's 64 lanes -- 64 consecutive
+// tets in device order -- read 512 contiguous bytes per plane):
+//
+//   U, Un, R   : plane p = c*NDOF + k at  base + p*stride,   element e at [e]
+//   inpoel     : 4 planes of int32 (device-order elements, renumbered nodes)
+//   nbr        : 4 planes of int32, neighbour across local face lf:
+//                  >= 0  device id of the neighbour (ghosts: >= nie)
+//                  <  0  physical boundary, -(1+bc), bc in {0 none, QDG_BC_*}
+//   finfo      : 4 planes of int32; bits 0-5: local node ids (2 bits each) in
+//                the NEIGHBOUR of this face's 3 nodes, taken in this element's
+//                lpofa[lf] order; bit 6: 1 if this element is the face's left
+//                element (esuf[2f]), i.e. the stored normal points outward
+//   fid        : 4 planes of int32, device face id -> farea/fnx/fny/fnz
+//   vol        : tet volume (geoElem(e,0)), x/y/z node coordinates
+//
+// Device order: interior tets are sorted along a Morton curve of their
+// centroids (neighbour gathers hit L2), nodes are renumbered by first touch,
+// faces are enumerated in device-element order; ghosts keep rows [nie, ne).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+namespace qdg {
+
+constexpr int NCOMP = 5;
+
+constexpr int ngfa(int ndof)   { return ndof == 1 ? 1 : ndof == 4 ? 3 : 6; }
+constexpr int ngvol(int ndof)  { return ndof == 1 ? 1 : ndof == 4 ? 5 : 11; }
+constexpr int ngdiag(int ndof) { return ndof == 1 ? 1 : ndof == 4 ? 4 : 14; }
+constexpr int nginit(int ndof) { return ndof == 1 ? 1 : 14; }
+
+struct DevMesh {
+  int nie;          // interior elements
+  int ne;           // interior + ghosts
+  int stride;       // plane stride (ne rounded up to 64)
+  int nnode;
+  int nfac;         // device faces
+  const int* inpoel;   // [4][stride]
+  const int* nbr;      // [4][stride]
+  const int* finfo;    // [4][stride]
+  const int* fid;      // [4][stride]
+  const double* x;
+  const double* y;
+  const double* z;
+  const double* farea;
+  const double* fnx;
+  const double* fny;
+  const double* fnz;
+  const double* vol;   // [stride]
+  const int* d2h;      // [ne] device row -> host row
+};
+
+struct Phys {
+  double gamma, pstiff, cweight;
+  double alpha, beta, p0;
+  int flux, problem, limiter;
+};
+
+// Quadrature / basis tables for one polynomial order, kept in constant memory
+// so that loop-uniform indices turn into scalar loads.
+template <int NDOF> struct Tables {
+  static constexpr int NGF = ngfa(NDOF);
+  static constexpr int NGV = ngvol(NDOF);
+  double fw[NGF];             // triangle weights          (Quadrature.cpp:261-339)
+  double fs[NGF][3];          // barycentric weights of the face's 3 nodes
+  double fB[4][NGF][NDOF];    // own basis at the Gauss points of local face lf
+  double vw[NGV];             // tet weights               (Quadrature.cpp:16-259)
+  double vc[NGV][3];          // tet Gauss point reference coordinates
+  double vB[NGV][NDOF];       // basis at the volume Gauss points
+  double vdB[NGV][3][NDOF];   // dB_k/dxi_j at the volume Gauss points
+};
+
+// generic tet rule (initialisation: 14 points; diagnostics: 1/4/14 points)
+struct QuadTet {
+  int ng;
+  double c[14][3];
+  double w[14];
+};
+
+}  // namespace qdg

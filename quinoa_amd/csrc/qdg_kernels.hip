@@ -1,0 +1,1027 @@
+// qdg_kernels.hip -- hand-written gfx950 (MI355X, CDNA4) kernels of the DG
+// compressible-flow path.  One lane = one tetrahedron; 64 consecutive tets of
+// the Morton-ordered device numbering per wavefront; all field planes are
+// struct-of-arrays (qdg_device.hpp), so own-element accesses are fully
+// coalesced 512-B wave transactions and neighbour accesses are short-range
+// gathers served by the XCD's L2.
+//
+// The right-hand side is ELEMENT-CENTRIC: every tet visits its 4 faces and
+// gathers the neighbour's DOFs, instead of the reference's face loop that
+// scatters into R[el] and R[er] (src/PDE/Integrate/Surface.cpp:233-271).
+// No atomics, R written exactly once, results independent of scheduling.
+// The Riemann flux of a face is always evaluated in the face's stored
+// orientation (left = esuf[2f], stored normal), by both of its elements, so
+// both sides see the same flux expression.
+//
+// Reference coordinates of face Gauss points are constant tables: on a
+// straight-sided tet they depend only on the local face id (own side) and on
+// the 3-node permutation code `finfo` (neighbour side), which removes the six
+// tk::Jacobian evaluations per Gauss point of Surface.cpp:159-166.
+#include <hip/hip_runtime.h>
+#include <cfloat>
+#include <cmath>
+#include "qdg_device.hpp"
+#include "qdg_kernels.hpp"
+
+namespace qdg {
+
+__constant__ Tables<1> c_tab1;
+__constant__ Tables<4> c_tab4;
+__constant__ Tables<10> c_tab10;
+__constant__ QuadTet c_qinit[3];   // NGinit rule per order index
+__constant__ QuadTet c_qdiag[3];   // NGdiag rule per order index
+
+template <int NDOF> __device__ __forceinline__ const Tables<NDOF>& tab();
+template <> __device__ __forceinline__ const Tables<1>& tab<1>() { return c_tab1; }
+template <> __device__ __forceinline__ const Tables<4>& tab<4>() { return c_tab4; }
+template <> __device__ __forceinline__ const Tables<10>& tab<10>() { return c_tab10; }
+
+template <int NDOF> constexpr int order_index() { return NDOF == 1 ? 0 : NDOF == 4 ? 1 : 2; }
+
+// ------------------------------------------------------------------ basics
+
+// Dubiner basis, src/PDE/Integrate/Basis.cpp:267-307
+template <int NDOF>
+__device__ __forceinline__ void eval_basis(double xi, double eta, double zeta, double* B)
+{
+  B[0] = 1.0;
+  if constexpr (NDOF > 1) {
+    B[1] = 2.0 * xi + eta + zeta - 1.0;
+    B[2] = 3.0 * eta + zeta - 1.0;
+    B[3] = 4.0 * zeta - 1.0;
+  }
+  if constexpr (NDOF > 4) {
+    B[4] = 6.0 * xi * xi + eta * eta + zeta * zeta + 6.0 * xi * eta + 6.0 * xi * zeta
+         + 2.0 * eta * zeta - 6.0 * xi - 2.0 * eta - 2.0 * zeta + 1.0;
+    B[5] = 5.0 * eta * eta + zeta * zeta + 10.0 * xi * eta + 2.0 * xi * zeta
+         + 6.0 * eta * zeta - 2.0 * xi - 6.0 * eta - 2.0 * zeta + 1.0;
+    B[6] = 6.0 * zeta * zeta + 12.0 * xi * zeta + 6.0 * eta * zeta - 2.0 * xi - eta
+         - 7.0 * zeta + 1.0;
+    B[7] = 10.0 * eta * eta + zeta * zeta + 8.0 * eta * zeta - 8.0 * eta - 2.0 * zeta + 1.0;
+    B[8] = 6.0 * zeta * zeta + 18.0 * eta * zeta - 3.0 * eta - 7.0 * zeta + 1.0;
+    B[9] = 15.0 * zeta * zeta - 10.0 * zeta + 1.0;
+  }
+}
+
+// src/PDE/EoS/EoS.hpp:66-84
+__device__ __forceinline__ double eos_pressure(const Phys& ph, double rho, double u, double v,
+                                               double w, double rhoE)
+{
+  return (rhoE - 0.5 * rho * (u * u + v * v + w * w) - ph.pstiff) * (ph.gamma - 1.0) - ph.pstiff;
+}
+// src/PDE/EoS/EoS.hpp:95-108
+__device__ __forceinline__ double eos_soundspeed(const Phys& ph, double rho, double pr)
+{
+  return sqrt(ph.gamma * (pr + ph.pstiff) / rho);
+}
+// src/PDE/EoS/EoS.hpp:123-140
+__device__ __forceinline__ double eos_totalenergy(const Phys& ph, double rho, double u,
+                                                  double v, double w, double pr)
+{
+  return (pr + ph.pstiff) / (ph.gamma - 1.0) + 0.5 * rho * (u * u + v * v + w * w) + ph.pstiff;
+}
+
+// HLLC, src/PDE/Integrate/Riemann/HLLC.hpp:36-125.  The 4-way branch is
+// evaluated as per-lane selects (no wave divergence).
+__device__ __forceinline__ void flux_hllc(const Phys& ph, const double* fn, const double* L,
+                                          const double* R, double* flx)
+{
+  const double rhol = L[0], rhor = R[0];
+  const double irl = 1.0 / rhol, irr = 1.0 / rhor;
+  const double ul = L[1] * irl, vl = L[2] * irl, wl = L[3] * irl;
+  const double ur = R[1] * irr, vr = R[2] * irr, wr = R[3] * irr;
+  const double pl = eos_pressure(ph, rhol, ul, vl, wl, L[4]);
+  const double pr = eos_pressure(ph, rhor, ur, vr, wr, R[4]);
+  const double al = eos_soundspeed(ph, rhol, pl);
+  const double ar = eos_soundspeed(ph, rhor, pr);
+  const double vnl = ul * fn[0] + vl * fn[1] + wl * fn[2];
+  const double vnr = ur * fn[0] + vr * fn[1] + wr * fn[2];
+  const double rlr = sqrt(rhor * irl);
+  const double irlr1 = 1.0 / (1.0 + rlr);
+  const double vnroe = (vnr * rlr + vnl) * irlr1;
+  const double aroe = (ar * rlr + al) * irlr1;
+  const double Sl = fmin(vnl - al, vnroe - aroe);
+  const double Sr = fmax(vnr + ar, vnroe + aroe);
+  const double Sm = (rhor * vnr * (Sr - vnr) - rhol * vnl * (Sl - vnl) + pl - pr)
+                  / (rhor * (Sr - vnr) - rhol * (Sl - vnl));
+  const double pStar = rhol * (vnl - Sl) * (vnl - Sm) + pl;
+  // branch ladder of HLLC.hpp:93-124 as per-lane predicates:
+  //   Sl > 0 -> left flux; else Sm > 0 -> left star; else Sr >= 0 -> right star;
+  //   else right flux
+  // (every comparison of the reference is kept: with a NaN wave speed -- e.g. a
+  // negative pressure at a Gauss point next to a strong shock -- all of them
+  // are false and the reference falls through to the right-state flux)
+  const bool c1 = Sl > 0.0;
+  const bool c2 = !c1 && (Sl <= 0.0) && (Sm > 0.0);
+  const bool c3 = !c1 && !c2 && (Sm <= 0.0) && (Sr >= 0.0);
+  const bool left = c1 || c2;
+  const bool star = c2 || c3;
+  const double S = left ? Sl : Sr;
+  const double vn = left ? vnl : vnr;
+  const double p = left ? pl : pr;
+  const double u0 = left ? L[0] : R[0], u1 = left ? L[1] : R[1], u2 = left ? L[2] : R[2],
+               u3 = left ? L[3] : R[3], u4 = left ? L[4] : R[4];
+  if (star) {
+    const double id = 1.0 / (S - Sm);
+    const double sv = S - vn, dp = pStar - p;
+    const double s0 = sv * u0 * id;
+    const double s1 = (sv * u1 + dp * fn[0]) * id;
+    const double s2 = (sv * u2 + dp * fn[1]) * id;
+    const double s3 = (sv * u3 + dp * fn[2]) * id;
+    const double s4 = (sv * u4 - p * vn + pStar * Sm) * id;
+    flx[0] = s0 * Sm;
+    flx[1] = s1 * Sm + pStar * fn[0];
+    flx[2] = s2 * Sm + pStar * fn[1];
+    flx[3] = s3 * Sm + pStar * fn[2];
+    flx[4] = (s4 + pStar) * Sm;
+  } else {
+    flx[0] = u0 * vn;
+    flx[1] = u1 * vn + p * fn[0];
+    flx[2] = u2 * vn + p * fn[1];
+    flx[3] = u3 * vn + p * fn[2];
+    flx[4] = (u4 + p) * vn;
+  }
+}
+
+// Lax-Friedrichs, src/PDE/Integrate/Riemann/LaxFriedrichs.hpp:34-88
+__device__ __forceinline__ void flux_lf(const Phys& ph, const double* fn, const double* L,
+                                        const double* R, double* flx)
+{
+  const double rhol = L[0], rhor = R[0];
+  const double ul = L[1] / rhol, vl = L[2] / rhol, wl = L[3] / rhol;
+  const double ur = R[1] / rhor, vr = R[2] / rhor, wr = R[3] / rhor;
+  const double pl = eos_pressure(ph, rhol, ul, vl, wl, L[4]);
+  const double pr = eos_pressure(ph, rhor, ur, vr, wr, R[4]);
+  const double al = eos_soundspeed(ph, rhol, pl);
+  const double ar = eos_soundspeed(ph, rhor, pr);
+  const double vnl = ul * fn[0] + vl * fn[1] + wl * fn[2];
+  const double vnr = ur * fn[0] + vr * fn[1] + wr * fn[2];
+  const double lambda = fmax(al, ar) + fmax(fabs(vnl), fabs(vnr));
+  const double fl0 = L[0] * vnl, fr0 = R[0] * vnr;
+  const double fl1 = L[1] * vnl + pl * fn[0], fr1 = R[1] * vnr + pr * fn[0];
+  const double fl2 = L[2] * vnl + pl * fn[1], fr2 = R[2] * vnr + pr * fn[1];
+  const double fl3 = L[3] * vnl + pl * fn[2], fr3 = R[3] * vnr + pr * fn[2];
+  const double fl4 = (L[4] + pl) * vnl, fr4 = (R[4] + pr) * vnr;
+  flx[0] = 0.5 * (fl0 + fr0 - lambda * (R[0] - L[0]));
+  flx[1] = 0.5 * (fl1 + fr1 - lambda * (R[1] - L[1]));
+  flx[2] = 0.5 * (fl2 + fr2 - lambda * (R[2] - L[2]));
+  flx[3] = 0.5 * (fl3 + fr3 - lambda * (R[3] - L[3]));
+  flx[4] = 0.5 * (fl4 + fr4 - lambda * (R[4] - L[4]));
+}
+
+__device__ __forceinline__ void riemann(const Phys& ph, const double* fn, const double* L,
+                                        const double* R, double* flx)
+{
+  if (ph.flux == 1) flux_lf(ph, fn, L, R, flx);
+  else flux_hllc(ph, fn, L, R, flx);
+}
+
+// Problem::solution (device functor per ProblemType):
+// SodShocktube.cpp:28-78, SedovBlastwave.cpp:28-75, VorticalFlow.cpp:28-64,
+// TaylorGreen.cpp:28-62 under src/PDE/CompFlow/Problem/
+__device__ __forceinline__ void prob_solution(const Phys& ph, double x, double y, double z,
+                                              double /*t*/, double* s)
+{
+  switch (ph.problem) {
+    case 1: {
+      const bool l = x < 0.5;
+      const double r = l ? 1.0 : 0.125, p = l ? 1.0 : 0.1;
+      s[0] = r; s[1] = 0.0; s[2] = 0.0; s[3] = 0.0;
+      s[4] = eos_totalenergy(ph, r, 0.0, 0.0, 0.0, p);
+      break;
+    }
+    case 2: {
+      const double r = 1.0, p = ((x < 0.05) && (y < 0.05)) ? 783.4112 : 1.0e-6;
+      s[0] = r; s[1] = 0.0; s[2] = 0.0; s[3] = 0.0;
+      s[4] = eos_totalenergy(ph, r, 0.0, 0.0, 0.0, p);
+      break;
+    }
+    case 3: {
+      const double a = ph.alpha, b = ph.beta;
+      const double ru = a * x - b * y, rv = b * x + a * y, rw = -2.0 * a * z;
+      s[0] = 1.0; s[1] = ru; s[2] = rv; s[3] = rw;
+      s[4] = (ru * ru + rv * rv + rw * rw) / 2.0 + (ph.p0 - 2.0 * a * a * z * z) / (ph.gamma - 1.0);
+      break;
+    }
+    case 4: {
+      const double pi = 3.14159265358979323846;
+      const double r = 1.0;
+      const double p = 10.0 + r / 4.0 * (cos(2.0 * pi * x) + cos(2.0 * pi * y));
+      const double u = sin(pi * x) * cos(pi * y), v = -cos(pi * x) * sin(pi * y), w = 0.0;
+      s[0] = r; s[1] = r * u; s[2] = r * v; s[3] = r * w;
+      s[4] = eos_totalenergy(ph, r, u, v, w, p);
+      break;
+    }
+    default:
+      s[0] = s[1] = s[2] = s[3] = s[4] = 0.0;
+  }
+}
+
+// Problem::src: VorticalFlow.cpp:80-115, TaylorGreen.cpp:77-90 (zero otherwise)
+__device__ __forceinline__ bool prob_has_source(const Phys& ph) { return ph.problem == 3 || ph.problem == 4; }
+__device__ __forceinline__ void prob_src(const Phys& ph, double x, double y, double z,
+                                         double /*t*/, double* r)
+{
+  if (ph.problem == 3) {
+    const double a = ph.alpha, b = ph.beta;
+    double s[5];
+    prob_solution(ph, x, y, z, 0.0, s);
+    r[0] = 0.0;
+    r[1] = a * s[1] / s[0] - b * s[2] / s[0];
+    r[2] = b * s[1] / s[0] + a * s[2] / s[0];
+    r[3] = 0.0;
+    r[4] = (r[1] * s[1] + r[2] * s[2]) / s[0] + 8.0 * a * a * a * z * z / (ph.gamma - 1.0);
+  } else if (ph.problem == 4) {
+    const double pi = 3.14159265358979323846;
+    r[0] = r[1] = r[2] = r[3] = 0.0;
+    r[4] = 3.0 * pi / 8.0 * (cos(3.0 * pi * x) * cos(pi * y) - cos(3.0 * pi * y) * cos(pi * x));
+  } else {
+    r[0] = r[1] = r[2] = r[3] = r[4] = 0.0;
+  }
+}
+
+// BC state functions, src/PDE/CompFlow/DGCompFlow.hpp:649-701
+__device__ __forceinline__ void bc_state(const Phys& ph, int bc, const double* ul, double x,
+                                         double y, double z, double t, const double* fn,
+                                         double* ur)
+{
+  if (bc == 1) {
+    prob_solution(ph, x, y, z, t, ur);
+  } else if (bc == 2) {
+    const double v1 = ul[1] / ul[0], v2 = ul[2] / ul[0], v3 = ul[3] / ul[0];
+    const double vn = v1 * fn[0] + v2 * fn[1] + v3 * fn[2];
+    ur[0] = ul[0];
+    ur[1] = ur[0] * (v1 - 2.0 * vn * fn[0]);
+    ur[2] = ur[0] * (v2 - 2.0 * vn * fn[1]);
+    ur[3] = ur[0] * (v3 - 2.0 * vn * fn[2]);
+    ur[4] = ul[4];
+  } else {
+    ur[0] = ul[0]; ur[1] = ul[1]; ur[2] = ul[2]; ur[3] = ul[3]; ur[4] = ul[4];
+  }
+}
+
+// local face -> local nodes (src/Mesh/DerivedData.hpp:36), as selects so that
+// no runtime-indexed array ends up in scratch
+__device__ __forceinline__ int lpofa(int lf, int j)
+{
+  // {1,2,3},{2,0,3},{3,0,1},{0,2,1}
+  const int packed = (lf == 0) ? 0x39 /*1,2,3*/ : (lf == 1) ? 0x32 /*2,0,3*/
+                   : (lf == 2) ? 0x13 /*3,0,1*/ : 0x18 /*0,2,1*/;
+  return (packed >> (2 * j)) & 3;
+}
+
+// reference coords in the neighbour of a face point with barycentric weights
+// (s0,s1,s2) on the face's nodes, whose neighbour-local ids are in `code`
+__device__ __forceinline__ void nbr_ref_coords(int code, double s0, double s1, double s2,
+                                               double& xi, double& eta, double& zeta)
+{
+  const int m0 = code & 3, m1 = (code >> 2) & 3, m2 = (code >> 4) & 3;
+  xi   = (m0 == 1 ? s0 : 0.0) + (m1 == 1 ? s1 : 0.0) + (m2 == 1 ? s2 : 0.0);
+  eta  = (m0 == 2 ? s0 : 0.0) + (m1 == 2 ? s1 : 0.0) + (m2 == 2 ? s2 : 0.0);
+  zeta = (m0 == 3 ? s0 : 0.0) + (m1 == 3 ? s1 : 0.0) + (m2 == 3 ? s2 : 0.0);
+}
+
+template <int NDOF>
+__device__ __forceinline__ void load_dofs(const double* __restrict__ U, int stride, int e,
+                                          double (&u)[NCOMP][NDOF])
+{
+#pragma unroll
+  for (int c = 0; c < NCOMP; ++c)
+#pragma unroll
+    for (int k = 0; k < NDOF; ++k) u[c][k] = U[(size_t)(c * NDOF + k) * stride + e];
+}
+
+template <int NDOF>
+__device__ __forceinline__ void state_from(const double (&u)[NCOMP][NDOF], const double* B,
+                                           double* s)
+{
+#pragma unroll
+  for (int c = 0; c < NCOMP; ++c) {
+    double a = u[c][0];
+#pragma unroll
+    for (int k = 1; k < NDOF; ++k) a += u[c][k] * B[k];
+    s[c] = a;
+  }
+}
+
+// state of element `n` at a point with basis B, streaming its DOFs from HBM/L2
+template <int NDOF>
+__device__ __forceinline__ void state_gather(const double* __restrict__ U, int stride, int n,
+                                             const double* B, double* s)
+{
+#pragma unroll
+  for (int c = 0; c < NCOMP; ++c) {
+    double a = U[(size_t)(c * NDOF) * stride + n];
+#pragma unroll
+    for (int k = 1; k < NDOF; ++k) a += U[(size_t)(c * NDOF + k) * stride + n] * B[k];
+    s[c] = a;
+  }
+}
+
+struct ElemGeom {
+  double p[4][3];
+};
+
+__device__ __forceinline__ void load_geom(const DevMesh& m, int e, ElemGeom& g)
+{
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = m.inpoel[(size_t)i * m.stride + e];
+    g.p[i][0] = m.x[n]; g.p[i][1] = m.y[n]; g.p[i][2] = m.z[n];
+  }
+}
+
+// physical coordinates of the point with weights (s0,s1,s2) on local face lf
+__device__ __forceinline__ void face_point(const ElemGeom& g, int lf, double s0, double s1,
+                                           double s2, double* P)
+{
+  // node weights of the 4 local nodes
+  double w[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n)
+    w[n] = (lpofa(lf, 0) == n ? s0 : 0.0) + (lpofa(lf, 1) == n ? s1 : 0.0)
+         + (lpofa(lf, 2) == n ? s2 : 0.0);
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+    P[d] = g.p[0][d] * w[0] + g.p[1][d] * w[1] + g.p[2][d] * w[2] + g.p[3][d] * w[3];
+}
+
+// inverse Jacobian of the tet map, src/Base/Vector.cpp:155-197
+__device__ __forceinline__ void inverse_jacobian(const ElemGeom& g, double (&ji)[3][3])
+{
+  const double (*v)[3] = g.p;
+  const double bx = v[1][0] - v[0][0], by = v[1][1] - v[0][1], bz = v[1][2] - v[0][2];
+  const double cx = v[2][0] - v[0][0], cy = v[2][1] - v[0][1], cz = v[2][2] - v[0][2];
+  const double dx = v[3][0] - v[0][0], dy = v[3][1] - v[0][1], dz = v[3][2] - v[0][2];
+  const double det = bx * (cy * dz - cz * dy) + by * (cz * dx - cx * dz) + bz * (cx * dy - cy * dx);
+  const double id = 1.0 / det;
+  ji[0][0] =  (cy * dz - dy * cz) * id;
+  ji[1][0] = -(by * dz - dy * bz) * id;
+  ji[2][0] =  (by * cz - cy * bz) * id;
+  ji[0][1] = -(cx * dz - dx * cz) * id;
+  ji[1][1] =  (bx * dz - dx * bz) * id;
+  ji[2][1] = -(bx * cz - cx * bz) * id;
+  ji[0][2] =  (cx * dy - dx * cy) * id;
+  ji[1][2] = -(bx * dy - dx * by) * id;
+  ji[2][2] =  (bx * cy - cx * by) * id;
+}
+
+// ------------------------------------------------------------- RHS kernel
+// dg::CompFlow::rhs (src/PDE/CompFlow/DGCompFlow.hpp:130-195) for interior
+// tets: surfInt + bndSurfInt (per local face), volInt, srcInt.
+template <int NDOF>
+__global__ __launch_bounds__(256) void k_rhs(DevMesh m, Phys ph, double t,
+                                             const double* __restrict__ U,
+                                             double* __restrict__ R)
+{
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= m.nie) return;
+  const Tables<NDOF>& T = tab<NDOF>();
+  constexpr int NGF = Tables<NDOF>::NGF, NGV = Tables<NDOF>::NGV;
+  const int stride = m.stride;
+
+  double acc[NCOMP][NDOF];
+#pragma unroll
+  for (int c = 0; c < NCOMP; ++c)
+#pragma unroll
+    for (int k = 0; k < NDOF; ++k) acc[c][k] = 0.0;
+
+  ElemGeom g;
+  load_geom(m, e, g);
+
+  // ---- faces ------------------------------------------------------------
+#pragma unroll 1
+  for (int lf = 0; lf < 4; ++lf) {
+    const int nb = m.nbr[(size_t)lf * stride + e];
+    if (nb == -1) continue;                     // boundary face without a BC
+    const int info = m.finfo[(size_t)lf * stride + e];
+    const int f = m.fid[(size_t)lf * stride + e];
+    const double area = m.farea[f];
+    const double fn[3] = { m.fnx[f], m.fny[f], m.fnz[f] };
+    const bool own_left = (info >> 6) & 1;
+#pragma unroll 1
+    for (int ig = 0; ig < NGF; ++ig) {
+      const double s0 = T.fs[ig][0], s1 = T.fs[ig][1], s2 = T.fs[ig][2];
+      double so[NCOMP], sn[NCOMP], fl[NCOMP];
+      state_gather<NDOF>(U, stride, e, T.fB[lf][ig], so);
+      if (nb >= 0) {
+        double xi, eta, zeta, Bn[NDOF];
+        nbr_ref_coords(info, s0, s1, s2, xi, eta, zeta);
+        eval_basis<NDOF>(xi, eta, zeta, Bn);
+        state_gather<NDOF>(U, stride, nb, Bn, sn);
+      } else {
+        double P[3];
+        face_point(g, lf, s0, s1, s2, P);
+        bc_state(ph, -nb - 1, so, P[0], P[1], P[2], t, fn, sn);
+      }
+      if (own_left) riemann(ph, fn, so, sn, fl);
+      else          riemann(ph, fn, sn, so, fl);
+      const double wt = (own_left ? -1.0 : 1.0) * T.fw[ig] * area;
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) {
+        const double wf = wt * fl[c];
+        acc[c][0] += wf;
+#pragma unroll
+        for (int k = 1; k < NDOF; ++k) acc[c][k] += wf * T.fB[lf][ig][k];
+      }
+    }
+  }
+
+  const double vol = m.vol[e];
+
+  // ---- volume integral, src/PDE/Integrate/Volume.cpp:20-168 -------------
+  if constexpr (NDOF > 1) {
+    double ji[3][3];
+    inverse_jacobian(g, ji);
+#pragma unroll 1
+    for (int ig = 0; ig < NGV; ++ig) {
+      double s[NCOMP];
+      state_gather<NDOF>(U, stride, e, T.vB[ig], s);
+      const double ir = 1.0 / s[0];
+      const double u = s[1] * ir, v = s[2] * ir, w = s[3] * ir;
+      const double p = eos_pressure(ph, s[0], u, v, w, s[4]);
+      const double wt = T.vw[ig] * vol;
+      // Euler flux F[c][d], src/PDE/CompFlow/DGCompFlow.hpp:599-635
+      const double F[NCOMP][3] = {
+        { s[1], s[2], s[3] },
+        { s[1] * u + p, s[2] * u, s[3] * u },
+        { s[1] * v, s[2] * v + p, s[3] * v },
+        { s[1] * w, s[2] * w, s[3] * w + p },
+        { u * (s[4] + p), v * (s[4] + p), w * (s[4] + p) } };
+#pragma unroll
+      for (int k = 1; k < NDOF; ++k) {
+        // dB_k/dx_d = sum_j dB_k/dxi_j * jacInv[j][d]   (Basis.cpp:77-265)
+        const double g0 = T.vdB[ig][0][k], g1 = T.vdB[ig][1][k], g2 = T.vdB[ig][2][k];
+        const double dx = g0 * ji[0][0] + g1 * ji[1][0] + g2 * ji[2][0];
+        const double dy = g0 * ji[0][1] + g1 * ji[1][1] + g2 * ji[2][1];
+        const double dz = g0 * ji[0][2] + g1 * ji[1][2] + g2 * ji[2][2];
+#pragma unroll
+        for (int c = 0; c < NCOMP; ++c)
+          acc[c][k] += wt * (F[c][0] * dx + F[c][1] * dy + F[c][2] * dz);
+      }
+    }
+  }
+
+  // ---- source integral, src/PDE/Integrate/Source.cpp:21-141 -------------
+  if (prob_has_source(ph)) {
+#pragma unroll 1
+    for (int ig = 0; ig < NGV; ++ig) {
+      const double xi = T.vc[ig][0], eta = T.vc[ig][1], zeta = T.vc[ig][2];
+      const double w0 = 1.0 - xi - eta - zeta;
+      double P[3], s[NCOMP];
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+        P[d] = g.p[0][d] * w0 + g.p[1][d] * xi + g.p[2][d] * eta + g.p[3][d] * zeta;
+      prob_src(ph, P[0], P[1], P[2], t, s);
+      const double wt = T.vw[ig] * vol;
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) {
+        const double ws = wt * s[c];
+        acc[c][0] += ws;
+#pragma unroll
+        for (int k = 1; k < NDOF; ++k) acc[c][k] += ws * T.vB[ig][k];
+      }
+    }
+  }
+
+#pragma unroll
+  for (int c = 0; c < NCOMP; ++c)
+#pragma unroll
+    for (int k = 0; k < NDOF; ++k) R[(size_t)(c * NDOF + k) * stride + e] = acc[c][k];
+}
+
+// ------------------------------------------------------------- limiters
+// Superbee_P1, src/PDE/Limiter.cpp:155-316: only neighbour MEANS are read, so
+// the in-place update is order independent.
+template <int NDOF>
+__global__ __launch_bounds__(256) void k_superbee(DevMesh m, double* __restrict__ U)
+{
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= m.nie) return;
+  if constexpr (NDOF > 1) {
+    const Tables<NDOF>& T = tab<NDOF>();
+    constexpr int NGF = Tables<NDOF>::NGF;
+    const int stride = m.stride;
+    double u0[NCOMP], uMin[NCOMP], uMax[NCOMP], phi[NCOMP];
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c) {
+      u0[c] = U[(size_t)(c * NDOF) * stride + e];
+      uMin[c] = uMax[c] = u0[c];
+      phi[c] = 1.0;
+    }
+#pragma unroll
+    for (int lf = 0; lf < 4; ++lf) {
+      const int nb = m.nbr[(size_t)lf * stride + e];
+      if (nb < 0) continue;
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) {
+        const double v = U[(size_t)(c * NDOF) * stride + nb];
+        uMin[c] = fmin(uMin[c], v);
+        uMax[c] = fmax(uMax[c], v);
+      }
+    }
+#pragma unroll 1
+    for (int lf = 0; lf < 4; ++lf)
+#pragma unroll 1
+      for (int ig = 0; ig < NGF; ++ig) {
+        double s[NCOMP];
+        state_gather<NDOF>(U, stride, e, T.fB[lf][ig], s);
+#pragma unroll
+        for (int c = 0; c < NCOMP; ++c) {
+          const double uNeg = s[c] - u0[c];
+          double pg = 1.0;
+          if (uNeg > 1.0e-14) pg = fmin(1.0, (uMax[c] - u0[c]) / (2.0 * uNeg));
+          else if (uNeg < -1.0e-14) pg = fmin(1.0, (uMin[c] - u0[c]) / (2.0 * uNeg));
+          pg = fmax(0.0, fmax(fmin(2.0 * pg, 1.0), fmin(pg, 2.0)));
+          phi[c] = fmin(phi[c], pg);
+        }
+      }
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c)
+#pragma unroll
+      for (int k = 1; k < 4; ++k) {
+        const size_t i = (size_t)(c * NDOF + k) * stride + e;
+        U[i] = phi[c] * U[i];
+      }
+  }
+}
+
+// WENO_P1, src/PDE/Limiter.cpp:29-153 (Jacobi: reads Uin, writes modes 1-3 of
+// Uout; all other planes are copied by the caller)
+template <int NDOF>
+__global__ __launch_bounds__(256) void k_weno(DevMesh m, double cweight,
+                                              const double* __restrict__ Uin,
+                                              double* __restrict__ Uout)
+{
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= m.nie) return;
+  if constexpr (NDOF > 1) {
+    const int stride = m.stride;
+    int nb[4];
+#pragma unroll
+    for (int lf = 0; lf < 4; ++lf) nb[lf] = m.nbr[(size_t)lf * stride + e];
+#pragma unroll 1
+    for (int c = 0; c < NCOMP; ++c) {
+      double g[5][3], wd[5], wtot = 0.0;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) g[0][d] = Uin[(size_t)(c * NDOF + 1 + d) * stride + e];
+#pragma unroll
+      for (int is = 1; is < 5; ++is) {
+        const int n = nb[is - 1];
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+          g[is][d] = (n >= 0) ? Uin[(size_t)(c * NDOF + 1 + d) * stride + n] : 0.0;
+      }
+#pragma unroll
+      for (int is = 0; is < 5; ++is) {
+        const double wst = (is == 0) ? cweight : (nb[is - (is > 0)] >= 0 ? 1.0 : 0.0);
+        const double osc = sqrt(g[is][0] * g[is][0] + g[is][1] * g[is][1] + g[is][2] * g[is][2]);
+        const double q = 1.0e-8 + osc;
+        wd[is] = wst / (q * q);
+        wtot += wd[is];
+      }
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        double a = 0.0;
+#pragma unroll
+        for (int is = 0; is < 5; ++is) a += (wd[is] / wtot) * g[is][d];
+        Uout[(size_t)(c * NDOF + 1 + d) * stride + e] = a;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------- time step
+// dg::CompFlow::dt, src/PDE/CompFlow/DGCompFlow.hpp:206-406, element-centric:
+// delt[e] = sum over own faces and Gauss points of max(dSV_own, dSV_nbr),
+// dSV = wt*(|vn|+a); returns per-block minima of vol/delt.
+template <int NDOF>
+__global__ __launch_bounds__(256) void k_dt(DevMesh m, Phys ph, const double* __restrict__ U,
+                                            double* __restrict__ blockmin)
+{
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  double dte = DBL_MAX;
+  if (e < m.nie) {
+    const Tables<NDOF>& T = tab<NDOF>();
+    constexpr int NGF = Tables<NDOF>::NGF;
+    const int stride = m.stride;
+    double delt = 0.0;
+#pragma unroll 1
+    for (int lf = 0; lf < 4; ++lf) {
+      const int nb = m.nbr[(size_t)lf * stride + e];
+      const int info = m.finfo[(size_t)lf * stride + e];
+      const int f = m.fid[(size_t)lf * stride + e];
+      const double area = m.farea[f];
+      const double fn[3] = { m.fnx[f], m.fny[f], m.fnz[f] };
+      const bool own_left = (info >> 6) & 1;
+#pragma unroll 1
+      for (int ig = 0; ig < NGF; ++ig) {
+        const double wt = T.fw[ig] * area;
+        double s[NCOMP];
+        state_gather<NDOF>(U, stride, e, T.fB[lf][ig], s);
+        double rho = s[0], u = s[1] / rho, v = s[2] / rho, w = s[3] / rho;
+        double p = eos_pressure(ph, rho, u, v, w, s[4]);
+        double a = eos_soundspeed(ph, rho, p);
+        double vn = u * fn[0] + v * fn[1] + w * fn[2];
+        const double dl = wt * (fabs(vn) + a);
+        double dr = 0.0;
+        if (nb >= 0) {
+          double xi, eta, zeta, Bn[NDOF];
+          nbr_ref_coords(info, T.fs[ig][0], T.fs[ig][1], T.fs[ig][2], xi, eta, zeta);
+          eval_basis<NDOF>(xi, eta, zeta, Bn);
+          state_gather<NDOF>(U, stride, nb, Bn, s);
+          rho = s[0]; u = s[1] / rho; v = s[2] / rho; w = s[3] / rho;
+          p = eos_pressure(ph, rho, u, v, w, s[4]);
+          a = eos_soundspeed(ph, rho, p);
+          vn = u * fn[0] + v * fn[1] + w * fn[2];
+          dr = wt * (fabs(vn) + a);
+        }
+        // std::max(dSV_l, dSV_r) with (face-left, face-right) argument order,
+        // i.e. (a < b) ? b : a -- keeps the reference's NaN behaviour
+        const double a_ = own_left ? dl : dr, b_ = own_left ? dr : dl;
+        delt += (a_ < b_) ? b_ : a_;
+      }
+    }
+    dte = m.vol[e] / delt;
+  }
+  // wave reduction (64 lanes), then across the 4 waves through LDS
+  for (int off = 32; off > 0; off >>= 1) dte = fmin(dte, __shfl_down(dte, off, 64));
+  __shared__ double wmin[4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) wmin[wv] = dte;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    blockmin[blockIdx.x] = fmin(fmin(wmin[0], wmin[1]), fmin(wmin[2], wmin[3]));
+}
+
+// final reduction of the block minima by one workgroup; applies the CFL scaling
+// dt = min * cfl/(2p+1) (src/Inciter/DG.cpp:1404-1418) and the cap to `tleft`
+__global__ __launch_bounds__(256) void k_dt_final(const double* __restrict__ blockmin, int n,
+                                                  double scale, double tleft,
+                                                  double* __restrict__ out_raw,
+                                                  double* __restrict__ out_dt)
+{
+  double v = DBL_MAX;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) v = fmin(v, blockmin[i]);
+  for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_down(v, off, 64));
+  __shared__ double wmin[4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) wmin[wv] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double mn = fmin(fmin(wmin[0], wmin[1]), fmin(wmin[2], wmin[3]));
+    out_raw[0] = mn;
+    out_dt[0] = fmin(mn * scale, tleft);
+  }
+}
+
+// ------------------------------------------------------------- RK update
+// src/Inciter/DG.cpp:39-40,1478-1488 with L = vol*massfac[k] (Mass.cpp:25-73)
+// recomputed instead of streamed.  One lane per (plane, element).
+template <int NDOF>
+__global__ __launch_bounds__(256) void k_rk(DevMesh m, double a, double b,
+                                            const double* __restrict__ dt,
+                                            const double* __restrict__ Un,
+                                            const double* __restrict__ R, double* __restrict__ U)
+{
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= m.nie) return;
+  constexpr double imf[10] = { 1.0, 10.0, 10.0 / 3.0, 5.0 / 3.0, 35.0, 21.0, 14.0, 7.0,
+                               14.0 / 3.0, 7.0 / 3.0 };
+  const double dtv = dt[0] / m.vol[e];
+#pragma unroll
+  for (int c = 0; c < NCOMP; ++c)
+#pragma unroll
+    for (int k = 0; k < NDOF; ++k) {
+      const size_t i = (size_t)(c * NDOF + k) * m.stride + e;
+      U[i] = a * Un[i] + b * (U[i] + dtv * imf[k] * R[i]);
+    }
+}
+
+// ------------------------------------------------------------- setup ops
+// tk::mass, src/PDE/Integrate/Mass.cpp:25-73 (written straight into the
+// caller's AoS layout on the host side; here SoA planes for all ne rows)
+template <int NDOF>
+__global__ void k_mass(DevMesh m, double* __restrict__ L)
+{
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= m.ne) return;
+  const double vol = m.vol[e];
+  const double f[10] = { vol, vol / 10.0, vol * 3.0 / 10.0, vol * 3.0 / 5.0, vol / 35.0,
+                         vol / 21.0, vol / 14.0, vol / 7.0, vol * 3.0 / 14.0, vol * 3.0 / 7.0 };
+#pragma unroll
+  for (int c = 0; c < NCOMP; ++c)
+#pragma unroll
+    for (int k = 0; k < NDOF; ++k) L[(size_t)(c * NDOF + k) * m.stride + e] = f[k];
+}
+
+// tk::initialize, src/PDE/Integrate/Initialize.cpp:29-201 (interior tets)
+template <int NDOF>
+__global__ __launch_bounds__(256) void k_init(DevMesh m, Phys ph, double t, double* __restrict__ U)
+{
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= m.nie) return;
+  const QuadTet& Q = c_qinit[order_index<NDOF>()];
+  ElemGeom g;
+  load_geom(m, e, g);
+  const double vol = m.vol[e];
+  double acc[NCOMP][NDOF];
+#pragma unroll
+  for (int c = 0; c < NCOMP; ++c)
+#pragma unroll
+    for (int k = 0; k < NDOF; ++k) acc[c][k] = 0.0;
+#pragma unroll 1
+  for (int ig = 0; ig < Q.ng; ++ig) {
+    const double xi = Q.c[ig][0], eta = Q.c[ig][1], zeta = Q.c[ig][2];
+    const double w0 = 1.0 - xi - eta - zeta;
+    double P[3], s[NCOMP], B[NDOF];
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+      P[d] = g.p[0][d] * w0 + g.p[1][d] * xi + g.p[2][d] * eta + g.p[3][d] * zeta;
+    eval_basis<NDOF>(xi, eta, zeta, B);
+    prob_solution(ph, P[0], P[1], P[2], t, s);
+    const double wt = Q.w[ig] * vol;
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c) {
+      acc[c][0] += wt * s[c];
+#pragma unroll
+      for (int k = 1; k < NDOF; ++k) acc[c][k] += wt * s[c] * B[k];
+    }
+  }
+  const double f[10] = { vol, vol / 10.0, vol * 3.0 / 10.0, vol * 3.0 / 5.0, vol / 35.0,
+                         vol / 21.0, vol / 14.0, vol / 7.0, vol * 3.0 / 14.0, vol * 3.0 / 7.0 };
+#pragma unroll
+  for (int c = 0; c < NCOMP; ++c)
+#pragma unroll
+    for (int k = 0; k < NDOF; ++k) U[(size_t)(c * NDOF + k) * m.stride + e] = acc[c][k] / f[k];
+}
+
+// ElemDiagnostics::compute_diag, src/Inciter/ElemDiagnostics.cpp:116-215.
+// Per-block partial sums (deterministic two-pass reduction): 15 doubles/block.
+template <int NDOF>
+__global__ __launch_bounds__(256) void k_diag(DevMesh m, Phys ph, double t_new,
+                                              const double* __restrict__ U,
+                                              double* __restrict__ part)
+{
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  double v[15];
+#pragma unroll
+  for (int i = 0; i < 15; ++i) v[i] = 0.0;
+  if (e < m.nie) {
+    const QuadTet& Q = c_qdiag[order_index<NDOF>()];
+    ElemGeom g;
+    load_geom(m, e, g);
+    const double vol = m.vol[e];
+#pragma unroll 1
+    for (int ig = 0; ig < Q.ng; ++ig) {
+      const double xi = Q.c[ig][0], eta = Q.c[ig][1], zeta = Q.c[ig][2];
+      const double w0 = 1.0 - xi - eta - zeta;
+      double P[3], s[NCOMP], u[NCOMP], B[NDOF];
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+        P[d] = g.p[0][d] * w0 + g.p[1][d] * xi + g.p[2][d] * eta + g.p[3][d] * zeta;
+      eval_basis<NDOF>(xi, eta, zeta, B);
+      prob_solution(ph, P[0], P[1], P[2], t_new, s);
+      state_gather<NDOF>(U, m.stride, e, B, u);
+      const double wt = Q.w[ig] * vol;
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) {
+        const double d = u[c] - s[c];
+        v[c] += wt * u[c] * u[c];
+        v[5 + c] += wt * d * d;
+        v[10 + c] = fmax(v[10 + c], fabs(d));
+      }
+    }
+  }
+  __shared__ double sh[4][15];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 15; ++i) {
+    double x = v[i];
+    for (int off = 32; off > 0; off >>= 1) {
+      const double y = __shfl_down(x, off, 64);
+      x = (i < 10) ? x + y : fmax(x, y);
+    }
+    if (lane == 0) sh[wv][i] = x;
+  }
+  __syncthreads();
+  if (threadIdx.x < 15) {
+    const int i = threadIdx.x;
+    const double r = (i < 10) ? ((sh[0][i] + sh[1][i]) + (sh[2][i] + sh[3][i]))
+                              : fmax(fmax(sh[0][i], sh[1][i]), fmax(sh[2][i], sh[3][i]));
+    part[(size_t)blockIdx.x * 15 + i] = r;
+  }
+}
+
+__global__ void k_diag_final(const double* __restrict__ part, int nblk, double* __restrict__ out)
+{
+  const int i = threadIdx.x;
+  if (i >= 15) return;
+  double r = 0.0;
+  for (int b = 0; b < nblk; ++b) {
+    const double y = part[(size_t)b * 15 + i];
+    r = (i < 10) ? r + y : fmax(r, y);
+  }
+  out[i] = r;
+}
+
+// ------------------------------------------------- layout transposition
+// host AoS rows (caller's element numbering) <-> device SoA planes.
+// One workgroup moves a 64-element x nprop tile through LDS so that both the
+// AoS side (rows of nprop doubles) and the SoA side (planes) see coalesced
+// accesses whenever device and host numbering coincide (ghost rows, or
+// identity permutations); permuted interior rows gather whole AoS rows.
+__global__ __launch_bounds__(256) void k_aos2soa(const double* __restrict__ aos, int nprop,
+                                                 const int* __restrict__ d2h, int n0, int n1,
+                                                 int stride, double* __restrict__ soa)
+{
+  extern __shared__ double tile[];   // [64][nprop+1]
+  const int base = n0 + blockIdx.x * 64;
+  const int ld = nprop + 1;
+  for (int i = threadIdx.x; i < 64 * nprop; i += blockDim.x) {
+    const int r = i / nprop, p = i - r * nprop;
+    const int d = base + r;
+    if (d < n1) tile[r * ld + p] = aos[(size_t)d2h[d] * nprop + p];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * nprop; i += blockDim.x) {
+    const int p = i >> 6, r = i & 63;
+    const int d = base + r;
+    if (d < n1) soa[(size_t)p * stride + d] = tile[r * ld + p];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_soa2aos(const double* __restrict__ soa, int nprop,
+                                                 const int* __restrict__ d2h, int n0, int n1,
+                                                 int stride, double* __restrict__ aos)
+{
+  extern __shared__ double tile[];
+  const int base = n0 + blockIdx.x * 64;
+  const int ld = nprop + 1;
+  for (int i = threadIdx.x; i < 64 * nprop; i += blockDim.x) {
+    const int p = i >> 6, r = i & 63;
+    const int d = base + r;
+    if (d < n1) tile[r * ld + p] = soa[(size_t)p * stride + d];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * nprop; i += blockDim.x) {
+    const int r = i / nprop, p = i - r * nprop;
+    const int d = base + r;
+    if (d < n1) aos[(size_t)d2h[d] * nprop + p] = tile[r * ld + p];
+  }
+}
+
+// copy all planes (rows [0,n)) -- used by the WENO ping-pong
+__global__ void k_copy_planes(const double* __restrict__ src, double* __restrict__ dst,
+                              int nprop, int n, int stride)
+{
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  for (int p = 0; p < nprop; ++p) dst[(size_t)p * stride + e] = src[(size_t)p * stride + e];
+}
+
+// ------------------------------------------------------------- halo
+// DG::next / DG::lim send side (src/Inciter/DG.cpp:1023-1036, 1266-1279):
+// slab row j = U[send_elem[j]] (element-major rows of nprop doubles)
+__global__ void k_halo_pack(const double* __restrict__ U, int nprop, int stride,
+                            const int* __restrict__ send_elem, int nsend,
+                            double* __restrict__ slab)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)nsend * nprop) return;
+  const int j = (int)(i / nprop), p = (int)(i - (size_t)j * nprop);
+  slab[i] = U[(size_t)p * stride + send_elem[j]];
+}
+
+// DG::lim / DG::dt receive side (DG.cpp:1239-1247, 1372-1380): ghost row
+// nie + j = slab row j
+__global__ void k_halo_unpack(const double* __restrict__ slab, int nprop, int stride, int nie,
+                              int nrecv, double* __restrict__ U)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)nrecv * nprop) return;
+  const int j = (int)(i / nprop), p = (int)(i - (size_t)j * nprop);
+  U[(size_t)p * stride + nie + j] = slab[i];
+}
+
+// ================================================================ launchers
+
+#define QDG_DISPATCH_NDOF(ndof, CALL)          \
+  do {                                          \
+    if ((ndof) == 1) { constexpr int N = 1; CALL; }       \
+    else if ((ndof) == 4) { constexpr int N = 4; CALL; }  \
+    else { constexpr int N = 10; CALL; }                  \
+  } while (0)
+
+static inline int nblk(int n, int b) { return (n + b - 1) / b; }
+
+hipError_t upload_tables(const Tables<1>& t1, const Tables<4>& t4, const Tables<10>& t10,
+                         const QuadTet* qinit, const QuadTet* qdiag)
+{
+  hipError_t e;
+  if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_tab1), &t1, sizeof(t1))) != hipSuccess) return e;
+  if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_tab4), &t4, sizeof(t4))) != hipSuccess) return e;
+  if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_tab10), &t10, sizeof(t10))) != hipSuccess) return e;
+  if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_qinit), qinit, 3 * sizeof(QuadTet))) != hipSuccess) return e;
+  if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_qdiag), qdiag, 3 * sizeof(QuadTet))) != hipSuccess) return e;
+  return hipSuccess;
+}
+
+void launch_rhs(int ndof, const DevMesh& m, const Phys& ph, double t, const double* U, double* R,
+                hipStream_t s)
+{
+  if (m.nie == 0) return;
+  QDG_DISPATCH_NDOF(ndof, (k_rhs<N><<<nblk(m.nie, 256), 256, 0, s>>>(m, ph, t, U, R)));
+}
+
+void launch_superbee(int ndof, const DevMesh& m, double* U, hipStream_t s)
+{
+  if (m.nie == 0 || ndof == 1) return;
+  QDG_DISPATCH_NDOF(ndof, (k_superbee<N><<<nblk(m.nie, 256), 256, 0, s>>>(m, U)));
+}
+
+void launch_weno(int ndof, const DevMesh& m, double cweight, const double* Uin, double* Uout,
+                 hipStream_t s)
+{
+  if (m.nie == 0 || ndof == 1) return;
+  QDG_DISPATCH_NDOF(ndof, (k_weno<N><<<nblk(m.nie, 256), 256, 0, s>>>(m, cweight, Uin, Uout)));
+}
+
+void launch_copy_planes(const double* src, double* dst, int nprop, int n, int stride, hipStream_t s)
+{
+  if (n == 0) return;
+  k_copy_planes<<<nblk(n, 256), 256, 0, s>>>(src, dst, nprop, n, stride);
+}
+
+int dt_blocks(const DevMesh& m) { return nblk(m.nie, 256); }
+
+void launch_dt(int ndof, const DevMesh& m, const Phys& ph, const double* U, double* blockmin,
+               double scale, double tleft, double* out_raw, double* out_dt, hipStream_t s)
+{
+  const int nb = dt_blocks(m);
+  if (nb > 0)
+    QDG_DISPATCH_NDOF(ndof, (k_dt<N><<<nb, 256, 0, s>>>(m, ph, U, blockmin)));
+  k_dt_final<<<1, 256, 0, s>>>(blockmin, nb, scale, tleft, out_raw, out_dt);
+}
+
+void launch_rk(int ndof, const DevMesh& m, double a, double b, const double* dt, const double* Un,
+               const double* R, double* U, hipStream_t s)
+{
+  if (m.nie == 0) return;
+  QDG_DISPATCH_NDOF(ndof, (k_rk<N><<<nblk(m.nie, 256), 256, 0, s>>>(m, a, b, dt, Un, R, U)));
+}
+
+void launch_mass(int ndof, const DevMesh& m, double* L, hipStream_t s)
+{
+  if (m.ne == 0) return;
+  QDG_DISPATCH_NDOF(ndof, (k_mass<N><<<nblk(m.ne, 256), 256, 0, s>>>(m, L)));
+}
+
+void launch_init(int ndof, const DevMesh& m, const Phys& ph, double t, double* U, hipStream_t s)
+{
+  if (m.nie == 0) return;
+  QDG_DISPATCH_NDOF(ndof, (k_init<N><<<nblk(m.nie, 256), 256, 0, s>>>(m, ph, t, U)));
+}
+
+void launch_diag(int ndof, const DevMesh& m, const Phys& ph, double t_new, const double* U,
+                 double* part, double* out, hipStream_t s)
+{
+  const int nb = nblk(m.nie, 256);
+  if (nb > 0)
+    QDG_DISPATCH_NDOF(ndof, (k_diag<N><<<nb, 256, 0, s>>>(m, ph, t_new, U, part)));
+  k_diag_final<<<1, 64, 0, s>>>(part, nb, out);
+}
+
+void launch_aos2soa(const double* aos, int nprop, const int* d2h, int n0, int n1, int stride,
+                    double* soa, hipStream_t s)
+{
+  if (n1 <= n0) return;
+  const size_t lds = (size_t)64 * (nprop + 1) * sizeof(double);
+  k_aos2soa<<<nblk(n1 - n0, 64), 256, lds, s>>>(aos, nprop, d2h, n0, n1, stride, soa);
+}
+
+void launch_soa2aos(const double* soa, int nprop, const int* d2h, int n0, int n1, int stride,
+                    double* aos, hipStream_t s)
+{
+  if (n1 <= n0) return;
+  const size_t lds = (size_t)64 * (nprop + 1) * sizeof(double);
+  k_soa2aos<<<nblk(n1 - n0, 64), 256, lds, s>>>(soa, nprop, d2h, n0, n1, stride, aos);
+}
+
+void launch_halo_pack(const double* U, int nprop, int stride, const int* send_elem, int nsend,
+                      double* slab, hipStream_t s)
+{
+  if (nsend == 0) return;
+  const size_t n = (size_t)nsend * nprop;
+  k_halo_pack<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(U, nprop, stride, send_elem, nsend, slab);
+}
+
+void launch_halo_unpack(const double* slab, int nprop, int stride, int nie, int nrecv, double* U,
+                        hipStream_t s)
+{
+  if (nrecv == 0) return;
+  const size_t n = (size_t)nrecv * nprop;
+  k_halo_unpack<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(slab, nprop, stride, nie, nrecv, U);
+}
+
+}  // namespace qdg

@@ -1,0 +1,37 @@
+// qdg_kernels.hpp -- host-callable launchers of the gfx950 kernels
+// (definitions in qdg_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "qdg_device.hpp"
+
+namespace qdg {
+
+hipError_t upload_tables(const Tables<1>& t1, const Tables<4>& t4, const Tables<10>& t10,
+                         const QuadTet* qinit, const QuadTet* qdiag);
+
+void launch_rhs(int ndof, const DevMesh& m, const Phys& ph, double t, const double* U, double* R,
+                hipStream_t s);
+void launch_superbee(int ndof, const DevMesh& m, double* U, hipStream_t s);
+void launch_weno(int ndof, const DevMesh& m, double cweight, const double* Uin, double* Uout,
+                 hipStream_t s);
+void launch_copy_planes(const double* src, double* dst, int nprop, int n, int stride,
+                        hipStream_t s);
+int dt_blocks(const DevMesh& m);
+void launch_dt(int ndof, const DevMesh& m, const Phys& ph, const double* U, double* blockmin,
+               double scale, double tleft, double* out_raw, double* out_dt, hipStream_t s);
+void launch_rk(int ndof, const DevMesh& m, double a, double b, const double* dt, const double* Un,
+               const double* R, double* U, hipStream_t s);
+void launch_mass(int ndof, const DevMesh& m, double* L, hipStream_t s);
+void launch_init(int ndof, const DevMesh& m, const Phys& ph, double t, double* U, hipStream_t s);
+void launch_diag(int ndof, const DevMesh& m, const Phys& ph, double t_new, const double* U,
+                 double* part, double* out, hipStream_t s);
+void launch_aos2soa(const double* aos, int nprop, const int* d2h, int n0, int n1, int stride,
+                    double* soa, hipStream_t s);
+void launch_soa2aos(const double* soa, int nprop, const int* d2h, int n0, int n1, int stride,
+                    double* aos, hipStream_t s);
+void launch_halo_pack(const double* U, int nprop, int stride, const int* send_elem, int nsend,
+                      double* slab, hipStream_t s);
+void launch_halo_unpack(const double* slab, int nprop, int stride, int nie, int nrecv, double* U,
+                        hipStream_t s);
+
+}  // namespace qdg
