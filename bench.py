@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""bench.py -- DG-P1 CompFlow element-updates/s on MI355X (BASELINE.json metric).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--nx NX]
+
+Workload (config.workload): BASELINE.json configs[1] -- CompFlow Euler Sod
+shock tube, DG-P1 (dgp1), HLLC, Superbee limiter, CFL 0.3, on a synthetic
+unstructured Kuhn-tet box of NX^3 hexes PER GPU (default 55 -> 998,250 tets),
+extrapolate on the x faces, symmetry elsewhere.  A "step" is one SSP-RK3 time
+step of the reference's loop: 3 x (halo, limiter, halo, [stage 0: CFL dt +
+min-reduce], RHS, RK update), all on device-resident fields.  One
+element-update = one tet through one RK stage's RHS evaluation, so
+value = tets * 3 * K / t.  N > 1: one process per GPU (torch.distributed,
+backend nccl = RCCL), block decomposition with one-layer ghost halo exchanged
+point-to-point, weak scaling (fixed tets per GPU).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(budget_s=12.0):
+    """The CPU oracle (plain-C restatement of the reference's loops, 1 core)
+    timed on a bounded sample of the same workload."""
+    import numpy as np
+    from oracle import oracle as O
+    from quinoa_amd import meshgen
+    n = 24
+    ch = meshgen.kuhn_box(n, n, n)
+    om = O.OracleMesh(ch["coord"], ch["inpoel"], ch["sidesets"])
+    cfg = O.make_cfg(4, flux="hllc", limiter="superbeep1", problem="sod_shocktube", gamma=1.4)
+    orc = O.Oracle(om, cfg, bc_sym=[3, 4, 5, 6], bc_extrapolate=[1, 2])
+    Lm = orc.lhs()
+    U = orc.initialize(Lm, 0.0)
+    work = (np.zeros_like(U), np.zeros(om.nelem * orc.npropr))
+    orc.step(0.0, U, Lm, cfl=0.3, work=work)          # warm-up
+    t0, steps = time.perf_counter(), 0
+    while time.perf_counter() - t0 < budget_s:
+        orc.step(0.0, U, Lm, cfl=0.3, work=work)
+        steps += 1
+    el = time.perf_counter() - t0
+    return {"value": om.nelem * 3 * steps / el / 1e6, "unit": "M element-updates/s",
+            "cores": 1, "kind": "port",
+            "sample": "oracle/dg_oracle.c, Sod DG-P1+Superbee CFL 0.3, %d-tet Kuhn box, %d full "
+                      "RK3 steps in %.1f s" % (om.nelem, steps, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--nx", type=int, default=55, help="hexes per direction PER GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    import numpy as np
+    import torch
+    from quinoa_amd import capi, dg, dgmesh, meshgen
+
+    comm = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        comm = dg.TorchComm()
+
+    # ---- synthetic mesh chunk of this rank (setup, untimed) ---------------
+    parts = meshgen.parts_for(world)
+    nx = args.nx
+    ch = meshgen.kuhn_box_chunk(nx * parts[0], nx * parts[1], nx * parts[2],
+                                lengths=(float(parts[0]), float(parts[1]), float(parts[2])),
+                                parts=parts, rank=rank)
+    chunk = dgmesh.build_chunk(ch["coord"], ch["inpoel"], ch["nielem"], ch["sidesets"])
+    ctx = capi.Context(4, flux="hllc", limiter="superbeep1", problem="sod_shocktube", gamma=1.4,
+                       cfl=0.3, bc_extrapolate=[1, 2], bc_sym=[3, 4, 5, 6], device=local_rank)
+    mesh = dgmesh.upload(ctx, chunk)
+    drv = dg.DGDriver(ctx, mesh, ch["nbr_rank"], ch["send_lists"], ch["recv_counts"], comm)
+    mesh.state_initialize(0.0)
+
+    def sync():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+
+    for _ in range(args.warmup):
+        drv.step(0.0)
+    sync()
+    mesh.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        drv.step(0.0)
+    sync()
+    el = time.perf_counter() - t0
+    nl, ms = mesh.profile_read()
+    mesh.profile_enable(False)
+    dt_last = drv.dt_taken()
+    if not (dt_last > 0.0 and np.isfinite(dt_last)):
+        raise SystemExit("invalid run: dt = %r" % dt_last)
+
+    ntet = chunk.nielem
+    if world > 1:
+        tt = torch.tensor([el, float(ntet)], dtype=torch.float64, device="cuda")
+        mx = tt.clone(); torch.distributed.all_reduce(mx, op=torch.distributed.ReduceOp.MAX)
+        sm = tt.clone(); torch.distributed.all_reduce(sm, op=torch.distributed.ReduceOp.SUM)
+        el, ntet = float(mx[0]), int(round(float(sm[1])))
+
+    if rank == 0:
+        avg_ms = ms / max(nl, 1)
+        alg = mesh.rhs_algorithmic_bytes()
+        achieved = alg / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as fh:
+                tj = json.load(fh)
+            if tj.get("nx") == nx and tj.get("n_gpus") == world:
+                traffic = tj.get("hbm_bytes_per_launch")
+        out = {
+            "metric": "M element-updates/sec, DG-P1 CompFlow on unstructured tets",
+            "value": ntet * 3 * args.steps / el / 1e6,
+            "unit": "M element-updates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": el / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "CompFlow Euler Sod shock-tube DG-P1 (dgp1, HLLC, superbeep1, "
+                                   "cfl 0.3), Kuhn-tet box %d^3 hexes per GPU" % nx,
+                       "tets_total": ntet, "tets_per_gpu": chunk.nielem,
+                       "parallelism": "block decomposition %dx%dx%d, ghost-face halo" % parts,
+                       "step": "SSP-RK3 time step = 3 x (halo, limiter, halo, [dt], rhs, update)"},
+            "roofline": {"bound": "hbm", "kernel": "qdg::k_rhs<4>", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "avg_launch_ms": avg_ms, "launches": nl,
+                         "algorithmic_bytes_per_launch": alg},
+            "dt_last": dt_last,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    mesh.close()
+    ctx.close()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -160,8 +160,25 @@ int qdg_halo_setup(qdg_mesh* mesh, size_t nnbr, const int32_t* nbr_rank,
                    const size_t* recv_off);
 int qdg_halo_buffers(qdg_mesh* mesh, void** send_dev, void** recv_dev,
                      size_t* row_bytes);
+/* use caller-owned device memory for the slabs / the dt scalar (e.g. buffers a
+ * communication library registered); sizes as reported by qdg_halo_sizes */
+int qdg_halo_use_buffers(qdg_mesh* mesh, void* send_dev, void* recv_dev);
+int qdg_halo_sizes(qdg_mesh* mesh, size_t* nsend_rows, size_t* nrecv_rows);
+int qdg_stage_dt_use_buffer(qdg_mesh* mesh, void* dt_dev);
 int qdg_halo_pack(qdg_mesh* mesh);     /* U[send list] -> send slab */
 int qdg_halo_unpack(qdg_mesh* mesh);   /* recv slab -> ghost rows of U */
+
+/* -- measurement ---------------------------------------------------------- */
+/* When enabled, every launch of the RHS kernel inside qdg_stage_rhs_update is
+ * bracketed by HIP events on the context's stream (no host sync in the timed
+ * path); qdg_profile_read synchronises and returns the number of launches and
+ * their summed duration since the last read. */
+int qdg_profile_enable(qdg_mesh* mesh, int on);
+int qdg_profile_read(qdg_mesh* mesh, size_t* nlaunch, double* total_ms);
+/* algorithmic bytes of one RHS launch: nielem * (16*5*ndof + 32) + 24*nnode
+ * (read U once, write R once, 8 int32 indices per tet, node coordinates once;
+ * SURVEY.md 8d) */
+int qdg_rhs_algorithmic_bytes(qdg_mesh* mesh, double* bytes);
 
 /* -- host-side mesh-derived data (mirror of FaceData / DerivedData) ------- */
 int qdg_gen_esuel(size_t nelem, const size_t* inpoel, int* esuel);

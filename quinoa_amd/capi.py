@@ -321,6 +321,30 @@ class Mesh:
         _chk(lib().qdg_halo_buffers(self.h, C.byref(a), C.byref(b), C.byref(r)))
         return a.value, b.value, r.value
 
+    def halo_use_buffers(self, send_ptr, recv_ptr):
+        _chk(lib().qdg_halo_use_buffers(self.h, C.c_void_p(send_ptr), C.c_void_p(recv_ptr)))
+
+    def halo_sizes(self):
+        a, b = C.c_size_t(), C.c_size_t()
+        _chk(lib().qdg_halo_sizes(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def stage_dt_use_buffer(self, ptr):
+        _chk(lib().qdg_stage_dt_use_buffer(self.h, C.c_void_p(ptr)))
+
+    def profile_enable(self, on=True):
+        _chk(lib().qdg_profile_enable(self.h, C.c_int(1 if on else 0)))
+
+    def profile_read(self):
+        n, ms = C.c_size_t(), C.c_double()
+        _chk(lib().qdg_profile_read(self.h, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+    def rhs_algorithmic_bytes(self):
+        b = C.c_double()
+        _chk(lib().qdg_rhs_algorithmic_bytes(self.h, C.byref(b)))
+        return b.value
+
     def halo_pack(self):
         _chk(lib().qdg_halo_pack(self.h))
 

@@ -94,6 +94,18 @@ struct qdg_mesh {
   std::vector<size_t> send_off, recv_off;
   DevBuf<int> send_elem;
   DevBuf<double> send_slab, recv_slab;
+  double* send_ptr = nullptr;     // slabs in use (own or caller-provided)
+  double* recv_ptr = nullptr;
+  double* dt_ptr = nullptr;       // dt scalar in use
+  size_t nnode_used = 0;
+  // measurement: event pairs around the RHS kernel
+  bool prof = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+  size_t ev_used = 0;
+  ~qdg_mesh()
+  {
+    for (auto& e : ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  }
 };
 
 // ---------------------------------------------------------------- misc
@@ -407,6 +419,8 @@ extern "C" int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t 
   HIPCHK(m->blockmin.alloc(nblk)); HIPCHK(m->dtraw.alloc(1)); HIPCHK(m->dtdev.alloc(1));
   HIPCHK(m->diagpart.alloc(nblk * 15)); HIPCHK(m->diagout.alloc(15));
   m->Ucur = m->U.p; m->Ualt = m->W.p;
+  m->dt_ptr = m->dtdev.p;
+  m->nnode_used = (size_t)ncount;
 
   DevMesh& dm = m->dm;
   dm.nie = (int)nie; dm.ne = (int)ne; dm.stride = (int)stride; dm.nnode = ncount; dm.nfac = nfd;
@@ -619,14 +633,14 @@ extern "C" int qdg_stage_dt(qdg_mesh* mesh, double tleft)
     // zero blocks to reduce: the final kernel writes min(DBL_MAX*1, v) = v
     DevMesh none{};
     launch_dt(mesh->ndof, none, ctx->ph, nullptr, mesh->blockmin.p, 1.0, v, mesh->dtraw.p,
-              mesh->dtdev.p, s);
+              mesh->dt_ptr, s);
     HIPCHK(hipGetLastError());
     return 0;
   }
   const double p = (mesh->ndof == 4) ? 1.0 : (mesh->ndof == 10) ? 2.0 : 0.0;
   const double scale = ctx->cfg.cfl / (2.0 * p + 1.0);     // DG.cpp:1404-1418
   launch_dt(mesh->ndof, mesh->dm, ctx->ph, mesh->Ucur, mesh->blockmin.p, scale, tleft,
-            mesh->dtraw.p, mesh->dtdev.p, s);
+            mesh->dtraw.p, mesh->dt_ptr, s);
   HIPCHK(hipGetLastError());
   return 0;
   QDG_CATCH
@@ -637,7 +651,7 @@ extern "C" int qdg_stage_dt_get(qdg_mesh* mesh, double* dt_host)
   QDG_TRY
   MESH_ENTER("qdg_stage_dt_get");
   if (!dt_host) return fail("qdg_stage_dt_get: null argument");
-  HIPCHK(hipMemcpyAsync(dt_host, mesh->dtdev.p, sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(dt_host, mesh->dt_ptr, sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   return 0;
   QDG_CATCH
@@ -647,7 +661,7 @@ extern "C" int qdg_stage_dt_set(qdg_mesh* mesh, double dt)
 {
   QDG_TRY
   MESH_ENTER("qdg_stage_dt_set");
-  HIPCHK(hipMemcpyAsync(mesh->dtdev.p, &dt, sizeof(double), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(mesh->dt_ptr, &dt, sizeof(double), hipMemcpyHostToDevice, s));
   HIPCHK(hipStreamSynchronize(s));
   return 0;
   QDG_CATCH
@@ -657,7 +671,7 @@ extern "C" int qdg_stage_dt_device_ptr(qdg_mesh* mesh, void** dptr)
 {
   QDG_TRY
   if (!mesh || !dptr) return fail("qdg_stage_dt_device_ptr: null argument");
-  *dptr = mesh->dtdev.p;
+  *dptr = mesh->dt_ptr;
   return 0;
   QDG_CATCH
 }
@@ -671,8 +685,20 @@ extern "C" int qdg_stage_rhs_update(qdg_mesh* mesh, int stage, double t)
   const size_t fsz = (size_t)mesh->nprop * mesh->stride * sizeof(double);
   if (stage == 0)   // m_un = m_u, DG.cpp:1472
     HIPCHK(hipMemcpyAsync(mesh->Un.p, mesh->Ucur, fsz, hipMemcpyDeviceToDevice, s));
+  std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
+  if (mesh->prof) {
+    if (mesh->ev_used == mesh->ev.size()) {
+      hipEvent_t a, b;
+      HIPCHK(hipEventCreate(&a));
+      HIPCHK(hipEventCreate(&b));
+      mesh->ev.emplace_back(a, b);
+    }
+    ev = &mesh->ev[mesh->ev_used++];
+    HIPCHK(hipEventRecord(ev->first, s));
+  }
   launch_rhs(mesh->ndof, mesh->dm, ctx->ph, t, mesh->Ucur, mesh->R.p, s);
-  launch_rk(mesh->ndof, mesh->dm, rk[0][stage], rk[1][stage], mesh->dtdev.p, mesh->Un.p,
+  if (ev) HIPCHK(hipEventRecord(ev->second, s));
+  launch_rk(mesh->ndof, mesh->dm, rk[0][stage], rk[1][stage], mesh->dt_ptr, mesh->Un.p,
             mesh->R.p, mesh->Ucur, s);
   HIPCHK(hipGetLastError());
   return 0;
@@ -740,6 +766,8 @@ extern "C" int qdg_halo_setup(qdg_mesh* mesh, size_t nnbr, const int32_t* nbr_ra
   HIPCHK(mesh->send_elem.upload(se, s));
   HIPCHK(mesh->send_slab.alloc(std::max<size_t>(1, mesh->nsend * mesh->nprop)));
   HIPCHK(mesh->recv_slab.alloc(std::max<size_t>(1, mesh->nrecv * mesh->nprop)));
+  mesh->send_ptr = mesh->send_slab.p;
+  mesh->recv_ptr = mesh->recv_slab.p;
   return 0;
   QDG_CATCH
 }
@@ -748,7 +776,7 @@ extern "C" int qdg_halo_buffers(qdg_mesh* mesh, void** send_dev, void** recv_dev
 {
   QDG_TRY
   if (!mesh || !send_dev || !recv_dev || !row_bytes) return fail("qdg_halo_buffers: null argument");
-  *send_dev = mesh->send_slab.p; *recv_dev = mesh->recv_slab.p;
+  *send_dev = mesh->send_ptr; *recv_dev = mesh->recv_ptr;
   *row_bytes = (size_t)mesh->nprop * sizeof(double);
   return 0;
   QDG_CATCH
@@ -759,7 +787,7 @@ extern "C" int qdg_halo_pack(qdg_mesh* mesh)
   QDG_TRY
   MESH_ENTER("qdg_halo_pack");
   launch_halo_pack(mesh->Ucur, mesh->nprop, (int)mesh->stride, mesh->send_elem.p, (int)mesh->nsend,
-                   mesh->send_slab.p, s);
+                   mesh->send_ptr, s);
   HIPCHK(hipGetLastError());
   return 0;
   QDG_CATCH
@@ -769,9 +797,79 @@ extern "C" int qdg_halo_unpack(qdg_mesh* mesh)
 {
   QDG_TRY
   MESH_ENTER("qdg_halo_unpack");
-  launch_halo_unpack(mesh->recv_slab.p, mesh->nprop, (int)mesh->stride, (int)mesh->nie,
+  launch_halo_unpack(mesh->recv_ptr, mesh->nprop, (int)mesh->stride, (int)mesh->nie,
                      (int)mesh->nrecv, mesh->Ucur, s);
   HIPCHK(hipGetLastError());
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_halo_use_buffers(qdg_mesh* mesh, void* send_dev, void* recv_dev)
+{
+  QDG_TRY
+  if (!mesh) return fail("qdg_halo_use_buffers: null mesh");
+  if ((mesh->nsend && !send_dev) || (mesh->nrecv && !recv_dev))
+    return fail("qdg_halo_use_buffers: null buffer");
+  mesh->send_ptr = (double*)send_dev;
+  mesh->recv_ptr = (double*)recv_dev;
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_halo_sizes(qdg_mesh* mesh, size_t* nsend_rows, size_t* nrecv_rows)
+{
+  QDG_TRY
+  if (!mesh || !nsend_rows || !nrecv_rows) return fail("qdg_halo_sizes: null argument");
+  *nsend_rows = mesh->nsend; *nrecv_rows = mesh->nrecv;
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_stage_dt_use_buffer(qdg_mesh* mesh, void* dt_dev)
+{
+  QDG_TRY
+  if (!mesh || !dt_dev) return fail("qdg_stage_dt_use_buffer: null argument");
+  mesh->dt_ptr = (double*)dt_dev;
+  return 0;
+  QDG_CATCH
+}
+
+// ---------------------------------------------------------------- measurement
+
+extern "C" int qdg_profile_enable(qdg_mesh* mesh, int on)
+{
+  QDG_TRY
+  if (!mesh) return fail("qdg_profile_enable: null mesh");
+  mesh->prof = on != 0;
+  mesh->ev_used = 0;
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_profile_read(qdg_mesh* mesh, size_t* nlaunch, double* total_ms)
+{
+  QDG_TRY
+  MESH_ENTER("qdg_profile_read");
+  if (!nlaunch || !total_ms) return fail("qdg_profile_read: null argument");
+  HIPCHK(hipStreamSynchronize(s));
+  double tot = 0.0;
+  for (size_t i = 0; i < mesh->ev_used; ++i) {
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, mesh->ev[i].first, mesh->ev[i].second));
+    tot += ms;
+  }
+  *nlaunch = mesh->ev_used;
+  *total_ms = tot;
+  mesh->ev_used = 0;
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_rhs_algorithmic_bytes(qdg_mesh* mesh, double* bytes)
+{
+  QDG_TRY
+  if (!mesh || !bytes) return fail("qdg_rhs_algorithmic_bytes: null argument");
+  *bytes = (double)mesh->nie * (16.0 * NCOMP * mesh->ndof + 32.0) + 24.0 * (double)mesh->nnode_used;
   return 0;
   QDG_CATCH
 }

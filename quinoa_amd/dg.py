@@ -1,0 +1,116 @@
+"""Time loop of one DG mesh chunk on the device-resident path.
+
+Mirror of the `DG` chare's per-stage sequence (src/Inciter/DG.cpp and dg.ci:57-70)
+
+    next   : send own boundary-adjacent solution      (DG.cpp:1009-1039)  -> exchange()
+    lim    : ghosts <- received, limiter, send limited (DG.cpp:1229-1282)  -> stage_limit(), exchange()
+    dt     : ghosts <- received, CFL dt, min-reduce    (DG.cpp:1360-1430)  -> stage_dt(), allreduce_min
+    solve  : Un=U (stage 0), rhs, SSP-RK3 update       (DG.cpp:1432-1508)  -> stage_rhs_update()
+
+with the Charm++ messages replaced by point-to-point sends between the ranks of
+one node (RCCL over xGMI when the backend is "nccl") and the `contribute(min)`
+by an all-reduce of one double that stays on the device.  The fields never
+leave HBM.  One process drives one GPU.
+"""
+import numpy as np
+
+
+class SerialComm:
+    """single chunk: nothing to exchange"""
+    rank, size, backend = 0, 1, "none"
+
+    def sendrecv(self, drv):
+        pass
+
+    def allreduce_min(self, drv):
+        pass
+
+
+class TorchComm:
+    """torch.distributed transport.  backend "nccl" (= RCCL on ROCm): device
+    slabs are sent directly, grouped per exchange; backend "gloo": slabs are
+    staged through the host (CPU tests, or several ranks sharing one GPU)."""
+
+    def __init__(self):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.rank, self.size = dist.get_rank(), dist.get_world_size()
+        self.backend = dist.get_backend()
+
+    def sendrecv(self, drv):
+        dist, torch = self.dist, self.torch
+        ops, keep = [], []
+        for i, q in enumerate(drv.nbr_rank):
+            s0, s1 = drv.send_off[i] * drv.nprop, drv.send_off[i + 1] * drv.nprop
+            r0, r1 = drv.recv_off[i] * drv.nprop, drv.recv_off[i + 1] * drv.nprop
+            if self.backend == "nccl":
+                sb, rb = drv.send_slab[s0:s1], drv.recv_slab[r0:r1]
+            else:
+                sb = drv.send_slab[s0:s1].cpu()
+                rb = torch.empty(r1 - r0, dtype=torch.float64)
+                keep.append((rb, r0, r1))
+            ops.append(dist.P2POp(dist.isend, sb, q))
+            ops.append(dist.P2POp(dist.irecv, rb, q))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        for rb, r0, r1 in keep:
+            drv.recv_slab[r0:r1].copy_(rb)
+
+    def allreduce_min(self, drv):
+        dist = self.dist
+        if self.backend == "nccl":
+            dist.all_reduce(drv.dt_buf, op=dist.ReduceOp.MIN)
+        else:
+            h = drv.dt_buf.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.MIN)
+            drv.dt_buf.copy_(h)
+
+
+class DGDriver:
+    def __init__(self, ctx, mesh, nbr_rank=(), send_lists=(), recv_counts=(), comm=None):
+        self.ctx, self.mesh = ctx, mesh
+        self.comm = comm or SerialComm()
+        self.nprop = mesh.nprop
+        self.nbr_rank = list(nbr_rank)
+        self.limiter_active = ctx.cfg.limiter != 0 and ctx.ndof > 1
+        self.send_slab = self.recv_slab = self.dt_buf = None
+        if self.comm.size > 1:
+            torch = self.comm.torch
+            dev = torch.device("cuda", torch.cuda.current_device())
+            mesh.halo_setup(self.nbr_rank, send_lists, recv_counts)
+            self.send_off, self.recv_off = mesh.send_off, mesh.recv_off
+            ns, nr = mesh.halo_sizes()
+            # torch owns the slabs and the dt scalar so that the communication
+            # library sees ordinary device tensors; the kernels write into them
+            self.send_slab = torch.zeros(max(1, ns * self.nprop), dtype=torch.float64, device=dev)
+            self.recv_slab = torch.zeros(max(1, nr * self.nprop), dtype=torch.float64, device=dev)
+            self.dt_buf = torch.zeros(1, dtype=torch.float64, device=dev)
+            mesh.halo_use_buffers(self.send_slab.data_ptr(), self.recv_slab.data_ptr())
+            mesh.stage_dt_use_buffer(self.dt_buf.data_ptr())
+            # all kernels and all communication on torch's current stream
+            ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def exchange(self):
+        if self.comm.size == 1 or not self.nbr_rank:
+            return
+        self.mesh.halo_pack()
+        self.comm.sendrecv(self)
+        self.mesh.halo_unpack()
+
+    def step(self, t, tleft=1e300):
+        m = self.mesh
+        for stage in range(3):
+            self.exchange()                      # comsol
+            m.stage_limit()
+            if self.limiter_active:
+                self.exchange()                  # comlim (a no-op copy without a limiter)
+            if stage == 0:
+                m.stage_dt(tleft)
+                if self.comm.size > 1:
+                    self.comm.allreduce_min(self)
+            m.stage_rhs_update(stage, t)
+
+    def dt_taken(self):
+        return self.mesh.stage_dt_get()

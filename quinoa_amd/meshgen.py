@@ -58,6 +58,14 @@ def _block_ranges(n, p):
     return [(edges[i], edges[i + 1]) for i in range(p)]
 
 
+def _hex_tets(I, J, K, npx, npy):
+    """global node ids [n*6,4] of the Kuhn tets of hexes (I,J,K)"""
+    gi = I[:, None, None] + _KUHN[None, :, :, 0]
+    gj = J[:, None, None] + _KUHN[None, :, :, 1]
+    gk = K[:, None, None] + _KUHN[None, :, :, 2]
+    return (gi + npx * (gj + npy * gk)).reshape(-1, 4)
+
+
 def kuhn_box_chunk(nx, ny, nz, lengths=(1.0, 1.0, 1.0), parts=(1, 1, 1), rank=0,
                    jitter=0.2, seed=12345, shuffle_seed=67890):
     """Return one chunk of the box mesh as a dict:
@@ -71,89 +79,94 @@ def kuhn_box_chunk(nx, ny, nz, lengths=(1.0, 1.0, 1.0), parts=(1, 1, 1), rank=0,
     nranks = px * py * pz
     assert 0 <= rank < nranks
     rx, ry, rz = rank % px, (rank // px) % py, rank // (px * py)
-    (i0, i1), (j0, j1), (k0, k1) = _block_ranges(nx, px)[rx], _block_ranges(ny, py)[ry], \
-        _block_ranges(nz, pz)[rz]
-    # extended hex range: one layer around the owned block, clipped
+    bx, by, bz = _block_ranges(nx, px), _block_ranges(ny, py), _block_ranges(nz, pz)
+    (i0, i1), (j0, j1), (k0, k1) = bx[rx], by[ry], bz[rz]
+    npx, npy = nx + 1, ny + 1
+    lpofa = np.array([[1, 2, 3], [2, 0, 3], [3, 0, 1], [0, 2, 1]])
+
+    # ---- owned tets (random local order emulates an unstructured input) ----
+    I, J, K = np.meshgrid(np.arange(i0, i1), np.arange(j0, j1), np.arange(k0, k1), indexing="ij")
+    I, J, K = I.ravel(), J.ravel(), K.ravel()
+    own_gnode = _hex_tets(I, J, K, npx, npy)
+    own_gid = ((I + nx * (J + ny * K))[:, None] * 6 + np.arange(6)[None, :]).reshape(-1)
+    surf = np.repeat((I == i0) | (I == i1 - 1) | (J == j0) | (J == j1 - 1) | (K == k0) | (K == k1 - 1), 6)
+    nielem = own_gnode.shape[0]
+    perm = np.random.default_rng(shuffle_seed + 7919 * rank).permutation(nielem)
+    own_gnode, own_gid, surf = own_gnode[perm], own_gid[perm], surf[perm]
+
+    # ---- halo hexes: one layer around the block, clipped to the domain -----
     ei0, ei1 = max(i0 - 1, 0), min(i1 + 1, nx)
     ej0, ej1 = max(j0 - 1, 0), min(j1 + 1, ny)
     ek0, ek1 = max(k0 - 1, 0), min(k1 + 1, nz)
-    I, J, K = np.meshgrid(np.arange(ei0, ei1), np.arange(ej0, ej1), np.arange(ek0, ek1),
-                          indexing="ij")
-    I, J, K = I.ravel(), J.ravel(), K.ravel()
-    owned_hex = (I >= i0) & (I < i1) & (J >= j0) & (J < j1) & (K >= k0) & (K < k1)
+    nbr_rank, send_lists, recv_counts = [], [], []
+    gho_gnode = np.zeros((0, 4), dtype=np.int64)
+    gho_gid = np.zeros(0, dtype=np.int64)
+    if nranks > 1:
+        HI, HJ, HK = np.meshgrid(np.arange(ei0, ei1), np.arange(ej0, ej1), np.arange(ek0, ek1),
+                                 indexing="ij")
+        HI, HJ, HK = HI.ravel(), HJ.ravel(), HK.ravel()
+        halo = ~((HI >= i0) & (HI < i1) & (HJ >= j0) & (HJ < j1) & (HK >= k0) & (HK < k1))
+        HI, HJ, HK = HI[halo], HJ[halo], HK[halo]
 
-    def owner_of(i, j, k):
-        def blk(v, n, p):
-            # inverse of _block_ranges: largest b with (n*b)//p <= v
-            b = np.minimum((v * p + p - 1) // n, p - 1)
-            lo = (n * b) // p
-            b = np.where(lo > v, b - 1, b)
-            hi = (n * (b + 1)) // p
-            b = np.where(hi <= v, b + 1, b)
+        def blk(v, ranges):
+            b = np.zeros_like(v)
+            for q, (lo, hi) in enumerate(ranges):
+                b[(v >= lo) & (v < hi)] = q
             return b
-        return blk(i, nx, px) + px * (blk(j, ny, py) + py * blk(k, nz, pz))
+        h_owner = np.repeat(blk(HI, bx) + px * (blk(HJ, by) + py * blk(HK, bz)), 6)
+        h_gnode = _hex_tets(HI, HJ, HK, npx, npy)
+        h_gid = ((HI + nx * (HJ + ny * HK))[:, None] * 6 + np.arange(6)[None, :]).reshape(-1)
+        # faces of surface-layer owned tets vs faces of halo tets (sort-based)
+        sidx = np.nonzero(surf)[0]
+        fa = np.sort(own_gnode[sidx][:, lpofa].reshape(-1, 3), axis=1)
+        fb = np.sort(h_gnode[:, lpofa].reshape(-1, 3), axis=1)
+        nn_glob = (nx + 1) * (ny + 1) * (nz + 1)
+        ka = (fa[:, 0] * nn_glob + fa[:, 1]) * nn_glob + fa[:, 2] if nn_glob < 2_000_000 else None
+        if ka is not None:
+            kb = (fb[:, 0] * nn_glob + fb[:, 1]) * nn_glob + fb[:, 2]
+        else:   # avoid int64 overflow on very large meshes: structured keys
+            ka = np.ascontiguousarray(fa).view([("", fa.dtype)] * 3).reshape(-1)
+            kb = np.ascontiguousarray(fb).view([("", fb.dtype)] * 3).reshape(-1)
+        ob = np.argsort(kb, kind="stable")
+        pos = np.searchsorted(kb[ob], ka)
+        pos = np.minimum(pos, len(ob) - 1)
+        hit = kb[ob][pos] == ka
+        pair_own = sidx[np.nonzero(hit)[0] // 4]          # local owned tet ids
+        pair_gho = ob[pos[hit]] // 4                       # halo tet ids
+        gsel = np.unique(pair_gho)
+        order = np.lexsort((h_gid[gsel], h_owner[gsel]))
+        gsel = gsel[order]
+        gho_gnode, gho_gid = h_gnode[gsel], h_gid[gsel]
+        nbr_rank = [int(q) for q in np.unique(h_owner[gsel])]
+        for q in nbr_rank:
+            recv_counts.append(int(np.sum(h_owner[gsel] == q)))
+            cand = np.unique(pair_own[h_owner[pair_gho] == q])
+            send_lists.append(cand[np.argsort(own_gid[cand])].astype(np.int64))
 
-    hex_owner = owner_of(I, J, K)
-    hex_gid = I + nx * (J + ny * K)
-    nh = len(I)
-    # tets of all extended hexes: global node ids
-    npx, npy = nx + 1, ny + 1
-    off = _KUHN                                             # [6][4][3]
-    gi = I[:, None, None] + off[None, :, :, 0]
-    gj = J[:, None, None] + off[None, :, :, 1]
-    gk = K[:, None, None] + off[None, :, :, 2]
-    gnode = (gi + npx * (gj + npy * gk)).reshape(nh * 6, 4)
-    tet_gid = (hex_gid[:, None] * 6 + np.arange(6)[None, :]).reshape(-1)
-    tet_owner = np.repeat(hex_owner, 6)
-    tet_owned = np.repeat(owned_hex, 6)
+    # ---- local nodes: the block's node box + extra ghost nodes, permuted ----
+    bnx, bny, bnz = i1 - i0 + 1, j1 - j0 + 1, k1 - k0 + 1
+    nbox = bnx * bny * bnz
 
-    # face adjacency on the extended set (sort-based)
-    lpofa = np.array([[1, 2, 3], [2, 0, 3], [3, 0, 1], [0, 2, 1]])
-    nt = gnode.shape[0]
-    fn = np.sort(gnode[:, lpofa].reshape(nt * 4, 3), axis=1)
-    order = np.lexsort((fn[:, 2], fn[:, 1], fn[:, 0]))
-    fs = fn[order]
-    same = np.all(fs[1:] == fs[:-1], axis=1)
-    a = order[:-1][same] // 4
-    b = order[1:][same] // 4
-    # ghosts: non-owned tets sharing a face with an owned tet
-    ghost_mask = np.zeros(nt, dtype=bool)
-    ga = tet_owned[a] & ~tet_owned[b]
-    gb = tet_owned[b] & ~tet_owned[a]
-    ghost_mask[b[ga]] = True
-    ghost_mask[a[gb]] = True
-    # send candidates: owned tets adjacent to a tet owned by rank q
-    pair_own = np.concatenate([a[ga], b[gb]])
-    pair_gho = np.concatenate([b[ga], a[gb]])
-
-    own_idx = np.nonzero(tet_owned)[0]
-    # emulate an unstructured input: random local order of the owned tets
-    rng = np.random.default_rng(shuffle_seed + 7919 * rank)
-    own_idx = own_idx[rng.permutation(len(own_idx))]
-    gho_idx = np.nonzero(ghost_mask)[0]
-    # ghosts grouped by owner rank, ascending global id within a rank
-    gorder = np.lexsort((tet_gid[gho_idx], tet_owner[gho_idx]))
-    gho_idx = gho_idx[gorder]
-    nbr_rank = np.unique(tet_owner[gho_idx]).astype(np.int64)
-    recv_counts = [int(np.sum(tet_owner[gho_idx] == q)) for q in nbr_rank]
-
-    sel = np.concatenate([own_idx, gho_idx])
-    nielem, nunk = len(own_idx), len(sel)
-    loc_of = np.full(nt, -1, dtype=np.int64)
-    loc_of[sel] = np.arange(nunk)
-
-    send_lists = []
-    for q in nbr_rank:
-        m = tet_owner[pair_gho] == q
-        cand = np.unique(pair_own[m])
-        cand = cand[np.argsort(tet_gid[cand])]
-        send_lists.append(loc_of[cand])
-
-    # local nodes: unique global ids, randomly permuted
-    g_used, inv = np.unique(gnode[sel].reshape(-1), return_inverse=True)
+    def box_local(g):
+        gi, gj, gk = g % npx, (g // npx) % npy, g // (npx * npy)
+        inside = (gi >= i0) & (gi <= i1) & (gj >= j0) & (gj <= j1) & (gk >= k0) & (gk <= k1)
+        return (gi - i0) + bnx * ((gj - j0) + bny * (gk - k0)), inside
+    own_loc, _ = box_local(own_gnode)
+    bi, bj, bk = np.meshgrid(np.arange(i0, i1 + 1), np.arange(j0, j1 + 1), np.arange(k0, k1 + 1),
+                             indexing="ij")
+    # box_local order: i fastest
+    g_box = (bi + npx * (bj + npy * bk)).transpose(2, 1, 0).reshape(-1)
+    g_used = g_box
+    gho_loc = np.zeros((0, 4), dtype=np.int64)
+    if len(gho_gnode):
+        gl, inside = box_local(gho_gnode)
+        extra, inv = np.unique(gho_gnode[~inside], return_inverse=True)
+        gho_loc = gl.copy()
+        gho_loc[~inside] = nbox + inv
+        g_used = np.concatenate([g_box, extra])
     nn = len(g_used)
     nperm = np.random.default_rng(shuffle_seed + 104729 * rank + 1).permutation(nn)
-    inpoel = nperm[inv].reshape(nunk, 4)
+    inpoel = nperm[np.concatenate([own_loc, gho_loc])]
     ni = g_used % npx
     nj = (g_used // npx) % npy
     nk = g_used // (npx * npy)
@@ -168,20 +181,20 @@ def kuhn_box_chunk(nx, ny, nz, lengths=(1.0, 1.0, 1.0), parts=(1, 1, 1), rank=0,
     coord = np.zeros((nn, 3))
     coord[nperm, 0], coord[nperm, 1], coord[nperm, 2] = cx, cy, cz
 
-    # side sets from the owned tets' faces lying on a domain plane
-    own_nodes = gnode[own_idx]
-    fo = own_nodes[:, lpofa]                                   # [n][4][3] global nodes
+    # ---- side sets: faces of owned surface-layer tets on a domain plane ----
+    sidx = np.nonzero(surf)[0]
+    fo = own_gnode[sidx][:, lpofa]                            # [n][4][3] global nodes
     fi, fj, fk = fo % npx, (fo // npx) % npy, fo // (npx * npy)
+    lfo = inpoel[sidx][:, lpofa]
     sidesets = {}
-    lfo = inpoel[:nielem][:, lpofa]
     for sid, arr, val in ((1, fi, 0), (2, fi, nx), (3, fj, 0), (4, fj, ny), (5, fk, 0), (6, fk, nz)):
         on = np.all(arr == val, axis=2)
         sidesets[sid] = lfo[on].reshape(-1, 3).astype(np.int64)
 
     return {"coord": coord, "inpoel": inpoel.astype(np.int64), "nielem": nielem,
-            "sidesets": sidesets, "gid": tet_gid[sel].astype(np.int64),
-            "nbr_rank": [int(q) for q in nbr_rank], "send_lists": send_lists,
-            "recv_counts": recv_counts, "ntet_global": nx * ny * nz * 6}
+            "sidesets": sidesets, "gid": np.concatenate([own_gid, gho_gid]).astype(np.int64),
+            "nbr_rank": nbr_rank, "send_lists": send_lists, "recv_counts": recv_counts,
+            "ntet_global": nx * ny * nz * 6}
 
 
 def kuhn_box(nx, ny, nz, lengths=(1.0, 1.0, 1.0), **kw):
