@@ -141,6 +141,12 @@ int qdg_stage_dt_get(qdg_mesh* mesh, double* dt_host);  /* sync + read local dt 
 int qdg_stage_dt_set(qdg_mesh* mesh, double dt);        /* reduced dt back */
 int qdg_stage_dt_device_ptr(qdg_mesh* mesh, void** dptr); /* for an in-place device min-reduction */
 int qdg_stage_rhs_update(qdg_mesh* mesh, int stage, double t);
+/* fused form used by qdg_step: the RHS of stage 0 also produces the local time
+ * step (CFL sum taken from the Riemann solver's wave speeds; constant dt when
+ * configured) into the dt scalar, capped to tleft; the caller min-reduces the
+ * scalar across chunks, then calls qdg_stage_update.  Stages 1,2: RHS only. */
+int qdg_stage_rhs_dt(qdg_mesh* mesh, int stage, double t, double tleft);
+int qdg_stage_update(qdg_mesh* mesh, int stage);
 /* whole step on one chunk without ghosts: 3 x (limit, [dt], rhs, update);
  * returns the dt taken (host sync only when dt_taken != NULL) */
 int qdg_step(qdg_mesh* mesh, double t, double tleft, double* dt_taken);

@@ -289,6 +289,12 @@ class Mesh:
     def stage_rhs_update(self, stage, t):
         _chk(lib().qdg_stage_rhs_update(self.h, C.c_int(stage), C.c_double(t)))
 
+    def stage_rhs_dt(self, stage, t, tleft=1e300):
+        _chk(lib().qdg_stage_rhs_dt(self.h, C.c_int(stage), C.c_double(t), C.c_double(tleft)))
+
+    def stage_update(self, stage):
+        _chk(lib().qdg_stage_update(self.h, C.c_int(stage)))
+
     def step(self, t, tleft=1e300, want_dt=True):
         v = C.c_double(0.0)
         _chk(lib().qdg_step(self.h, C.c_double(t), C.c_double(tleft),

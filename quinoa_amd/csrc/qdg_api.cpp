@@ -504,6 +504,24 @@ static int run_limiter(qdg_mesh* mesh, double*& Ucur, double*& Ualt)
   return 0;
 }
 
+// RHS dispatch: DG-P1 runs the specialised kernel (QDG_GENERIC_RHS=1 forces the
+// generic one, for A/B parity runs)
+static bool use_p1_fast(const qdg_mesh* mesh)
+{
+  static const bool generic = std::getenv("QDG_GENERIC_RHS") != nullptr;
+  return mesh->ndof == 4 && !generic;
+}
+
+static void run_rhs(qdg_mesh* mesh, double t, const double* U, double* R)
+{
+  qdg_ctx* ctx = mesh->ctx;
+  if (use_p1_fast(mesh))
+    launch_rhs_p1(mesh->dm, ctx->ph, t, U, R, false, mesh->blockmin.p, 1.0, DBL_MAX,
+                  mesh->dtraw.p, mesh->dt_ptr, ctx->stream);
+  else
+    launch_rhs(mesh->ndof, mesh->dm, ctx->ph, t, U, R, ctx->stream);
+}
+
 // ---------------------------------------------------------------- stateless
 
 extern "C" int qdg_lhs(qdg_mesh* mesh, double* L_aos)
@@ -536,7 +554,7 @@ extern "C" int qdg_rhs(qdg_mesh* mesh, double t, const double* U_aos, double* R_
   if (!U_aos || !R_aos) return fail("qdg_rhs: null U/R");
   double* w = mesh->Ualt;
   if (int rc = host_to_planes(mesh, U_aos, w)) return rc;
-  launch_rhs(mesh->ndof, mesh->dm, ctx->ph, t, w, mesh->R.p, s);
+  run_rhs(mesh, t, w, mesh->R.p);
   HIPCHK(hipGetLastError());
   // ghost rows of R are returned as zero (the reference leaves partial sums
   // there that DG::solve never reads back: ghosts are overwritten by comsol)
@@ -696,10 +714,68 @@ extern "C" int qdg_stage_rhs_update(qdg_mesh* mesh, int stage, double t)
     ev = &mesh->ev[mesh->ev_used++];
     HIPCHK(hipEventRecord(ev->first, s));
   }
-  launch_rhs(mesh->ndof, mesh->dm, ctx->ph, t, mesh->Ucur, mesh->R.p, s);
+  run_rhs(mesh, t, mesh->Ucur, mesh->R.p);
   if (ev) HIPCHK(hipEventRecord(ev->second, s));
   launch_rk(mesh->ndof, mesh->dm, rk[0][stage], rk[1][stage], mesh->dt_ptr, mesh->Un.p,
             mesh->R.p, mesh->Ucur, s);
+  HIPCHK(hipGetLastError());
+  return 0;
+  QDG_CATCH
+}
+
+static int prof_begin(qdg_mesh* mesh, std::pair<hipEvent_t, hipEvent_t>** ev)
+{
+  *ev = nullptr;
+  if (!mesh->prof) return 0;
+  if (mesh->ev_used == mesh->ev.size()) {
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a));
+    HIPCHK(hipEventCreate(&b));
+    mesh->ev.emplace_back(a, b);
+  }
+  *ev = &mesh->ev[mesh->ev_used++];
+  HIPCHK(hipEventRecord((*ev)->first, mesh->ctx->stream));
+  return 0;
+}
+
+extern "C" int qdg_stage_rhs_dt(qdg_mesh* mesh, int stage, double t, double tleft)
+{
+  QDG_TRY
+  MESH_ENTER("qdg_stage_rhs_dt");
+  if (stage < 0 || stage > 2) return fail("qdg_stage_rhs_dt: stage must be 0,1,2");
+  const size_t fsz = (size_t)mesh->nprop * mesh->stride * sizeof(double);
+  if (stage == 0)   // m_un = m_u, DG.cpp:1472
+    HIPCHK(hipMemcpyAsync(mesh->Un.p, mesh->Ucur, fsz, hipMemcpyDeviceToDevice, s));
+  const bool cfl_dt = stage == 0 && !(ctx->cfg.dt > 0.0);
+  if (stage == 0 && !cfl_dt) if (int rc = qdg_stage_dt(mesh, tleft)) return rc;
+  std::pair<hipEvent_t, hipEvent_t>* ev;
+  if (cfl_dt && use_p1_fast(mesh)) {
+    const double scale = ctx->cfg.cfl / 3.0;     // cfl/(2p+1), p = 1 (DG.cpp:1404-1418)
+    if (int rc = prof_begin(mesh, &ev)) return rc;
+    // the event pair brackets the RHS kernel only when it is launched alone;
+    // here it also covers the 1-block dt reduction (~5 us)
+    launch_rhs_p1(mesh->dm, ctx->ph, t, mesh->Ucur, mesh->R.p, true, mesh->blockmin.p, scale,
+                  tleft, mesh->dtraw.p, mesh->dt_ptr, s);
+    if (ev) HIPCHK(hipEventRecord(ev->second, s));
+  } else {
+    if (cfl_dt) if (int rc = qdg_stage_dt(mesh, tleft)) return rc;
+    if (int rc = prof_begin(mesh, &ev)) return rc;
+    run_rhs(mesh, t, mesh->Ucur, mesh->R.p);
+    if (ev) HIPCHK(hipEventRecord(ev->second, s));
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_stage_update(qdg_mesh* mesh, int stage)
+{
+  QDG_TRY
+  MESH_ENTER("qdg_stage_update");
+  if (stage < 0 || stage > 2) return fail("qdg_stage_update: stage must be 0,1,2");
+  static const double rk[2][3] = { { 0.0, 3.0 / 4.0, 1.0 / 3.0 }, { 1.0, 1.0 / 4.0, 2.0 / 3.0 } };
+  launch_rk(mesh->ndof, mesh->dm, rk[0][stage], rk[1][stage], mesh->dt_ptr, mesh->Un.p, mesh->R.p,
+            mesh->Ucur, s);
   HIPCHK(hipGetLastError());
   return 0;
   QDG_CATCH
@@ -714,8 +790,8 @@ extern "C" int qdg_step(qdg_mesh* mesh, double t, double tleft, double* dt_taken
                 "explicitly (qdg_stage_* + qdg_halo_*)");
   for (int stage = 0; stage < 3; ++stage) {
     if (int rc = qdg_stage_limit(mesh)) return rc;
-    if (stage == 0) if (int rc = qdg_stage_dt(mesh, tleft)) return rc;
-    if (int rc = qdg_stage_rhs_update(mesh, stage, t)) return rc;
+    if (int rc = qdg_stage_rhs_dt(mesh, stage, t, tleft)) return rc;
+    if (int rc = qdg_stage_update(mesh, stage)) return rc;
   }
   if (dt_taken) return qdg_stage_dt_get(mesh, dt_taken);
   return 0;

@@ -490,6 +490,278 @@ __global__ __launch_bounds__(256) void k_rhs(DevMesh m, Phys ph, double t,
     for (int k = 0; k < NDOF; ++k) R[(size_t)(c * NDOF + k) * stride + e] = acc[c][k];
 }
 
+// ------------------------------------------------------- fast fp64 helpers
+// 1/x and sqrt(x) from the hardware seeds (v_rcp_f64 / v_rsq_f64) plus Newton
+// steps: ~1 ulp, without the div_scale/div_fixup range handling of the full
+// IEEE expansions (operands here are densities, pressures, wave-speed
+// differences: far from the subnormal/overflow range).  NaN in -> NaN out.
+__device__ __forceinline__ double fast_rcp(double x)
+{
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ double fast_sqrt(double x)
+{
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  g = fma(fma(-g, g, x), h, g);
+  return (x == 0.0) ? 0.0 : g;
+}
+
+// primitive quantities of one side of a face
+struct Prim {
+  double ir, u, v, w, p, a, vn;
+};
+__device__ __forceinline__ void primitives(const Phys& ph, const double* fn, const double* s, Prim& q)
+{
+  q.ir = fast_rcp(s[0]);
+  q.u = s[1] * q.ir; q.v = s[2] * q.ir; q.w = s[3] * q.ir;
+  q.p = eos_pressure(ph, s[0], q.u, q.v, q.w, s[4]);
+  q.a = fast_sqrt(ph.gamma * (q.p + ph.pstiff) * q.ir);
+  q.vn = q.u * fn[0] + q.v * fn[1] + q.w * fn[2];
+}
+
+// HLLC with precomputed primitives (same ladder as flux_hllc above)
+__device__ __forceinline__ void flux_hllc_q(const double* fn, const double* L, const double* R,
+                                            const Prim& ql, const Prim& qr, double* flx)
+{
+  const double rhol = L[0], rhor = R[0];
+  const double rlr = fast_sqrt(rhor * ql.ir);
+  const double irlr1 = fast_rcp(1.0 + rlr);
+  const double vnroe = (qr.vn * rlr + ql.vn) * irlr1;
+  const double aroe = (qr.a * rlr + ql.a) * irlr1;
+  const double Sl = fmin(ql.vn - ql.a, vnroe - aroe);
+  const double Sr = fmax(qr.vn + qr.a, vnroe + aroe);
+  const double ml = rhol * (Sl - ql.vn), mr = rhor * (Sr - qr.vn);
+  const double Sm = (mr * qr.vn - ml * ql.vn + ql.p - qr.p) * fast_rcp(mr - ml);
+  const double pStar = rhol * (ql.vn - Sl) * (ql.vn - Sm) + ql.p;
+  const bool c1 = Sl > 0.0;
+  const bool c2 = !c1 && (Sl <= 0.0) && (Sm > 0.0);
+  const bool c3 = !c1 && !c2 && (Sm <= 0.0) && (Sr >= 0.0);
+  const bool left = c1 || c2;
+  const bool star = c2 || c3;
+  const double S = left ? Sl : Sr;
+  const double vn = left ? ql.vn : qr.vn;
+  const double p = left ? ql.p : qr.p;
+  const double u0 = left ? L[0] : R[0], u1 = left ? L[1] : R[1], u2 = left ? L[2] : R[2],
+               u3 = left ? L[3] : R[3], u4 = left ? L[4] : R[4];
+  // star:  F = U* Sm + (0, p* n, p* Sm),  U* = ((S-vn) U + (0, (p*-p) n, p* Sm - p vn)) / (S-Sm)
+  // plain: F = U vn + (0, p n, p vn)          -> one expression with selected factors
+  const double id = star ? fast_rcp(S - Sm) : 1.0;
+  const double sv = star ? (S - vn) * id * Sm : vn;         // factor on U
+  const double dp = star ? (pStar - p) * id * Sm + pStar : p; // factor on n
+  const double e4 = star ? ((pStar * Sm - p * vn) * id + pStar) * Sm : p * vn;
+  flx[0] = sv * u0;
+  flx[1] = sv * u1 + dp * fn[0];
+  flx[2] = sv * u2 + dp * fn[1];
+  flx[3] = sv * u3 + dp * fn[2];
+  flx[4] = sv * u4 + e4;
+}
+
+__device__ __forceinline__ void flux_lf_q(const double* fn, const double* L, const double* R,
+                                          const Prim& ql, const Prim& qr, double* flx)
+{
+  const double lambda = fmax(ql.a, qr.a) + fmax(fabs(ql.vn), fabs(qr.vn));
+  const double fl[5] = { L[0] * ql.vn, L[1] * ql.vn + ql.p * fn[0], L[2] * ql.vn + ql.p * fn[1],
+                         L[3] * ql.vn + ql.p * fn[2], (L[4] + ql.p) * ql.vn };
+  const double fr[5] = { R[0] * qr.vn, R[1] * qr.vn + qr.p * fn[0], R[2] * qr.vn + qr.p * fn[1],
+                         R[3] * qr.vn + qr.p * fn[2], (R[4] + qr.p) * qr.vn };
+#pragma unroll
+  for (int c = 0; c < 5; ++c) flx[c] = 0.5 * (fl[c] + fr[c] - lambda * (R[c] - L[c]));
+}
+
+// ------------------------------------------------- DG-P1 RHS (headline kernel)
+// Same algorithm as k_rhs<4>, specialised for throughput:
+//  * own DOFs live in registers (one coalesced pass), the neighbour's 20 DOFs
+//    of face lf+1 are gathered while face lf is computed (software prefetch),
+//    so each wave has ~25 independent loads in flight instead of a dependent
+//    chain of 60 gathers per face;
+//  * 1/x and sqrt from hardware seeds + Newton steps;
+//  * dB/dx is constant on a P1 tet: the volume integral accumulates the
+//    quadrature-weighted Euler flux once and contracts it with dB/dx at the end;
+//  * WITH_DT (RK stage 0): the CFL sum of dg::CompFlow::dt
+//    (DGCompFlow.hpp:206-406) is accumulated from the wave speeds the Riemann
+//    solver already has -- the separate dt face loop disappears.
+template <bool WITH_DT>
+__global__ __launch_bounds__(256) void k_rhs_p1(DevMesh m, Phys ph, double t,
+                                                const double* __restrict__ U,
+                                                double* __restrict__ R,
+                                                double* __restrict__ blockmin)
+{
+  constexpr int NDOF = 4, NGF = 3, NGV = 5;
+  const Tables<4>& T = c_tab4;
+  const int stride = m.stride;
+  const int e0 = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = e0 < m.nie;
+  const int e = active ? e0 : 0;
+  double dte = DBL_MAX;
+
+  double u[NCOMP][NDOF], acc[NCOMP][NDOF];
+  load_dofs<NDOF>(U, stride, e, u);
+#pragma unroll
+  for (int c = 0; c < NCOMP; ++c)
+#pragma unroll
+    for (int k = 0; k < NDOF; ++k) acc[c][k] = 0.0;
+
+  const int nb0 = m.nbr[e], nb1 = m.nbr[(size_t)stride + e], nb2 = m.nbr[(size_t)2 * stride + e],
+            nb3 = m.nbr[(size_t)3 * stride + e];
+  ElemGeom g;
+  load_geom(m, e, g);
+  const double vol = m.vol[e];
+  double delt = 0.0;
+
+  double un[NCOMP][NDOF];
+  {
+    const int n = nb0 >= 0 ? nb0 : e;
+    load_dofs<NDOF>(U, stride, n, un);
+  }
+
+#pragma unroll 1
+  for (int lf = 0; lf < 4; ++lf) {
+    const int nb = (lf == 0) ? nb0 : (lf == 1) ? nb1 : (lf == 2) ? nb2 : nb3;
+    const int nbn = (lf == 0) ? nb1 : (lf == 1) ? nb2 : nb3;      // next face (unused for lf==3)
+    const int info = m.finfo[(size_t)lf * stride + e];
+    const int f = m.fid[(size_t)lf * stride + e];
+    const double area = m.farea[f];
+    const double fn[3] = { m.fnx[f], m.fny[f], m.fnz[f] };
+    const bool own_left = (info >> 6) & 1;
+    double cur[NCOMP][NDOF];
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c)
+#pragma unroll
+      for (int k = 0; k < NDOF; ++k) cur[c][k] = un[c][k];
+    if (lf < 3) {   // prefetch the next neighbour while this face is computed
+      const int n = nbn >= 0 ? nbn : e;
+      load_dofs<NDOF>(U, stride, n, un);
+    }
+    if (nb == -1 && !WITH_DT) continue;    // boundary face without a BC: no flux
+#pragma unroll
+    for (int ig = 0; ig < NGF; ++ig) {
+      const double s0 = T.fs[ig][0], s1 = T.fs[ig][1], s2 = T.fs[ig][2];
+      double so[NCOMP], sn[NCOMP], fl[NCOMP];
+      state_from<NDOF>(u, T.fB[lf][ig], so);
+      if (nb >= 0) {
+        double xi, eta, zeta, Bn[NDOF];
+        nbr_ref_coords(info, s0, s1, s2, xi, eta, zeta);
+        eval_basis<NDOF>(xi, eta, zeta, Bn);
+        state_from<NDOF>(cur, Bn, sn);
+      } else {
+        double P[3];
+        face_point(g, lf, s0, s1, s2, P);
+        bc_state(ph, -nb - 1, so, P[0], P[1], P[2], t, fn, sn);
+      }
+      const double* sl = own_left ? so : sn;
+      const double* sr = own_left ? sn : so;
+      double L[NCOMP], Rr[NCOMP];
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) { L[c] = own_left ? so[c] : sn[c]; Rr[c] = own_left ? sn[c] : so[c]; }
+      (void)sl; (void)sr;
+      Prim ql, qr;
+      primitives(ph, fn, L, ql);
+      primitives(ph, fn, Rr, qr);
+      const double wq = T.fw[ig] * area;
+      if (WITH_DT) {
+        // delt += std::max(dSV_l, dSV_r); boundary faces: dSV_r = 0
+        const double dl = wq * (fabs(ql.vn) + ql.a);
+        const double dr = (nb >= 0) ? wq * (fabs(qr.vn) + qr.a) : 0.0;
+        delt += (dl < dr) ? dr : dl;
+      }
+      if (nb == -1) continue;
+      if (ph.flux == 1) flux_lf_q(fn, L, Rr, ql, qr, fl);
+      else flux_hllc_q(fn, L, Rr, ql, qr, fl);
+      const double wt = own_left ? -wq : wq;
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) {
+        const double wf = wt * fl[c];
+        acc[c][0] += wf;
+#pragma unroll
+        for (int k = 1; k < NDOF; ++k) acc[c][k] += wf * T.fB[lf][ig][k];
+      }
+    }
+  }
+
+  // ---- volume integral: dB/dx constant on a P1 tet --------------------------
+  {
+    double ji[3][3];
+    inverse_jacobian(g, ji);
+    double Fs[NCOMP][3];
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c) Fs[c][0] = Fs[c][1] = Fs[c][2] = 0.0;
+#pragma unroll
+    for (int ig = 0; ig < NGV; ++ig) {
+      double s[NCOMP];
+      state_from<NDOF>(u, T.vB[ig], s);
+      const double ir = fast_rcp(s[0]);
+      const double uu = s[1] * ir, vv = s[2] * ir, ww = s[3] * ir;
+      const double p = eos_pressure(ph, s[0], uu, vv, ww, s[4]);
+      const double wg = T.vw[ig];
+      const double h = s[4] + p;
+      Fs[0][0] += wg * s[1];            Fs[0][1] += wg * s[2];            Fs[0][2] += wg * s[3];
+      Fs[1][0] += wg * (s[1] * uu + p); Fs[1][1] += wg * (s[2] * uu);     Fs[1][2] += wg * (s[3] * uu);
+      Fs[2][0] += wg * (s[1] * vv);     Fs[2][1] += wg * (s[2] * vv + p); Fs[2][2] += wg * (s[3] * vv);
+      Fs[3][0] += wg * (s[1] * ww);     Fs[3][1] += wg * (s[2] * ww);     Fs[3][2] += wg * (s[3] * ww + p);
+      Fs[4][0] += wg * (uu * h);        Fs[4][1] += wg * (vv * h);        Fs[4][2] += wg * (ww * h);
+    }
+#pragma unroll
+    for (int k = 1; k < NDOF; ++k) {
+      const double g0 = T.vdB[0][0][k], g1 = T.vdB[0][1][k], g2 = T.vdB[0][2][k];
+      const double dx = vol * (g0 * ji[0][0] + g1 * ji[1][0] + g2 * ji[2][0]);
+      const double dy = vol * (g0 * ji[0][1] + g1 * ji[1][1] + g2 * ji[2][1]);
+      const double dz = vol * (g0 * ji[0][2] + g1 * ji[1][2] + g2 * ji[2][2]);
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) acc[c][k] += Fs[c][0] * dx + Fs[c][1] * dy + Fs[c][2] * dz;
+    }
+  }
+
+  // ---- source integral (manufactured-solution problems only) ----------------
+  if (prob_has_source(ph)) {
+#pragma unroll 1
+    for (int ig = 0; ig < NGV; ++ig) {
+      const double xi = T.vc[ig][0], eta = T.vc[ig][1], zeta = T.vc[ig][2];
+      const double w0 = 1.0 - xi - eta - zeta;
+      double P[3], s[NCOMP];
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+        P[d] = g.p[0][d] * w0 + g.p[1][d] * xi + g.p[2][d] * eta + g.p[3][d] * zeta;
+      prob_src(ph, P[0], P[1], P[2], t, s);
+      const double wt = T.vw[ig] * vol;
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) {
+        const double ws = wt * s[c];
+        acc[c][0] += ws;
+#pragma unroll
+        for (int k = 1; k < NDOF; ++k) acc[c][k] += ws * T.vB[ig][k];
+      }
+    }
+  }
+
+  if (active) {
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c)
+#pragma unroll
+      for (int k = 0; k < NDOF; ++k) R[(size_t)(c * NDOF + k) * stride + e] = acc[c][k];
+  }
+
+  if (WITH_DT) {
+    if (active) dte = vol / delt;
+    for (int off = 32; off > 0; off >>= 1) dte = fmin(dte, __shfl_down(dte, off, 64));
+    __shared__ double wmin[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) wmin[wv] = dte;
+    __syncthreads();
+    if (threadIdx.x == 0)
+      blockmin[blockIdx.x] = fmin(fmin(wmin[0], wmin[1]), fmin(wmin[2], wmin[3]));
+  }
+}
+
 // ------------------------------------------------------------- limiters
 // Superbee_P1, src/PDE/Limiter.cpp:155-316: only neighbour MEANS are read, so
 // the in-place update is order independent.
@@ -932,6 +1204,21 @@ void launch_rhs(int ndof, const DevMesh& m, const Phys& ph, double t, const doub
 {
   if (m.nie == 0) return;
   QDG_DISPATCH_NDOF(ndof, (k_rhs<N><<<nblk(m.nie, 256), 256, 0, s>>>(m, ph, t, U, R)));
+}
+
+// P1 fast path; with_dt: also reduce min(vol/delt) into out_raw/out_dt
+void launch_rhs_p1(const DevMesh& m, const Phys& ph, double t, const double* U, double* R,
+                   bool with_dt, double* blockmin, double scale, double tleft, double* out_raw,
+                   double* out_dt, hipStream_t s)
+{
+  const int nb = nblk(m.nie, 256);
+  if (nb == 0) return;
+  if (with_dt) {
+    k_rhs_p1<true><<<nb, 256, 0, s>>>(m, ph, t, U, R, blockmin);
+    k_dt_final<<<1, 256, 0, s>>>(blockmin, nb, scale, tleft, out_raw, out_dt);
+  } else {
+    k_rhs_p1<false><<<nb, 256, 0, s>>>(m, ph, t, U, R, blockmin);
+  }
 }
 
 void launch_superbee(int ndof, const DevMesh& m, double* U, hipStream_t s)

@@ -4,8 +4,8 @@ Mirror of the `DG` chare's per-stage sequence (src/Inciter/DG.cpp and dg.ci:57-7
 
     next   : send own boundary-adjacent solution      (DG.cpp:1009-1039)  -> exchange()
     lim    : ghosts <- received, limiter, send limited (DG.cpp:1229-1282)  -> stage_limit(), exchange()
-    dt     : ghosts <- received, CFL dt, min-reduce    (DG.cpp:1360-1430)  -> stage_dt(), allreduce_min
-    solve  : Un=U (stage 0), rhs, SSP-RK3 update       (DG.cpp:1432-1508)  -> stage_rhs_update()
+    dt     : ghosts <- received, CFL dt, min-reduce    (DG.cpp:1360-1430)  -> stage_rhs_dt(), allreduce_min
+    solve  : Un=U (stage 0), rhs, SSP-RK3 update       (DG.cpp:1432-1508)  -> stage_rhs_dt(), stage_update()
 
 with the Charm++ messages replaced by point-to-point sends between the ranks of
 one node (RCCL over xGMI when the backend is "nccl") and the `contribute(min)`
@@ -106,11 +106,12 @@ class DGDriver:
             m.stage_limit()
             if self.limiter_active:
                 self.exchange()                  # comlim (a no-op copy without a limiter)
-            if stage == 0:
-                m.stage_dt(tleft)
-                if self.comm.size > 1:
-                    self.comm.allreduce_min(self)
-            m.stage_rhs_update(stage, t)
+            # rhs; at stage 0 it also yields the local dt (the reference computes
+            # dt first, DG.cpp:1360-1430, from the same state; R does not depend on dt)
+            m.stage_rhs_dt(stage, t, tleft)
+            if stage == 0 and self.comm.size > 1:
+                self.comm.allreduce_min(self)        # contribute(min), DG.cpp:1428-1429
+            m.stage_update(stage)
 
     def dt_taken(self):
         return self.mesh.stage_dt_get()
