@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libqdg.so")
+# QDG_LIB selects an alternative build of the same library (kernel A/B runs)
+LIB_PATH = os.environ.get("QDG_LIB") or os.path.join(_HERE, "lib", "libqdg.so")
 
 FLUX = {"hllc": 0, "laxfriedrichs": 1}
 LIMITER = {"nolimiter": 0, "wenop1": 1, "superbeep1": 2}

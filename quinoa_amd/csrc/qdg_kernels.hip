@@ -23,6 +23,10 @@
 #include "qdg_device.hpp"
 #include "qdg_kernels.hpp"
 
+#ifndef QDG_P1_WAVES
+#define QDG_P1_WAVES 2   // waves per SIMD the DG-P1 RHS kernel is register-budgeted for
+#endif
+
 namespace qdg {
 
 __constant__ Tables<1> c_tab1;
@@ -39,6 +43,21 @@ template <> __device__ __forceinline__ const Tables<10>& tab<10>() { return c_ta
 template <int NDOF> constexpr int order_index() { return NDOF == 1 ? 0 : NDOF == 4 ? 1 : 2; }
 
 // ------------------------------------------------------------------ basics
+
+// XCD-aware workgroup -> element-tile map.  Workgroups are dealt round-robin
+// over the 8 XCDs (b and b+8 share an XCD and its private 4 MiB L2), while a
+// tet's face neighbours sit close to it in the Morton-ordered numbering.
+// Giving XCD x the contiguous tile range [x*n/8, (x+1)*n/8) keeps the
+// neighbour gathers inside one L2 instead of re-fetching the same DOFs through
+// the fabric once per XCD.  Bijective for any grid size; placement affects
+// speed only, never results.
+__device__ __forceinline__ int xcd_tile(int bid, int nwg)
+{
+  constexpr int NXCD = 8;
+  const int per = nwg / NXCD, rem = nwg - per * NXCD;
+  const int xcd = bid % NXCD, idx = bid / NXCD;
+  return xcd * per + (xcd < rem ? xcd : rem) + idx;
+}
 
 // Dubiner basis, src/PDE/Integrate/Basis.cpp:267-307
 template <int NDOF>
@@ -179,59 +198,52 @@ __device__ __forceinline__ void riemann(const Phys& ph, const double* fn, const 
 // Problem::solution (device functor per ProblemType):
 // SodShocktube.cpp:28-78, SedovBlastwave.cpp:28-75, VorticalFlow.cpp:28-64,
 // TaylorGreen.cpp:28-62 under src/PDE/CompFlow/Problem/
+template <int PROB>
 __device__ __forceinline__ void prob_solution(const Phys& ph, double x, double y, double z,
                                               double /*t*/, double* s)
 {
-  switch (ph.problem) {
-    case 1: {
-      const bool l = x < 0.5;
-      const double r = l ? 1.0 : 0.125, p = l ? 1.0 : 0.1;
-      s[0] = r; s[1] = 0.0; s[2] = 0.0; s[3] = 0.0;
-      s[4] = eos_totalenergy(ph, r, 0.0, 0.0, 0.0, p);
-      break;
-    }
-    case 2: {
-      const double r = 1.0, p = ((x < 0.05) && (y < 0.05)) ? 783.4112 : 1.0e-6;
-      s[0] = r; s[1] = 0.0; s[2] = 0.0; s[3] = 0.0;
-      s[4] = eos_totalenergy(ph, r, 0.0, 0.0, 0.0, p);
-      break;
-    }
-    case 3: {
-      const double a = ph.alpha, b = ph.beta;
-      const double ru = a * x - b * y, rv = b * x + a * y, rw = -2.0 * a * z;
-      s[0] = 1.0; s[1] = ru; s[2] = rv; s[3] = rw;
-      s[4] = (ru * ru + rv * rv + rw * rw) / 2.0 + (ph.p0 - 2.0 * a * a * z * z) / (ph.gamma - 1.0);
-      break;
-    }
-    case 4: {
-      const double pi = 3.14159265358979323846;
-      const double r = 1.0;
-      const double p = 10.0 + r / 4.0 * (cos(2.0 * pi * x) + cos(2.0 * pi * y));
-      const double u = sin(pi * x) * cos(pi * y), v = -cos(pi * x) * sin(pi * y), w = 0.0;
-      s[0] = r; s[1] = r * u; s[2] = r * v; s[3] = r * w;
-      s[4] = eos_totalenergy(ph, r, u, v, w, p);
-      break;
-    }
-    default:
-      s[0] = s[1] = s[2] = s[3] = s[4] = 0.0;
+  if constexpr (PROB == 1) {
+    const bool l = x < 0.5;
+    const double r = l ? 1.0 : 0.125, p = l ? 1.0 : 0.1;
+    s[0] = r; s[1] = 0.0; s[2] = 0.0; s[3] = 0.0;
+    s[4] = eos_totalenergy(ph, r, 0.0, 0.0, 0.0, p);
+  } else if constexpr (PROB == 2) {
+    const double r = 1.0, p = ((x < 0.05) && (y < 0.05)) ? 783.4112 : 1.0e-6;
+    s[0] = r; s[1] = 0.0; s[2] = 0.0; s[3] = 0.0;
+    s[4] = eos_totalenergy(ph, r, 0.0, 0.0, 0.0, p);
+  } else if constexpr (PROB == 3) {
+    const double a = ph.alpha, b = ph.beta;
+    const double ru = a * x - b * y, rv = b * x + a * y, rw = -2.0 * a * z;
+    s[0] = 1.0; s[1] = ru; s[2] = rv; s[3] = rw;
+    s[4] = (ru * ru + rv * rv + rw * rw) / 2.0 + (ph.p0 - 2.0 * a * a * z * z) / (ph.gamma - 1.0);
+  } else if constexpr (PROB == 4) {
+    const double pi = 3.14159265358979323846;
+    const double r = 1.0;
+    const double p = 10.0 + r / 4.0 * (cos(2.0 * pi * x) + cos(2.0 * pi * y));
+    const double u = sin(pi * x) * cos(pi * y), v = -cos(pi * x) * sin(pi * y), w = 0.0;
+    s[0] = r; s[1] = r * u; s[2] = r * v; s[3] = r * w;
+    s[4] = eos_totalenergy(ph, r, u, v, w, p);
+  } else {
+    s[0] = s[1] = s[2] = s[3] = s[4] = 0.0;
   }
 }
 
 // Problem::src: VorticalFlow.cpp:80-115, TaylorGreen.cpp:77-90 (zero otherwise)
-__device__ __forceinline__ bool prob_has_source(const Phys& ph) { return ph.problem == 3 || ph.problem == 4; }
+template <int PROB> constexpr bool prob_has_source() { return PROB == 3 || PROB == 4; }
+template <int PROB>
 __device__ __forceinline__ void prob_src(const Phys& ph, double x, double y, double z,
                                          double /*t*/, double* r)
 {
-  if (ph.problem == 3) {
+  if constexpr (PROB == 3) {
     const double a = ph.alpha, b = ph.beta;
     double s[5];
-    prob_solution(ph, x, y, z, 0.0, s);
+    prob_solution<3>(ph, x, y, z, 0.0, s);
     r[0] = 0.0;
     r[1] = a * s[1] / s[0] - b * s[2] / s[0];
     r[2] = b * s[1] / s[0] + a * s[2] / s[0];
     r[3] = 0.0;
     r[4] = (r[1] * s[1] + r[2] * s[2]) / s[0] + 8.0 * a * a * a * z * z / (ph.gamma - 1.0);
-  } else if (ph.problem == 4) {
+  } else if constexpr (PROB == 4) {
     const double pi = 3.14159265358979323846;
     r[0] = r[1] = r[2] = r[3] = 0.0;
     r[4] = 3.0 * pi / 8.0 * (cos(3.0 * pi * x) * cos(pi * y) - cos(3.0 * pi * y) * cos(pi * x));
@@ -241,12 +253,13 @@ __device__ __forceinline__ void prob_src(const Phys& ph, double x, double y, dou
 }
 
 // BC state functions, src/PDE/CompFlow/DGCompFlow.hpp:649-701
+template <int PROB>
 __device__ __forceinline__ void bc_state(const Phys& ph, int bc, const double* ul, double x,
                                          double y, double z, double t, const double* fn,
                                          double* ur)
 {
   if (bc == 1) {
-    prob_solution(ph, x, y, z, t, ur);
+    prob_solution<PROB>(ph, x, y, z, t, ur);
   } else if (bc == 2) {
     const double v1 = ul[1] / ul[0], v2 = ul[2] / ul[0], v3 = ul[3] / ul[0];
     const double vn = v1 * fn[0] + v2 * fn[1] + v3 * fn[2];
@@ -369,12 +382,12 @@ __device__ __forceinline__ void inverse_jacobian(const ElemGeom& g, double (&ji)
 // ------------------------------------------------------------- RHS kernel
 // dg::CompFlow::rhs (src/PDE/CompFlow/DGCompFlow.hpp:130-195) for interior
 // tets: surfInt + bndSurfInt (per local face), volInt, srcInt.
-template <int NDOF>
+template <int NDOF, int PROB>
 __global__ __launch_bounds__(256) void k_rhs(DevMesh m, Phys ph, double t,
                                              const double* __restrict__ U,
                                              double* __restrict__ R)
 {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int e = xcd_tile(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   if (e >= m.nie) return;
   const Tables<NDOF>& T = tab<NDOF>();
   constexpr int NGF = Tables<NDOF>::NGF, NGV = Tables<NDOF>::NGV;
@@ -412,7 +425,7 @@ __global__ __launch_bounds__(256) void k_rhs(DevMesh m, Phys ph, double t,
       } else {
         double P[3];
         face_point(g, lf, s0, s1, s2, P);
-        bc_state(ph, -nb - 1, so, P[0], P[1], P[2], t, fn, sn);
+        bc_state<PROB>(ph, -nb - 1, so, P[0], P[1], P[2], t, fn, sn);
       }
       if (own_left) riemann(ph, fn, so, sn, fl);
       else          riemann(ph, fn, sn, so, fl);
@@ -463,7 +476,7 @@ __global__ __launch_bounds__(256) void k_rhs(DevMesh m, Phys ph, double t,
   }
 
   // ---- source integral, src/PDE/Integrate/Source.cpp:21-141 -------------
-  if (prob_has_source(ph)) {
+  if constexpr (prob_has_source<PROB>()) {
 #pragma unroll 1
     for (int ig = 0; ig < NGV; ++ig) {
       const double xi = T.vc[ig][0], eta = T.vc[ig][1], zeta = T.vc[ig][2];
@@ -472,7 +485,7 @@ __global__ __launch_bounds__(256) void k_rhs(DevMesh m, Phys ph, double t,
 #pragma unroll
       for (int d = 0; d < 3; ++d)
         P[d] = g.p[0][d] * w0 + g.p[1][d] * xi + g.p[2][d] * eta + g.p[3][d] * zeta;
-      prob_src(ph, P[0], P[1], P[2], t, s);
+      prob_src<PROB>(ph, P[0], P[1], P[2], t, s);
       const double wt = T.vw[ig] * vol;
 #pragma unroll
       for (int c = 0; c < NCOMP; ++c) {
@@ -590,8 +603,8 @@ __device__ __forceinline__ void flux_lf_q(const double* fn, const double* L, con
 //  * WITH_DT (RK stage 0): the CFL sum of dg::CompFlow::dt
 //    (DGCompFlow.hpp:206-406) is accumulated from the wave speeds the Riemann
 //    solver already has -- the separate dt face loop disappears.
-template <bool WITH_DT>
-__global__ __launch_bounds__(256) void k_rhs_p1(DevMesh m, Phys ph, double t,
+template <bool WITH_DT, int PROB>
+__global__ __launch_bounds__(256, QDG_P1_WAVES) void k_rhs_p1(DevMesh m, Phys ph, double t,
                                                 const double* __restrict__ U,
                                                 double* __restrict__ R,
                                                 double* __restrict__ blockmin)
@@ -599,7 +612,7 @@ __global__ __launch_bounds__(256) void k_rhs_p1(DevMesh m, Phys ph, double t,
   constexpr int NDOF = 4, NGF = 3, NGV = 5;
   const Tables<4>& T = c_tab4;
   const int stride = m.stride;
-  const int e0 = blockIdx.x * blockDim.x + threadIdx.x;
+  const int e0 = xcd_tile(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   const bool active = e0 < m.nie;
   const int e = active ? e0 : 0;
   double dte = DBL_MAX;
@@ -613,37 +626,26 @@ __global__ __launch_bounds__(256) void k_rhs_p1(DevMesh m, Phys ph, double t,
 
   const int nb0 = m.nbr[e], nb1 = m.nbr[(size_t)stride + e], nb2 = m.nbr[(size_t)2 * stride + e],
             nb3 = m.nbr[(size_t)3 * stride + e];
+  // node coordinates: needed inside the face loop only for Dirichlet states
+  // (problems with an analytic solution); otherwise loaded after it
+  constexpr bool GEOM_EARLY = (PROB == 3 || PROB == 4 || PROB == 0);
   ElemGeom g;
-  load_geom(m, e, g);
+  if (GEOM_EARLY) load_geom(m, e, g);
   const double vol = m.vol[e];
   double delt = 0.0;
-
-  double un[NCOMP][NDOF];
-  {
-    const int n = nb0 >= 0 ? nb0 : e;
-    load_dofs<NDOF>(U, stride, n, un);
-  }
 
 #pragma unroll 1
   for (int lf = 0; lf < 4; ++lf) {
     const int nb = (lf == 0) ? nb0 : (lf == 1) ? nb1 : (lf == 2) ? nb2 : nb3;
-    const int nbn = (lf == 0) ? nb1 : (lf == 1) ? nb2 : nb3;      // next face (unused for lf==3)
     const int info = m.finfo[(size_t)lf * stride + e];
     const int f = m.fid[(size_t)lf * stride + e];
     const double area = m.farea[f];
     const double fn[3] = { m.fnx[f], m.fny[f], m.fnz[f] };
     const bool own_left = (info >> 6) & 1;
     double cur[NCOMP][NDOF];
-#pragma unroll
-    for (int c = 0; c < NCOMP; ++c)
-#pragma unroll
-      for (int k = 0; k < NDOF; ++k) cur[c][k] = un[c][k];
-    if (lf < 3) {   // prefetch the next neighbour while this face is computed
-      const int n = nbn >= 0 ? nbn : e;
-      load_dofs<NDOF>(U, stride, n, un);
-    }
+    load_dofs<NDOF>(U, stride, nb >= 0 ? nb : e, cur);
     if (nb == -1 && !WITH_DT) continue;    // boundary face without a BC: no flux
-#pragma unroll
+#pragma unroll 1
     for (int ig = 0; ig < NGF; ++ig) {
       const double s0 = T.fs[ig][0], s1 = T.fs[ig][1], s2 = T.fs[ig][2];
       double so[NCOMP], sn[NCOMP], fl[NCOMP];
@@ -654,9 +656,9 @@ __global__ __launch_bounds__(256) void k_rhs_p1(DevMesh m, Phys ph, double t,
         eval_basis<NDOF>(xi, eta, zeta, Bn);
         state_from<NDOF>(cur, Bn, sn);
       } else {
-        double P[3];
-        face_point(g, lf, s0, s1, s2, P);
-        bc_state(ph, -nb - 1, so, P[0], P[1], P[2], t, fn, sn);
+        double P[3] = { 0.0, 0.0, 0.0 };
+        if (GEOM_EARLY) face_point(g, lf, s0, s1, s2, P);
+        bc_state<PROB>(ph, -nb - 1, so, P[0], P[1], P[2], t, fn, sn);
       }
       const double* sl = own_left ? so : sn;
       const double* sr = own_left ? sn : so;
@@ -689,6 +691,7 @@ __global__ __launch_bounds__(256) void k_rhs_p1(DevMesh m, Phys ph, double t,
   }
 
   // ---- volume integral: dB/dx constant on a P1 tet --------------------------
+  if (!GEOM_EARLY) load_geom(m, e, g);
   {
     double ji[3][3];
     inverse_jacobian(g, ji);
@@ -722,7 +725,7 @@ __global__ __launch_bounds__(256) void k_rhs_p1(DevMesh m, Phys ph, double t,
   }
 
   // ---- source integral (manufactured-solution problems only) ----------------
-  if (prob_has_source(ph)) {
+  if constexpr (prob_has_source<PROB>()) {
 #pragma unroll 1
     for (int ig = 0; ig < NGV; ++ig) {
       const double xi = T.vc[ig][0], eta = T.vc[ig][1], zeta = T.vc[ig][2];
@@ -731,7 +734,7 @@ __global__ __launch_bounds__(256) void k_rhs_p1(DevMesh m, Phys ph, double t,
 #pragma unroll
       for (int d = 0; d < 3; ++d)
         P[d] = g.p[0][d] * w0 + g.p[1][d] * xi + g.p[2][d] * eta + g.p[3][d] * zeta;
-      prob_src(ph, P[0], P[1], P[2], t, s);
+      prob_src<PROB>(ph, P[0], P[1], P[2], t, s);
       const double wt = T.vw[ig] * vol;
 #pragma unroll
       for (int c = 0; c < NCOMP; ++c) {
@@ -768,7 +771,7 @@ __global__ __launch_bounds__(256) void k_rhs_p1(DevMesh m, Phys ph, double t,
 template <int NDOF>
 __global__ __launch_bounds__(256) void k_superbee(DevMesh m, double* __restrict__ U)
 {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int e = xcd_tile(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   if (e >= m.nie) return;
   if constexpr (NDOF > 1) {
     const Tables<NDOF>& T = tab<NDOF>();
@@ -825,7 +828,7 @@ __global__ __launch_bounds__(256) void k_weno(DevMesh m, double cweight,
                                               const double* __restrict__ Uin,
                                               double* __restrict__ Uout)
 {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int e = xcd_tile(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   if (e >= m.nie) return;
   if constexpr (NDOF > 1) {
     const int stride = m.stride;
@@ -871,7 +874,7 @@ template <int NDOF>
 __global__ __launch_bounds__(256) void k_dt(DevMesh m, Phys ph, const double* __restrict__ U,
                                             double* __restrict__ blockmin)
 {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int e = xcd_tile(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   double dte = DBL_MAX;
   if (e < m.nie) {
     const Tables<NDOF>& T = tab<NDOF>();
@@ -988,7 +991,7 @@ __global__ void k_mass(DevMesh m, double* __restrict__ L)
 }
 
 // tk::initialize, src/PDE/Integrate/Initialize.cpp:29-201 (interior tets)
-template <int NDOF>
+template <int NDOF, int PROB>
 __global__ __launch_bounds__(256) void k_init(DevMesh m, Phys ph, double t, double* __restrict__ U)
 {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1011,7 +1014,7 @@ __global__ __launch_bounds__(256) void k_init(DevMesh m, Phys ph, double t, doub
     for (int d = 0; d < 3; ++d)
       P[d] = g.p[0][d] * w0 + g.p[1][d] * xi + g.p[2][d] * eta + g.p[3][d] * zeta;
     eval_basis<NDOF>(xi, eta, zeta, B);
-    prob_solution(ph, P[0], P[1], P[2], t, s);
+    prob_solution<PROB>(ph, P[0], P[1], P[2], t, s);
     const double wt = Q.w[ig] * vol;
 #pragma unroll
     for (int c = 0; c < NCOMP; ++c) {
@@ -1030,7 +1033,7 @@ __global__ __launch_bounds__(256) void k_init(DevMesh m, Phys ph, double t, doub
 
 // ElemDiagnostics::compute_diag, src/Inciter/ElemDiagnostics.cpp:116-215.
 // Per-block partial sums (deterministic two-pass reduction): 15 doubles/block.
-template <int NDOF>
+template <int NDOF, int PROB>
 __global__ __launch_bounds__(256) void k_diag(DevMesh m, Phys ph, double t_new,
                                               const double* __restrict__ U,
                                               double* __restrict__ part)
@@ -1053,7 +1056,7 @@ __global__ __launch_bounds__(256) void k_diag(DevMesh m, Phys ph, double t_new,
       for (int d = 0; d < 3; ++d)
         P[d] = g.p[0][d] * w0 + g.p[1][d] * xi + g.p[2][d] * eta + g.p[3][d] * zeta;
       eval_basis<NDOF>(xi, eta, zeta, B);
-      prob_solution(ph, P[0], P[1], P[2], t_new, s);
+      prob_solution<PROB>(ph, P[0], P[1], P[2], t_new, s);
       state_gather<NDOF>(U, m.stride, e, B, u);
       const double wt = Q.w[ig] * vol;
 #pragma unroll
@@ -1185,6 +1188,17 @@ __global__ void k_halo_unpack(const double* __restrict__ slab, int nprop, int st
     else { constexpr int N = 10; CALL; }                  \
   } while (0)
 
+#define QDG_DISPATCH_PROB(prob, CALL)                      \
+  do {                                                      \
+    switch (prob) {                                         \
+      case 1: { constexpr int P = 1; CALL; } break;         \
+      case 2: { constexpr int P = 2; CALL; } break;         \
+      case 3: { constexpr int P = 3; CALL; } break;         \
+      case 4: { constexpr int P = 4; CALL; } break;         \
+      default: { constexpr int P = 0; CALL; } break;        \
+    }                                                       \
+  } while (0)
+
 static inline int nblk(int n, int b) { return (n + b - 1) / b; }
 
 hipError_t upload_tables(const Tables<1>& t1, const Tables<4>& t4, const Tables<10>& t10,
@@ -1203,7 +1217,7 @@ void launch_rhs(int ndof, const DevMesh& m, const Phys& ph, double t, const doub
                 hipStream_t s)
 {
   if (m.nie == 0) return;
-  QDG_DISPATCH_NDOF(ndof, (k_rhs<N><<<nblk(m.nie, 256), 256, 0, s>>>(m, ph, t, U, R)));
+  QDG_DISPATCH_NDOF(ndof, QDG_DISPATCH_PROB(ph.problem, (k_rhs<N, P><<<nblk(m.nie, 256), 256, 0, s>>>(m, ph, t, U, R))));
 }
 
 // P1 fast path; with_dt: also reduce min(vol/delt) into out_raw/out_dt
@@ -1214,10 +1228,10 @@ void launch_rhs_p1(const DevMesh& m, const Phys& ph, double t, const double* U, 
   const int nb = nblk(m.nie, 256);
   if (nb == 0) return;
   if (with_dt) {
-    k_rhs_p1<true><<<nb, 256, 0, s>>>(m, ph, t, U, R, blockmin);
+    QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1<true, P><<<nb, 256, 0, s>>>(m, ph, t, U, R, blockmin)));
     k_dt_final<<<1, 256, 0, s>>>(blockmin, nb, scale, tleft, out_raw, out_dt);
   } else {
-    k_rhs_p1<false><<<nb, 256, 0, s>>>(m, ph, t, U, R, blockmin);
+    QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1<false, P><<<nb, 256, 0, s>>>(m, ph, t, U, R, blockmin)));
   }
 }
 
@@ -1267,7 +1281,7 @@ void launch_mass(int ndof, const DevMesh& m, double* L, hipStream_t s)
 void launch_init(int ndof, const DevMesh& m, const Phys& ph, double t, double* U, hipStream_t s)
 {
   if (m.nie == 0) return;
-  QDG_DISPATCH_NDOF(ndof, (k_init<N><<<nblk(m.nie, 256), 256, 0, s>>>(m, ph, t, U)));
+  QDG_DISPATCH_NDOF(ndof, QDG_DISPATCH_PROB(ph.problem, (k_init<N, P><<<nblk(m.nie, 256), 256, 0, s>>>(m, ph, t, U))));
 }
 
 void launch_diag(int ndof, const DevMesh& m, const Phys& ph, double t_new, const double* U,
@@ -1275,7 +1289,7 @@ void launch_diag(int ndof, const DevMesh& m, const Phys& ph, double t_new, const
 {
   const int nb = nblk(m.nie, 256);
   if (nb > 0)
-    QDG_DISPATCH_NDOF(ndof, (k_diag<N><<<nb, 256, 0, s>>>(m, ph, t_new, U, part)));
+    QDG_DISPATCH_NDOF(ndof, QDG_DISPATCH_PROB(ph.problem, (k_diag<N, P><<<nb, 256, 0, s>>>(m, ph, t_new, U, part))));
   k_diag_final<<<1, 64, 0, s>>>(part, nb, out);
 }
 
