@@ -1,11 +1,17 @@
 // qdg_device.hpp -- data structures shared by the host layer and the gfx950
 // kernels of the DG compressible-flow path (MI355X / CDNA4 only).
 //
-// HBM layout (all fp64 fields are struct-of-arrays by DOF, one "plane" per
-// (component, mode) pair, so that a wavefront's 64 lanes -- 64 consecutive
-// tets in device order -- read 512 contiguous bytes per plane):
+// HBM layout
 //
-//   U, Un, R   : plane p = c*NDOF + k at  base + p*stride,   element e at [e]
+//   U, Un, R   : element-major rows in DEVICE element order,
+//                  U[e*NPROP + c*NDOF + k],  NPROP = 5*NDOF
+//                (the reference's tk::Fields row, src/Base/Data.hpp:462-471).
+//                A face-neighbour gather reads one contiguous row (P1: 160 B,
+//                1.25 cache lines) with 16-byte loads; measured fabric traffic
+//                of the P1 RHS is 1.7x lower than with per-DOF planes, where
+//                the same gather touches 20 different lines.
+//   integer connectivity and per-element scalars are struct-of-arrays planes
+//   (they are only ever read by their own element, fully coalesced):
 //   inpoel     : 4 planes of int32 (device-order elements, renumbered nodes)
 //   nbr        : 4 planes of int32, neighbour across local face lf:
 //                  >= 0  device id of the neighbour (ghosts: >= nie)

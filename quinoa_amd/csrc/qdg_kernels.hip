@@ -1,9 +1,8 @@
 // qdg_kernels.hip -- hand-written gfx950 (MI355X, CDNA4) kernels of the DG
 // compressible-flow path.  One lane = one tetrahedron; 64 consecutive tets of
-// the Morton-ordered device numbering per wavefront; all field planes are
-// struct-of-arrays (qdg_device.hpp), so own-element accesses are fully
-// coalesced 512-B wave transactions and neighbour accesses are short-range
-// gathers served by the XCD's L2.
+// the Morton-ordered device numbering per wavefront; fields are element-major
+// rows (qdg_device.hpp) read and written with 16-byte accesses, so a
+// face-neighbour gather costs one contiguous row served by the XCD's L2.
 //
 // The right-hand side is ELEMENT-CENTRIC: every tet visits its 4 faces and
 // gathers the neighbour's DOFs, instead of the reference's face loop that
@@ -43,6 +42,41 @@ template <> __device__ __forceinline__ const Tables<10>& tab<10>() { return c_ta
 template <int NDOF> constexpr int order_index() { return NDOF == 1 ? 0 : NDOF == 4 ? 1 : 2; }
 
 // ------------------------------------------------------------------ basics
+
+// Field layout in HBM: element-major rows, U[e*NPROP + c*NDOF + k] -- the same
+// order as the reference's tk::Fields rows, in device element numbering.  A
+// face-neighbour gather then touches the 160 (P1) contiguous bytes of one row
+// (1.25 cache lines) instead of 20 different lines of 20 separate planes.
+__device__ __forceinline__ size_t fidx(int p, int e, int nprop) { return (size_t)e * nprop + p; }
+
+// whole row of element e into registers with 16-byte loads (rows are 16-byte
+// aligned when NPROP is even: P1 160 B, P2 400 B; P0 rows are 40 B)
+template <int NPROP>
+__device__ __forceinline__ void load_row(const double* __restrict__ U, int e, double* r)
+{
+  const double* p = U + (size_t)e * NPROP;
+  if constexpr (NPROP % 2 == 0) {
+    const double2* q = reinterpret_cast<const double2*>(__builtin_assume_aligned(p, 16));
+#pragma unroll
+    for (int i = 0; i < NPROP / 2; ++i) { const double2 v = q[i]; r[2 * i] = v.x; r[2 * i + 1] = v.y; }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NPROP; ++i) r[i] = p[i];
+  }
+}
+template <int NPROP>
+__device__ __forceinline__ void store_row(double* __restrict__ U, int e, const double* r)
+{
+  double* p = U + (size_t)e * NPROP;
+  if constexpr (NPROP % 2 == 0) {
+    double2* q = reinterpret_cast<double2*>(__builtin_assume_aligned(p, 16));
+#pragma unroll
+    for (int i = 0; i < NPROP / 2; ++i) q[i] = make_double2(r[2 * i], r[2 * i + 1]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < NPROP; ++i) p[i] = r[i];
+  }
+}
 
 // XCD-aware workgroup -> element-tile map.  Workgroups are dealt round-robin
 // over the 8 XCDs (b and b+8 share an XCD and its private 4 MiB L2), while a
@@ -295,13 +329,10 @@ __device__ __forceinline__ void nbr_ref_coords(int code, double s0, double s1, d
 }
 
 template <int NDOF>
-__device__ __forceinline__ void load_dofs(const double* __restrict__ U, int stride, int e,
+__device__ __forceinline__ void load_dofs(const double* __restrict__ U, int /*stride*/, int e,
                                           double (&u)[NCOMP][NDOF])
 {
-#pragma unroll
-  for (int c = 0; c < NCOMP; ++c)
-#pragma unroll
-    for (int k = 0; k < NDOF; ++k) u[c][k] = U[(size_t)(c * NDOF + k) * stride + e];
+  load_row<NCOMP * NDOF>(U, e, &u[0][0]);
 }
 
 template <int NDOF>
@@ -317,18 +348,14 @@ __device__ __forceinline__ void state_from(const double (&u)[NCOMP][NDOF], const
   }
 }
 
-// state of element `n` at a point with basis B, streaming its DOFs from HBM/L2
+// state of element `n` at a point with basis B, reading its row from HBM/L2
 template <int NDOF>
-__device__ __forceinline__ void state_gather(const double* __restrict__ U, int stride, int n,
+__device__ __forceinline__ void state_gather(const double* __restrict__ U, int /*stride*/, int n,
                                              const double* B, double* s)
 {
-#pragma unroll
-  for (int c = 0; c < NCOMP; ++c) {
-    double a = U[(size_t)(c * NDOF) * stride + n];
-#pragma unroll
-    for (int k = 1; k < NDOF; ++k) a += U[(size_t)(c * NDOF + k) * stride + n] * B[k];
-    s[c] = a;
-  }
+  double r[NCOMP][NDOF];
+  load_row<NCOMP * NDOF>(U, n, &r[0][0]);
+  state_from<NDOF>(r, B, s);
 }
 
 struct ElemGeom {
@@ -497,10 +524,7 @@ __global__ __launch_bounds__(256) void k_rhs(DevMesh m, Phys ph, double t,
     }
   }
 
-#pragma unroll
-  for (int c = 0; c < NCOMP; ++c)
-#pragma unroll
-    for (int k = 0; k < NDOF; ++k) R[(size_t)(c * NDOF + k) * stride + e] = acc[c][k];
+  store_row<NCOMP * NDOF>(R, e, &acc[0][0]);
 }
 
 // ------------------------------------------------------- fast fp64 helpers
@@ -746,12 +770,7 @@ __global__ __launch_bounds__(256, QDG_P1_WAVES) void k_rhs_p1(DevMesh m, Phys ph
     }
   }
 
-  if (active) {
-#pragma unroll
-    for (int c = 0; c < NCOMP; ++c)
-#pragma unroll
-      for (int k = 0; k < NDOF; ++k) R[(size_t)(c * NDOF + k) * stride + e] = acc[c][k];
-  }
+  if (active) store_row<NCOMP * NDOF>(R, e, &acc[0][0]);
 
   if (WITH_DT) {
     if (active) dte = vol / delt;
@@ -776,37 +795,36 @@ __global__ __launch_bounds__(256) void k_superbee(DevMesh m, double* __restrict_
   if constexpr (NDOF > 1) {
     const Tables<NDOF>& T = tab<NDOF>();
     constexpr int NGF = Tables<NDOF>::NGF;
+    constexpr int NPROP = NCOMP * NDOF;
     const int stride = m.stride;
-    double u0[NCOMP], uMin[NCOMP], uMax[NCOMP], phi[NCOMP];
+    double u[NCOMP][NDOF];
+    load_row<NPROP>(U, e, &u[0][0]);
+    double uMin[NCOMP], uMax[NCOMP], phi[NCOMP];
 #pragma unroll
-    for (int c = 0; c < NCOMP; ++c) {
-      u0[c] = U[(size_t)(c * NDOF) * stride + e];
-      uMin[c] = uMax[c] = u0[c];
-      phi[c] = 1.0;
-    }
+    for (int c = 0; c < NCOMP; ++c) { uMin[c] = uMax[c] = u[c][0]; phi[c] = 1.0; }
 #pragma unroll
     for (int lf = 0; lf < 4; ++lf) {
       const int nb = m.nbr[(size_t)lf * stride + e];
       if (nb < 0) continue;
 #pragma unroll
       for (int c = 0; c < NCOMP; ++c) {
-        const double v = U[(size_t)(c * NDOF) * stride + nb];
+        const double v = U[fidx(c * NDOF, nb, NPROP)];
         uMin[c] = fmin(uMin[c], v);
         uMax[c] = fmax(uMax[c], v);
       }
     }
 #pragma unroll 1
     for (int lf = 0; lf < 4; ++lf)
-#pragma unroll 1
+#pragma unroll
       for (int ig = 0; ig < NGF; ++ig) {
         double s[NCOMP];
-        state_gather<NDOF>(U, stride, e, T.fB[lf][ig], s);
+        state_from<NDOF>(u, T.fB[lf][ig], s);
 #pragma unroll
         for (int c = 0; c < NCOMP; ++c) {
-          const double uNeg = s[c] - u0[c];
+          const double uNeg = s[c] - u[c][0];
           double pg = 1.0;
-          if (uNeg > 1.0e-14) pg = fmin(1.0, (uMax[c] - u0[c]) / (2.0 * uNeg));
-          else if (uNeg < -1.0e-14) pg = fmin(1.0, (uMin[c] - u0[c]) / (2.0 * uNeg));
+          if (uNeg > 1.0e-14) pg = fmin(1.0, (uMax[c] - u[c][0]) / (2.0 * uNeg));
+          else if (uNeg < -1.0e-14) pg = fmin(1.0, (uMin[c] - u[c][0]) / (2.0 * uNeg));
           pg = fmax(0.0, fmax(fmin(2.0 * pg, 1.0), fmin(pg, 2.0)));
           phi[c] = fmin(phi[c], pg);
         }
@@ -814,10 +832,9 @@ __global__ __launch_bounds__(256) void k_superbee(DevMesh m, double* __restrict_
 #pragma unroll
     for (int c = 0; c < NCOMP; ++c)
 #pragma unroll
-      for (int k = 1; k < 4; ++k) {
-        const size_t i = (size_t)(c * NDOF + k) * stride + e;
-        U[i] = phi[c] * U[i];
-      }
+      for (int k = 1; k < 4; ++k) u[c][k] = phi[c] * u[c][k];
+    // only modes 1-3 change, but the row is stored whole (16-byte stores)
+    store_row<NPROP>(U, e, &u[0][0]);
   }
 }
 
@@ -839,13 +856,13 @@ __global__ __launch_bounds__(256) void k_weno(DevMesh m, double cweight,
     for (int c = 0; c < NCOMP; ++c) {
       double g[5][3], wd[5], wtot = 0.0;
 #pragma unroll
-      for (int d = 0; d < 3; ++d) g[0][d] = Uin[(size_t)(c * NDOF + 1 + d) * stride + e];
+      for (int d = 0; d < 3; ++d) g[0][d] = Uin[fidx(c * NDOF + 1 + d, e, NCOMP * NDOF)];
 #pragma unroll
       for (int is = 1; is < 5; ++is) {
         const int n = nb[is - 1];
 #pragma unroll
         for (int d = 0; d < 3; ++d)
-          g[is][d] = (n >= 0) ? Uin[(size_t)(c * NDOF + 1 + d) * stride + n] : 0.0;
+          g[is][d] = (n >= 0) ? Uin[fidx(c * NDOF + 1 + d, n, NCOMP * NDOF)] : 0.0;
       }
 #pragma unroll
       for (int is = 0; is < 5; ++is) {
@@ -860,7 +877,7 @@ __global__ __launch_bounds__(256) void k_weno(DevMesh m, double cweight,
         double a = 0.0;
 #pragma unroll
         for (int is = 0; is < 5; ++is) a += (wd[is] / wtot) * g[is][d];
-        Uout[(size_t)(c * NDOF + 1 + d) * stride + e] = a;
+        Uout[fidx(c * NDOF + 1 + d, e, NCOMP * NDOF)] = a;
       }
     }
   }
@@ -959,18 +976,20 @@ __global__ __launch_bounds__(256) void k_rk(DevMesh m, double a, double b,
                                             const double* __restrict__ Un,
                                             const double* __restrict__ R, double* __restrict__ U)
 {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= m.nie) return;
+  // flat, fully coalesced sweep over the nie*NPROP doubles of the interior rows
+  constexpr int NPROP = NCOMP * NDOF;
   constexpr double imf[10] = { 1.0, 10.0, 10.0 / 3.0, 5.0 / 3.0, 35.0, 21.0, 14.0, 7.0,
                                14.0 / 3.0, 7.0 / 3.0 };
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)m.nie * NPROP) return;
+  const int e = (int)(i / NPROP);
+  const int k = (int)(i - (size_t)e * NPROP) % NDOF;
+  // imf[k] through selects (no runtime-indexed array)
+  double f = imf[0];
+#pragma unroll
+  for (int j = 1; j < NDOF; ++j) f = (k == j) ? imf[j] : f;
   const double dtv = dt[0] / m.vol[e];
-#pragma unroll
-  for (int c = 0; c < NCOMP; ++c)
-#pragma unroll
-    for (int k = 0; k < NDOF; ++k) {
-      const size_t i = (size_t)(c * NDOF + k) * m.stride + e;
-      U[i] = a * Un[i] + b * (U[i] + dtv * imf[k] * R[i]);
-    }
+  U[i] = a * Un[i] + b * (U[i] + dtv * f * R[i]);
 }
 
 // ------------------------------------------------------------- setup ops
@@ -987,7 +1006,7 @@ __global__ void k_mass(DevMesh m, double* __restrict__ L)
 #pragma unroll
   for (int c = 0; c < NCOMP; ++c)
 #pragma unroll
-    for (int k = 0; k < NDOF; ++k) L[(size_t)(c * NDOF + k) * m.stride + e] = f[k];
+    for (int k = 0; k < NDOF; ++k) L[fidx(c * NDOF + k, e, NCOMP * NDOF)] = f[k];
 }
 
 // tk::initialize, src/PDE/Integrate/Initialize.cpp:29-201 (interior tets)
@@ -1028,7 +1047,7 @@ __global__ __launch_bounds__(256) void k_init(DevMesh m, Phys ph, double t, doub
 #pragma unroll
   for (int c = 0; c < NCOMP; ++c)
 #pragma unroll
-    for (int k = 0; k < NDOF; ++k) U[(size_t)(c * NDOF + k) * m.stride + e] = acc[c][k] / f[k];
+    for (int k = 0; k < NDOF; ++k) U[fidx(c * NDOF + k, e, NCOMP * NDOF)] = acc[c][k] / f[k];
 }
 
 // ElemDiagnostics::compute_diag, src/Inciter/ElemDiagnostics.cpp:116-215.
@@ -1100,83 +1119,60 @@ __global__ void k_diag_final(const double* __restrict__ part, int nblk, double* 
   out[i] = r;
 }
 
-// ------------------------------------------------- layout transposition
-// host AoS rows (caller's element numbering) <-> device SoA planes.
-// One workgroup moves a 64-element x nprop tile through LDS so that both the
-// AoS side (rows of nprop doubles) and the SoA side (planes) see coalesced
-// accesses whenever device and host numbering coincide (ghost rows, or
-// identity permutations); permuted interior rows gather whole AoS rows.
-__global__ __launch_bounds__(256) void k_aos2soa(const double* __restrict__ aos, int nprop,
+// ------------------------------------------------- host <-> device rows
+// Host rows (caller's element numbering) <-> device rows (device numbering):
+// both are element-major, so this is a row permutation; consecutive lanes move
+// consecutive doubles of one row.
+__global__ __launch_bounds__(256) void k_rows_in(const double* __restrict__ host, int nprop,
                                                  const int* __restrict__ d2h, int n0, int n1,
-                                                 int stride, double* __restrict__ soa)
+                                                 double* __restrict__ dev)
 {
-  extern __shared__ double tile[];   // [64][nprop+1]
-  const int base = n0 + blockIdx.x * 64;
-  const int ld = nprop + 1;
-  for (int i = threadIdx.x; i < 64 * nprop; i += blockDim.x) {
-    const int r = i / nprop, p = i - r * nprop;
-    const int d = base + r;
-    if (d < n1) tile[r * ld + p] = aos[(size_t)d2h[d] * nprop + p];
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < 64 * nprop; i += blockDim.x) {
-    const int p = i >> 6, r = i & 63;
-    const int d = base + r;
-    if (d < n1) soa[(size_t)p * stride + d] = tile[r * ld + p];
-  }
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t n = (size_t)(n1 - n0) * nprop;
+  if (i >= n) return;
+  const int d = n0 + (int)(i / nprop), p = (int)(i % nprop);
+  dev[(size_t)d * nprop + p] = host[(size_t)d2h[d] * nprop + p];
 }
 
-__global__ __launch_bounds__(256) void k_soa2aos(const double* __restrict__ soa, int nprop,
-                                                 const int* __restrict__ d2h, int n0, int n1,
-                                                 int stride, double* __restrict__ aos)
+__global__ __launch_bounds__(256) void k_rows_out(const double* __restrict__ dev, int nprop,
+                                                  const int* __restrict__ d2h, int n0, int n1,
+                                                  double* __restrict__ host)
 {
-  extern __shared__ double tile[];
-  const int base = n0 + blockIdx.x * 64;
-  const int ld = nprop + 1;
-  for (int i = threadIdx.x; i < 64 * nprop; i += blockDim.x) {
-    const int p = i >> 6, r = i & 63;
-    const int d = base + r;
-    if (d < n1) tile[r * ld + p] = soa[(size_t)p * stride + d];
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < 64 * nprop; i += blockDim.x) {
-    const int r = i / nprop, p = i - r * nprop;
-    const int d = base + r;
-    if (d < n1) aos[(size_t)d2h[d] * nprop + p] = tile[r * ld + p];
-  }
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t n = (size_t)(n1 - n0) * nprop;
+  if (i >= n) return;
+  const int d = n0 + (int)(i / nprop), p = (int)(i % nprop);
+  host[(size_t)d2h[d] * nprop + p] = dev[(size_t)d * nprop + p];
 }
 
-// copy all planes (rows [0,n)) -- used by the WENO ping-pong
-__global__ void k_copy_planes(const double* __restrict__ src, double* __restrict__ dst,
-                              int nprop, int n, int stride)
+// copy rows [0,n) -- used by the WENO ping-pong
+__global__ void k_copy_rows(const double* __restrict__ src, double* __restrict__ dst, size_t n)
 {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n) return;
-  for (int p = 0; p < nprop; ++p) dst[(size_t)p * stride + e] = src[(size_t)p * stride + e];
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
 }
 
 // ------------------------------------------------------------- halo
 // DG::next / DG::lim send side (src/Inciter/DG.cpp:1023-1036, 1266-1279):
 // slab row j = U[send_elem[j]] (element-major rows of nprop doubles)
-__global__ void k_halo_pack(const double* __restrict__ U, int nprop, int stride,
+__global__ void k_halo_pack(const double* __restrict__ U, int nprop,
                             const int* __restrict__ send_elem, int nsend,
                             double* __restrict__ slab)
 {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)nsend * nprop) return;
   const int j = (int)(i / nprop), p = (int)(i - (size_t)j * nprop);
-  slab[i] = U[(size_t)p * stride + send_elem[j]];
+  slab[i] = U[(size_t)send_elem[j] * nprop + p];
 }
 
-// DG::lim / DG::dt receive side (DG.cpp:1239-1247, 1372-1380): ghost row
-// nie + j = slab row j
-__global__ void k_halo_unpack(const double* __restrict__ slab, int nprop, int stride, int nie,
-                              int nrecv, double* __restrict__ U)
+// DG::lim / DG::dt receive side (DG.cpp:1239-1247, 1372-1380): ghost rows
+// [nie, nie+nrecv) are contiguous, so unpacking is one contiguous copy
+__global__ void k_halo_unpack(const double* __restrict__ slab, int nprop, int nie, int nrecv,
+                              double* __restrict__ U)
 {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)nrecv * nprop) return;
-  const int j = (int)(i / nprop), p = (int)(i - (size_t)j * nprop);
-  U[(size_t)p * stride + nie + j] = slab[i];
+  U[(size_t)nie * nprop + i] = slab[i];
 }
 
 // ================================================================ launchers
@@ -1248,10 +1244,11 @@ void launch_weno(int ndof, const DevMesh& m, double cweight, const double* Uin, 
   QDG_DISPATCH_NDOF(ndof, (k_weno<N><<<nblk(m.nie, 256), 256, 0, s>>>(m, cweight, Uin, Uout)));
 }
 
-void launch_copy_planes(const double* src, double* dst, int nprop, int n, int stride, hipStream_t s)
+void launch_copy_planes(const double* src, double* dst, int nprop, int n, int /*stride*/, hipStream_t s)
 {
   if (n == 0) return;
-  k_copy_planes<<<nblk(n, 256), 256, 0, s>>>(src, dst, nprop, n, stride);
+  const size_t tot = (size_t)n * nprop;
+  k_copy_rows<<<(unsigned)((tot + 255) / 256), 256, 0, s>>>(src, dst, tot);
 }
 
 int dt_blocks(const DevMesh& m) { return nblk(m.nie, 256); }
@@ -1269,7 +1266,7 @@ void launch_rk(int ndof, const DevMesh& m, double a, double b, const double* dt,
                const double* R, double* U, hipStream_t s)
 {
   if (m.nie == 0) return;
-  QDG_DISPATCH_NDOF(ndof, (k_rk<N><<<nblk(m.nie, 256), 256, 0, s>>>(m, a, b, dt, Un, R, U)));
+  QDG_DISPATCH_NDOF(ndof, (k_rk<N><<<(unsigned)(((size_t)m.nie * NCOMP * N + 255) / 256), 256, 0, s>>>(m, a, b, dt, Un, R, U)));
 }
 
 void launch_mass(int ndof, const DevMesh& m, double* L, hipStream_t s)
@@ -1293,36 +1290,36 @@ void launch_diag(int ndof, const DevMesh& m, const Phys& ph, double t_new, const
   k_diag_final<<<1, 64, 0, s>>>(part, nb, out);
 }
 
-void launch_aos2soa(const double* aos, int nprop, const int* d2h, int n0, int n1, int stride,
+void launch_aos2soa(const double* aos, int nprop, const int* d2h, int n0, int n1, int /*stride*/,
                     double* soa, hipStream_t s)
 {
   if (n1 <= n0) return;
-  const size_t lds = (size_t)64 * (nprop + 1) * sizeof(double);
-  k_aos2soa<<<nblk(n1 - n0, 64), 256, lds, s>>>(aos, nprop, d2h, n0, n1, stride, soa);
+  const size_t n = (size_t)(n1 - n0) * nprop;
+  k_rows_in<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(aos, nprop, d2h, n0, n1, soa);
 }
 
-void launch_soa2aos(const double* soa, int nprop, const int* d2h, int n0, int n1, int stride,
+void launch_soa2aos(const double* soa, int nprop, const int* d2h, int n0, int n1, int /*stride*/,
                     double* aos, hipStream_t s)
 {
   if (n1 <= n0) return;
-  const size_t lds = (size_t)64 * (nprop + 1) * sizeof(double);
-  k_soa2aos<<<nblk(n1 - n0, 64), 256, lds, s>>>(soa, nprop, d2h, n0, n1, stride, aos);
+  const size_t n = (size_t)(n1 - n0) * nprop;
+  k_rows_out<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(soa, nprop, d2h, n0, n1, aos);
 }
 
-void launch_halo_pack(const double* U, int nprop, int stride, const int* send_elem, int nsend,
+void launch_halo_pack(const double* U, int nprop, int /*stride*/, const int* send_elem, int nsend,
                       double* slab, hipStream_t s)
 {
   if (nsend == 0) return;
   const size_t n = (size_t)nsend * nprop;
-  k_halo_pack<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(U, nprop, stride, send_elem, nsend, slab);
+  k_halo_pack<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(U, nprop, send_elem, nsend, slab);
 }
 
-void launch_halo_unpack(const double* slab, int nprop, int stride, int nie, int nrecv, double* U,
+void launch_halo_unpack(const double* slab, int nprop, int /*stride*/, int nie, int nrecv, double* U,
                         hipStream_t s)
 {
   if (nrecv == 0) return;
   const size_t n = (size_t)nrecv * nprop;
-  k_halo_unpack<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(slab, nprop, stride, nie, nrecv, U);
+  k_halo_unpack<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(slab, nprop, nie, nrecv, U);
 }
 
 }  // namespace qdg

@@ -1,0 +1,8 @@
+#!/bin/bash
+# rocprofv3 kernel-trace stats of bench.py.  Usage: tools/prof_stats.sh <outdir> [bench args]
+out=${1:-gpurun_out/stats}; shift
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline "$@" > $out/bench.log 2>&1
+tail -1 $out/bench.log | cut -c1-400
+cat $out/*/*kernel_stats.csv | cut -c1-160 | head -12
