@@ -181,6 +181,47 @@ class OracleMesh:
             self._set_face = np.zeros(1, dtype=np.int64)
 
 
+class ChunkMesh:
+    """Oracle view of a chunk WITH ghosts, built from arrays in the reference's
+    data model (inpoel[4*nunk], esuel[4*nielem], esuf/inpofa/geoFace incl. the
+    chare-boundary faces, geoElem[4*nunk], bface).  Used by the multi-rank
+    tests: the reference's ghost set-up (src/Inciter/DG.cpp:134-949) is not
+    restated by the oracle, so these arrays come from the chunk under test."""
+
+    def __init__(self, coord, inpoel, nielem, esuel, esuf, inpofa, geoFace, geoElem, bface, nbfac):
+        self.coord = np.ascontiguousarray(coord, dtype=np.float64)
+        self.x = np.ascontiguousarray(self.coord[:, 0])
+        self.y = np.ascontiguousarray(self.coord[:, 1])
+        self.z = np.ascontiguousarray(self.coord[:, 2])
+        self.inpoel = np.ascontiguousarray(inpoel, dtype=np.int64).reshape(-1, 4)
+        self.nelem = self.inpoel.shape[0]          # nunk
+        self.nielem = int(nielem)
+        self.npoin = self.coord.shape[0]
+        self.esuel = np.ascontiguousarray(esuel, dtype=np.int32)
+        self.esuf = np.ascontiguousarray(esuf, dtype=np.int32)
+        self.inpofa = np.ascontiguousarray(inpofa, dtype=np.int64)
+        self.geoFace = np.ascontiguousarray(geoFace, dtype=np.float64)
+        self.geoElem = np.ascontiguousarray(geoElem, dtype=np.float64)
+        self.nbfac, self.nfac = int(nbfac), len(self.esuf) // 2
+        self.bface = {int(k): np.asarray(v, dtype=np.int64) for k, v in bface.items()}
+        self.meshvol = float(self.geoElem[0:4 * self.nielem:4].sum())
+        ids = sorted(self.bface)
+        self._set_id = np.array(ids or [0], dtype=np.int64)[:len(ids)] if ids else np.zeros(0, np.int64)
+        self._set_off = np.zeros(len(ids) + 1, dtype=np.int64)
+        faces = []
+        for i, s in enumerate(ids):
+            faces.append(self.bface[s])
+            self._set_off[i + 1] = self._set_off[i] + len(self.bface[s])
+        self._set_face = (np.concatenate(faces) if faces else np.zeros(1, np.int64)).astype(np.int64)
+        if self._set_face.size == 0:
+            self._set_face = np.zeros(1, dtype=np.int64)
+        if self._set_id.size == 0:
+            self._set_id = np.zeros(1, dtype=np.int64)
+            self._nset = 0
+        else:
+            self._nset = len(ids)
+
+
 class Oracle:
     """Reference time loop on one mesh chunk (CPU, AoS fields)."""
 
@@ -189,7 +230,8 @@ class Oracle:
         self._dir = np.array(list(bc_dirichlet) or [0], dtype=np.int64)
         self._sym = np.array(list(bc_sym) or [0], dtype=np.int64)
         self._ext = np.array(list(bc_extrapolate) or [0], dtype=np.int64)
-        self.bc = Bc(nset=len(mesh._set_id), set_id=_p(mesh._set_id, c_i64p),
+        self.nie = getattr(mesh, "nielem", mesh.nelem)
+        self.bc = Bc(nset=getattr(mesh, "_nset", len(mesh._set_id)), set_id=_p(mesh._set_id, c_i64p),
                      set_off=_p(mesh._set_off, c_i64p), set_face=_p(mesh._set_face, c_i64p),
                      ndir=len(bc_dirichlet), nsym=len(bc_sym), nextrap=len(bc_extrapolate),
                      dir=_p(self._dir, c_i64p), sym=_p(self._sym, c_i64p),
@@ -209,7 +251,7 @@ class Oracle:
         U = np.zeros(m.nelem * self.nprop)
         self.L_.orc_initialize(C.byref(self.cfg), _p(Lm, c_f64p), _p(m.inpoel.reshape(-1), c_i64p),
                                _p(m.x, c_f64p), _p(m.y, c_f64p), _p(m.z, c_f64p),
-                               _p(U, c_f64p), C.c_double(t), C.c_int64(m.nelem))
+                               _p(U, c_f64p), C.c_double(t), C.c_int64(self.nie))
         return U
 
     def rhs(self, t, U):
@@ -233,7 +275,7 @@ class Oracle:
     def limit(self, U):
         """In place, like the reference (src/Inciter/DG.cpp:1251-1260)."""
         m = self.m
-        self.L_.orc_limit(C.byref(self.cfg), _p(m.esuel, c_i32p), C.c_int64(m.nelem),
+        self.L_.orc_limit(C.byref(self.cfg), _p(m.esuel, c_i32p), C.c_int64(self.nie),
                           _p(m.inpoel.reshape(-1), c_i64p), _p(m.x, c_f64p), _p(m.y, c_f64p),
                           _p(m.z, c_f64p), _p(U, c_f64p))
         return U
@@ -250,7 +292,7 @@ class Oracle:
         out = np.zeros(15)
         self.L_.orc_diag(C.byref(self.cfg), C.c_double(t_new), _p(m.inpoel.reshape(-1), c_i64p),
                          _p(m.x, c_f64p), _p(m.y, c_f64p), _p(m.z, c_f64p),
-                         _p(m.geoElem, c_f64p), _p(U, c_f64p), C.c_int64(m.nelem), _p(out, c_f64p))
+                         _p(m.geoElem, c_f64p), _p(U, c_f64p), C.c_int64(self.nie), _p(out, c_f64p))
         return np.sqrt(out[:10] / m.meshvol), out[10:]
 
     def step(self, t, U, Lm, fixed_dt=0.0, cfl=0.0, tleft=1e300, work=None):

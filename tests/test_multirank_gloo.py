@@ -1,0 +1,118 @@
+"""N > 1 path on CPU: two ranks over gloo.
+
+What is shared with the GPU path and therefore exercised here: the chunked mesh
+generator and its halo plan (quinoa_amd.meshgen), the chunk assembly with ghost
+tets and chare-boundary faces (quinoa_amd.dgmesh), the stage ordering and the
+transport class (quinoa_amd.dg.TorchComm: grouped isend/irecv per neighbour +
+min all-reduce of dt).  The per-chunk numerics are done by the CPU oracle (this
+is a test: there is no GPU here), and the result must equal the serial oracle
+run on the undivided mesh -- the reference asserts the same thing by sharing
+one diag*.std between its 1-PE and 4-PE runs.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import oracle as O
+from quinoa_amd import dg, dgmesh, meshgen
+
+NX, NY, NZ = 6, 4, 4
+KW = dict(flux="hllc", limiter="superbeep1", problem="sedov_blastwave", gamma=1.4)
+BC = dict(bc_sym=[1, 3, 5, 6], bc_extrapolate=[2, 4])
+CFL, NSTEP = 0.3, 3
+
+
+class _CpuDriver:
+    """what TorchComm needs from a driver, with host tensors"""
+
+    def __init__(self, ch, nprop):
+        self.nprop = nprop
+        self.nbr_rank = ch["nbr_rank"]
+        self.send_lists = ch["send_lists"]
+        self.send_off = np.concatenate([[0], np.cumsum([len(s) for s in ch["send_lists"]])]).astype(np.int64)
+        self.recv_off = np.concatenate([[0], np.cumsum(ch["recv_counts"])]).astype(np.int64)
+        self.send_slab = torch.zeros(max(1, int(self.send_off[-1]) * nprop), dtype=torch.float64)
+        self.recv_slab = torch.zeros(max(1, int(self.recv_off[-1]) * nprop), dtype=torch.float64)
+        self.dt_buf = torch.zeros(1, dtype=torch.float64)
+
+
+def _exchange(comm, drv, U, nielem):
+    Um = U.reshape(-1, drv.nprop)
+    send = np.concatenate([Um[s] for s in drv.send_lists]) if drv.send_lists else np.zeros((0, drv.nprop))
+    drv.send_slab[:send.size] = torch.from_numpy(send.reshape(-1))          # halo_pack
+    comm.sendrecv(drv)
+    n = int(drv.recv_off[-1])
+    Um[nielem:nielem + n] = drv.recv_slab[:n * drv.nprop].numpy().reshape(n, drv.nprop)   # halo_unpack
+
+
+def _rank_main(rank, world, port, parts, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ch = meshgen.kuhn_box_chunk(NX, NY, NZ, parts=parts, rank=rank)
+        ck = dgmesh.build_chunk(ch["coord"], ch["inpoel"], ch["nielem"], ch["sidesets"])
+        cm = O.ChunkMesh(ck.coord, ck.inpoel, ck.nielem, ck.esuel, ck.esuf, ck.inpofa, ck.geoFace,
+                         ck.geoElem, ck.bface, ck.nbfac)
+        orc = O.Oracle(cm, O.make_cfg(4, **KW), bc_sym=BC["bc_sym"], bc_extrapolate=BC["bc_extrapolate"])
+        comm = dg.TorchComm()
+        drv = _CpuDriver(ch, 20)
+        nie = ck.nielem
+        Lm = orc.lhs()
+        U = orc.initialize(Lm, 0.0)
+        t = 0.0
+        for _ in range(NSTEP):
+            for stage in range(3):
+                _exchange(comm, drv, U, nie)          # comsol
+                orc.limit(U)
+                _exchange(comm, drv, U, nie)          # comlim
+                if stage == 0:
+                    drv.dt_buf[0] = orc.dt(U) * CFL / 3.0
+                    comm.allreduce_min(drv)           # contribute(min)
+                    dt = float(drv.dt_buf[0])
+                    Un = U.copy()
+                R = orc.rhs(t, U)
+                orc.rk_update(stage, dt, Un, R, Lm, U)
+            t += dt
+        np.savez(out % rank, gid=ch["gid"][:nie], U=U.reshape(-1, 20)[:nie], t=t)
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("parts", [(2, 1, 1)])
+def test_two_rank_halo_run_equals_serial(tmp_path, parts):
+    world = parts[0] * parts[1] * parts[2]
+    out = str(tmp_path / "rank%d.npz")
+    mp.spawn(_rank_main, args=(world, _free_port(), parts, out), nprocs=world, join=True)
+    # serial oracle on the undivided mesh
+    ch = meshgen.kuhn_box(NX, NY, NZ)
+    om = O.OracleMesh(ch["coord"], ch["inpoel"], ch["sidesets"])
+    orc = O.Oracle(om, O.make_cfg(4, **KW), bc_sym=BC["bc_sym"], bc_extrapolate=BC["bc_extrapolate"])
+    Lm = orc.lhs()
+    U = orc.initialize(Lm, 0.0)
+    t = 0.0
+    for _ in range(NSTEP):
+        t += orc.step(t, U, Lm, cfl=CFL)
+    ref = np.zeros((om.nelem, 20))
+    ref[ch["gid"]] = U.reshape(-1, 20)           # index by global tet id
+    seen = 0
+    for r in range(world):
+        d = np.load(out % r)
+        assert abs(float(d["t"]) - t) <= 1e-12 * t   # dt sums run in a different face order per chunk
+        err = np.abs(d["U"] - ref[d["gid"]]).max() / np.abs(ref).max()
+        assert err <= 1e-12, (r, err)
+        seen += len(d["gid"])
+    assert seen == om.nelem
