@@ -1,0 +1,331 @@
+// qdg_dgpde.hpp -- C++ host layer above the C ABI (include/qdg.h): a class that
+// models Inciter's `DGPDE` concept for compressible flow with the reference's
+// exact method names, argument lists and const-ness, so that it can be
+// registered in the reference's DGFactory under the same key and nothing above
+// the PDE layer changes.
+//
+//   reference                                      here
+//   ---------------------------------------------  -----------------------------
+//   inciter::dg::CompFlow<Physics,Problem>         qdg::dg::CompFlowHIP<Physics,Problem>
+//     (src/PDE/CompFlow/DGCompFlow.hpp:49-706)
+//   DGPDE::initialize/lhs/rhs/dt signatures        identical (src/PDE/DGPDE.hpp:80-114)
+//   tk::Fields, inciter::FaceData, UnsMesh::Coords  template-free aliases below:
+//     inside Quinoa define QDG_WITH_QUINOA and the reference's own types are
+//     used; standalone (tests, bench) the minimal mirrors in this header are.
+//   tk::Exception via Throw()                       qdg::Exception (std::runtime_error)
+//   WENO_P1 / Superbee_P1 free functions            qdg::limit() (DG.cpp:1251-1260)
+//
+// Per-chare device state: `g_dgpde` is one const object per PE shared by all
+// chares, so the mesh handle cannot live in the PDE object by value.  The
+// adapter keeps a handle cache keyed by the identity of the chare's `inpoel`
+// storage (stable for the life of a DG chare between AMR/LB events, SURVEY
+// 8b); `DG` calls release(inpoel) from its destructor / before resizePostAMR.
+#ifndef QDG_DGPDE_HPP
+#define QDG_DGPDE_HPP
+
+#include <array>
+#include <cstddef>
+#include <algorithm>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#include "qdg.h"
+
+#ifdef QDG_WITH_QUINOA
+#include "Fields.hpp"
+#include "FaceData.hpp"
+#include "UnsMesh.hpp"
+namespace qdg {
+using real = tk::real;
+using Fields = tk::Fields;
+using FaceData = inciter::FaceData;
+using Coords = tk::UnsMesh::Coords;
+}
+#else
+namespace qdg {
+
+using real = double;
+using Coords = std::array<std::vector<real>, 3>;   // tk::UnsMesh::Coords
+
+// tk::Data<UnkEqComp> (src/Base/Data.hpp:36-566): vec[unknown*nprop + offset + component]
+class Fields {
+ public:
+  using ncomp_t = std::size_t;
+  Fields() = default;
+  Fields(ncomp_t nu, ncomp_t np) : m_vec(nu * np), m_nunk(nu), m_nprop(np) {}
+  real& operator()(ncomp_t unknown, ncomp_t component, ncomp_t offset)
+  { return m_vec[unknown * m_nprop + offset + component]; }
+  const real& operator()(ncomp_t unknown, ncomp_t component, ncomp_t offset) const
+  { return m_vec[unknown * m_nprop + offset + component]; }
+  ncomp_t nunk() const noexcept { return m_nunk; }
+  ncomp_t nprop() const noexcept { return m_nprop; }
+  void fill(real v) { std::fill(m_vec.begin(), m_vec.end(), v); }
+  void resize(ncomp_t nu, real v = 0.0) { m_vec.resize(nu * m_nprop, v); m_nunk = nu; }
+  std::vector<real>& data() { return m_vec; }
+  const std::vector<real>& data() const { return m_vec; }
+ private:
+  std::vector<real> m_vec;
+  ncomp_t m_nunk = 0, m_nprop = 0;
+};
+
+class Exception : public std::runtime_error {
+ public:
+  explicit Exception(const std::string& m) : std::runtime_error(m) {}
+};
+
+inline void check(int rc)
+{
+  if (rc != 0) throw Exception(std::string("qdg: ") + qdg_last_error());
+}
+
+// inciter::FaceData (src/Inciter/FaceData.hpp:41-106): same constructor
+// arguments and accessors; built by libqdg's host mirrors.
+class FaceData {
+ public:
+  FaceData() = default;
+  FaceData(const std::vector<std::size_t>& inpoel,
+           const std::map<int, std::vector<std::size_t>>& bface,
+           const std::vector<std::size_t>& triinpoel)
+    : m_bface(bface), m_triinpoel(triinpoel)
+  {
+    const std::size_t ne = inpoel.size() / 4;
+    std::size_t nb = 0;
+    for (const auto& s : m_bface) nb += s.second.size();
+    m_esuel.resize(4 * ne);
+    check(qdg_gen_esuel(ne, inpoel.data(), m_esuel.data()));
+    m_nipfac = qdg_gen_nipfac(ne, nb, m_esuel.data());
+    m_inpofa.resize(3 * m_nipfac);
+    check(qdg_gen_inpofa(ne, nb, inpoel.data(), m_triinpoel.data(), m_esuel.data(), m_inpofa.data()));
+    m_belem.resize(nb);
+    check(qdg_gen_belem(ne, nb, inpoel.data(), m_inpofa.data(), m_belem.data()));
+    m_esuf.resize(2 * m_nipfac);
+    check(qdg_gen_esuf(ne, nb, m_belem.data(), m_esuel.data(), m_esuf.data()));
+  }
+  const std::map<int, std::vector<std::size_t>>& Bface() const { return m_bface; }
+  const std::vector<std::size_t>& Triinpoel() const { return m_triinpoel; }
+  std::size_t Nbfac() const { std::size_t n = 0; for (const auto& s : m_bface) n += s.second.size(); return n; }
+  const std::vector<int>& Esuel() const { return m_esuel; }
+  std::vector<int>& Esuel() { return m_esuel; }
+  std::size_t Nipfac() const { return m_nipfac; }
+  const std::vector<std::size_t>& Inpofa() const { return m_inpofa; }
+  std::vector<std::size_t>& Inpofa() { return m_inpofa; }
+  const std::vector<std::size_t>& Belem() const { return m_belem; }
+  const std::vector<int>& Esuf() const { return m_esuf; }
+  std::vector<int>& Esuf() { return m_esuf; }
+ private:
+  std::map<int, std::vector<std::size_t>> m_bface;
+  std::vector<std::size_t> m_triinpoel;
+  std::vector<int> m_esuel;
+  std::size_t m_nipfac = 0;
+  std::vector<std::size_t> m_inpofa;
+  std::vector<std::size_t> m_belem;
+  std::vector<int> m_esuf;
+};
+
+// tk::genGeoFaceTri / tk::genGeoElemTet (src/Mesh/DerivedData.cpp:1292-1491)
+inline Fields genGeoFaceTri(std::size_t nipfac, const std::vector<std::size_t>& inpofa, const Coords& coord)
+{
+  Fields g(nipfac, 7);
+  check(qdg_gen_geoface(nipfac, inpofa.data(), coord[0].data(), coord[1].data(), coord[2].data(),
+                        g.data().data()));
+  return g;
+}
+inline Fields genGeoElemTet(const std::vector<std::size_t>& inpoel, const Coords& coord)
+{
+  Fields g(inpoel.size() / 4, 4);
+  check(qdg_gen_geoelem(inpoel.size() / 4, inpoel.data(), coord[0].data(), coord[1].data(),
+                        coord[2].data(), g.data().data()));
+  return g;
+}
+
+}  // namespace qdg
+#endif  // QDG_WITH_QUINOA
+
+namespace qdg {
+
+#ifdef QDG_WITH_QUINOA
+class Exception : public std::runtime_error {
+ public:
+  explicit Exception(const std::string& m) : std::runtime_error(m) {}
+};
+inline void check(int rc)
+{
+  if (rc != 0) throw Exception(std::string("qdg: ") + qdg_last_error());
+}
+#endif
+
+// what dg::CompFlow's constructor reads from g_inputdeck
+// (src/PDE/CompFlow/DGCompFlow.hpp:80-93; defaults InputDeck.hpp:191-238)
+struct InputDeck {
+  std::size_t ndof = 1, rdof = 1;            // discr::ndof, rdof
+  int flux = QDG_FLUX_HLLC;                  // discr::flux
+  int limiter = QDG_LIMITER_NONE;            // discr::limiter
+  real cweight = 1.0;                        // discr::cweight
+  real cfl = 0.0, dt = 0.0;                  // discr::cfl | dt
+  real gamma = 1.4, pstiff = 0.0, cv = 717.5;
+  real alpha = 0.0, beta = 0.0, p0 = 0.0;
+  std::vector<std::string> bcdir, bcsym, bcextrapolate;   // side set id strings, as parsed
+  int device = 0;
+};
+
+namespace dg {
+
+struct Euler { };   // Physics policy (src/PDE/CompFlow/Physics/DGEuler.hpp): no-op for DG
+
+// Problem policies: only type() is needed on the device path
+struct UserDefined    { static int type() noexcept { return QDG_PROBLEM_USER_DEFINED; } };
+struct SodShocktube   { static int type() noexcept { return QDG_PROBLEM_SOD_SHOCKTUBE; } };
+struct SedovBlastwave { static int type() noexcept { return QDG_PROBLEM_SEDOV_BLASTWAVE; } };
+struct VorticalFlow   { static int type() noexcept { return QDG_PROBLEM_VORTICAL_FLOW; } };
+struct TaylorGreen    { static int type() noexcept { return QDG_PROBLEM_TAYLOR_GREEN; } };
+
+template <class Physics, class Problem>
+class CompFlowHIP {
+ public:
+  using ncomp_t = std::size_t;
+
+  //! \param[in] c Equation system index (as dg::CompFlow; only system 0 is on the device)
+  //! \param[in] deck The values dg::CompFlow reads from g_inputdeck
+  explicit CompFlowHIP(ncomp_t c, const InputDeck& deck) : m_system(c), m_deck(deck), m_state(new State)
+  {
+    if (c != 0) throw Exception("CompFlowHIP: only equation system 0 is supported");
+    for (const auto& s : deck.bcdir) { m_bcset.push_back(std::stoi(s)); m_bctype.push_back(QDG_BC_DIRICHLET); }
+    for (const auto& s : deck.bcsym) { m_bcset.push_back(std::stoi(s)); m_bctype.push_back(QDG_BC_SYMMETRY); }
+    for (const auto& s : deck.bcextrapolate) { m_bcset.push_back(std::stoi(s)); m_bctype.push_back(QDG_BC_EXTRAPOLATE); }
+    qdg_config cfg{};
+    cfg.struct_size = (int32_t)sizeof(qdg_config);
+    cfg.device = deck.device;
+    cfg.ndof = (int32_t)deck.ndof; cfg.rdof = (int32_t)deck.rdof;
+    cfg.flux = deck.flux; cfg.limiter = deck.limiter; cfg.problem = Problem::type();
+    cfg.nbc = (int32_t)m_bcset.size();
+    cfg.bc_sideset = m_bcset.data(); cfg.bc_type = m_bctype.data();
+    cfg.gamma = deck.gamma; cfg.pstiff = deck.pstiff; cfg.cv = deck.cv; cfg.cweight = deck.cweight;
+    cfg.alpha = deck.alpha; cfg.beta = deck.beta; cfg.p0 = deck.p0; cfg.cfl = deck.cfl; cfg.dt = deck.dt;
+    check(qdg_ctx_create(&cfg, &m_state->ctx));
+  }
+
+  //! DGPDE::initialize (src/PDE/DGPDE.hpp:80-86)
+  void initialize(const Fields& L, const std::vector<std::size_t>& inpoel, const Coords& coord,
+                  Fields& unk, real t, const std::size_t nielem) const
+  {
+    (void)L; (void)coord; (void)nielem;
+    check(qdg_initialize(handle(inpoel), t, unk.data().data()));
+  }
+
+  //! DGPDE::lhs (src/PDE/DGPDE.hpp:89-90).  The mass matrix depends on geoElem
+  //! only; before the chare's mesh is registered it is evaluated on the host.
+  void lhs(const Fields& geoElem, Fields& l) const
+  {
+    static const real f[10] = { 1.0, 1.0 / 10.0, 3.0 / 10.0, 3.0 / 5.0, 1.0 / 35.0, 1.0 / 21.0,
+                                1.0 / 14.0, 1.0 / 7.0, 3.0 / 14.0, 3.0 / 7.0 };
+    const std::size_t nd = m_deck.ndof;
+    for (std::size_t e = 0; e < geoElem.nunk(); ++e)
+      for (std::size_t c = 0; c < 5; ++c) {
+        const real vol = geoElem(e, 0, 0);
+        l(e, c * nd, 0) = vol;
+        if (nd > 1) { l(e, c*nd+1, 0) = vol / 10.0; l(e, c*nd+2, 0) = vol * 3.0 / 10.0; l(e, c*nd+3, 0) = vol * 3.0 / 5.0; }
+        if (nd > 4) {
+          l(e, c*nd+4, 0) = vol / 35.0; l(e, c*nd+5, 0) = vol / 21.0; l(e, c*nd+6, 0) = vol / 14.0;
+          l(e, c*nd+7, 0) = vol / 7.0;  l(e, c*nd+8, 0) = vol * 3.0 / 14.0; l(e, c*nd+9, 0) = vol * 3.0 / 7.0;
+        }
+      }
+    (void)f;
+  }
+
+  //! Register (upload) the mesh of one DG chare; also done lazily by rhs()/dt().
+  void attach(const Fields& geoFace, const Fields& geoElem, const FaceData& fd,
+              const std::vector<std::size_t>& inpoel, const Coords& coord) const
+  {
+    std::lock_guard<std::mutex> lock(m_state->mtx);
+    if (m_state->meshes.count(inpoel.data())) return;
+    std::vector<int32_t> ids; std::vector<std::size_t> off{0}, faces;
+    for (const auto& s : fd.Bface()) {
+      ids.push_back(s.first);
+      faces.insert(faces.end(), s.second.begin(), s.second.end());
+      off.push_back(faces.size());
+    }
+    if (faces.empty()) faces.push_back(0);
+    if (ids.empty()) ids.push_back(0);
+    qdg_bface bf{ fd.Bface().size(), ids.data(), off.data(), faces.data() };
+    qdg_mesh* m = nullptr;
+    const std::size_t nielem = fd.Esuel().size() / 4, nunk = inpoel.size() / 4;
+    check(qdg_mesh_upload(m_state->ctx, nielem, nunk, coord[0].size(), inpoel.data(), coord[0].data(),
+                          coord[1].data(), coord[2].data(), fd.Nbfac(), fd.Esuf().size() / 2,
+                          fd.Esuf().data(), fd.Esuel().data(), fd.Inpofa().data(),
+                          geoFace.data().data(), geoElem.data().data(), &bf, &m));
+    m_state->meshes[inpoel.data()] = m;
+  }
+
+  //! Forget a chare's mesh (DG dtor, before resizePostAMR / migration)
+  void release(const std::vector<std::size_t>& inpoel) const
+  {
+    std::lock_guard<std::mutex> lock(m_state->mtx);
+    auto it = m_state->meshes.find(inpoel.data());
+    if (it != m_state->meshes.end()) { qdg_mesh_destroy(it->second); m_state->meshes.erase(it); }
+  }
+
+  //! DGPDE::rhs (src/PDE/DGPDE.hpp:93-104, dg::CompFlow::rhs DGCompFlow.hpp:130-195)
+  void rhs(real t, const Fields& geoFace, const Fields& geoElem, const FaceData& fd,
+           const std::vector<std::size_t>& inpoel, const Coords& coord, const Fields& U,
+           const std::vector<std::size_t>& ndofel, Fields& R) const
+  {
+    (void)ndofel;   // p-adaptive DG (pdg) is not on the device path yet
+    attach(geoFace, geoElem, fd, inpoel, coord);
+    check(qdg_rhs(handle(inpoel), t, U.data().data(), R.data().data()));
+  }
+
+  //! DGPDE::dt (src/PDE/DGPDE.hpp:107-114, dg::CompFlow::dt DGCompFlow.hpp:206-406)
+  real dt(const Coords& coord, const std::vector<std::size_t>& inpoel, const FaceData& fd,
+          const Fields& geoFace, const Fields& geoElem, const std::vector<std::size_t>& ndofel,
+          const Fields& U) const
+  {
+    (void)ndofel;
+    attach(geoFace, geoElem, fd, inpoel, coord);
+    real v = 0.0;
+    check(qdg_dt(handle(inpoel), U.data().data(), &v));
+    return v;
+  }
+
+  //! WENO_P1 / Superbee_P1 as DG::lim calls them (src/Inciter/DG.cpp:1251-1260)
+  void limit(const std::vector<std::size_t>& inpoel, Fields& U) const
+  { check(qdg_limit(handle(inpoel), U.data().data())); }
+
+  //! Problem::side via the configured BC lists (DGCompFlow.hpp:430-434)
+  void side(std::unordered_set<int>& conf) const { for (int s : m_bcset) conf.insert(s); }
+
+  //! the device handle of a chare's mesh, for the resident fast path (qdg_step etc.)
+  qdg_mesh* handle(const std::vector<std::size_t>& inpoel) const
+  {
+    std::lock_guard<std::mutex> lock(m_state->mtx);
+    auto it = m_state->meshes.find(inpoel.data());
+    if (it == m_state->meshes.end()) throw Exception("CompFlowHIP: mesh not attached");
+    return it->second;
+  }
+
+ private:
+  struct State {
+    qdg_ctx* ctx = nullptr;
+    std::mutex mtx;
+    std::unordered_map<const std::size_t*, qdg_mesh*> meshes;
+    ~State()
+    {
+      for (auto& m : meshes) qdg_mesh_destroy(m.second);
+      if (ctx) qdg_ctx_destroy(ctx);
+    }
+  };
+  ncomp_t m_system;
+  InputDeck m_deck;
+  std::vector<int32_t> m_bcset, m_bctype;
+  std::shared_ptr<State> m_state;   // copies of the PDE object share the device state
+};
+
+}  // namespace dg
+}  // namespace qdg
+
+#endif  // QDG_DGPDE_HPP

@@ -1,0 +1,103 @@
+// test_dgpde_adapter.cpp -- drives the C++ DGPDE-shaped adapter
+// (include/qdg_dgpde.hpp) the way Inciter's DG chare drives g_dgpde:
+// FaceData ctor, geometry, lhs, initialize, rhs, dt, limiter, then two
+// resident time steps.  Reads a mesh written by tests/test_gpu_cpp_adapter.py
+// and writes the results for it to compare with the oracle.
+//
+//   usage: test_dgpde_adapter mesh.bin out.bin
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "qdg_dgpde.hpp"
+
+template <class T> static std::vector<T> rd(FILE* f, size_t n)
+{
+  std::vector<T> v(n);
+  if (n && fread(v.data(), sizeof(T), n, f) != n) { fprintf(stderr, "short read\n"); exit(2); }
+  return v;
+}
+template <class T> static void wr(FILE* f, const std::vector<T>& v)
+{
+  uint64_t n = v.size();
+  fwrite(&n, 8, 1, f);
+  fwrite(v.data(), sizeof(T), v.size(), f);
+}
+
+int main(int argc, char** argv)
+{
+  if (argc != 3) { fprintf(stderr, "usage: %s mesh.bin out.bin\n", argv[0]); return 2; }
+  try {
+    FILE* f = fopen(argv[1], "rb");
+    if (!f) { perror("mesh"); return 2; }
+    auto hdr = rd<uint64_t>(f, 3);                      // nnode, nelem, ntri
+    const size_t nnode = hdr[0], nelem = hdr[1], ntri = hdr[2];
+    qdg::Coords coord;
+    for (int d = 0; d < 3; ++d) coord[d] = rd<double>(f, nnode);
+    std::vector<std::size_t> inpoel;
+    { auto v = rd<uint64_t>(f, 4 * nelem); inpoel.assign(v.begin(), v.end()); }
+    std::vector<std::size_t> tri;
+    { auto v = rd<uint64_t>(f, 3 * ntri); tri.assign(v.begin(), v.end()); }
+    auto triset = rd<int32_t>(f, ntri);
+    fclose(f);
+
+    // boundary faces as the mesh loader regenerates them (Partitioner.cpp:357-393)
+    std::vector<std::size_t> triinpoel(3 * ntri);
+    std::vector<int32_t> fset(ntri);
+    size_t nb = 0;
+    qdg::check(qdg_bnd_faces(nelem, inpoel.data(), ntri, tri.data(), triset.data(), &nb,
+                             triinpoel.data(), fset.data()));
+    triinpoel.resize(3 * nb);
+    std::map<int, std::vector<std::size_t>> bface;
+    for (size_t i = 0; i < nb; ++i) bface[fset[i]].push_back(i);
+
+    // what DG::DG builds (src/Inciter/DG.cpp:46-103)
+    qdg::FaceData fd(inpoel, bface, triinpoel);
+    auto geoFace = qdg::genGeoFaceTri(fd.Nipfac(), fd.Inpofa(), coord);
+    auto geoElem = qdg::genGeoElemTet(inpoel, coord);
+
+    qdg::InputDeck deck;
+    deck.ndof = deck.rdof = 4;
+    deck.limiter = QDG_LIMITER_SUPERBEEP1;
+    deck.cfl = 0.3;
+    deck.bcextrapolate = { "1", "2" };
+    deck.bcsym = { "3", "4", "5", "6" };
+    qdg::dg::CompFlowHIP<qdg::dg::Euler, qdg::dg::SodShocktube> eq(0, deck);
+
+    const size_t nprop = 20;
+    qdg::Fields L(nelem, nprop), U(nelem, nprop), R(nelem, nprop);
+    std::vector<std::size_t> ndofel(nelem, 4);
+    eq.lhs(geoElem, L);
+    eq.attach(geoFace, geoElem, fd, inpoel, coord);
+    eq.initialize(L, inpoel, coord, U, 0.0, nelem);
+    eq.rhs(0.0, geoFace, geoElem, fd, inpoel, coord, U, ndofel, R);
+    const double dt = eq.dt(coord, inpoel, fd, geoFace, geoElem, ndofel, U);
+    qdg::Fields Ulim = U;
+    eq.limit(inpoel, Ulim);
+
+    // resident fast path: two full time steps
+    qdg_mesh* m = eq.handle(inpoel);
+    qdg::check(qdg_state_upload(m, U.data().data()));
+    double t = 0.0, dts[2];
+    for (int s = 0; s < 2; ++s) { qdg::check(qdg_step(m, t, 1e300, &dts[s])); t += dts[s]; }
+    qdg::Fields U2(nelem, nprop);
+    qdg::check(qdg_state_download(m, U2.data().data()));
+
+    // error behaviour: a bad call reports, never crashes
+    bool threw = false;
+    try { qdg::Fields bad(1, 1); eq.limit(std::vector<std::size_t>{0, 1, 2, 3}, bad); }
+    catch (const qdg::Exception&) { threw = true; }
+
+    FILE* o = fopen(argv[2], "wb");
+    wr(o, L.data()); wr(o, U.data()); wr(o, R.data()); wr(o, Ulim.data()); wr(o, U2.data());
+    wr(o, std::vector<double>{ dt, dts[0], dts[1], threw ? 1.0 : 0.0 });
+    fclose(o);
+    eq.release(inpoel);
+    printf("adapter ok: %zu tets, %zu faces, %zu boundary faces, dt=%.6e\n", nelem, fd.Nipfac(), nb, dt);
+  } catch (const std::exception& e) {
+    fprintf(stderr, "FAILED: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}

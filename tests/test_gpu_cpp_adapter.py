@@ -1,0 +1,66 @@
+"""The C++ DGPDE-shaped adapter (include/qdg_dgpde.hpp), driven like Inciter's DG
+chare drives g_dgpde, against the oracle.  The driver is compiled by
+__graft_entry__.build() with plain g++ against the C ABI only."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+EXE = os.path.join(ROOT, "tests", "cpp", "test_dgpde_adapter")
+
+
+def _read_vecs(path):
+    out = []
+    with open(path, "rb") as f:
+        while True:
+            h = f.read(8)
+            if not h:
+                break
+            n = struct.unpack("<Q", h)[0]
+            out.append(np.frombuffer(f.read(8 * n), dtype=np.float64))
+    return out
+
+
+def test_cpp_adapter_matches_oracle(tmp_path):
+    from quinoa_amd import meshgen
+    assert os.path.exists(EXE), "run __graft_entry__.build() first"
+    ch = meshgen.kuhn_box(10, 6, 5)
+    coord, inpoel = ch["coord"], ch["inpoel"]
+    ids = sorted(ch["sidesets"])
+    tri = np.concatenate([ch["sidesets"][s] for s in ids]).astype(np.uint64)
+    tset = np.concatenate([np.full(len(ch["sidesets"][s]), s, np.int32) for s in ids])
+    mesh = tmp_path / "mesh.bin"
+    with open(mesh, "wb") as f:
+        f.write(struct.pack("<QQQ", coord.shape[0], inpoel.shape[0], tri.shape[0]))
+        for d in range(3):
+            f.write(np.ascontiguousarray(coord[:, d]).tobytes())
+        f.write(inpoel.astype(np.uint64).tobytes())
+        f.write(tri.tobytes())
+        f.write(tset.tobytes())
+    out = tmp_path / "out.bin"
+    r = subprocess.run([EXE, str(mesh), str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    L, U, R, Ulim, U2, sc = _read_vecs(out)
+    kw = dict(flux="hllc", limiter="superbeep1", problem="sod_shocktube", gamma=1.4)
+    om = O.OracleMesh(coord, inpoel, ch["sidesets"])
+    orc = O.Oracle(om, O.make_cfg(4, **kw), bc_sym=[3, 4, 5, 6], bc_extrapolate=[1, 2])
+    Lo = orc.lhs(); Uo = orc.initialize(Lo, 0.0)
+    assert np.abs(L - Lo).max() <= 1e-15 * Lo.max()
+    assert np.abs(U - Uo).max() <= 1e-12
+    Ro = orc.rhs(0.0, Uo)
+    assert np.abs(R - Ro).max() <= 1e-11 * max(1.0, np.abs(Ro).max())
+    assert abs(sc[0] - orc.dt(Uo)) <= 1e-12 * sc[0]
+    assert np.abs(Ulim - orc.limit(Uo.copy())).max() <= 1e-12
+    t = 0.0
+    for s in range(2):
+        dt = orc.step(t, Uo, Lo, cfl=0.3)
+        assert abs(sc[1 + s] - dt) <= 1e-11 * dt
+        t += dt
+    assert np.abs(U2 - Uo).max() <= 1e-10
+    assert sc[3] == 1.0      # the bad call threw qdg::Exception

@@ -1,0 +1,72 @@
+"""N > 1 path on the GPU box: two ranks sharing the one MI355X of the test box,
+slabs staged through the host over gloo (RCCL needs one GPU per rank; the
+nccl transport differs from this one only in handing the device slabs to
+batch_isend_irecv directly -- see quinoa_amd/dg.py:TorchComm).  Exercises the
+HIP pack/unpack kernels, the ghost rows, the fused dt + min all-reduce and the
+stage ordering of DGDriver; the result must equal the single-chunk GPU run."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+NX, NY, NZ = 12, 8, 8
+KW = dict(flux="hllc", limiter="superbeep1", problem="sod_shocktube", gamma=1.4)
+BC = dict(bc_sym=[3, 4, 5, 6], bc_extrapolate=[1, 2])
+NSTEP = 4
+
+
+def _run(rank, world, port, parts, out):
+    import torch
+    import torch.distributed as dist
+    from quinoa_amd import capi, dg, dgmesh, meshgen
+    comm = None
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        comm = dg.TorchComm()
+    try:
+        ch = meshgen.kuhn_box_chunk(NX, NY, NZ, parts=parts, rank=rank)
+        ck = dgmesh.build_chunk(ch["coord"], ch["inpoel"], ch["nielem"], ch["sidesets"])
+        ctx = capi.Context(4, cfl=0.3, device=0, **KW, **BC)
+        mesh = dgmesh.upload(ctx, ck)
+        drv = dg.DGDriver(ctx, mesh, ch["nbr_rank"], ch["send_lists"], ch["recv_counts"], comm)
+        mesh.state_initialize(0.0)
+        t = 0.0
+        for _ in range(NSTEP):
+            drv.step(t)
+            t += drv.dt_taken()
+        U = mesh.state_download().reshape(-1, 20)[:ck.nielem]
+        np.savez(out % rank, gid=ch["gid"][:ck.nielem], U=U, t=t)
+        mesh.close(); ctx.close()
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def test_two_ranks_on_one_gpu_equal_single_chunk(tmp_path):
+    import torch.multiprocessing as mp
+    out1 = str(tmp_path / "single%d.npz")
+    out2 = str(tmp_path / "rank%d.npz")
+    mp.spawn(_run, args=(1, 0, (1, 1, 1), out1), nprocs=1, join=True)
+    mp.spawn(_run, args=(2, _free_port(), (2, 1, 1), out2), nprocs=2, join=True)
+    s = np.load(out1 % 0)
+    ref = np.zeros((NX * NY * NZ * 6, 20))
+    ref[s["gid"]] = s["U"]
+    n = 0
+    for r in range(2):
+        d = np.load(out2 % r)
+        assert abs(float(d["t"]) - float(s["t"])) <= 1e-12 * float(s["t"])
+        err = np.abs(d["U"] - ref[d["gid"]]).max() / np.abs(ref).max()
+        assert err <= 1e-10, (r, err)     # north_star: same fields as the 1-GPU run to <= 1e-10
+        n += len(d["gid"])
+    assert n == ref.shape[0]
