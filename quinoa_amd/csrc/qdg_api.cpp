@@ -81,7 +81,7 @@ struct qdg_mesh {
   size_t nie = 0, ne = 0, stride = 0;
   // mesh
   DevBuf<int> inpoel, nbr, finfo, fid, d2h;
-  DevBuf<double> x, y, z, farea, fnx, fny, fnz, vol;
+  DevBuf<double> x, y, z, farea, fnx, fny, fnz, vol, fgeo, xyz4;
   // fields (SoA planes [nprop][stride])
   DevBuf<double> U, Un, R, W;     // W: scratch state (stateless ops, WENO ping-pong)
   DevBuf<double> aos;             // [ne*nprop] staging in the caller's layout
@@ -408,6 +408,13 @@ extern "C" int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t 
   HIPCHK(m->farea.upload(h_area, s)); HIPCHK(m->fnx.upload(h_nx, s));
   HIPCHK(m->fny.upload(h_ny, s)); HIPCHK(m->fnz.upload(h_nz, s));
   HIPCHK(m->vol.upload(h_vol, s));
+  {
+    std::vector<double> h_fgeo(4 * (size_t)std::max(nfd, 1)), h_xyz4(4 * (size_t)std::max(ncount, 1), 0.0);
+    for (int i = 0; i < nfd; ++i) { h_fgeo[4*i] = h_area[i]; h_fgeo[4*i+1] = h_nx[i]; h_fgeo[4*i+2] = h_ny[i]; h_fgeo[4*i+3] = h_nz[i]; }
+    for (int i = 0; i < ncount; ++i) { h_xyz4[4*i] = hx[i]; h_xyz4[4*i+1] = hy[i]; h_xyz4[4*i+2] = hz[i]; }
+    HIPCHK(m->fgeo.upload(h_fgeo, s));
+    HIPCHK(m->xyz4.upload(h_xyz4, s));
+  }
   const size_t fsz = (size_t)m->nprop * stride;
   HIPCHK(m->U.alloc(fsz)); HIPCHK(m->Un.alloc(fsz)); HIPCHK(m->R.alloc(fsz)); HIPCHK(m->W.alloc(fsz));
   HIPCHK(m->aos.alloc(ne * (size_t)m->nprop));
@@ -428,6 +435,7 @@ extern "C" int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t 
   dm.x = m->x.p; dm.y = m->y.p; dm.z = m->z.p;
   dm.farea = m->farea.p; dm.fnx = m->fnx.p; dm.fny = m->fny.p; dm.fnz = m->fnz.p;
   dm.vol = m->vol.p; dm.d2h = m->d2h.p;
+  dm.fgeo = m->fgeo.p; dm.xyz4 = m->xyz4.p;
   HIPCHK(hipStreamSynchronize(s));
   *out = m.release();
   return 0;
@@ -949,3 +957,14 @@ extern "C" int qdg_rhs_algorithmic_bytes(qdg_mesh* mesh, double* bytes)
   return 0;
   QDG_CATCH
 }
+
+#ifdef QDG_STAMPS
+namespace qdg { hipError_t read_stamps(unsigned long long* out16, bool reset); }
+extern "C" int qdg_debug_stamps(double* out16, int reset)
+{
+  unsigned long long v[16];
+  if (qdg::read_stamps(v, reset != 0) != hipSuccess) return fail("qdg_debug_stamps failed");
+  for (int i = 0; i < 16; ++i) out16[i] = (double)v[i];
+  return 0;
+}
+#endif

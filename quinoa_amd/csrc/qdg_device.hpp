@@ -57,6 +57,8 @@ struct DevMesh {
   const double* fny;
   const double* fnz;
   const double* vol;   // [stride]
+  const double* fgeo;  // [nfac][4] packed {area, nx, ny, nz}: one 32-byte record per face
+  const double* xyz4;  // [nnode][4] packed {x, y, z, 0}: one 32-byte record per node
   const int* d2h;      // [ne] device row -> host row
 };
 

@@ -34,6 +34,25 @@ __constant__ Tables<10> c_tab10;
 __constant__ QuadTet c_qinit[3];   // NGinit rule per order index
 __constant__ QuadTet c_qdiag[3];   // NGdiag rule per order index
 
+#ifdef QDG_STAMPS
+// diagnostic build only: per-segment cycle sums of the P1 RHS kernel (lane 0 of
+// every wave adds its s_memtime differences); never part of a timed build
+__device__ unsigned long long g_stamp[16];
+#define STAMP(i)                                                               \
+  do {                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                         \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();                \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                        \
+    if ((threadIdx.x & 63) == 0) atomicAdd(&g_stamp[i], t_ - tprev_);          \
+    tprev_ = __builtin_amdgcn_s_memtime();                                     \
+    __builtin_amdgcn_sched_barrier(0);                                         \
+  } while (0)
+#define STAMP_INIT unsigned long long tprev_ = __builtin_amdgcn_s_memtime()
+#else
+#define STAMP(i) do {} while (0)
+#define STAMP_INIT do {} while (0)
+#endif
+
 template <int NDOF> __device__ __forceinline__ const Tables<NDOF>& tab();
 template <> __device__ __forceinline__ const Tables<1>& tab<1>() { return c_tab1; }
 template <> __device__ __forceinline__ const Tables<4>& tab<4>() { return c_tab4; }
@@ -633,89 +652,55 @@ __global__ __launch_bounds__(256, QDG_P1_WAVES) void k_rhs_p1(DevMesh m, Phys ph
                                                 double* __restrict__ R,
                                                 double* __restrict__ blockmin)
 {
-  constexpr int NDOF = 4, NGF = 3, NGV = 5;
+  constexpr int NDOF = 4, NGF = 3, NGV = 5, NPROP = NCOMP * NDOF;
   const Tables<4>& T = c_tab4;
   const int stride = m.stride;
   const int e0 = xcd_tile(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   const bool active = e0 < m.nie;
-  const int e = active ? e0 : 0;
+  const int e = active ? e0 : m.nie - 1;
   double dte = DBL_MAX;
+  STAMP_INIT;
 
+  // ---- load schedule -------------------------------------------------------
+  // level 1 (independent): own row, the 4 neighbour ids / face codes / face ids,
+  //   the 4 node ids, the volume;
+  // level 2 (needs level 1): node coordinates, neighbour row + geometry of face 0;
+  // then the volume term runs while level 2 for face 0 is still in flight, and
+  // inside the face loop the row + geometry of face lf+1 are requested before
+  // face lf is computed.  A wave therefore exposes two memory latencies in
+  // total instead of two per face.
   double u[NCOMP][NDOF], acc[NCOMP][NDOF];
-  load_dofs<NDOF>(U, stride, e, u);
+  load_row<NPROP>(U, e, &u[0][0]);
+  const int nb0 = m.nbr[e], nb1 = m.nbr[(size_t)stride + e], nb2 = m.nbr[(size_t)2 * stride + e],
+            nb3 = m.nbr[(size_t)3 * stride + e];
+  const int in0 = m.finfo[e], in1 = m.finfo[(size_t)stride + e], in2 = m.finfo[(size_t)2 * stride + e],
+            in3 = m.finfo[(size_t)3 * stride + e];
+  const int f0 = m.fid[e], f1 = m.fid[(size_t)stride + e], f2 = m.fid[(size_t)2 * stride + e],
+            f3 = m.fid[(size_t)3 * stride + e];
+  const int n0 = m.inpoel[e], n1 = m.inpoel[(size_t)stride + e], n2 = m.inpoel[(size_t)2 * stride + e],
+            n3 = m.inpoel[(size_t)3 * stride + e];
+  const double vol = m.vol[e];
+  STAMP(0);
+
+  double nxt[NCOMP][NDOF], gnx[4];
+  load_row<NPROP>(U, nb0 >= 0 ? nb0 : e, &nxt[0][0]);
+  load_row<4>(m.fgeo, f0, gnx);
+  ElemGeom g;
+  {
+    double q[4];
+    load_row<4>(m.xyz4, n0, q); g.p[0][0] = q[0]; g.p[0][1] = q[1]; g.p[0][2] = q[2];
+    load_row<4>(m.xyz4, n1, q); g.p[1][0] = q[0]; g.p[1][1] = q[1]; g.p[1][2] = q[2];
+    load_row<4>(m.xyz4, n2, q); g.p[2][0] = q[0]; g.p[2][1] = q[1]; g.p[2][2] = q[2];
+    load_row<4>(m.xyz4, n3, q); g.p[3][0] = q[0]; g.p[3][1] = q[1]; g.p[3][2] = q[2];
+  }
+  STAMP(1);
+
 #pragma unroll
   for (int c = 0; c < NCOMP; ++c)
 #pragma unroll
     for (int k = 0; k < NDOF; ++k) acc[c][k] = 0.0;
 
-  const int nb0 = m.nbr[e], nb1 = m.nbr[(size_t)stride + e], nb2 = m.nbr[(size_t)2 * stride + e],
-            nb3 = m.nbr[(size_t)3 * stride + e];
-  // node coordinates: needed inside the face loop only for Dirichlet states
-  // (problems with an analytic solution); otherwise loaded after it
-  constexpr bool GEOM_EARLY = (PROB == 3 || PROB == 4 || PROB == 0);
-  ElemGeom g;
-  if (GEOM_EARLY) load_geom(m, e, g);
-  const double vol = m.vol[e];
-  double delt = 0.0;
-
-#pragma unroll 1
-  for (int lf = 0; lf < 4; ++lf) {
-    const int nb = (lf == 0) ? nb0 : (lf == 1) ? nb1 : (lf == 2) ? nb2 : nb3;
-    const int info = m.finfo[(size_t)lf * stride + e];
-    const int f = m.fid[(size_t)lf * stride + e];
-    const double area = m.farea[f];
-    const double fn[3] = { m.fnx[f], m.fny[f], m.fnz[f] };
-    const bool own_left = (info >> 6) & 1;
-    double cur[NCOMP][NDOF];
-    load_dofs<NDOF>(U, stride, nb >= 0 ? nb : e, cur);
-    if (nb == -1 && !WITH_DT) continue;    // boundary face without a BC: no flux
-#pragma unroll 1
-    for (int ig = 0; ig < NGF; ++ig) {
-      const double s0 = T.fs[ig][0], s1 = T.fs[ig][1], s2 = T.fs[ig][2];
-      double so[NCOMP], sn[NCOMP], fl[NCOMP];
-      state_from<NDOF>(u, T.fB[lf][ig], so);
-      if (nb >= 0) {
-        double xi, eta, zeta, Bn[NDOF];
-        nbr_ref_coords(info, s0, s1, s2, xi, eta, zeta);
-        eval_basis<NDOF>(xi, eta, zeta, Bn);
-        state_from<NDOF>(cur, Bn, sn);
-      } else {
-        double P[3] = { 0.0, 0.0, 0.0 };
-        if (GEOM_EARLY) face_point(g, lf, s0, s1, s2, P);
-        bc_state<PROB>(ph, -nb - 1, so, P[0], P[1], P[2], t, fn, sn);
-      }
-      const double* sl = own_left ? so : sn;
-      const double* sr = own_left ? sn : so;
-      double L[NCOMP], Rr[NCOMP];
-#pragma unroll
-      for (int c = 0; c < NCOMP; ++c) { L[c] = own_left ? so[c] : sn[c]; Rr[c] = own_left ? sn[c] : so[c]; }
-      (void)sl; (void)sr;
-      Prim ql, qr;
-      primitives(ph, fn, L, ql);
-      primitives(ph, fn, Rr, qr);
-      const double wq = T.fw[ig] * area;
-      if (WITH_DT) {
-        // delt += std::max(dSV_l, dSV_r); boundary faces: dSV_r = 0
-        const double dl = wq * (fabs(ql.vn) + ql.a);
-        const double dr = (nb >= 0) ? wq * (fabs(qr.vn) + qr.a) : 0.0;
-        delt += (dl < dr) ? dr : dl;
-      }
-      if (nb == -1) continue;
-      if (ph.flux == 1) flux_lf_q(fn, L, Rr, ql, qr, fl);
-      else flux_hllc_q(fn, L, Rr, ql, qr, fl);
-      const double wt = own_left ? -wq : wq;
-#pragma unroll
-      for (int c = 0; c < NCOMP; ++c) {
-        const double wf = wt * fl[c];
-        acc[c][0] += wf;
-#pragma unroll
-        for (int k = 1; k < NDOF; ++k) acc[c][k] += wf * T.fB[lf][ig][k];
-      }
-    }
-  }
-
   // ---- volume integral: dB/dx constant on a P1 tet --------------------------
-  if (!GEOM_EARLY) load_geom(m, e, g);
   {
     double ji[3][3];
     inverse_jacobian(g, ji);
@@ -769,8 +754,93 @@ __global__ __launch_bounds__(256, QDG_P1_WAVES) void k_rhs_p1(DevMesh m, Phys ph
       }
     }
   }
+  STAMP(2);
 
-  if (active) store_row<NCOMP * NDOF>(R, e, &acc[0][0]);
+  // ---- faces ----------------------------------------------------------------
+  double delt = 0.0;
+  constexpr bool HAS_DIRICHLET = (PROB == 3 || PROB == 4 || PROB == 0);
+#pragma unroll 1
+  for (int lf = 0; lf < 4; ++lf) {
+    const int nb = (lf == 0) ? nb0 : (lf == 1) ? nb1 : (lf == 2) ? nb2 : nb3;
+    const int info = (lf == 0) ? in0 : (lf == 1) ? in1 : (lf == 2) ? in2 : in3;
+    double cur[NCOMP][NDOF];
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c)
+#pragma unroll
+      for (int k = 0; k < NDOF; ++k) cur[c][k] = nxt[c][k];
+    const double area = gnx[0];
+    const double fn[3] = { gnx[1], gnx[2], gnx[3] };
+    if (lf < 3) {
+      const int nbn = (lf == 0) ? nb1 : (lf == 1) ? nb2 : nb3;
+      const int fnx_ = (lf == 0) ? f1 : (lf == 1) ? f2 : f3;
+      load_row<NPROP>(U, nbn >= 0 ? nbn : e, &nxt[0][0]);
+      load_row<4>(m.fgeo, fnx_, gnx);
+    }
+    STAMP(3);
+    const bool own_left = (info >> 6) & 1;
+    // Boundary faces run through the SAME straight-line code as interior ones
+    // (no wave divergence): the "neighbour" state is the own state, mirrored
+    // for Symmetry (DGCompFlow.hpp:672-690: u_r = u_l - 2 (u_l.n) n, same rho
+    // and rhoE), untouched for Extrapolate; a face without a configured BC
+    // gets weight 0.  Only Dirichlet needs the analytic solution (a real
+    // branch, compiled in for the manufactured-solution problems only).
+    const bool bnd = nb < 0;
+    const int bc = bnd ? -nb - 1 : 0;
+    const double refl = (bc == 2) ? 2.0 : 0.0;
+    const double wsel = (bnd && bc == 0) ? 0.0 : 1.0;
+#pragma unroll 1
+    for (int ig = 0; ig < NGF; ++ig) {
+      const double s0 = T.fs[ig][0], s1 = T.fs[ig][1], s2 = T.fs[ig][2];
+      double so[NCOMP], sn[NCOMP], fl[NCOMP];
+      state_from<NDOF>(u, T.fB[lf][ig], so);
+      {
+        double xi, eta, zeta, Bn[NDOF];
+        nbr_ref_coords(info, s0, s1, s2, xi, eta, zeta);
+        eval_basis<NDOF>(xi, eta, zeta, Bn);
+        state_from<NDOF>(cur, Bn, sn);
+      }
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) sn[c] = bnd ? so[c] : sn[c];
+      {
+        const double vn2 = refl * (sn[1] * fn[0] + sn[2] * fn[1] + sn[3] * fn[2]);
+        sn[1] -= vn2 * fn[0]; sn[2] -= vn2 * fn[1]; sn[3] -= vn2 * fn[2];
+      }
+      if constexpr (HAS_DIRICHLET) {
+        if (bc == 1) {
+          double P[3];
+          face_point(g, lf, s0, s1, s2, P);
+          prob_solution<PROB>(ph, P[0], P[1], P[2], t, sn);
+        }
+      }
+      double L[NCOMP], Rr[NCOMP];
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) { L[c] = own_left ? so[c] : sn[c]; Rr[c] = own_left ? sn[c] : so[c]; }
+      Prim ql, qr;
+      primitives(ph, fn, L, ql);
+      primitives(ph, fn, Rr, qr);
+      const double wq = T.fw[ig] * area;
+      if (WITH_DT) {
+        // delt += std::max(dSV_l, dSV_r); boundary faces: dSV_r = 0
+        const double dl = wq * (fabs(ql.vn) + ql.a);
+        const double dr = bnd ? 0.0 : wq * (fabs(qr.vn) + qr.a);
+        delt += (dl < dr) ? dr : dl;
+      }
+      if (ph.flux == 1) flux_lf_q(fn, L, Rr, ql, qr, fl);
+      else flux_hllc_q(fn, L, Rr, ql, qr, fl);
+      const double wt = (own_left ? -wq : wq) * wsel;
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) {
+        const double wf = wt * fl[c];
+        acc[c][0] += wf;
+#pragma unroll
+        for (int k = 1; k < NDOF; ++k) acc[c][k] += wf * T.fB[lf][ig][k];
+      }
+    }
+    STAMP(4);
+  }
+
+  if (active) store_row<NPROP>(R, e, &acc[0][0]);
+  STAMP(5);
 
   if (WITH_DT) {
     if (active) dte = vol / delt;
@@ -1196,6 +1266,18 @@ __global__ void k_halo_unpack(const double* __restrict__ slab, int nprop, int ni
   } while (0)
 
 static inline int nblk(int n, int b) { return (n + b - 1) / b; }
+
+#ifdef QDG_STAMPS
+hipError_t read_stamps(unsigned long long* out16, bool reset)
+{
+  hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamp), 16 * sizeof(unsigned long long));
+  if (e == hipSuccess && reset) {
+    unsigned long long z[16] = { 0 };
+    e = hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z));
+  }
+  return e;
+}
+#endif
 
 hipError_t upload_tables(const Tables<1>& t1, const Tables<4>& t4, const Tables<10>& t10,
                          const QuadTet* qinit, const QuadTet* qdiag)
