@@ -61,6 +61,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--nx", type=int, default=55, help="hexes per direction PER GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (nccl) even for one rank: exercises the "
+                         "device-tensor slabs, the shared stream and the dt all-reduce")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -74,9 +77,12 @@ def main():
     from quinoa_amd import capi, dg, dgmesh, meshgen
 
     comm = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         comm = dg.TorchComm()
@@ -97,7 +103,7 @@ def main():
     def sync():
         ctx.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if comm is not None:
             torch.distributed.barrier()
 
     for _ in range(args.warmup):
@@ -157,7 +163,7 @@ def main():
         print(json.dumps(out))
     mesh.close()
     ctx.close()
-    if world > 1:
+    if comm is not None:
         torch.distributed.destroy_process_group()
 
 

@@ -356,6 +356,7 @@ extern "C" int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t 
   const size_t stride = (ne + 63) / 64 * 64;
   std::vector<int> h_inpoel(4 * stride, 0), h_nbr(4 * stride, -1), h_finfo(4 * stride, 0), h_fid(4 * stride, 0);
   std::vector<double> h_vol(stride, 1.0);
+  const bool debug_self_nbr = std::getenv("QDG_DEBUG_SELF_NBR") != nullptr;
   std::vector<int> fmap(nfac, -1);
   int nfd = 0;
   for (size_t d = 0; d < ne; ++d) {
@@ -372,7 +373,8 @@ extern "C" int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t 
       if (nb < 0) {
         h_nbr[lf * stride + d] = -(1 + bcface[f]);
       } else {
-        h_nbr[lf * stride + d] = h2d[nb];
+        // QDG_DEBUG_SELF_NBR: timing experiment only (wrong results): every gather hits the own row
+        h_nbr[lf * stride + d] = debug_self_nbr ? (int)d : h2d[nb];
         for (int j = 0; j < 3; ++j) {
           const size_t g = inpoel[4 * h + LPOFA[lf][j]];
           int m = -1;

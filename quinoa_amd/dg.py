@@ -76,7 +76,8 @@ class DGDriver:
         self.nbr_rank = list(nbr_rank)
         self.limiter_active = ctx.cfg.limiter != 0 and ctx.ndof > 1
         self.send_slab = self.recv_slab = self.dt_buf = None
-        if self.comm.size > 1:
+        self.distributed = isinstance(self.comm, TorchComm)
+        if self.distributed:
             torch = self.comm.torch
             dev = torch.device("cuda", torch.cuda.current_device())
             mesh.halo_setup(self.nbr_rank, send_lists, recv_counts)
@@ -93,7 +94,7 @@ class DGDriver:
             ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 
     def exchange(self):
-        if self.comm.size == 1 or not self.nbr_rank:
+        if not self.distributed or not self.nbr_rank:
             return
         self.mesh.halo_pack()
         self.comm.sendrecv(self)
@@ -109,7 +110,7 @@ class DGDriver:
             # rhs; at stage 0 it also yields the local dt (the reference computes
             # dt first, DG.cpp:1360-1430, from the same state; R does not depend on dt)
             m.stage_rhs_dt(stage, t, tleft)
-            if stage == 0 and self.comm.size > 1:
+            if stage == 0 and self.distributed:
                 self.comm.allreduce_min(self)        # contribute(min), DG.cpp:1428-1429
             m.stage_update(stage)
 
