@@ -1,4 +1,2 @@
-for v in w2u1 w2u3; do
-QDG_LIB=$PWD/quinoa_amd/lib/libqdg_$v.so timeout -k 10 300 python -m pytest tests/test_gpu_parity.py -m gpu -q -x 2>&1 | tail -1
-QDG_LIB=$PWD/quinoa_amd/lib/libqdg_$v.so timeout -k 10 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v', round(d['value']), round(d['ms_per_step'],3), round(d['roofline']['avg_launch_ms'],4), round(d['roofline']['frac'],4))"
-done
+timeout -k 10 600 python -m pytest tests -m gpu -q -x 2>&1 | tail -2
+timeout -k 10 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value']), round(d['ms_per_step'],3), round(d['roofline']['avg_launch_ms'],4), round(d['roofline']['frac'],4))"

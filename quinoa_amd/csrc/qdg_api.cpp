@@ -86,8 +86,13 @@ struct qdg_mesh {
   DevBuf<double> U, Un, R, W;     // W: scratch state (stateless ops, WENO ping-pong)
   DevBuf<double> aos;             // [ne*nprop] staging in the caller's layout
   DevBuf<double> blockmin, dtraw, dtdev, diagpart, diagout;
-  double* Ucur = nullptr;         // resident state (U or W after a WENO swap)
-  double* Ualt = nullptr;
+  // the three field buffers U, Un, W rotate: Ucur = current state, Unp = the
+  // stage-0 state of the running step (may alias Ucur until the first update),
+  // the remaining one is free (RK output / WENO ping-pong)
+  double* Ucur = nullptr;
+  double* Unp = nullptr;
+  double* Upending = nullptr;     // output of a fused RHS+RK launch, adopted by qdg_stage_update
+  DevBuf<double> S1, S2;          // scratch of the stateless operators (allocated on first use)
   // halo
   size_t nnbr = 0, nsend = 0, nrecv = 0;
   std::vector<int32_t> nbr_rank;
@@ -427,7 +432,7 @@ extern "C" int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t 
   const size_t nblk = (nie + 255) / 256;
   HIPCHK(m->blockmin.alloc(nblk)); HIPCHK(m->dtraw.alloc(1)); HIPCHK(m->dtdev.alloc(1));
   HIPCHK(m->diagpart.alloc(nblk * 15)); HIPCHK(m->diagout.alloc(15));
-  m->Ucur = m->U.p; m->Ualt = m->W.p;
+  m->Ucur = m->U.p;
   m->dt_ptr = m->dtdev.p;
   m->nnode_used = (size_t)ncount;
 
@@ -498,8 +503,24 @@ static int planes_to_host(qdg_mesh* mesh, const double* src, size_t nrows, doubl
   return 0;
 }
 
-static int run_limiter(qdg_mesh* mesh, double*& Ucur, double*& Ualt)
+static double* free_buf(qdg_mesh* mesh, const double* a, const double* b)
 {
+  double* all[3] = { mesh->U.p, mesh->Un.p, mesh->W.p };
+  for (double* p : all) if (p != a && p != b) return p;
+  return nullptr;
+}
+
+static int scratch(qdg_mesh* mesh)
+{
+  const size_t fsz = (size_t)mesh->nprop * mesh->stride;
+  if (!mesh->S1.p) HIPCHK(mesh->S1.alloc(fsz));
+  if (!mesh->S2.p) HIPCHK(mesh->S2.alloc(fsz));
+  return 0;
+}
+
+static int run_limiter(qdg_mesh* mesh, double*& Ucur, double* Ualt_in)
+{
+  double* Ualt = Ualt_in;
   qdg_ctx* ctx = mesh->ctx;
   hipStream_t s = ctx->stream;
   if (mesh->ndof == 1) return 0;          // DG.cpp:1251: rdof > 1 only
@@ -539,9 +560,10 @@ extern "C" int qdg_lhs(qdg_mesh* mesh, double* L_aos)
   QDG_TRY
   MESH_ENTER("qdg_lhs");
   if (!L_aos) return fail("qdg_lhs: null L");
-  launch_mass(mesh->ndof, mesh->dm, mesh->R.p, s);
+  if (int rc = scratch(mesh)) return rc;
+  launch_mass(mesh->ndof, mesh->dm, mesh->S1.p, s);
   HIPCHK(hipGetLastError());
-  return planes_to_host(mesh, mesh->R.p, mesh->ne, L_aos, false);
+  return planes_to_host(mesh, mesh->S1.p, mesh->ne, L_aos, false);
   QDG_CATCH
 }
 
@@ -550,7 +572,8 @@ extern "C" int qdg_initialize(qdg_mesh* mesh, double t, double* U_aos)
   QDG_TRY
   MESH_ENTER("qdg_initialize");
   if (!U_aos) return fail("qdg_initialize: null U");
-  double* w = mesh->Ualt;
+  if (int rc = scratch(mesh)) return rc;
+  double* w = mesh->S1.p;
   launch_init(mesh->ndof, mesh->dm, ctx->ph, t, w, s);
   HIPCHK(hipGetLastError());
   return planes_to_host(mesh, w, mesh->nie, U_aos, false);
@@ -562,13 +585,14 @@ extern "C" int qdg_rhs(qdg_mesh* mesh, double t, const double* U_aos, double* R_
   QDG_TRY
   MESH_ENTER("qdg_rhs");
   if (!U_aos || !R_aos) return fail("qdg_rhs: null U/R");
-  double* w = mesh->Ualt;
+  if (int rc = scratch(mesh)) return rc;
+  double* w = mesh->S1.p;
   if (int rc = host_to_planes(mesh, U_aos, w)) return rc;
-  run_rhs(mesh, t, w, mesh->R.p);
+  run_rhs(mesh, t, w, mesh->S2.p);
   HIPCHK(hipGetLastError());
   // ghost rows of R are returned as zero (the reference leaves partial sums
   // there that DG::solve never reads back: ghosts are overwritten by comsol)
-  return planes_to_host(mesh, mesh->R.p, mesh->nie, R_aos, true);
+  return planes_to_host(mesh, mesh->S2.p, mesh->nie, R_aos, true);
   QDG_CATCH
 }
 
@@ -577,7 +601,8 @@ extern "C" int qdg_dt(qdg_mesh* mesh, const double* U_aos, double* mindt)
   QDG_TRY
   MESH_ENTER("qdg_dt");
   if (!U_aos || !mindt) return fail("qdg_dt: null argument");
-  double* w = mesh->Ualt;
+  if (int rc = scratch(mesh)) return rc;
+  double* w = mesh->S1.p;
   if (int rc = host_to_planes(mesh, U_aos, w)) return rc;
   launch_dt(mesh->ndof, mesh->dm, ctx->ph, w, mesh->blockmin.p, 1.0, DBL_MAX, mesh->dtraw.p,
             mesh->diagout.p /*scratch*/, s);
@@ -594,10 +619,10 @@ extern "C" int qdg_limit(qdg_mesh* mesh, double* U_aos)
   MESH_ENTER("qdg_limit");
   if (!U_aos) return fail("qdg_limit: null U");
   // scratch pair that does not alias the resident state
-  double* a = mesh->Ualt;
-  double* b = mesh->R.p;
+  if (int rc = scratch(mesh)) return rc;
+  double* a = mesh->S1.p;
   if (int rc = host_to_planes(mesh, U_aos, a)) return rc;
-  if (int rc = run_limiter(mesh, a, b)) return rc;
+  if (int rc = run_limiter(mesh, a, mesh->S2.p)) return rc;
   return planes_to_host(mesh, a, mesh->ne, U_aos, false);
   QDG_CATCH
 }
@@ -647,7 +672,7 @@ extern "C" int qdg_stage_limit(qdg_mesh* mesh)
 {
   QDG_TRY
   MESH_ENTER("qdg_stage_limit");
-  return run_limiter(mesh, mesh->Ucur, mesh->Ualt);
+  return run_limiter(mesh, mesh->Ucur, free_buf(mesh, mesh->Ucur, mesh->Unp));
   QDG_CATCH
 }
 
@@ -704,34 +729,7 @@ extern "C" int qdg_stage_dt_device_ptr(qdg_mesh* mesh, void** dptr)
   QDG_CATCH
 }
 
-extern "C" int qdg_stage_rhs_update(qdg_mesh* mesh, int stage, double t)
-{
-  QDG_TRY
-  MESH_ENTER("qdg_stage_rhs_update");
-  if (stage < 0 || stage > 2) return fail("qdg_stage_rhs_update: stage must be 0,1,2");
-  static const double rk[2][3] = { { 0.0, 3.0 / 4.0, 1.0 / 3.0 }, { 1.0, 1.0 / 4.0, 2.0 / 3.0 } };
-  const size_t fsz = (size_t)mesh->nprop * mesh->stride * sizeof(double);
-  if (stage == 0)   // m_un = m_u, DG.cpp:1472
-    HIPCHK(hipMemcpyAsync(mesh->Un.p, mesh->Ucur, fsz, hipMemcpyDeviceToDevice, s));
-  std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
-  if (mesh->prof) {
-    if (mesh->ev_used == mesh->ev.size()) {
-      hipEvent_t a, b;
-      HIPCHK(hipEventCreate(&a));
-      HIPCHK(hipEventCreate(&b));
-      mesh->ev.emplace_back(a, b);
-    }
-    ev = &mesh->ev[mesh->ev_used++];
-    HIPCHK(hipEventRecord(ev->first, s));
-  }
-  run_rhs(mesh, t, mesh->Ucur, mesh->R.p);
-  if (ev) HIPCHK(hipEventRecord(ev->second, s));
-  launch_rk(mesh->ndof, mesh->dm, rk[0][stage], rk[1][stage], mesh->dt_ptr, mesh->Un.p,
-            mesh->R.p, mesh->Ucur, s);
-  HIPCHK(hipGetLastError());
-  return 0;
-  QDG_CATCH
-}
+static const double RK[2][3] = { { 0.0, 3.0 / 4.0, 1.0 / 3.0 }, { 1.0, 1.0 / 4.0, 2.0 / 3.0 } };   // DG.cpp:39-40
 
 static int prof_begin(qdg_mesh* mesh, std::pair<hipEvent_t, hipEvent_t>** ev)
 {
@@ -748,22 +746,56 @@ static int prof_begin(qdg_mesh* mesh, std::pair<hipEvent_t, hipEvent_t>** ev)
   return 0;
 }
 
+// rhs + update with dt already in the device scalar (in-place form; Un is a copy)
+extern "C" int qdg_stage_rhs_update(qdg_mesh* mesh, int stage, double t)
+{
+  QDG_TRY
+  MESH_ENTER("qdg_stage_rhs_update");
+  if (stage < 0 || stage > 2) return fail("qdg_stage_rhs_update: stage must be 0,1,2");
+  const size_t fsz = (size_t)mesh->nprop * mesh->stride * sizeof(double);
+  if (stage == 0) {   // m_un = m_u, DG.cpp:1472
+    mesh->Unp = free_buf(mesh, mesh->Ucur, nullptr);
+    HIPCHK(hipMemcpyAsync(mesh->Unp, mesh->Ucur, fsz, hipMemcpyDeviceToDevice, s));
+  }
+  if (!mesh->Unp || mesh->Unp == mesh->Ucur) return fail("qdg_stage_rhs_update: call stage 0 first");
+  std::pair<hipEvent_t, hipEvent_t>* ev;
+  if (int rc = prof_begin(mesh, &ev)) return rc;
+  run_rhs(mesh, t, mesh->Ucur, mesh->R.p);
+  if (ev) HIPCHK(hipEventRecord(ev->second, s));
+  launch_rk(mesh->ndof, mesh->dm, RK[0][stage], RK[1][stage], mesh->dt_ptr, mesh->Unp, mesh->R.p,
+            mesh->Ucur, mesh->Ucur, s);
+  HIPCHK(hipGetLastError());
+  if (stage == 2) mesh->Unp = nullptr;
+  return 0;
+  QDG_CATCH
+}
+
+// Fused form.  Stage 0: Un is the current buffer itself (no copy: the update
+// writes the new state to another buffer), R <- rhs(U) and, with a CFL time
+// step, dt from the same kernel.  Stages 1, 2 on the DG-P1 fast path: the RK
+// update is fused into the RHS kernel (dt is known), R never goes to memory.
 extern "C" int qdg_stage_rhs_dt(qdg_mesh* mesh, int stage, double t, double tleft)
 {
   QDG_TRY
   MESH_ENTER("qdg_stage_rhs_dt");
   if (stage < 0 || stage > 2) return fail("qdg_stage_rhs_dt: stage must be 0,1,2");
-  const size_t fsz = (size_t)mesh->nprop * mesh->stride * sizeof(double);
-  if (stage == 0)   // m_un = m_u, DG.cpp:1472
-    HIPCHK(hipMemcpyAsync(mesh->Un.p, mesh->Ucur, fsz, hipMemcpyDeviceToDevice, s));
+  if (stage == 0) mesh->Unp = mesh->Ucur;           // m_un = m_u, DG.cpp:1472
+  if (!mesh->Unp) return fail("qdg_stage_rhs_dt: call stage 0 first");
+  mesh->Upending = nullptr;
   const bool cfl_dt = stage == 0 && !(ctx->cfg.dt > 0.0);
   if (stage == 0 && !cfl_dt) if (int rc = qdg_stage_dt(mesh, tleft)) return rc;
   std::pair<hipEvent_t, hipEvent_t>* ev;
-  if (cfl_dt && use_p1_fast(mesh)) {
+  if (use_p1_fast(mesh) && stage > 0) {
+    double* out = free_buf(mesh, mesh->Ucur, mesh->Unp);
+    if (int rc = prof_begin(mesh, &ev)) return rc;
+    launch_rhs_p1_rk(mesh->dm, ctx->ph, t, mesh->Ucur, out, RK[0][stage], RK[1][stage],
+                     mesh->dt_ptr, mesh->Unp, s);
+    if (ev) HIPCHK(hipEventRecord(ev->second, s));
+    mesh->Upending = out;
+  } else if (cfl_dt && use_p1_fast(mesh)) {
     const double scale = ctx->cfg.cfl / 3.0;     // cfl/(2p+1), p = 1 (DG.cpp:1404-1418)
     if (int rc = prof_begin(mesh, &ev)) return rc;
-    // the event pair brackets the RHS kernel only when it is launched alone;
-    // here it also covers the 1-block dt reduction (~5 us)
+    // here the event pair also covers the 1-block dt reduction (~5 us)
     launch_rhs_p1(mesh->dm, ctx->ph, t, mesh->Ucur, mesh->R.p, true, mesh->blockmin.p, scale,
                   tleft, mesh->dtraw.p, mesh->dt_ptr, s);
     if (ev) HIPCHK(hipEventRecord(ev->second, s));
@@ -783,10 +815,24 @@ extern "C" int qdg_stage_update(qdg_mesh* mesh, int stage)
   QDG_TRY
   MESH_ENTER("qdg_stage_update");
   if (stage < 0 || stage > 2) return fail("qdg_stage_update: stage must be 0,1,2");
-  static const double rk[2][3] = { { 0.0, 3.0 / 4.0, 1.0 / 3.0 }, { 1.0, 1.0 / 4.0, 2.0 / 3.0 } };
-  launch_rk(mesh->ndof, mesh->dm, rk[0][stage], rk[1][stage], mesh->dt_ptr, mesh->Un.p, mesh->R.p,
-            mesh->Ucur, s);
-  HIPCHK(hipGetLastError());
+  if (!mesh->Unp) return fail("qdg_stage_update: no stage in flight");
+  if (mesh->Upending) {                       // the fused kernel already wrote the new state
+    mesh->Ucur = mesh->Upending;
+    mesh->Upending = nullptr;
+  } else {
+    double* out = free_buf(mesh, mesh->Ucur, mesh->Unp);
+    launch_rk(mesh->ndof, mesh->dm, RK[0][stage], RK[1][stage], mesh->dt_ptr, mesh->Unp, mesh->R.p,
+              mesh->Ucur, out, s);
+    HIPCHK(hipGetLastError());
+    // ghost rows are not touched by the update; carry them over so that a
+    // caller reading ghosts before the next exchange sees the old values
+    if (mesh->ne > mesh->nie)
+      HIPCHK(hipMemcpyAsync(out + mesh->nie * (size_t)mesh->nprop, mesh->Ucur + mesh->nie * (size_t)mesh->nprop,
+                            (mesh->ne - mesh->nie) * (size_t)mesh->nprop * sizeof(double),
+                            hipMemcpyDeviceToDevice, s));
+    mesh->Ucur = out;
+  }
+  if (stage == 2) mesh->Unp = nullptr;
   return 0;
   QDG_CATCH
 }

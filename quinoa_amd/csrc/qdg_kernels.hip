@@ -646,11 +646,14 @@ __device__ __forceinline__ void flux_lf_q(const double* fn, const double* L, con
 //  * WITH_DT (RK stage 0): the CFL sum of dg::CompFlow::dt
 //    (DGCompFlow.hpp:206-406) is accumulated from the wave speeds the Riemann
 //    solver already has -- the separate dt face loop disappears.
-template <bool WITH_DT, int PROB>
+template <bool WITH_DT, bool FUSE_RK, int PROB>
 __global__ __launch_bounds__(256, QDG_P1_WAVES) void k_rhs_p1(DevMesh m, Phys ph, double t,
                                                 const double* __restrict__ U,
                                                 double* __restrict__ R,
-                                                double* __restrict__ blockmin)
+                                                double* __restrict__ blockmin,
+                                                double rk_a, double rk_b,
+                                                const double* __restrict__ dtp,
+                                                const double* __restrict__ Un)
 {
   constexpr int NDOF = 4, NGF = 3, NGV = 5, NPROP = NCOMP * NDOF;
   const Tables<4>& T = c_tab4;
@@ -839,6 +842,20 @@ __global__ __launch_bounds__(256, QDG_P1_WAVES) void k_rhs_p1(DevMesh m, Phys ph
     STAMP(4);
   }
 
+  if (FUSE_RK) {
+    // SSP-RK3 stage update fused into the RHS (stages 1 and 2, dt known):
+    // `R` is the NEW state buffer, R itself never goes to memory
+    //   U_new = a*Un + b*(U + dt*R/L),  L = vol*massfac[k]   (DG.cpp:1478-1488)
+    constexpr double imf[4] = { 1.0, 10.0, 10.0 / 3.0, 5.0 / 3.0 };
+    const double dtv = dtp[0] / vol;
+    double un[NCOMP][NDOF];
+    load_row<NPROP>(Un, e, &un[0][0]);
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c)
+#pragma unroll
+      for (int k = 0; k < NDOF; ++k)
+        acc[c][k] = rk_a * un[c][k] + rk_b * (u[c][k] + dtv * imf[k] * acc[c][k]);
+  }
   if (active) store_row<NPROP>(R, e, &acc[0][0]);
   STAMP(5);
 
@@ -1044,7 +1061,8 @@ template <int NDOF>
 __global__ __launch_bounds__(256) void k_rk(DevMesh m, double a, double b,
                                             const double* __restrict__ dt,
                                             const double* __restrict__ Un,
-                                            const double* __restrict__ R, double* __restrict__ U)
+                                            const double* __restrict__ R, const double* U,
+                                            double* Uout)
 {
   // flat, fully coalesced sweep over the nie*NPROP doubles of the interior rows
   constexpr int NPROP = NCOMP * NDOF;
@@ -1059,7 +1077,7 @@ __global__ __launch_bounds__(256) void k_rk(DevMesh m, double a, double b,
 #pragma unroll
   for (int j = 1; j < NDOF; ++j) f = (k == j) ? imf[j] : f;
   const double dtv = dt[0] / m.vol[e];
-  U[i] = a * Un[i] + b * (U[i] + dtv * f * R[i]);
+  Uout[i] = a * Un[i] + b * (U[i] + dtv * f * R[i]);   // Uout may alias U (in place)
 }
 
 // ------------------------------------------------------------- setup ops
@@ -1306,11 +1324,20 @@ void launch_rhs_p1(const DevMesh& m, const Phys& ph, double t, const double* U, 
   const int nb = nblk(m.nie, 256);
   if (nb == 0) return;
   if (with_dt) {
-    QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1<true, P><<<nb, 256, 0, s>>>(m, ph, t, U, R, blockmin)));
+    QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1<true, false, P><<<nb, 256, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr)));
     k_dt_final<<<1, 256, 0, s>>>(blockmin, nb, scale, tleft, out_raw, out_dt);
   } else {
-    QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1<false, P><<<nb, 256, 0, s>>>(m, ph, t, U, R, blockmin)));
+    QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1<false, false, P><<<nb, 256, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr)));
   }
+}
+
+// P1 RHS with the SSP-RK3 update fused in: Uout = a*Un + b*(U + dt*R/L)
+void launch_rhs_p1_rk(const DevMesh& m, const Phys& ph, double t, const double* U, double* Uout,
+                      double a, double b, const double* dt, const double* Un, hipStream_t s)
+{
+  const int nb = nblk(m.nie, 256);
+  if (nb == 0) return;
+  QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1<false, true, P><<<nb, 256, 0, s>>>(m, ph, t, U, Uout, nullptr, a, b, dt, Un)));
 }
 
 void launch_superbee(int ndof, const DevMesh& m, double* U, hipStream_t s)
@@ -1345,10 +1372,10 @@ void launch_dt(int ndof, const DevMesh& m, const Phys& ph, const double* U, doub
 }
 
 void launch_rk(int ndof, const DevMesh& m, double a, double b, const double* dt, const double* Un,
-               const double* R, double* U, hipStream_t s)
+               const double* R, const double* U, double* Uout, hipStream_t s)
 {
   if (m.nie == 0) return;
-  QDG_DISPATCH_NDOF(ndof, (k_rk<N><<<(unsigned)(((size_t)m.nie * NCOMP * N + 255) / 256), 256, 0, s>>>(m, a, b, dt, Un, R, U)));
+  QDG_DISPATCH_NDOF(ndof, (k_rk<N><<<(unsigned)(((size_t)m.nie * NCOMP * N + 255) / 256), 256, 0, s>>>(m, a, b, dt, Un, R, U, Uout)));
 }
 
 void launch_mass(int ndof, const DevMesh& m, double* L, hipStream_t s)

@@ -23,7 +23,9 @@ int dt_blocks(const DevMesh& m);
 void launch_dt(int ndof, const DevMesh& m, const Phys& ph, const double* U, double* blockmin,
                double scale, double tleft, double* out_raw, double* out_dt, hipStream_t s);
 void launch_rk(int ndof, const DevMesh& m, double a, double b, const double* dt, const double* Un,
-               const double* R, double* U, hipStream_t s);
+               const double* R, const double* U, double* Uout, hipStream_t s);
+void launch_rhs_p1_rk(const DevMesh& m, const Phys& ph, double t, const double* U, double* Uout,
+                      double a, double b, const double* dt, const double* Un, hipStream_t s);
 void launch_mass(int ndof, const DevMesh& m, double* L, hipStream_t s);
 void launch_init(int ndof, const DevMesh& m, const Phys& ph, double t, double* U, hipStream_t s);
 void launch_diag(int ndof, const DevMesh& m, const Phys& ph, double t_new, const double* U,
