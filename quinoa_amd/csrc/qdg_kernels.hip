@@ -97,6 +97,59 @@ __device__ __forceinline__ void store_row(double* __restrict__ U, int e, const d
   }
 }
 
+// ---- coalesced row I/O of a 256-tet tile through LDS -------------------------
+// The rows of a workgroup's 256 consecutive tets are one contiguous span of
+// 256*NPROP doubles.  These helpers move that span with unit-stride 16-byte
+// accesses (full 1 KiB wave transactions) instead of a 160-byte (P1) lane
+// stride, and keep it in LDS, where in-tile face neighbours (about three
+// quarters of all neighbours of a Morton-ordered tile) can be read without
+// touching L1/L2.  Rows beyond `nrows` get benign filler.  All 256 threads call.
+template <int NPROP>
+__device__ __forceinline__ void tile_stage_rows(const double* __restrict__ U, int tile_e0, int nrows,
+                                                double* __restrict__ lds)
+{
+  static_assert(NPROP % 2 == 0, "row staging needs 16-byte rows");
+  const int tid = threadIdx.x;
+  const double2* src = reinterpret_cast<const double2*>(U + (size_t)tile_e0 * NPROP);
+  double2* dst = reinterpret_cast<double2*>(lds);
+  const int nvalid = (nrows - tile_e0 < 256 ? nrows - tile_e0 : 256) * (NPROP / 2);
+#pragma unroll
+  for (int j = 0; j < NPROP / 2; ++j) {
+    const int i = j * 256 + tid;
+    dst[i] = (i < nvalid) ? src[i] : make_double2(1.0, 1.0);
+  }
+  __syncthreads();
+}
+
+template <int NPROP>
+__device__ __forceinline__ void lds_row(const double* __restrict__ lds, int r, double* out)
+{
+  const double2* q = reinterpret_cast<const double2*>(lds + (size_t)r * NPROP);
+#pragma unroll
+  for (int j = 0; j < NPROP / 2; ++j) { const double2 v = q[j]; out[2 * j] = v.x; out[2 * j + 1] = v.y; }
+}
+
+// rows of the tile back to HBM, coalesced (every lane first deposits its row)
+template <int NPROP>
+__device__ __forceinline__ void tile_store_rows(double* __restrict__ U, int tile_e0, int nrows,
+                                                double* __restrict__ lds, const double* r)
+{
+  const int tid = threadIdx.x;
+  __syncthreads();            // all readers of the staged rows are done
+  double2* row = reinterpret_cast<double2*>(lds + (size_t)tid * NPROP);
+#pragma unroll
+  for (int j = 0; j < NPROP / 2; ++j) row[j] = make_double2(r[2 * j], r[2 * j + 1]);
+  __syncthreads();
+  const double2* src = reinterpret_cast<const double2*>(lds);
+  double2* dst = reinterpret_cast<double2*>(U + (size_t)tile_e0 * NPROP);
+  const int nvalid = (nrows - tile_e0 < 256 ? nrows - tile_e0 : 256) * (NPROP / 2);
+#pragma unroll
+  for (int j = 0; j < NPROP / 2; ++j) {
+    const int i = j * 256 + tid;
+    if (i < nvalid) dst[i] = src[i];
+  }
+}
+
 // XCD-aware workgroup -> element-tile map.  Workgroups are dealt round-robin
 // over the 8 XCDs (b and b+8 share an XCD and its private 4 MiB L2), while a
 // tet's face neighbours sit close to it in the Morton-ordered numbering.
@@ -877,15 +930,19 @@ __global__ __launch_bounds__(256, QDG_P1_WAVES) void k_rhs_p1(DevMesh m, Phys ph
 template <int NDOF>
 __global__ __launch_bounds__(256) void k_superbee(DevMesh m, double* __restrict__ U)
 {
-  const int e = xcd_tile(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
-  if (e >= m.nie) return;
   if constexpr (NDOF > 1) {
     const Tables<NDOF>& T = tab<NDOF>();
     constexpr int NGF = Tables<NDOF>::NGF;
     constexpr int NPROP = NCOMP * NDOF;
+    __shared__ double lds[256 * NPROP];
+    const int tile_e0 = xcd_tile(blockIdx.x, gridDim.x) * 256;
+    const int e0 = tile_e0 + threadIdx.x;
+    const bool active = e0 < m.nie;
+    const int e = active ? e0 : m.nie - 1;
     const int stride = m.stride;
+    tile_stage_rows<NPROP>(U, tile_e0, m.nie, lds);
     double u[NCOMP][NDOF];
-    load_row<NPROP>(U, e, &u[0][0]);
+    lds_row<NPROP>(lds, threadIdx.x, &u[0][0]);
     double uMin[NCOMP], uMax[NCOMP], phi[NCOMP];
 #pragma unroll
     for (int c = 0; c < NCOMP; ++c) { uMin[c] = uMax[c] = u[c][0]; phi[c] = 1.0; }
@@ -893,11 +950,21 @@ __global__ __launch_bounds__(256) void k_superbee(DevMesh m, double* __restrict_
     for (int lf = 0; lf < 4; ++lf) {
       const int nb = m.nbr[(size_t)lf * stride + e];
       if (nb < 0) continue;
+      const int r = nb - tile_e0;
+      if ((unsigned)r < 256u) {            // in-tile neighbour: means from LDS
 #pragma unroll
-      for (int c = 0; c < NCOMP; ++c) {
-        const double v = U[fidx(c * NDOF, nb, NPROP)];
-        uMin[c] = fmin(uMin[c], v);
-        uMax[c] = fmax(uMax[c], v);
+        for (int c = 0; c < NCOMP; ++c) {
+          const double v = lds[(size_t)r * NPROP + c * NDOF];
+          uMin[c] = fmin(uMin[c], v);
+          uMax[c] = fmax(uMax[c], v);
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < NCOMP; ++c) {
+          const double v = U[fidx(c * NDOF, nb, NPROP)];
+          uMin[c] = fmin(uMin[c], v);
+          uMax[c] = fmax(uMax[c], v);
+        }
       }
     }
 #pragma unroll 1
@@ -908,10 +975,13 @@ __global__ __launch_bounds__(256) void k_superbee(DevMesh m, double* __restrict_
         state_from<NDOF>(u, T.fB[lf][ig], s);
 #pragma unroll
         for (int c = 0; c < NCOMP; ++c) {
+          // Limiter.cpp:283-301 without the three-way branch: one numerator
+          // select, one reciprocal (|uNeg| <= 1e-14 -> phi_gp = 1)
           const double uNeg = s[c] - u[c][0];
-          double pg = 1.0;
-          if (uNeg > 1.0e-14) pg = fmin(1.0, (uMax[c] - u[c][0]) / (2.0 * uNeg));
-          else if (uNeg < -1.0e-14) pg = fmin(1.0, (uMin[c] - u[c][0]) / (2.0 * uNeg));
+          const double num = (uNeg > 0.0 ? uMax[c] : uMin[c]) - u[c][0];
+          const bool flat = fabs(uNeg) <= 1.0e-14;
+          double pg = fmin(1.0, num * fast_rcp(2.0 * (flat ? 1.0 : uNeg)));
+          pg = flat ? 1.0 : pg;
           pg = fmax(0.0, fmax(fmin(2.0 * pg, 1.0), fmin(pg, 2.0)));
           phi[c] = fmin(phi[c], pg);
         }
@@ -920,8 +990,9 @@ __global__ __launch_bounds__(256) void k_superbee(DevMesh m, double* __restrict_
     for (int c = 0; c < NCOMP; ++c)
 #pragma unroll
       for (int k = 1; k < 4; ++k) u[c][k] = phi[c] * u[c][k];
-    // only modes 1-3 change, but the row is stored whole (16-byte stores)
-    store_row<NPROP>(U, e, &u[0][0]);
+    // Out-of-tile neighbours may be read from U while another tile has already
+    // stored its limited rows: safe, Superbee never changes a mean.
+    tile_store_rows<NPROP>(U, tile_e0, m.nie, lds, &u[0][0]);
   }
 }
 
