@@ -1,2 +1,7 @@
-timeout -k 10 600 python -m pytest tests -m gpu -q -x 2>&1 | tail -2
+for v in "" nr1; do
+if [ -n "$v" ]; then export QDG_LIB=$PWD/quinoa_amd/lib/libqdg_$v.so; fi
+echo "variant: ${v:-default}"
+timeout -k 10 300 python tools/acc_test.py 2>&1 | tail -2
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -m gpu -q 2>&1 | tail -1
 timeout -k 10 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value']), round(d['ms_per_step'],3), round(d['roofline']['avg_launch_ms'],4), round(d['roofline']['frac'],4))"
+done

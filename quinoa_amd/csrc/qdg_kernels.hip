@@ -22,6 +22,12 @@
 #include "qdg_device.hpp"
 #include "qdg_kernels.hpp"
 
+#ifndef QDG_RCP_NR
+#define QDG_RCP_NR 1    // Newton steps after v_rcp_f64 (1 step: R agrees with the oracle to 1e-15)
+#endif
+#ifndef QDG_SQRT_NR
+#define QDG_SQRT_NR 1   // Goldschmidt steps after v_rsq_f64 (plus one residual correction)
+#endif
 #ifndef QDG_P1_WAVES
 #define QDG_P1_WAVES 2   // waves per SIMD the DG-P1 RHS kernel is register-budgeted for
 #endif
@@ -607,8 +613,12 @@ __global__ __launch_bounds__(256) void k_rhs(DevMesh m, Phys ph, double t,
 __device__ __forceinline__ double fast_rcp(double x)
 {
   double r = __builtin_amdgcn_rcp(x);
+#if QDG_RCP_NR >= 1
   r = fma(fma(-x, r, 1.0), r, r);
+#endif
+#if QDG_RCP_NR >= 2
   r = fma(fma(-x, r, 1.0), r, r);
+#endif
   return r;
 }
 __device__ __forceinline__ double fast_sqrt(double x)
@@ -618,9 +628,11 @@ __device__ __forceinline__ double fast_sqrt(double x)
   double r = fma(-h, g, 0.5);
   g = fma(g, r, g);
   h = fma(h, r, h);
+#if QDG_SQRT_NR >= 2
   r = fma(-h, g, 0.5);
   g = fma(g, r, g);
   h = fma(h, r, h);
+#endif
   g = fma(fma(-g, g, x), h, g);
   return (x == 0.0) ? 0.0 : g;
 }
