@@ -1,0 +1,32 @@
+#!/bin/bash
+# Round-end measurement pass on the GPU box: bench line, rocprofv3 kernel stats,
+# PMC traffic of the RHS kernel.  Outputs under gpurun_out/final/ (copy what is
+# to be judged into profiles/).   Usage: tools/collect_profiles.sh [nx]
+nx=${1:-55}
+out=gpurun_out/final_nx$nx
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+timeout -k 10 900 python3 bench.py --nx $nx > $out/bench.json 2> $out/bench.err
+tail -1 $out/bench.json | cut -c1-200
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --nx $nx --steps 10 --warmup 2 --no-cpu-baseline > $out/stats.log 2>&1
+cp $out/stats/*/*kernel_stats.csv $out/kernel_stats.csv
+i=0
+for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  timeout -k 10 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/pmc$i -- python3 bench.py --nx $nx --steps 3 --warmup 1 --no-cpu-baseline > $out/pmc$i.log 2>&1 || echo "pmc pass $i failed"
+done
+python3 - <<PY
+import csv, glob, collections, json
+agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+for f in glob.glob("$out/pmc*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(k, r["Counter_Name"])] += 1
+res = {k: {c: x / cnt[(k, c)] for c, x in v.items()} for k, v in agg.items()}
+json.dump(res, open("$out/pmc_per_launch.json", "w"), indent=1)
+for k, v in res.items():
+    if "FETCH_SIZE" in v and ("k_rhs" in k or "superbee" in k or "k_rk" in k):
+        # FETCH_SIZE/WRITE_SIZE are in KiB; FETCH_SIZE counts 128-B requests as 64 B on gfx950 -> x2
+        hbm = (2 * v["FETCH_SIZE"] + v.get("WRITE_SIZE", 0.0)) * 1024
+        print("%-40s fetch %.1f MB (x2 corrected %.1f) write %.1f MB -> %.1f MB/launch" % (k, v["FETCH_SIZE"] / 1024 * 1.048576, 2 * v["FETCH_SIZE"] * 1024 / 1e6, v.get("WRITE_SIZE", 0) * 1024 / 1e6, hbm / 1e6))
+PY
