@@ -152,7 +152,7 @@ def main():
                        "tets_total": ntet, "tets_per_gpu": chunk.nielem,
                        "parallelism": "block decomposition %dx%dx%d, ghost-face halo" % parts,
                        "step": "SSP-RK3 time step = 3 x (halo, limiter, halo, [dt], rhs, update)"},
-            "roofline": {"bound": "hbm", "kernel": "qdg::k_rhs<4>", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "qdg::k_rhs_p1 (stage 0: RHS + CFL dt; stages 1,2: RHS with the RK update fused in; 357 B/tet counted for every launch)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "avg_launch_ms": avg_ms, "launches": nl,
                          "algorithmic_bytes_per_launch": alg},
