@@ -1253,3 +1253,229 @@ double orc_step(const orc_cfg* k, const orc_bc* bc, double t, double fixed_dt,
   }
   return dt;
 }
+
+/* =====================================================================
+ * Scalar transport (BASELINE config 1: Inciter Transport slot_cyl DG-P0).
+ * dg::Transport::rhs, src/PDE/Transport/DGTransport.hpp:129-186: the same
+ * integrators with ncomp = 1, Upwind flux (src/PDE/Integrate/Riemann/
+ * Upwind.hpp:35-55) and the Problem's prescribed velocity.
+ * ===================================================================== */
+
+enum { ORC_TR_SLOT_CYL = 1 };
+enum { TR_BC_EXTRAPOLATE = 0, TR_BC_INLET = 1, TR_BC_OUTLET = 2, TR_BC_DIRICHLET = 3 };
+
+/* TransportProblemSlotCyl::solution, src/PDE/Transport/Problem/SlotCyl.cpp:30-110 (ncomp = 1) */
+static double tr_solution(int problem, double x, double y, double z, double t)
+{
+  (void)z; (void)problem;
+  {
+    const double T = t;          /* t + 2*pi/ncomp*c with c = 0 */
+    const double R0 = 0.15;
+    double s = 0.0;
+    double x0 = 0.5, y0 = 0.25;
+    double r = sqrt((x0 - 0.5) * (x0 - 0.5) + (y0 - 0.5) * (y0 - 0.5));
+    const double kx = 0.5 + r * sin(T), ky = 0.5 - r * cos(T);
+    double hx, hy, cx, cy, i1x, i1y, i2x, i2y, i3x, i3y;
+    double ri1x, ri1y, ri2x, ri2y, ri3x, ri3y, v1x, v1y, v2x, v2y, v1, v2, d1, d2;
+    x0 = 0.25; y0 = 0.5;
+    r = sqrt((x0 - 0.5) * (x0 - 0.5) + (y0 - 0.5) * (y0 - 0.5));
+    hx = 0.5 + r * sin(T - M_PI / 2.0); hy = 0.5 - r * cos(T - M_PI / 2.0);
+    x0 = 0.5; y0 = 0.75;
+    r = sqrt((x0 - 0.5) * (x0 - 0.5) + (y0 - 0.5) * (y0 - 0.5));
+    cx = 0.5 + r * sin(T + M_PI); cy = 0.5 - r * cos(T + M_PI);
+    i1x = 0.525; i1y = cy - r * cos(asin(0.025 / r));
+    i2x = 0.525; i2y = 0.8;
+    i3x = 0.475; i3y = 0.8;
+    ri1x = 0.5 + cos(T) * (i1x - 0.5) - sin(T) * (i1y - 0.5);
+    ri1y = 0.5 + sin(T) * (i1x - 0.5) + cos(T) * (i1y - 0.5);
+    ri2x = 0.5 + cos(T) * (i2x - 0.5) - sin(T) * (i2y - 0.5);
+    ri2y = 0.5 + sin(T) * (i2x - 0.5) + cos(T) * (i2y - 0.5);
+    ri3x = 0.5 + cos(T) * (i3x - 0.5) - sin(T) * (i3y - 0.5);
+    ri3y = 0.5 + sin(T) * (i3x - 0.5) + cos(T) * (i3y - 0.5);
+    v1x = ri2x - ri1x; v1y = ri2y - ri1y; v2x = ri3x - ri2x; v2y = ri3y - ri2y;
+    v1 = sqrt(v1x * v1x + v1y * v1y); v2 = sqrt(v2x * v2x + v2y * v2y);
+    r = sqrt((x - kx) * (x - kx) + (y - ky) * (y - ky)) / R0;
+    if (r < 1.0) s = 0.6 * (1.0 - r);
+    r = sqrt((x - hx) * (x - hx) + (y - hy) * (y - hy)) / R0;
+    if (r < 1.0) s = 0.2 * (1.0 + cos(M_PI * (r < 1.0 ? r : 1.0)));
+    r = sqrt((x - cx) * (x - cx) + (y - cy) * (y - cy)) / R0;
+    d1 = (v1x * (y - ri1y) - (x - ri1x) * v1y) / v1;
+    d2 = (v2x * (y - ri2y) - (x - ri2x) * v2y) / v2;
+    if (r < 1.0 && (d1 > 0.05 || d1 < 0.0 || d2 < 0.0)) s = 0.6;
+    return s;
+  }
+}
+
+/* TransportProblemSlotCyl::prescribedVelocity, SlotCyl.cpp:152-170 */
+static void tr_velocity(int problem, double x, double y, double z, double* v)
+{
+  (void)problem; (void)z;
+  v[0] = 0.5 - y; v[1] = x - 0.5; v[2] = 0.0;
+}
+
+/* Upwind::flux, Upwind.hpp:35-55 (one component) */
+static double tr_upwind(const double* fn, double ul, double ur, const double* v)
+{
+  const double swave = v[0] * fn[0] + v[1] * fn[1] + v[2] * fn[2];
+  const double splus = 0.5 * (swave + fabs(swave));
+  const double sminus = 0.5 * (swave - fabs(swave));
+  return splus * ul + sminus * ur;
+}
+
+static double tr_state(const double* U, int64_t e, int64_t ndof, const double* B)
+{
+  const double* u = U + e * ndof;
+  double s = u[0];
+  if (ndof > 1) s += u[1] * B[1] + u[2] * B[2] + u[3] * B[3];
+  if (ndof > 4) s += u[4] * B[4] + u[5] * B[5] + u[6] * B[6] + u[7] * B[7] + u[8] * B[8] + u[9] * B[9];
+  return s;
+}
+
+void orc_tr_mass(int64_t ndof, const double* geoElem, int64_t nunk, double* L)
+{
+  static const double f[10] = { 1.0, 1.0/10.0, 3.0/10.0, 3.0/5.0, 1.0/35.0, 1.0/21.0,
+                                1.0/14.0, 1.0/7.0, 3.0/14.0, 3.0/7.0 };
+  int64_t e, k;
+  for (e = 0; e < nunk; ++e)
+    for (k = 0; k < ndof; ++k) L[e * ndof + k] = geoElem[4 * e] * f[k];
+}
+
+/* tk::initialize with ncomp = 1 (Initialize.cpp:29-201) */
+void orc_tr_initialize(int problem, int64_t ndof, const double* L, const int64_t* inpoel,
+                       const double* x, const double* y, const double* z, double* U, double t,
+                       int64_t nielem)
+{
+  const int ng = ng_init(ndof);
+  double cg[3][14], wg[14], p[4][3], R[10], B[10], gp[3];
+  int64_t e, k; int ig;
+  quad_tet(ng, cg, wg);
+  for (e = 0; e < nielem; ++e) {
+    elem_coords(inpoel, e, x, y, z, p);
+    for (k = 0; k < 10; ++k) R[k] = 0.0;
+    for (ig = 0; ig < ng; ++ig) {
+      double s, wt;
+      gp_tet(p, cg[0][ig], cg[1][ig], cg[2][ig], gp);
+      eval_basis(ndof, cg[0][ig], cg[1][ig], cg[2][ig], B);
+      s = tr_solution(problem, gp[0], gp[1], gp[2], t);
+      wt = wg[ig] * L[e * ndof];
+      R[0] += wt * s;
+      for (k = 1; k < ndof; ++k) R[k] += wt * s * B[k];
+    }
+    for (k = 0; k < ndof; ++k) U[e * ndof + k] = R[k] / L[e * ndof + k];
+  }
+}
+
+/* dg::Transport::rhs for one scalar; BC order Extrapolate, Inlet, Outlet,
+ * Dirichlet (DGTransport.hpp:163-168); `bctype[s]` gives the type of bc->set_id[s]
+ * or -1 when the side set is not configured */
+void orc_tr_rhs(int problem, int64_t ndof, const orc_bc* bc, const int32_t* bctype, double t,
+                int64_t nunk, int64_t nbfac, int64_t nfac, const int32_t* esuf,
+                const int64_t* inpofa, const int64_t* inpoel, const double* x, const double* y,
+                const double* z, const double* geoFace, const double* geoElem, const double* U,
+                double* R)
+{
+  const int ngf = ng_fa(ndof), ngv = ng_vol(ndof);
+  double cf[2][6], wf[6], cv[3][14], wv[14];
+  int64_t f, e, k, is, q; int ig, i, type;
+  quad_tri(ngf, cf, wf);
+  memset(R, 0, (size_t)(nunk * ndof) * sizeof(double));
+  /* surfInt */
+  for (f = nbfac; f < nfac; ++f) {
+    const int64_t el = esuf[2 * f], er = esuf[2 * f + 1];
+    double pl[4][3], pr[4][3], pf[3][3], detl, detr;
+    const double* fn = geoFace + 7 * f + 1;
+    elem_coords(inpoel, el, x, y, z, pl);
+    elem_coords(inpoel, er, x, y, z, pr);
+    detl = jacobian(pl[0], pl[1], pl[2], pl[3]);
+    detr = jacobian(pr[0], pr[1], pr[2], pr[3]);
+    for (i = 0; i < 3; ++i) { const int64_t n = inpofa[3 * f + i]; pf[i][0] = x[n]; pf[i][1] = y[n]; pf[i][2] = z[n]; }
+    for (ig = 0; ig < ngf; ++ig) {
+      double gp[3], xi, eta, zeta, Bl[10], Br[10], v[3], fl, wt;
+      gp_tri(pf, cf[0][ig], cf[1][ig], gp);
+      ref_coords(pl, detl, gp, &xi, &eta, &zeta); eval_basis(ndof, xi, eta, zeta, Bl);
+      ref_coords(pr, detr, gp, &xi, &eta, &zeta); eval_basis(ndof, xi, eta, zeta, Br);
+      wt = wf[ig] * geoFace[7 * f];
+      tr_velocity(problem, gp[0], gp[1], gp[2], v);
+      fl = tr_upwind(fn, tr_state(U, el, ndof, Bl), tr_state(U, er, ndof, Br), v);
+      R[el * ndof] -= wt * fl; R[er * ndof] += wt * fl;
+      for (k = 1; k < ndof; ++k) { R[el * ndof + k] -= wt * fl * Bl[k]; R[er * ndof + k] += wt * fl * Br[k]; }
+    }
+  }
+  /* volInt */
+  if (ndof > 1) {
+    quad_tet(ngv, cv, wv);
+    for (e = 0; e < nunk; ++e) {
+      double p[4][3], ji[3][3], dBdx[3][10];
+      elem_coords(inpoel, e, x, y, z, p);
+      inverse_jacobian(p[0], p[1], p[2], p[3], ji);
+      eval_dBdx_p1(ji, dBdx);
+      for (ig = 0; ig < ngv; ++ig) {
+        double B[10], gp[3], v[3], s, wt;
+        if (ndof > 4) eval_dBdx_p2(cv[0][ig], cv[1][ig], cv[2][ig], ji, dBdx);
+        gp_tet(p, cv[0][ig], cv[1][ig], cv[2][ig], gp);
+        eval_basis(ndof, cv[0][ig], cv[1][ig], cv[2][ig], B);
+        wt = wv[ig] * geoElem[4 * e];
+        s = tr_state(U, e, ndof, B);
+        tr_velocity(problem, gp[0], gp[1], gp[2], v);
+        for (k = 1; k < ndof; ++k)
+          R[e * ndof + k] += wt * (v[0] * s * dBdx[0][k] + v[1] * s * dBdx[1][k] + v[2] * s * dBdx[2][k]);
+      }
+    }
+  }
+  /* bndSurfInt per BC type in the reference's order */
+  for (type = 0; type < 4; ++type)
+    for (is = 0; is < bc->nset; ++is) {
+      if (bctype[is] != type) continue;
+      for (q = bc->set_off[is]; q < bc->set_off[is + 1]; ++q) {
+        double pl[4][3], pf[3][3], detl;
+        const double* fn;
+        int64_t el;
+        f = bc->set_face[q];
+        el = esuf[2 * f];
+        fn = geoFace + 7 * f + 1;
+        elem_coords(inpoel, el, x, y, z, pl);
+        detl = jacobian(pl[0], pl[1], pl[2], pl[3]);
+        for (i = 0; i < 3; ++i) { const int64_t n = inpofa[3 * f + i]; pf[i][0] = x[n]; pf[i][1] = y[n]; pf[i][2] = z[n]; }
+        for (ig = 0; ig < ngf; ++ig) {
+          double gp[3], xi, eta, zeta, Bl[10], v[3], ul, ur, fl, wt;
+          gp_tri(pf, cf[0][ig], cf[1][ig], gp);
+          ref_coords(pl, detl, gp, &xi, &eta, &zeta); eval_basis(ndof, xi, eta, zeta, Bl);
+          wt = wf[ig] * geoFace[7 * f];
+          ul = tr_state(U, el, ndof, Bl);
+          ur = (type == TR_BC_INLET) ? 0.0
+             : (type == TR_BC_DIRICHLET) ? tr_solution(problem, gp[0], gp[1], gp[2], t) : ul;
+          tr_velocity(problem, gp[0], gp[1], gp[2], v);
+          fl = tr_upwind(fn, ul, ur, v);
+          R[el * ndof] -= wt * fl;
+          for (k = 1; k < ndof; ++k) R[el * ndof + k] -= wt * fl * Bl[k];
+        }
+      }
+    }
+}
+
+/* SSP-RK3 stage for one scalar (DG.cpp:1478-1488) */
+void orc_tr_rk_update(int64_t ndof, int stage, double dt, const double* Un, const double* R,
+                      const double* L, double* U, int64_t nunk)
+{
+  static const double rk[2][3] = { { 0.0, 3.0 / 4.0, 1.0 / 3.0 }, { 1.0, 1.0 / 4.0, 2.0 / 3.0 } };
+  int64_t i;
+  for (i = 0; i < nunk * ndof; ++i)
+    U[i] = rk[0][stage] * Un[i] + rk[1][stage] * (U[i] + dt * R[i] / L[i]);
+}
+
+/* sum_e sum_g wt*u^2 over interior elements (ElemDiagnostics.cpp:116-215, ncomp = 1) */
+double orc_tr_diag_l2sum(int64_t ndof, const double* geoElem, const double* U, int64_t nielem)
+{
+  const int ng = ng_diag(ndof);
+  double cg[3][14], wg[14], B[10], sum = 0.0;
+  int64_t e; int ig;
+  quad_tet(ng, cg, wg);
+  for (e = 0; e < nielem; ++e)
+    for (ig = 0; ig < ng; ++ig) {
+      double u;
+      eval_basis(ndof, cg[0][ig], cg[1][ig], cg[2][ig], B);
+      u = tr_state(U, e, ndof, B);
+      sum += wg[ig] * geoElem[4 * e] * u * u;
+    }
+  return sum;
+}

@@ -353,3 +353,48 @@ def run_case(case, fix, nstep=None, on_step=None):
     return {"mesh": mesh, "oracle": orc, "U": U, "L": Lm, "t": t,
             "diag": np.array(diag_rows), "fields": np.array(fields),
             "times": np.array(times)}
+
+
+# ---------------------------------------------------------------- transport
+def run_transport_case(case, fix, nstep=None):
+    """BASELINE config 1: Transport slot_cyl DG (dg::Transport with Upwind flux,
+    src/PDE/Transport/DGTransport.hpp:129-186) on one chunk, fixed dt."""
+    L = lib()
+    L.orc_tr_diag_l2sum.restype = C.c_double
+    m = OracleMesh(fix["coord"], fix["inpoel"],
+                   {int(s): fix["ss_tri_%d" % s] for s in fix["ss_ids"]})
+    ndof = case["ndof"]
+    ne = m.nelem
+    # BC type per side set in the bface map (DGTransport.hpp:163-168 order)
+    types = {"bc_extrapolate": 0, "bc_inlet": 1, "bc_outlet": 2, "bc_dirichlet": 3}
+    bctype = np.full(len(m._set_id), -1, dtype=np.int32)
+    for key, t in types.items():
+        for sid in case.get(key, []):
+            bctype[list(m._set_id).index(sid)] = t
+    zero = np.zeros(1, dtype=np.int64)
+    bc = Bc(nset=len(m._set_id), set_id=_p(m._set_id, c_i64p), set_off=_p(m._set_off, c_i64p),
+            set_face=_p(m._set_face, c_i64p), ndir=0, nsym=0, nextrap=0,
+            dir=_p(zero, c_i64p), sym=_p(zero, c_i64p), extrap=_p(zero, c_i64p))
+    inp = m.inpoel.reshape(-1)
+    Lm = np.zeros(ne * ndof)
+    L.orc_tr_mass(C.c_int64(ndof), _p(m.geoElem, c_f64p), C.c_int64(ne), _p(Lm, c_f64p))
+    U = np.zeros(ne * ndof)
+    L.orc_tr_initialize(C.c_int(1), C.c_int64(ndof), _p(Lm, c_f64p), _p(inp, c_i64p), _p(m.x, c_f64p),
+                        _p(m.y, c_f64p), _p(m.z, c_f64p), _p(U, c_f64p), C.c_double(0.0), C.c_int64(ne))
+    Un, R = np.zeros_like(U), np.zeros_like(U)
+    t, dt, rows = 0.0, case["dt"], []
+    for it in range(nstep or case["nstep"]):
+        for stage in range(3):
+            if stage == 0:
+                Un[:] = U
+            L.orc_tr_rhs(C.c_int(1), C.c_int64(ndof), C.byref(bc), _p(bctype, c_i32p), C.c_double(t),
+                         C.c_int64(ne), C.c_int64(m.nbfac), C.c_int64(m.nfac), _p(m.esuf, c_i32p),
+                         _p(m.inpofa, c_i64p), _p(inp, c_i64p), _p(m.x, c_f64p), _p(m.y, c_f64p),
+                         _p(m.z, c_f64p), _p(m.geoFace, c_f64p), _p(m.geoElem, c_f64p), _p(U, c_f64p),
+                         _p(R, c_f64p))
+            L.orc_tr_rk_update(C.c_int64(ndof), C.c_int(stage), C.c_double(dt), _p(Un, c_f64p),
+                               _p(R, c_f64p), _p(Lm, c_f64p), _p(U, c_f64p), C.c_int64(ne))
+        s = L.orc_tr_diag_l2sum(C.c_int64(ndof), _p(m.geoElem, c_f64p), _p(U, c_f64p), C.c_int64(ne))
+        t += dt
+        rows.append([it + 1, t, dt, np.sqrt(s / m.meshvol)])
+    return {"mesh": m, "U": U, "diag": np.array(rows), "t": t}

@@ -118,6 +118,27 @@ def main():
             out["exo_times"] = t
             out["exo_names"] = np.array([names[i] for i in keep])
             out["exo_vals"] = vals[:, keep, :]
+        if c.get("golden_exo_chunks"):
+            # per-chare golden chunks of a partitioned run (partition-local order):
+            # keep, per tet, its centroid and the numerical solution at the last
+            # output time; tests match tets to the input mesh by centroid
+            cents, vals, tlast = [], [], None
+            for fn in c["golden_exo_chunks"]:
+                f = netcdf_file(os.path.join(d, fn), "r", mmap=False)
+                v = f.variables
+                xyz = np.stack([v["coordx"][:], v["coordy"][:], v["coordz"][:]], axis=1).astype(np.float64)
+                blk = [b for b in range(1, f.dimensions["num_el_blk"] + 1)
+                       if v["connect%d" % b].elem_type.decode().upper().startswith("TET")][0]
+                conn = np.array(v["connect%d" % blk][:], dtype=np.int64) - 1
+                names = [_str(r) for r in v["name_elem_var"][:]]
+                iv = names.index("c0_numerical") + 1
+                cents.append(xyz[conn].mean(axis=1))
+                vals.append(np.array(v["vals_elem_var%deb%d" % (iv, blk)][:], dtype=np.float64)[-1])
+                tlast = float(v["time_whole"][:][-1])
+                f.close()
+            out["chunk_centroid"] = np.concatenate(cents)
+            out["chunk_c0_last"] = np.concatenate(vals)
+            out["chunk_time_last"] = np.array([tlast])
         if c.get("golden_diag"):
             out["diag"] = read_diag(os.path.join(d, c["golden_diag"]))
         path = os.path.join(HERE, name + ".npz")

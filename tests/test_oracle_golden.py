@@ -76,3 +76,26 @@ def test_oracle_matches_reference_build_jacobian_and_quadrature():
         assert np.array_equal(a, b)
     for nd, (v, f, d, i) in {1: (1, 1, 1, 1), 4: (5, 3, 4, 14), 10: (11, 6, 14, 14)}.items():
         assert (R.ref_ngvol(nd), R.ref_ngfa(nd), R.ref_ngdiag(nd), R.ref_nginit(nd)) == (v, f, d, i)
+
+
+def test_oracle_reproduces_transport_slot_cyl_config1(cases):
+    """BASELINE configs[0]: Inciter Transport slot_cyl DG-P0 on the 31 304-tet
+    fixture (the reference's CPU plumbing case): diag_dg.std (6 printed digits)
+    and the cell values of the reference's 4-PE golden chunks, matched by tet
+    centroid (partition-independent to the harness' 1e-7)."""
+    case, fix = cases["slot_cyl_dg"], load_fixture("slot_cyl_dg")
+    r = O.run_transport_case(case, fix)
+    for row, g in zip(r["diag"], fix["diag"]):
+        assert int(row[0]) == int(g[0]) and abs(row[1] - g[1]) < 1e-12
+        assert abs(row[3] - g[3]) <= 6e-6 * g[3], (row, g)
+    m = r["mesh"]
+    cent = m.geoElem.reshape(-1, 4)[:, 1:]
+    # match by centroid: sort both by a rounded lexicographic key
+    def order(c):
+        q = np.round(c * 1e9).astype(np.int64)
+        return np.lexsort((q[:, 2], q[:, 1], q[:, 0]))
+    oa, ob = order(cent), order(fix["chunk_centroid"])
+    assert np.abs(cent[oa] - fix["chunk_centroid"][ob]).max() < 1e-12
+    assert abs(r["t"] - float(fix["chunk_time_last"][0])) < 1e-14
+    err = np.abs(r["U"][oa] - fix["chunk_c0_last"][ob]).max()
+    assert err <= 1e-13, err
