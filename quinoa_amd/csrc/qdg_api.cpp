@@ -82,6 +82,7 @@ struct qdg_mesh {
   // mesh
   DevBuf<int> inpoel, nbr, finfo, fid, d2h;
   DevBuf<double> x, y, z, farea, fnx, fny, fnz, vol, fgeo, xyz4;
+  DevBuf<int> tile_off, task_a, task_nb, task_f;
   // fields (SoA planes [nprop][stride])
   DevBuf<double> U, Un, R, W;     // W: scratch state (stateless ops, WENO ping-pong)
   DevBuf<double> aos;             // [ne*nprop] staging in the caller's layout
@@ -400,6 +401,37 @@ extern "C" int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t 
       h_nz[fmap[f]] = geoFace[7 * f + 3];
     }
 
+  // ---- face tasks per tile (k_rhs_p1t) -----------------------------------------
+  const int ntile = (int)((nie + TILE - 1) / TILE);
+  std::vector<int> h_tile_off(ntile + 1, 0), h_task_a, h_task_nb, h_task_f;
+  h_task_a.reserve(3 * nie); h_task_nb.reserve(3 * nie); h_task_f.reserve(3 * nie);
+  {
+    struct Task { int key, a, nb, f; };
+    std::vector<Task> tt;
+    for (int t = 0; t < ntile; ++t) {
+      const size_t e0 = (size_t)t * TILE, e1 = std::min(nie, e0 + TILE);
+      tt.clear();
+      for (size_t d = e0; d < e1; ++d)
+        for (int lf = 0; lf < 4; ++lf) {
+          const int nb = h_nbr[lf * stride + d], info = h_finfo[lf * stride + d];
+          const int own_left = (info >> 6) & 1, code = info & 63;
+          int kind, bc = 0, pl = 0, nbid = 0;
+          if (nb < 0) { kind = TASK_BND; bc = -nb - 1; }
+          else if ((size_t)nb >= e0 && (size_t)nb < e1) {
+            if (!own_left) continue;            // listed by the face's left tet
+            kind = TASK_INT; pl = nb - (int)e0;
+          } else { kind = TASK_EXT; nbid = nb; }
+          const int a = (int)(d - e0) | (lf << 8) | (own_left << 10) | (code << 11) | (kind << 17) |
+                        (bc << 19) | (pl << 21);
+          tt.push_back({ (kind << 2) | lf, a, nbid, h_fid[lf * stride + d] });
+        }
+      // same kind / local face next to each other: fewer divergent branches per wave
+      std::stable_sort(tt.begin(), tt.end(), [](const Task& p, const Task& q) { return p.key < q.key; });
+      for (const Task& k : tt) { h_task_a.push_back(k.a); h_task_nb.push_back(k.nb); h_task_f.push_back(k.f); }
+      h_tile_off[t + 1] = (int)h_task_a.size();
+    }
+  }
+
   std::unique_ptr<qdg_mesh> m(new qdg_mesh);
   m->ctx = ctx;
   m->ndof = ctx->cfg.ndof;
@@ -429,7 +461,7 @@ extern "C" int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t 
   HIPCHK(hipMemsetAsync(m->Un.p, 0, fsz * sizeof(double), s));
   HIPCHK(hipMemsetAsync(m->R.p, 0, fsz * sizeof(double), s));
   HIPCHK(hipMemsetAsync(m->W.p, 0, fsz * sizeof(double), s));
-  const size_t nblk = (nie + 255) / 256;
+  const size_t nblk = std::max((nie + 255) / 256, (size_t)ntile);
   HIPCHK(m->blockmin.alloc(nblk)); HIPCHK(m->dtraw.alloc(1)); HIPCHK(m->dtdev.alloc(1));
   HIPCHK(m->diagpart.alloc(nblk * 15)); HIPCHK(m->diagout.alloc(15));
   m->Ucur = m->U.p;
@@ -443,6 +475,10 @@ extern "C" int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t 
   dm.farea = m->farea.p; dm.fnx = m->fnx.p; dm.fny = m->fny.p; dm.fnz = m->fnz.p;
   dm.vol = m->vol.p; dm.d2h = m->d2h.p;
   dm.fgeo = m->fgeo.p; dm.xyz4 = m->xyz4.p;
+  HIPCHK(m->tile_off.upload(h_tile_off, s)); HIPCHK(m->task_a.upload(h_task_a, s));
+  HIPCHK(m->task_nb.upload(h_task_nb, s)); HIPCHK(m->task_f.upload(h_task_f, s));
+  dm.ntile = ntile; dm.tile_off = m->tile_off.p; dm.task_a = m->task_a.p;
+  dm.task_nb = m->task_nb.p; dm.task_f = m->task_f.p;
   HIPCHK(hipStreamSynchronize(s));
   *out = m.release();
   return 0;
@@ -543,10 +579,21 @@ static bool use_p1_fast(const qdg_mesh* mesh)
   return mesh->ndof == 4 && !generic;
 }
 
+// tile / face-task kernel (each in-tile face evaluated once, LDS accumulation with
+// ds_add_f64) unless bitwise run-to-run reproducibility is requested
+static bool use_tile(const qdg_mesh*)
+{
+  static const bool det = std::getenv("QDG_DETERMINISTIC_RHS") != nullptr;
+  return !det;
+}
+
 static void run_rhs(qdg_mesh* mesh, double t, const double* U, double* R)
 {
   qdg_ctx* ctx = mesh->ctx;
-  if (use_p1_fast(mesh))
+  if (use_p1_fast(mesh) && use_tile(mesh))
+    launch_rhs_p1t(mesh->dm, ctx->ph, t, U, R, false, mesh->blockmin.p, 1.0, DBL_MAX,
+                   mesh->dtraw.p, mesh->dt_ptr, ctx->stream);
+  else if (use_p1_fast(mesh))
     launch_rhs_p1(mesh->dm, ctx->ph, t, U, R, false, mesh->blockmin.p, 1.0, DBL_MAX,
                   mesh->dtraw.p, mesh->dt_ptr, ctx->stream);
   else
@@ -788,16 +835,24 @@ extern "C" int qdg_stage_rhs_dt(qdg_mesh* mesh, int stage, double t, double tlef
   if (use_p1_fast(mesh) && stage > 0) {
     double* out = free_buf(mesh, mesh->Ucur, mesh->Unp);
     if (int rc = prof_begin(mesh, &ev)) return rc;
-    launch_rhs_p1_rk(mesh->dm, ctx->ph, t, mesh->Ucur, out, RK[0][stage], RK[1][stage],
-                     mesh->dt_ptr, mesh->Unp, s);
+    if (use_tile(mesh))
+      launch_rhs_p1t_rk(mesh->dm, ctx->ph, t, mesh->Ucur, out, RK[0][stage], RK[1][stage],
+                        mesh->dt_ptr, mesh->Unp, s);
+    else
+      launch_rhs_p1_rk(mesh->dm, ctx->ph, t, mesh->Ucur, out, RK[0][stage], RK[1][stage],
+                       mesh->dt_ptr, mesh->Unp, s);
     if (ev) HIPCHK(hipEventRecord(ev->second, s));
     mesh->Upending = out;
   } else if (cfl_dt && use_p1_fast(mesh)) {
     const double scale = ctx->cfg.cfl / 3.0;     // cfl/(2p+1), p = 1 (DG.cpp:1404-1418)
     if (int rc = prof_begin(mesh, &ev)) return rc;
     // here the event pair also covers the 1-block dt reduction (~5 us)
-    launch_rhs_p1(mesh->dm, ctx->ph, t, mesh->Ucur, mesh->R.p, true, mesh->blockmin.p, scale,
-                  tleft, mesh->dtraw.p, mesh->dt_ptr, s);
+    if (use_tile(mesh))
+      launch_rhs_p1t(mesh->dm, ctx->ph, t, mesh->Ucur, mesh->R.p, true, mesh->blockmin.p, scale,
+                     tleft, mesh->dtraw.p, mesh->dt_ptr, s);
+    else
+      launch_rhs_p1(mesh->dm, ctx->ph, t, mesh->Ucur, mesh->R.p, true, mesh->blockmin.p, scale,
+                    tleft, mesh->dtraw.p, mesh->dt_ptr, s);
     if (ev) HIPCHK(hipEventRecord(ev->second, s));
   } else {
     if (cfl_dt) if (int rc = qdg_stage_dt(mesh, tleft)) return rc;

@@ -60,7 +60,18 @@ struct DevMesh {
   const double* fgeo;  // [nfac][4] packed {area, nx, ny, nz}: one 32-byte record per face
   const double* xyz4;  // [nnode][4] packed {x, y, z, 0}: one 32-byte record per node
   const int* d2h;      // [ne] device row -> host row
+  // face tasks of the tile kernel (qdg_kernels.hip: k_rhs_p1t): the interior tets
+  // are cut into tiles of TILE consecutive device rows; every face of a tile is
+  // listed ONCE (by its left tet when both tets are in the tile)
+  int ntile;
+  const int* tile_off; // [ntile+1] first task of each tile
+  const int* task_a;   // packed: e_local(8) lf(2) own_left(1) code(6) kind(2) bc(2) partner_local(8)
+  const int* task_nb;  // neighbour device row (kind EXT), else 0
+  const int* task_f;   // device face id
 };
+
+constexpr int TILE = 248;   // tets per tile: 2 x (rows + accumulators + dt sums) fit the CU's 160 KiB LDS
+enum { TASK_INT = 0, TASK_EXT = 1, TASK_BND = 2 };
 
 struct Phys {
   double gamma, pstiff, cweight;
