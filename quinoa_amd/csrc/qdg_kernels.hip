@@ -639,15 +639,16 @@ __device__ __forceinline__ double fast_sqrt(double x)
 
 // primitive quantities of one side of a face
 struct Prim {
-  double ir, u, v, w, p, a, vn;
+  double ir, p, a, vn;
 };
 __device__ __forceinline__ void primitives(const Phys& ph, const double* fn, const double* s, Prim& q)
 {
+  // p = (rhoE - |m|^2/(2 rho) - pc)(gamma-1) - pc,  a = sqrt(gamma (p+pc)/rho),  vn = (m.n)/rho
   q.ir = fast_rcp(s[0]);
-  q.u = s[1] * q.ir; q.v = s[2] * q.ir; q.w = s[3] * q.ir;
-  q.p = eos_pressure(ph, s[0], q.u, q.v, q.w, s[4]);
+  const double m2 = s[1] * s[1] + s[2] * s[2] + s[3] * s[3];
+  q.p = (s[4] - 0.5 * m2 * q.ir - ph.pstiff) * (ph.gamma - 1.0) - ph.pstiff;
   q.a = fast_sqrt(ph.gamma * (q.p + ph.pstiff) * q.ir);
-  q.vn = q.u * fn[0] + q.v * fn[1] + q.w * fn[2];
+  q.vn = (s[1] * fn[0] + s[2] * fn[1] + s[3] * fn[2]) * q.ir;
 }
 
 // HLLC with precomputed primitives (same ladder as flux_hllc above)
