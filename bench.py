@@ -64,6 +64,13 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (nccl) even for one rank: exercises the "
                          "device-tensor slabs, the shared stream and the dt all-reduce")
+    ap.add_argument("--comm", choices=["rccl", "torch"], default="rccl",
+                    help="multi-rank transport: libqdg's own RCCL calls (default) or "
+                         "torch.distributed point-to-point")
+    ap.add_argument("--self-halo", action="store_true",
+                    help="one rank, chunk 0 of a 2x1x1 cut whose neighbour is the rank itself: "
+                         "measures the halo machinery (pack, RCCL send/recv, unpack, all-reduce) "
+                         "on a single GPU; not a physical set-up, prints the same JSON line")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -77,7 +84,7 @@ def main():
     from quinoa_amd import capi, dg, dgmesh, meshgen
 
     comm = None
-    if world > 1 or args.force_dist:
+    if world > 1 or args.force_dist or args.self_halo:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -85,18 +92,22 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        comm = dg.TorchComm()
+        comm = "pending"
 
     # ---- synthetic mesh chunk of this rank (setup, untimed) ---------------
-    parts = meshgen.parts_for(world)
+    parts = meshgen.parts_for(world) if not args.self_halo else (2, 1, 1)
     nx = args.nx
     ch = meshgen.kuhn_box_chunk(nx * parts[0], nx * parts[1], nx * parts[2],
                                 lengths=(float(parts[0]), float(parts[1]), float(parts[2])),
                                 parts=parts, rank=rank)
+    if args.self_halo:
+        ch["nbr_rank"] = [0 for _ in ch["nbr_rank"]]
     chunk = dgmesh.build_chunk(ch["coord"], ch["inpoel"], ch["nielem"], ch["sidesets"])
     ctx = capi.Context(4, flux="hllc", limiter="superbeep1", problem="sod_shocktube", gamma=1.4,
                        cfl=0.3, bc_extrapolate=[1, 2], bc_sym=[3, 4, 5, 6], device=local_rank)
     mesh = dgmesh.upload(ctx, chunk)
+    if comm is not None:
+        comm = dg.RcclComm(ctx) if args.comm == "rccl" else dg.TorchComm()
     drv = dg.DGDriver(ctx, mesh, ch["nbr_rank"], ch["send_lists"], ch["recv_counts"], comm)
     mesh.state_initialize(0.0)
 
@@ -150,9 +161,11 @@ def main():
             "config": {"workload": "CompFlow Euler Sod shock-tube DG-P1 (dgp1, HLLC, superbeep1, "
                                    "cfl 0.3), Kuhn-tet box %d^3 hexes per GPU" % nx,
                        "tets_total": ntet, "tets_per_gpu": chunk.nielem,
-                       "parallelism": "block decomposition %dx%dx%d, ghost-face halo" % parts,
+                       "parallelism": "block decomposition %dx%dx%d, ghost-face halo" % parts
+                                      + ("" if comm is None else ", transport " + comm.backend)
+                                      + (" (SELF-HALO TEST: the neighbour is this rank)" if args.self_halo else ""),
                        "step": "SSP-RK3 time step = 3 x (halo, limiter, halo, [dt], rhs, update)"},
-            "roofline": {"bound": "hbm", "kernel": "qdg::k_rhs_p1 (stage 0: RHS + CFL dt; stages 1,2: RHS with the RK update fused in; 357 B/tet counted for every launch)", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "qdg::k_rhs_p1t (tile/face-task RHS; stage 0: + CFL dt; stages 1,2: + fused RK update; 357 B/tet counted for every launch)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "avg_launch_ms": avg_ms, "launches": nl,
                          "algorithmic_bytes_per_launch": alg},
@@ -162,6 +175,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     mesh.close()
+    if isinstance(comm, dg.RcclComm):
+        comm.close()
     ctx.close()
     if comm is not None:
         torch.distributed.destroy_process_group()

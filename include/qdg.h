@@ -174,6 +174,27 @@ int qdg_stage_dt_use_buffer(qdg_mesh* mesh, void* dt_dev);
 int qdg_halo_pack(qdg_mesh* mesh);     /* U[send list] -> send slab */
 int qdg_halo_unpack(qdg_mesh* mesh);   /* recv slab -> ghost rows of U */
 
+/* -- RCCL transport (one process per GPU, xGMI) ----------------------------
+ * Replaces the Charm++ messages of DG::next/comsol/lim/comlim (DG.cpp:1009-1086,
+ * 1229-1282) by grouped ncclSend/ncclRecv between the ranks of halo_setup's
+ * nbr_rank[], and contribute(min) of the time step (DG.cpp:1428-1429) by an
+ * in-place ncclAllReduce(min) on the device scalar; everything is enqueued on
+ * the context's stream, nothing synchronises the host.  RCCL is loaded with
+ * dlopen at the first qdg_comm_* call (librccl.so.1).
+ * Bootstrap: rank 0 calls qdg_comm_unique_id, the 128 bytes reach the other
+ * ranks by any means (MPI, torch.distributed, a file), then every rank calls
+ * qdg_comm_create at the same time (it is a collective). */
+typedef struct qdg_comm qdg_comm;
+int qdg_comm_unique_id(void* id128);
+int qdg_comm_create(qdg_ctx* ctx, int nranks, int rank, const void* id128, qdg_comm** out);
+int qdg_comm_destroy(qdg_comm* comm);
+int qdg_halo_exchange(qdg_mesh* mesh, qdg_comm* comm);   /* pack, send/recv, unpack */
+int qdg_stage_dt_allreduce(qdg_mesh* mesh, qdg_comm* comm);
+/* whole SSP-RK3 step of one chunk of a partitioned mesh:
+ * 3 x (exchange, limit, exchange, rhs [+dt, min over ranks], update); the dt
+ * taken is read back (host sync) only when dt_taken != NULL */
+int qdg_step_comm(qdg_mesh* mesh, qdg_comm* comm, double t, double tleft, double* dt_taken);
+
 /* -- measurement ---------------------------------------------------------- */
 /* When enabled, every launch of the RHS kernel inside qdg_stage_rhs_update is
  * bracketed by HIP events on the context's stream (no host sync in the timed

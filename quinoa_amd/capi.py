@@ -355,10 +355,44 @@ class Mesh:
     def halo_pack(self):
         _chk(lib().qdg_halo_pack(self.h))
 
+    def halo_exchange(self, comm):
+        _chk(lib().qdg_halo_exchange(self.h, comm.h))
+
+    def stage_dt_allreduce(self, comm):
+        _chk(lib().qdg_stage_dt_allreduce(self.h, comm.h))
+
+    def step_comm(self, comm, t, tleft=1e300, want_dt=False):
+        v = C.c_double(0.0)
+        _chk(lib().qdg_step_comm(self.h, comm.h, C.c_double(t), C.c_double(tleft),
+                                 C.byref(v) if want_dt else None))
+        return v.value
+
     def halo_unpack(self):
         _chk(lib().qdg_halo_unpack(self.h))
 
     def close(self):
         if self.h:
             lib().qdg_mesh_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+class Comm:
+    """RCCL communicator of libqdg (qdg_comm_*): one rank per GPU."""
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_ubyte * 128)()
+        _chk(lib().qdg_comm_unique_id(buf))
+        return bytes(buf)
+
+    def __init__(self, ctx, nranks, rank, unique_id):
+        assert len(unique_id) == 128
+        self.h = C.c_void_p()
+        self.nranks, self.rank = nranks, rank
+        buf = (C.c_ubyte * 128).from_buffer_copy(unique_id)
+        _chk(lib().qdg_comm_create(ctx.h, C.c_int(nranks), C.c_int(rank), buf, C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            _chk(lib().qdg_comm_destroy(self.h))
             self.h = C.c_void_p()

@@ -4,6 +4,8 @@
 // `tk::Fields`-layout arrays (the DGPDE-shaped calls) or runs on the
 // device-resident state.  There is no CPU fallback in this library.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>   // types and prototypes only: the library is dlopen'ed (see rccl_api)
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cfloat>
@@ -1017,6 +1019,164 @@ extern "C" int qdg_stage_dt_use_buffer(qdg_mesh* mesh, void* dt_dev)
   QDG_TRY
   if (!mesh || !dt_dev) return fail("qdg_stage_dt_use_buffer: null argument");
   mesh->dt_ptr = (double*)dt_dev;
+  return 0;
+  QDG_CATCH
+}
+
+// ---------------------------------------------------------------- RCCL transport
+
+namespace {
+// RCCL entry points, resolved at run time so that libqdg has no link-time
+// dependency on a particular librccl (a process that already loaded one, e.g.
+// through PyTorch, keeps using that copy)
+struct RcclApi {
+  void* handle = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  std::string error;
+};
+
+RcclApi* rccl_api()
+{
+  static RcclApi api;
+  static bool tried = false;
+  if (tried) return &api;
+  tried = true;
+  const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+  for (const char* n : names) {
+    api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (api.handle) break;
+  }
+  if (!api.handle) { api.error = std::string("cannot load librccl: ") + dlerror(); return &api; }
+#define QDG_RCCL_SYM(f)                                                        \
+  api.f = reinterpret_cast<decltype(api.f)>(dlsym(api.handle, "nccl" #f));     \
+  if (!api.f) { api.error = "librccl lacks nccl" #f; return &api; }
+  QDG_RCCL_SYM(GetUniqueId) QDG_RCCL_SYM(CommInitRank) QDG_RCCL_SYM(CommDestroy)
+  QDG_RCCL_SYM(GetErrorString) QDG_RCCL_SYM(GroupStart) QDG_RCCL_SYM(GroupEnd)
+  QDG_RCCL_SYM(Send) QDG_RCCL_SYM(Recv) QDG_RCCL_SYM(AllReduce)
+#undef QDG_RCCL_SYM
+  return &api;
+}
+}  // namespace
+
+#define RCCLCHK(call)                                                             \
+  do {                                                                            \
+    ncclResult_t r_ = (call);                                                     \
+    if (r_ != ncclSuccess)                                                        \
+      return ::qdg::fail(std::string(#call) + ": " + rccl_api()->GetErrorString(r_)); \
+  } while (0)
+
+struct qdg_comm {
+  ncclComm_t comm = nullptr;
+  int nranks = 1, rank = 0, device = 0;
+};
+
+extern "C" int qdg_comm_unique_id(void* id128)
+{
+  QDG_TRY
+  if (!id128) return fail("qdg_comm_unique_id: null argument");
+  RcclApi* a = rccl_api();
+  if (!a->error.empty()) return fail("qdg_comm_unique_id: " + a->error);
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes in the ABI of qdg.h");
+  ncclUniqueId id;
+  RCCLCHK(a->GetUniqueId(&id));
+  std::memcpy(id128, &id, sizeof id);
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_comm_create(qdg_ctx* ctx, int nranks, int rank, const void* id128, qdg_comm** out)
+{
+  QDG_TRY
+  if (!ctx || !id128 || !out) return fail("qdg_comm_create: null argument");
+  if (nranks < 1 || rank < 0 || rank >= nranks) return fail("qdg_comm_create: bad rank / nranks");
+  RcclApi* a = rccl_api();
+  if (!a->error.empty()) return fail("qdg_comm_create: " + a->error);
+  HIPCHK(hipSetDevice(ctx->device));
+  ncclUniqueId id;
+  std::memcpy(&id, id128, sizeof id);
+  std::unique_ptr<qdg_comm> c(new qdg_comm);
+  c->nranks = nranks; c->rank = rank; c->device = ctx->device;
+  RCCLCHK(a->CommInitRank(&c->comm, nranks, id, rank));
+  *out = c.release();
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_comm_destroy(qdg_comm* comm)
+{
+  QDG_TRY
+  if (!comm) return 0;
+  if (comm->comm) {
+    (void)hipSetDevice(comm->device);
+    RCCLCHK(rccl_api()->CommDestroy(comm->comm));
+  }
+  delete comm;
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_halo_exchange(qdg_mesh* mesh, qdg_comm* comm)
+{
+  QDG_TRY
+  MESH_ENTER("qdg_halo_exchange");
+  if (mesh->nnbr == 0) return 0;
+  if (!comm) return fail("qdg_halo_exchange: null communicator");
+  for (size_t i = 0; i < mesh->nnbr; ++i)
+    if (mesh->nbr_rank[i] < 0 || mesh->nbr_rank[i] >= comm->nranks)
+      return fail("qdg_halo_exchange: neighbour rank outside the communicator");
+  RcclApi* a = rccl_api();
+  const size_t np = (size_t)mesh->nprop;
+  launch_halo_pack(mesh->Ucur, mesh->nprop, (int)mesh->stride, mesh->send_elem.p, (int)mesh->nsend,
+                   mesh->send_ptr, s);
+  HIPCHK(hipGetLastError());
+  RCCLCHK(a->GroupStart());
+  for (size_t i = 0; i < mesh->nnbr; ++i) {
+    const size_t ns = (mesh->send_off[i + 1] - mesh->send_off[i]) * np;
+    const size_t nr = (mesh->recv_off[i + 1] - mesh->recv_off[i]) * np;
+    if (ns) RCCLCHK(a->Send(mesh->send_ptr + mesh->send_off[i] * np, ns, ncclDouble, mesh->nbr_rank[i], comm->comm, s));
+    if (nr) RCCLCHK(a->Recv(mesh->recv_ptr + mesh->recv_off[i] * np, nr, ncclDouble, mesh->nbr_rank[i], comm->comm, s));
+  }
+  RCCLCHK(a->GroupEnd());
+  launch_halo_unpack(mesh->recv_ptr, mesh->nprop, (int)mesh->stride, (int)mesh->nie,
+                     (int)mesh->nrecv, mesh->Ucur, s);
+  HIPCHK(hipGetLastError());
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_stage_dt_allreduce(qdg_mesh* mesh, qdg_comm* comm)
+{
+  QDG_TRY
+  MESH_ENTER("qdg_stage_dt_allreduce");
+  if (!comm) return fail("qdg_stage_dt_allreduce: null communicator");
+  RCCLCHK(rccl_api()->AllReduce(mesh->dt_ptr, mesh->dt_ptr, 1, ncclDouble, ncclMin, comm->comm, s));
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_step_comm(qdg_mesh* mesh, qdg_comm* comm, double t, double tleft, double* dt_taken)
+{
+  QDG_TRY
+  if (!mesh) return fail("qdg_step_comm: null mesh");
+  if (!comm) return fail("qdg_step_comm: null communicator");
+  const bool limited = mesh->ctx->cfg.limiter != QDG_LIMITER_NONE && mesh->ndof > 1;
+  for (int stage = 0; stage < 3; ++stage) {
+    if (int rc = qdg_halo_exchange(mesh, comm)) return rc;              // DG::next -> comsol
+    if (int rc = qdg_stage_limit(mesh)) return rc;                      // DG::lim
+    if (limited) if (int rc = qdg_halo_exchange(mesh, comm)) return rc; // -> comlim
+    if (int rc = qdg_stage_rhs_dt(mesh, stage, t, tleft)) return rc;    // DG::dt, DG::solve
+    if (stage == 0) if (int rc = qdg_stage_dt_allreduce(mesh, comm)) return rc;
+    if (int rc = qdg_stage_update(mesh, stage)) return rc;
+  }
+  if (dt_taken) return qdg_stage_dt_get(mesh, dt_taken);
   return 0;
   QDG_CATCH
 }

@@ -70,7 +70,16 @@ struct DevMesh {
   const int* task_f;   // device face id
 };
 
-constexpr int TILE = 248;   // tets per tile: 2 x (rows + accumulators + dt sums) fit the CU's 160 KiB LDS
+#ifndef QDG_TILE
+#define QDG_TILE 248
+#endif
+#ifndef QDG_TILE_BS
+#define QDG_TILE_BS 256
+#endif
+constexpr int TILE = QDG_TILE;
+constexpr int TILE_BS = QDG_TILE_BS;   // workgroup size of the tile kernel
+static_assert(TILE <= TILE_BS && TILE <= 256, "one lane per tet; local ids are 8 bits");
+//   // tets per tile: 2 x (rows + accumulators + dt sums) fit the CU's 160 KiB LDS
 enum { TASK_INT = 0, TASK_EXT = 1, TASK_BND = 2 };
 
 struct Phys {

@@ -23,10 +23,13 @@
 #include "qdg_kernels.hpp"
 
 #ifndef QDG_RCP_NR
-#define QDG_RCP_NR 1    // Newton steps after v_rcp_f64 (1 step: R agrees with the oracle to 1e-15)
+#define QDG_RCP_NR 1    // Newton steps after v_rcp_f64 (1 step: R agrees with the fp64-division CPU result to 1e-15)
 #endif
 #ifndef QDG_SQRT_NR
 #define QDG_SQRT_NR 1   // Goldschmidt steps after v_rsq_f64 (plus one residual correction)
+#endif
+#ifndef QDG_TILE_GP_UNROLL
+#define QDG_TILE_GP_UNROLL 1
 #endif
 #ifndef QDG_P1_WAVES
 #define QDG_P1_WAVES 2   // waves per SIMD the DG-P1 RHS kernel is register-budgeted for
@@ -966,7 +969,7 @@ __device__ __forceinline__ void vertex_basis(int v, double& b1, double& b2, doub
 }
 
 template <bool WITH_DT, bool FUSE_RK, int PROB>
-__global__ __launch_bounds__(256, 2) void k_rhs_p1t(DevMesh m, Phys ph, double t,
+__global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1t(DevMesh m, Phys ph, double t,
                                                      const double* __restrict__ U,
                                                      double* __restrict__ R,
                                                      double* __restrict__ blockmin,
@@ -994,7 +997,7 @@ __global__ __launch_bounds__(256, 2) void k_rhs_p1t(DevMesh m, Phys ph, double t
   int ta[MAXT], tf[MAXT], tn[MAXT];
 #pragma unroll
   for (int q = 0; q < MAXT; ++q) {
-    const int it = t0 + tid + 256 * q;
+    const int it = t0 + tid + TILE_BS * q;
     const bool ok = it < t1;
     ta[q] = ok ? m.task_a[it] : -1;
     tf[q] = ok ? m.task_f[it] : 0;
@@ -1035,7 +1038,7 @@ __global__ __launch_bounds__(256, 2) void k_rhs_p1t(DevMesh m, Phys ph, double t
 
   // ---- phase 1: one lane per face task ------------------------------------------
   constexpr bool HAS_DIRICHLET = (PROB == 3 || PROB == 4 || PROB == 0);
-  if ((t1 - t0) > 256 * MAXT) __builtin_trap();   // cannot happen: <= 4*TILE tasks per tile
+  if ((t1 - t0) > TILE_BS * MAXT) __builtin_trap();   // cannot happen: <= 4*TILE tasks per tile
 #pragma unroll 1
   for (int q = 0; q < MAXT; ++q) {
     const int a = (q == 0) ? ta[0] : (q == 1) ? ta[1] : (q == 2) ? ta[2] : ta[3];
@@ -1111,7 +1114,7 @@ __global__ __launch_bounds__(256, 2) void k_rhs_p1t(DevMesh m, Phys ph, double t
 #pragma unroll
       for (int c = 0; c < NCOMP; ++c) W[j][c] = 0.0;
 
-#pragma unroll 1
+#pragma unroll QDG_TILE_GP_UNROLL
     for (int ig = 0; ig < NGF; ++ig) {
       const double s0 = T.fs[ig][0], s1 = T.fs[ig][1], s2 = T.fs[ig][2];
       double so[NCOMP], sn[NCOMP], fl[NCOMP];
@@ -1278,11 +1281,15 @@ __global__ __launch_bounds__(256, 2) void k_rhs_p1t(DevMesh m, Phys ph, double t
 
   if (WITH_DT) {
     for (int off = 32; off > 0; off >>= 1) dte = fmin(dte, __shfl_down(dte, off, 64));
-    __shared__ double wmin[4];
+    __shared__ double wmin[TILE_BS / 64];
     const int lane = tid & 63, wv = tid >> 6;
     if (lane == 0) wmin[wv] = dte;
     __syncthreads();
-    if (tid == 0) blockmin[blockIdx.x] = fmin(fmin(wmin[0], wmin[1]), fmin(wmin[2], wmin[3]));
+    if (tid == 0) {
+      double mn = wmin[0];
+      for (int w = 1; w < TILE_BS / 64; ++w) mn = fmin(mn, wmin[w]);
+      blockmin[blockIdx.x] = mn;
+    }
   }
 }
 
@@ -1772,10 +1779,10 @@ void launch_rhs_p1t(const DevMesh& m, const Phys& ph, double t, const double* U,
   const int nb = m.ntile;
   if (nb == 0) return;
   if (with_dt) {
-    QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1t<true, false, P><<<nb, 256, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr)));
+    QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1t<true, false, P><<<nb, TILE_BS, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr)));
     k_dt_final<<<1, 256, 0, s>>>(blockmin, nb, scale, tleft, out_raw, out_dt);
   } else {
-    QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1t<false, false, P><<<nb, 256, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr)));
+    QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1t<false, false, P><<<nb, TILE_BS, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr)));
   }
 }
 
@@ -1784,7 +1791,7 @@ void launch_rhs_p1t_rk(const DevMesh& m, const Phys& ph, double t, const double*
 {
   const int nb = m.ntile;
   if (nb == 0) return;
-  QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1t<false, true, P><<<nb, 256, 0, s>>>(m, ph, t, U, Uout, nullptr, a, b, dt, Un)));
+  QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1t<false, true, P><<<nb, TILE_BS, 0, s>>>(m, ph, t, U, Uout, nullptr, a, b, dt, Un)));
 }
 
 // P1 RHS with the SSP-RK3 update fused in: Uout = a*Un + b*(U + dt*R/L)

@@ -8,9 +8,16 @@ Mirror of the `DG` chare's per-stage sequence (src/Inciter/DG.cpp and dg.ci:57-7
     solve  : Un=U (stage 0), rhs, SSP-RK3 update       (DG.cpp:1432-1508)  -> stage_rhs_dt(), stage_update()
 
 with the Charm++ messages replaced by point-to-point sends between the ranks of
-one node (RCCL over xGMI when the backend is "nccl") and the `contribute(min)`
-by an all-reduce of one double that stays on the device.  The fields never
-leave HBM.  One process drives one GPU.
+one node and the `contribute(min)` by an all-reduce of one double that stays on
+the device.  The fields never leave HBM.  One process drives one GPU.
+
+Transports:
+  RcclComm   the product path on GPUs: libqdg's own RCCL calls (qdg_halo_exchange,
+             qdg_stage_dt_allreduce; the whole step is ONE call, qdg_step_comm);
+             torch.distributed only carries the 128-byte RCCL id at start-up
+  TorchComm  torch.distributed point-to-point; with backend "gloo" the slabs are
+             staged through the host (CPU test of the multi-rank logic, or several
+             ranks sharing one GPU)
 """
 import numpy as np
 
@@ -68,6 +75,47 @@ class TorchComm:
             drv.dt_buf.copy_(h)
 
 
+class SelfComm(TorchComm):
+    """One rank whose halo neighbours are itself (send slab -> recv slab on the
+    device).  Not a physical set-up: the reference transport against which the
+    RCCL self send/recv is checked on a single GPU."""
+
+    def __init__(self):
+        import torch
+        self.torch, self.dist = torch, None
+        self.rank, self.size, self.backend = 0, 1, "self"
+
+    def sendrecv(self, drv):
+        drv.recv_slab.copy_(drv.send_slab)
+
+    def allreduce_min(self, drv):
+        pass
+
+
+class RcclComm:
+    """libqdg's RCCL transport.  `bootstrap` spreads rank 0's unique id: by
+    default a torch.distributed broadcast (any backend)."""
+    backend = "rccl"
+
+    def __init__(self, ctx, rank=None, size=None, unique_id=None):
+        from . import capi
+        if unique_id is None:
+            import torch
+            import torch.distributed as dist
+            rank, size = dist.get_rank(), dist.get_world_size()
+            dev = torch.device("cuda", ctx.cfg.device) if dist.get_backend() == "nccl" else torch.device("cpu")
+            t = torch.zeros(128, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                t = torch.frombuffer(bytearray(capi.Comm.unique_id()), dtype=torch.uint8).to(dev)
+            dist.broadcast(t, src=0)
+            unique_id = bytes(t.cpu().numpy().tobytes())
+        self.rank, self.size = rank, size
+        self.comm = capi.Comm(ctx, size, rank, unique_id)
+
+    def close(self):
+        self.comm.close()
+
+
 class DGDriver:
     def __init__(self, ctx, mesh, nbr_rank=(), send_lists=(), recv_counts=(), comm=None):
         self.ctx, self.mesh = ctx, mesh
@@ -77,6 +125,9 @@ class DGDriver:
         self.limiter_active = ctx.cfg.limiter != 0 and ctx.ndof > 1
         self.send_slab = self.recv_slab = self.dt_buf = None
         self.distributed = isinstance(self.comm, TorchComm)
+        self.rccl = isinstance(self.comm, RcclComm)
+        if self.rccl:
+            mesh.halo_setup(self.nbr_rank, send_lists, recv_counts)
         if self.distributed:
             torch = self.comm.torch
             dev = torch.device("cuda", torch.cuda.current_device())
@@ -102,6 +153,9 @@ class DGDriver:
 
     def step(self, t, tleft=1e300):
         m = self.mesh
+        if self.rccl:                            # the same sequence, inside libqdg
+            m.step_comm(self.comm.comm, t, tleft)
+            return
         for stage in range(3):
             self.exchange()                      # comsol
             m.stage_limit()

@@ -29,4 +29,18 @@ for k, v in res.items():
         # FETCH_SIZE/WRITE_SIZE are in KiB; FETCH_SIZE counts 128-B requests as 64 B on gfx950 -> x2
         hbm = (2 * v["FETCH_SIZE"] + v.get("WRITE_SIZE", 0.0)) * 1024
         print("%-40s fetch %.1f MB (x2 corrected %.1f) write %.1f MB -> %.1f MB/launch" % (k, v["FETCH_SIZE"] / 1024 * 1.048576, 2 * v["FETCH_SIZE"] * 1024 / 1e6, v.get("WRITE_SIZE", 0) * 1024 / 1e6, hbm / 1e6))
+# traffic.json for bench.py: launch-weighted mean over the RHS kernels of one step
+rhs = {k: v for k, v in res.items() if "k_rhs" in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v}
+if rhs:
+    tot = 0.0; n = 0; ker = {}
+    for k, v in rhs.items():
+        b = (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
+        nl = cnt[(k, "FETCH_SIZE")]
+        ker[k] = {"hbm_bytes_per_launch": b, "launches_counted": nl}
+        tot += b * nl; n += nl
+    json.dump({"nx": $nx, "n_gpus": 1, "round": 1,
+               "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes), per-launch means; "
+                         "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts 128-B requests as 64 B; "
+                         "confirmed on k_rk: 480 MB of coalesced reads report 243.6 MB)",
+               "kernels": ker, "hbm_bytes_per_launch": tot / n}, open("$out/traffic.json", "w"), indent=1)
 PY
