@@ -188,7 +188,7 @@ typedef struct qdg_comm qdg_comm;
 int qdg_comm_unique_id(void* id128);
 int qdg_comm_create(qdg_ctx* ctx, int nranks, int rank, const void* id128, qdg_comm** out);
 int qdg_comm_destroy(qdg_comm* comm);
-int qdg_halo_exchange(qdg_mesh* mesh, qdg_comm* comm);   /* pack, send/recv, unpack */
+int qdg_halo_exchange(qdg_mesh* mesh, qdg_comm* comm);   /* pack, send / recv into ghost rows */
 int qdg_stage_dt_allreduce(qdg_mesh* mesh, qdg_comm* comm);
 /* whole SSP-RK3 step of one chunk of a partitioned mesh:
  * 3 x (exchange, limit, exchange, rhs [+dt, min over ranks], update); the dt

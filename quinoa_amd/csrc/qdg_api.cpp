@@ -106,9 +106,14 @@ struct qdg_mesh {
   double* recv_ptr = nullptr;
   double* dt_ptr = nullptr;       // dt scalar in use
   size_t nnode_used = 0;
-  // measurement: event pairs around the RHS kernel
+  // halo overlap (qdg_step_comm): when set, the limiter / the tile RHS run the
+  // rows without a ghost neighbour first, then wait for this event (end of the
+  // exchange on the communication stream) before the rows next to the halo
+  hipEvent_t split_lim = nullptr, split_rhs = nullptr;
+  // measurement: event pairs around the RHS kernel (cont: second part of a split launch)
   bool prof = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+  std::vector<char> ev_cont;
   size_t ev_used = 0;
   ~qdg_mesh()
   {
@@ -285,6 +290,16 @@ extern "C" int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t 
     }
     std::sort(key.begin(), key.end());
     for (size_t d = 0; d < nie; ++d) d2h[d] = key[d].second;
+  }
+  // tets with a ghost neighbour go last (still in curve order): launches over the
+  // leading rows never touch the halo and can overlap the exchange (qdg_step_comm)
+  size_t ninner = nie;
+  if (ne > nie) {
+    auto at_halo = [&](int e) {
+      for (int lf = 0; lf < 4; ++lf) if (esuel[4 * (size_t)e + lf] >= (int)nie) return true;
+      return false;
+    };
+    ninner = std::stable_partition(d2h.begin(), d2h.begin() + nie, [&](int e) { return !at_halo(e); }) - d2h.begin();
   }
   for (size_t d = 0; d < ne; ++d) h2d[d2h[d]] = (int)d;
 
@@ -481,6 +496,7 @@ extern "C" int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t 
   HIPCHK(m->task_nb.upload(h_task_nb, s)); HIPCHK(m->task_f.upload(h_task_f, s));
   dm.ntile = ntile; dm.tile_off = m->tile_off.p; dm.task_a = m->task_a.p;
   dm.task_nb = m->task_nb.p; dm.task_f = m->task_f.p;
+  dm.blk0 = 0; dm.ninner = (int)ninner;
   HIPCHK(hipStreamSynchronize(s));
   *out = m.release();
   return 0;
@@ -563,7 +579,14 @@ static int run_limiter(qdg_mesh* mesh, double*& Ucur, double* Ualt_in)
   hipStream_t s = ctx->stream;
   if (mesh->ndof == 1) return 0;          // DG.cpp:1251: rdof > 1 only
   if (ctx->cfg.limiter == QDG_LIMITER_SUPERBEEP1) {
-    launch_superbee(mesh->ndof, mesh->dm, Ucur, s);
+    if (mesh->split_lim) {
+      const int inner = mesh->dm.ninner / 256;
+      launch_superbee(mesh->ndof, mesh->dm, Ucur, s, 0, inner);
+      HIPCHK(hipStreamWaitEvent(s, mesh->split_lim, 0));
+      launch_superbee(mesh->ndof, mesh->dm, Ucur, s, inner, -1);
+    } else {
+      launch_superbee(mesh->ndof, mesh->dm, Ucur, s);
+    }
   } else if (ctx->cfg.limiter == QDG_LIMITER_WENOP1) {
     launch_copy_planes(Ucur, Ualt, mesh->nprop, (int)mesh->ne, (int)mesh->stride, s);
     launch_weno(mesh->ndof, mesh->dm, ctx->ph.cweight, Ucur, Ualt, s);
@@ -592,7 +615,14 @@ static bool use_tile(const qdg_mesh*)
 static void run_rhs(qdg_mesh* mesh, double t, const double* U, double* R)
 {
   qdg_ctx* ctx = mesh->ctx;
-  if (use_p1_fast(mesh) && use_tile(mesh))
+  if (use_p1_fast(mesh) && use_tile(mesh) && mesh->split_rhs) {
+    const int inner = mesh->dm.ninner / TILE;
+    launch_rhs_p1t(mesh->dm, ctx->ph, t, U, R, false, mesh->blockmin.p, 1.0, DBL_MAX,
+                   mesh->dtraw.p, mesh->dt_ptr, ctx->stream, 0, inner);
+    (void)hipStreamWaitEvent(ctx->stream, mesh->split_rhs, 0);
+    launch_rhs_p1t(mesh->dm, ctx->ph, t, U, R, false, mesh->blockmin.p, 1.0, DBL_MAX,
+                   mesh->dtraw.p, mesh->dt_ptr, ctx->stream, inner, -1);
+  } else if (use_p1_fast(mesh) && use_tile(mesh))
     launch_rhs_p1t(mesh->dm, ctx->ph, t, U, R, false, mesh->blockmin.p, 1.0, DBL_MAX,
                    mesh->dtraw.p, mesh->dt_ptr, ctx->stream);
   else if (use_p1_fast(mesh))
@@ -780,7 +810,7 @@ extern "C" int qdg_stage_dt_device_ptr(qdg_mesh* mesh, void** dptr)
 
 static const double RK[2][3] = { { 0.0, 3.0 / 4.0, 1.0 / 3.0 }, { 1.0, 1.0 / 4.0, 2.0 / 3.0 } };   // DG.cpp:39-40
 
-static int prof_begin(qdg_mesh* mesh, std::pair<hipEvent_t, hipEvent_t>** ev)
+static int prof_begin(qdg_mesh* mesh, std::pair<hipEvent_t, hipEvent_t>** ev, bool cont = false)
 {
   *ev = nullptr;
   if (!mesh->prof) return 0;
@@ -789,7 +819,9 @@ static int prof_begin(qdg_mesh* mesh, std::pair<hipEvent_t, hipEvent_t>** ev)
     HIPCHK(hipEventCreate(&a));
     HIPCHK(hipEventCreate(&b));
     mesh->ev.emplace_back(a, b);
+    mesh->ev_cont.push_back(0);
   }
+  mesh->ev_cont[mesh->ev_used] = cont ? 1 : 0;
   *ev = &mesh->ev[mesh->ev_used++];
   HIPCHK(hipEventRecord((*ev)->first, mesh->ctx->stream));
   return 0;
@@ -837,7 +869,16 @@ extern "C" int qdg_stage_rhs_dt(qdg_mesh* mesh, int stage, double t, double tlef
   if (use_p1_fast(mesh) && stage > 0) {
     double* out = free_buf(mesh, mesh->Ucur, mesh->Unp);
     if (int rc = prof_begin(mesh, &ev)) return rc;
-    if (use_tile(mesh))
+    if (use_tile(mesh) && mesh->split_rhs) {
+      const int inner = mesh->dm.ninner / TILE;
+      launch_rhs_p1t_rk(mesh->dm, ctx->ph, t, mesh->Ucur, out, RK[0][stage], RK[1][stage],
+                        mesh->dt_ptr, mesh->Unp, s, 0, inner);
+      if (ev) HIPCHK(hipEventRecord(ev->second, s));
+      HIPCHK(hipStreamWaitEvent(s, mesh->split_rhs, 0));
+      if (int rc = prof_begin(mesh, &ev, true)) return rc;
+      launch_rhs_p1t_rk(mesh->dm, ctx->ph, t, mesh->Ucur, out, RK[0][stage], RK[1][stage],
+                        mesh->dt_ptr, mesh->Unp, s, inner, -1);
+    } else if (use_tile(mesh))
       launch_rhs_p1t_rk(mesh->dm, ctx->ph, t, mesh->Ucur, out, RK[0][stage], RK[1][stage],
                         mesh->dt_ptr, mesh->Unp, s);
     else
@@ -849,7 +890,16 @@ extern "C" int qdg_stage_rhs_dt(qdg_mesh* mesh, int stage, double t, double tlef
     const double scale = ctx->cfg.cfl / 3.0;     // cfl/(2p+1), p = 1 (DG.cpp:1404-1418)
     if (int rc = prof_begin(mesh, &ev)) return rc;
     // here the event pair also covers the 1-block dt reduction (~5 us)
-    if (use_tile(mesh))
+    if (use_tile(mesh) && mesh->split_rhs) {
+      const int inner = mesh->dm.ninner / TILE;
+      launch_rhs_p1t(mesh->dm, ctx->ph, t, mesh->Ucur, mesh->R.p, true, mesh->blockmin.p, scale,
+                     tleft, mesh->dtraw.p, mesh->dt_ptr, s, 0, inner);
+      if (ev) HIPCHK(hipEventRecord(ev->second, s));
+      HIPCHK(hipStreamWaitEvent(s, mesh->split_rhs, 0));
+      if (int rc = prof_begin(mesh, &ev, true)) return rc;
+      launch_rhs_p1t(mesh->dm, ctx->ph, t, mesh->Ucur, mesh->R.p, true, mesh->blockmin.p, scale,
+                     tleft, mesh->dtraw.p, mesh->dt_ptr, s, inner, -1);
+    } else if (use_tile(mesh))
       launch_rhs_p1t(mesh->dm, ctx->ph, t, mesh->Ucur, mesh->R.p, true, mesh->blockmin.p, scale,
                      tleft, mesh->dtraw.p, mesh->dt_ptr, s);
     else
@@ -1076,6 +1126,9 @@ RcclApi* rccl_api()
 struct qdg_comm {
   ncclComm_t comm = nullptr;
   int nranks = 1, rank = 0, device = 0;
+  // communication stream and events of the overlapped step (qdg_step_comm)
+  hipStream_t cs = nullptr;
+  hipEvent_t ev_ready = nullptr, ev_x1 = nullptr, ev_x2 = nullptr;
 };
 
 extern "C" int qdg_comm_unique_id(void* id128)
@@ -1105,6 +1158,10 @@ extern "C" int qdg_comm_create(qdg_ctx* ctx, int nranks, int rank, const void* i
   std::unique_ptr<qdg_comm> c(new qdg_comm);
   c->nranks = nranks; c->rank = rank; c->device = ctx->device;
   RCCLCHK(a->CommInitRank(&c->comm, nranks, id, rank));
+  HIPCHK(hipStreamCreateWithFlags(&c->cs, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&c->ev_x1, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&c->ev_x2, hipEventDisableTiming));
   *out = c.release();
   return 0;
   QDG_CATCH
@@ -1118,15 +1175,16 @@ extern "C" int qdg_comm_destroy(qdg_comm* comm)
     (void)hipSetDevice(comm->device);
     RCCLCHK(rccl_api()->CommDestroy(comm->comm));
   }
+  if (comm->cs) { (void)hipStreamSynchronize(comm->cs); (void)hipStreamDestroy(comm->cs); }
+  for (hipEvent_t e : { comm->ev_ready, comm->ev_x1, comm->ev_x2 }) if (e) (void)hipEventDestroy(e);
   delete comm;
   return 0;
   QDG_CATCH
 }
 
-extern "C" int qdg_halo_exchange(qdg_mesh* mesh, qdg_comm* comm)
+// pack, grouped send / receive into the ghost rows -- all enqueued on stream `s`
+static int exchange_on(qdg_mesh* mesh, qdg_comm* comm, hipStream_t s)
 {
-  QDG_TRY
-  MESH_ENTER("qdg_halo_exchange");
   if (mesh->nnbr == 0) return 0;
   if (!comm) return fail("qdg_halo_exchange: null communicator");
   for (size_t i = 0; i < mesh->nnbr; ++i)
@@ -1142,13 +1200,18 @@ extern "C" int qdg_halo_exchange(qdg_mesh* mesh, qdg_comm* comm)
     const size_t ns = (mesh->send_off[i + 1] - mesh->send_off[i]) * np;
     const size_t nr = (mesh->recv_off[i + 1] - mesh->recv_off[i]) * np;
     if (ns) RCCLCHK(a->Send(mesh->send_ptr + mesh->send_off[i] * np, ns, ncclDouble, mesh->nbr_rank[i], comm->comm, s));
-    if (nr) RCCLCHK(a->Recv(mesh->recv_ptr + mesh->recv_off[i] * np, nr, ncclDouble, mesh->nbr_rank[i], comm->comm, s));
+    // ghost rows are contiguous per neighbour: received in place, no unpack pass
+    if (nr) RCCLCHK(a->Recv(mesh->Ucur + (mesh->nie + mesh->recv_off[i]) * np, nr, ncclDouble, mesh->nbr_rank[i], comm->comm, s));
   }
   RCCLCHK(a->GroupEnd());
-  launch_halo_unpack(mesh->recv_ptr, mesh->nprop, (int)mesh->stride, (int)mesh->nie,
-                     (int)mesh->nrecv, mesh->Ucur, s);
-  HIPCHK(hipGetLastError());
   return 0;
+}
+
+extern "C" int qdg_halo_exchange(qdg_mesh* mesh, qdg_comm* comm)
+{
+  QDG_TRY
+  MESH_ENTER("qdg_halo_exchange");
+  return exchange_on(mesh, comm, s);
   QDG_CATCH
 }
 
@@ -1162,19 +1225,71 @@ extern "C" int qdg_stage_dt_allreduce(qdg_mesh* mesh, qdg_comm* comm)
   QDG_CATCH
 }
 
+// Optional (QDG_OVERLAP=1): the exchanges of a stage hide behind the work on tets
+// that have no ghost neighbour (device rows [0, ninner)):
+//   comm stream:  [exchange U]            [exchange limited U]        [min dt]
+//   main stream:  limiter(inner) | wait | limiter(halo side)  RHS(inner tiles) | wait | RHS(rest)
+// for the DG-P1 tile kernel with Superbee / no limiter (in-place state).
+// Off by default: at ~1 M tets per GPU an exchange costs ~17 us on the stream
+// while each cross-stream event edge costs more than that on this runtime
+// (measured, self-halo bench: 1.37 ms/step overlapped vs 1.12 ms in sequence;
+// DESIGN.md "Multi-GPU").  It pays only where the exchange is long.
+static bool can_overlap(const qdg_mesh* mesh)
+{
+  static const bool on = std::getenv("QDG_OVERLAP") != nullptr;
+  return on && mesh->nnbr > 0 && use_p1_fast(mesh) && use_tile(mesh) &&
+         mesh->ctx->cfg.limiter != QDG_LIMITER_WENOP1 && mesh->dm.ninner / TILE > 0 &&
+         mesh->dm.ninner / 256 > 0;
+}
+
 extern "C" int qdg_step_comm(qdg_mesh* mesh, qdg_comm* comm, double t, double tleft, double* dt_taken)
 {
   QDG_TRY
-  if (!mesh) return fail("qdg_step_comm: null mesh");
+  MESH_ENTER("qdg_step_comm");
   if (!comm) return fail("qdg_step_comm: null communicator");
-  const bool limited = mesh->ctx->cfg.limiter != QDG_LIMITER_NONE && mesh->ndof > 1;
+  const bool limited = ctx->cfg.limiter != QDG_LIMITER_NONE && mesh->ndof > 1;
+  const bool overlap = can_overlap(mesh);
+  hipStream_t cs = comm->cs;
   for (int stage = 0; stage < 3; ++stage) {
-    if (int rc = qdg_halo_exchange(mesh, comm)) return rc;              // DG::next -> comsol
-    if (int rc = qdg_stage_limit(mesh)) return rc;                      // DG::lim
-    if (limited) if (int rc = qdg_halo_exchange(mesh, comm)) return rc; // -> comlim
-    if (int rc = qdg_stage_rhs_dt(mesh, stage, t, tleft)) return rc;    // DG::dt, DG::solve
-    if (stage == 0) if (int rc = qdg_stage_dt_allreduce(mesh, comm)) return rc;
-    if (int rc = qdg_stage_update(mesh, stage)) return rc;
+    if (!overlap) {
+      if (int rc = exchange_on(mesh, comm, s)) return rc;                 // DG::next -> comsol
+      if (int rc = qdg_stage_limit(mesh)) return rc;                       // DG::lim
+      if (limited) if (int rc = exchange_on(mesh, comm, s)) return rc;    // -> comlim
+      if (int rc = qdg_stage_rhs_dt(mesh, stage, t, tleft)) return rc;     // DG::dt, DG::solve
+      if (stage == 0) if (int rc = qdg_stage_dt_allreduce(mesh, comm)) return rc;
+      if (int rc = qdg_stage_update(mesh, stage)) return rc;
+      continue;
+    }
+    HIPCHK(hipEventRecord(comm->ev_ready, s));
+    HIPCHK(hipStreamWaitEvent(cs, comm->ev_ready, 0));
+    if (int rc = exchange_on(mesh, comm, cs)) return rc;
+    HIPCHK(hipEventRecord(comm->ev_x1, cs));
+    int rc = 0;
+    if (limited) {
+      mesh->split_lim = comm->ev_x1;
+      rc = qdg_stage_limit(mesh);
+      mesh->split_lim = nullptr;
+      if (rc) return rc;
+      HIPCHK(hipEventRecord(comm->ev_ready, s));
+      HIPCHK(hipStreamWaitEvent(cs, comm->ev_ready, 0));
+      if ((rc = exchange_on(mesh, comm, cs))) return rc;
+      HIPCHK(hipEventRecord(comm->ev_x2, cs));
+      mesh->split_rhs = comm->ev_x2;
+    } else {
+      mesh->split_rhs = comm->ev_x1;
+    }
+    rc = qdg_stage_rhs_dt(mesh, stage, t, tleft);
+    mesh->split_rhs = nullptr;
+    if (rc) return rc;
+    if (stage == 0) {
+      // every RCCL call of the overlapped step is issued on the communication stream
+      HIPCHK(hipEventRecord(comm->ev_ready, s));
+      HIPCHK(hipStreamWaitEvent(cs, comm->ev_ready, 0));
+      RCCLCHK(rccl_api()->AllReduce(mesh->dt_ptr, mesh->dt_ptr, 1, ncclDouble, ncclMin, comm->comm, cs));
+      HIPCHK(hipEventRecord(comm->ev_x1, cs));
+      HIPCHK(hipStreamWaitEvent(s, comm->ev_x1, 0));
+    }
+    if ((rc = qdg_stage_update(mesh, stage))) return rc;
   }
   if (dt_taken) return qdg_stage_dt_get(mesh, dt_taken);
   return 0;
@@ -1200,12 +1315,14 @@ extern "C" int qdg_profile_read(qdg_mesh* mesh, size_t* nlaunch, double* total_m
   if (!nlaunch || !total_ms) return fail("qdg_profile_read: null argument");
   HIPCHK(hipStreamSynchronize(s));
   double tot = 0.0;
+  size_t nl = 0;
   for (size_t i = 0; i < mesh->ev_used; ++i) {
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, mesh->ev[i].first, mesh->ev[i].second));
     tot += ms;
+    if (!mesh->ev_cont[i]) ++nl;
   }
-  *nlaunch = mesh->ev_used;
+  *nlaunch = nl;
   *total_ms = tot;
   mesh->ev_used = 0;
   return 0;

@@ -68,6 +68,11 @@ struct DevMesh {
   const int* task_a;   // packed: e_local(8) lf(2) own_left(1) code(6) kind(2) bc(2) partner_local(8)
   const int* task_nb;  // neighbour device row (kind EXT), else 0
   const int* task_f;   // device face id
+  // range launches (halo overlap): first workgroup-tile of this launch.  Device
+  // rows [0, ninner) are tets without a ghost neighbour, [ninner, nie) the tets
+  // next to the halo, so a launch over the leading tiles never reads a ghost row.
+  int blk0;
+  int ninner;
 };
 
 #ifndef QDG_TILE

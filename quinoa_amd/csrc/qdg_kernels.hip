@@ -986,7 +986,7 @@ __global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1t(DevMesh m, Phys ph, doub
   __shared__ double accN[TILE * NPROP];
   __shared__ double sdelt[WITH_DT ? TILE : 1];
   const int tid = threadIdx.x;
-  const int tile = xcd_tile(blockIdx.x, gridDim.x);
+  const int tile = m.blk0 + xcd_tile(blockIdx.x, gridDim.x);
   const int tile_e0 = tile * TILE;
   const int nloc = (m.nie - tile_e0 < TILE) ? m.nie - tile_e0 : TILE;
 
@@ -1288,7 +1288,7 @@ __global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1t(DevMesh m, Phys ph, doub
     if (tid == 0) {
       double mn = wmin[0];
       for (int w = 1; w < TILE_BS / 64; ++w) mn = fmin(mn, wmin[w]);
-      blockmin[blockIdx.x] = mn;
+      blockmin[tile] = mn;
     }
   }
 }
@@ -1304,7 +1304,7 @@ __global__ __launch_bounds__(256) void k_superbee(DevMesh m, double* __restrict_
     constexpr int NGF = Tables<NDOF>::NGF;
     constexpr int NPROP = NCOMP * NDOF;
     __shared__ double lds[256 * NPROP];
-    const int tile_e0 = xcd_tile(blockIdx.x, gridDim.x) * 256;
+    const int tile_e0 = (m.blk0 + xcd_tile(blockIdx.x, gridDim.x)) * 256;
     const int e0 = tile_e0 + threadIdx.x;
     const bool active = e0 < m.nie;
     const int e = active ? e0 : m.nie - 1;
@@ -1771,26 +1771,37 @@ void launch_rhs_p1(const DevMesh& m, const Phys& ph, double t, const double* U, 
   }
 }
 
-// tile / face-task form of the P1 RHS (same arguments; grid = number of tiles)
-void launch_rhs_p1t(const DevMesh& m, const Phys& ph, double t, const double* U, double* R,
+// tile / face-task form of the P1 RHS; tiles [first, first+count) (count < 0: all).
+// With with_dt the launch that ends at the last tile also reduces the per-tile
+// minima to the time step.
+void launch_rhs_p1t(const DevMesh& m0, const Phys& ph, double t, const double* U, double* R,
                     bool with_dt, double* blockmin, double scale, double tleft, double* out_raw,
-                    double* out_dt, hipStream_t s)
+                    double* out_dt, hipStream_t s, int first, int count)
 {
-  const int nb = m.ntile;
-  if (nb == 0) return;
-  if (with_dt) {
-    QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1t<true, false, P><<<nb, TILE_BS, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr)));
-    k_dt_final<<<1, 256, 0, s>>>(blockmin, nb, scale, tleft, out_raw, out_dt);
-  } else {
-    QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1t<false, false, P><<<nb, TILE_BS, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr)));
+  if (m0.ntile == 0) return;
+  DevMesh m = m0;
+  m.blk0 = first;
+  const int nb = count < 0 ? m.ntile - first : count;
+  if (nb > 0) {
+    if (with_dt) {
+      QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1t<true, false, P><<<nb, TILE_BS, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr)));
+    } else {
+      QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1t<false, false, P><<<nb, TILE_BS, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr)));
+    }
   }
+  if (with_dt && first + nb == m.ntile)
+    k_dt_final<<<1, 256, 0, s>>>(blockmin, m.ntile, scale, tleft, out_raw, out_dt);
 }
 
-void launch_rhs_p1t_rk(const DevMesh& m, const Phys& ph, double t, const double* U, double* Uout,
-                       double a, double b, const double* dt, const double* Un, hipStream_t s)
+void launch_rhs_p1t_rk(const DevMesh& m0, const Phys& ph, double t, const double* U, double* Uout,
+                       double a, double b, const double* dt, const double* Un, hipStream_t s,
+                       int first, int count)
 {
-  const int nb = m.ntile;
-  if (nb == 0) return;
+  if (m0.ntile == 0) return;
+  DevMesh m = m0;
+  m.blk0 = first;
+  const int nb = count < 0 ? m.ntile - first : count;
+  if (nb <= 0) return;
   QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1t<false, true, P><<<nb, TILE_BS, 0, s>>>(m, ph, t, U, Uout, nullptr, a, b, dt, Un)));
 }
 
@@ -1803,10 +1814,15 @@ void launch_rhs_p1_rk(const DevMesh& m, const Phys& ph, double t, const double* 
   QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1<false, true, P><<<nb, 256, 0, s>>>(m, ph, t, U, Uout, nullptr, a, b, dt, Un)));
 }
 
-void launch_superbee(int ndof, const DevMesh& m, double* U, hipStream_t s)
+// 256-row blocks [first, first+count) (count < 0: all)
+void launch_superbee(int ndof, const DevMesh& m0, double* U, hipStream_t s, int first, int count)
 {
-  if (m.nie == 0 || ndof == 1) return;
-  QDG_DISPATCH_NDOF(ndof, (k_superbee<N><<<nblk(m.nie, 256), 256, 0, s>>>(m, U)));
+  if (m0.nie == 0 || ndof == 1) return;
+  DevMesh m = m0;
+  m.blk0 = first;
+  const int nb = count < 0 ? (int)nblk(m.nie, 256) - first : count;
+  if (nb <= 0) return;
+  QDG_DISPATCH_NDOF(ndof, (k_superbee<N><<<nb, 256, 0, s>>>(m, U)));
 }
 
 void launch_weno(int ndof, const DevMesh& m, double cweight, const double* Uin, double* Uout,

@@ -14,12 +14,15 @@ void launch_rhs(int ndof, const DevMesh& m, const Phys& ph, double t, const doub
 void launch_rhs_p1(const DevMesh& m, const Phys& ph, double t, const double* U, double* R,
                    bool with_dt, double* blockmin, double scale, double tleft, double* out_raw,
                    double* out_dt, hipStream_t s);
+// range launches: workgroup tiles [first, first+count), count < 0 = all the rest
 void launch_rhs_p1t(const DevMesh& m, const Phys& ph, double t, const double* U, double* R,
                     bool with_dt, double* blockmin, double scale, double tleft, double* out_raw,
-                    double* out_dt, hipStream_t s);
+                    double* out_dt, hipStream_t s, int first = 0, int count = -1);
 void launch_rhs_p1t_rk(const DevMesh& m, const Phys& ph, double t, const double* U, double* Uout,
-                       double a, double b, const double* dt, const double* Un, hipStream_t s);
-void launch_superbee(int ndof, const DevMesh& m, double* U, hipStream_t s);
+                       double a, double b, const double* dt, const double* Un, hipStream_t s,
+                       int first = 0, int count = -1);
+void launch_superbee(int ndof, const DevMesh& m, double* U, hipStream_t s, int first = 0,
+                     int count = -1);
 void launch_weno(int ndof, const DevMesh& m, double cweight, const double* Uin, double* Uout,
                  hipStream_t s);
 void launch_copy_planes(const double* src, double* dst, int nprop, int n, int stride,
