@@ -22,6 +22,9 @@ import os
 import sys
 import time
 
+# this pool's host driver only supports dmabuf IPC (RCCL / device-tensor sharing)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -107,7 +110,14 @@ def main():
                        cfl=0.3, bc_extrapolate=[1, 2], bc_sym=[3, 4, 5, 6], device=local_rank)
     mesh = dgmesh.upload(ctx, chunk)
     if comm is not None:
-        comm = dg.RcclComm(ctx) if args.comm == "rccl" else dg.TorchComm()
+        if args.comm == "rccl":
+            try:
+                comm = dg.RcclComm(ctx)
+            except capi.QdgError as ex:          # e.g. librccl not loadable: same on every rank
+                sys.stderr.write("rank %d: RCCL transport unavailable (%s); using torch.distributed\n" % (rank, ex))
+                comm = dg.TorchComm()
+        else:
+            comm = dg.TorchComm()
     drv = dg.DGDriver(ctx, mesh, ch["nbr_rank"], ch["send_lists"], ch["recv_counts"], comm)
     mesh.state_initialize(0.0)
 
