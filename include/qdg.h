@@ -63,15 +63,26 @@ typedef struct qdg_ctx qdg_ctx;
 typedef struct qdg_mesh qdg_mesh;
 
 /* discr::flux (src/Control/Inciter/Options/Flux.hpp) */
-enum { QDG_FLUX_HLLC = 0, QDG_FLUX_LAXFRIEDRICHS = 1 };
+enum { QDG_FLUX_HLLC = 0, QDG_FLUX_LAXFRIEDRICHS = 1,
+       QDG_FLUX_UPWIND = 2 /* Transport only, Riemann/Upwind.hpp:35-55 */ };
 /* discr::limiter (src/Control/Inciter/Options/Limiter.hpp) */
 enum { QDG_LIMITER_NONE = 0, QDG_LIMITER_WENOP1 = 1, QDG_LIMITER_SUPERBEEP1 = 2 };
 /* Problem policy (src/PDE/CompFlow/Problem.hpp:14-80) */
 enum { QDG_PROBLEM_USER_DEFINED = 0, QDG_PROBLEM_SOD_SHOCKTUBE = 1,
        QDG_PROBLEM_SEDOV_BLASTWAVE = 2, QDG_PROBLEM_VORTICAL_FLOW = 3,
-       QDG_PROBLEM_TAYLOR_GREEN = 4 };
+       QDG_PROBLEM_TAYLOR_GREEN = 4,
+       /* Transport problem policies (src/PDE/Transport/Problem/SlotCyl.cpp:30-170) */
+       QDG_PROBLEM_SLOT_CYL = 5 };
 /* BC state functions (src/PDE/CompFlow/DGCompFlow.hpp:649-701) */
-enum { QDG_BC_DIRICHLET = 1, QDG_BC_SYMMETRY = 2, QDG_BC_EXTRAPOLATE = 3 };
+enum { QDG_BC_DIRICHLET = 1, QDG_BC_SYMMETRY = 2, QDG_BC_EXTRAPOLATE = 3,
+       /* Transport only (src/PDE/Transport/DGTransport.hpp:163-168, 276-352) */
+       QDG_BC_INLET = 4, QDG_BC_OUTLET = 5 };
+/* which DGPDE: dg::CompFlow (5 conserved variables, DGCompFlow.hpp) or dg::Transport
+ * with one transported scalar (DGTransport.hpp:129-186; BASELINE config 1).
+ * Transport: flux UPWIND, problem SLOT_CYL, BCs Dirichlet/Extrapolate/Inlet/Outlet,
+ * constant dt only (dg::Transport::dt returns max, DGTransport.hpp:189-199), no limiter;
+ * rows of every field are ndof doubles. */
+enum { QDG_PDE_COMPFLOW = 0, QDG_PDE_TRANSPORT = 1 };
 
 typedef struct qdg_config {
   int32_t struct_size;     /* = sizeof(qdg_config), ABI check */
@@ -88,6 +99,8 @@ typedef struct qdg_config {
   double alpha, beta, p0;    /* vortical_flow parameters */
   double cfl;                /* discr::cfl; used when dt <= 0 */
   double dt;                 /* discr::dt; > 0 selects constant time step */
+  int32_t pde;               /* QDG_PDE_* */
+  int32_t reserved_;         /* 0 */
 } qdg_config;
 
 /* flattened std::map<int, std::vector<std::size_t>> FaceData::m_bface */

@@ -171,6 +171,7 @@ struct InputDeck {
   real gamma = 1.4, pstiff = 0.0, cv = 717.5;
   real alpha = 0.0, beta = 0.0, p0 = 0.0;
   std::vector<std::string> bcdir, bcsym, bcextrapolate;   // side set id strings, as parsed
+  std::vector<std::string> bcinlet, bcoutlet;              // transport only (DGTransport.hpp:163-168)
   int device = 0;
 };
 
@@ -184,25 +185,37 @@ struct SodShocktube   { static int type() noexcept { return QDG_PROBLEM_SOD_SHOC
 struct SedovBlastwave { static int type() noexcept { return QDG_PROBLEM_SEDOV_BLASTWAVE; } };
 struct VorticalFlow   { static int type() noexcept { return QDG_PROBLEM_VORTICAL_FLOW; } };
 struct TaylorGreen    { static int type() noexcept { return QDG_PROBLEM_TAYLOR_GREEN; } };
+// Transport (src/PDE/Transport/Physics/DGAdvection.hpp, Problem/SlotCyl.hpp)
+struct Advection { };
+struct SlotCyl        { static int type() noexcept { return QDG_PROBLEM_SLOT_CYL; } };
 
-template <class Physics, class Problem>
-class CompFlowHIP {
+namespace detail {
+
+// The members of a DGPDE model (src/PDE/DGPDE.hpp:205-259) on top of the C ABI,
+// shared by the CompFlow and Transport adapters below.
+template <int PDE>
+class DeviceDG {
  public:
   using ncomp_t = std::size_t;
 
-  //! \param[in] c Equation system index (as dg::CompFlow; only system 0 is on the device)
-  //! \param[in] deck The values dg::CompFlow reads from g_inputdeck
-  explicit CompFlowHIP(ncomp_t c, const InputDeck& deck) : m_system(c), m_deck(deck), m_state(new State)
+ protected:
+  DeviceDG(ncomp_t c, const InputDeck& deck, int problem) : m_system(c), m_deck(deck), m_state(new State)
   {
-    if (c != 0) throw Exception("CompFlowHIP: only equation system 0 is supported");
+    if (c != 0) throw Exception("qdg: only equation system 0 is supported");
     for (const auto& s : deck.bcdir) { m_bcset.push_back(std::stoi(s)); m_bctype.push_back(QDG_BC_DIRICHLET); }
-    for (const auto& s : deck.bcsym) { m_bcset.push_back(std::stoi(s)); m_bctype.push_back(QDG_BC_SYMMETRY); }
+    if (PDE == QDG_PDE_COMPFLOW)
+      for (const auto& s : deck.bcsym) { m_bcset.push_back(std::stoi(s)); m_bctype.push_back(QDG_BC_SYMMETRY); }
     for (const auto& s : deck.bcextrapolate) { m_bcset.push_back(std::stoi(s)); m_bctype.push_back(QDG_BC_EXTRAPOLATE); }
+    if (PDE == QDG_PDE_TRANSPORT) {
+      for (const auto& s : deck.bcinlet) { m_bcset.push_back(std::stoi(s)); m_bctype.push_back(QDG_BC_INLET); }
+      for (const auto& s : deck.bcoutlet) { m_bcset.push_back(std::stoi(s)); m_bctype.push_back(QDG_BC_OUTLET); }
+    }
     qdg_config cfg{};
     cfg.struct_size = (int32_t)sizeof(qdg_config);
+    cfg.pde = PDE;
     cfg.device = deck.device;
     cfg.ndof = (int32_t)deck.ndof; cfg.rdof = (int32_t)deck.rdof;
-    cfg.flux = deck.flux; cfg.limiter = deck.limiter; cfg.problem = Problem::type();
+    cfg.flux = deck.flux; cfg.limiter = deck.limiter; cfg.problem = problem;
     cfg.nbc = (int32_t)m_bcset.size();
     cfg.bc_sideset = m_bcset.data(); cfg.bc_type = m_bctype.data();
     cfg.gamma = deck.gamma; cfg.pstiff = deck.pstiff; cfg.cv = deck.cv; cfg.cweight = deck.cweight;
@@ -210,6 +223,7 @@ class CompFlowHIP {
     check(qdg_ctx_create(&cfg, &m_state->ctx));
   }
 
+ public:
   //! DGPDE::initialize (src/PDE/DGPDE.hpp:80-86)
   void initialize(const Fields& L, const std::vector<std::size_t>& inpoel, const Coords& coord,
                   Fields& unk, real t, const std::size_t nielem) const
@@ -224,9 +238,9 @@ class CompFlowHIP {
   {
     static const real f[10] = { 1.0, 1.0 / 10.0, 3.0 / 10.0, 3.0 / 5.0, 1.0 / 35.0, 1.0 / 21.0,
                                 1.0 / 14.0, 1.0 / 7.0, 3.0 / 14.0, 3.0 / 7.0 };
-    const std::size_t nd = m_deck.ndof;
+    const std::size_t nd = m_deck.ndof, ncomp = PDE == QDG_PDE_TRANSPORT ? 1 : 5;
     for (std::size_t e = 0; e < geoElem.nunk(); ++e)
-      for (std::size_t c = 0; c < 5; ++c) {
+      for (std::size_t c = 0; c < ncomp; ++c) {
         const real vol = geoElem(e, 0, 0);
         l(e, c * nd, 0) = vol;
         if (nd > 1) { l(e, c*nd+1, 0) = vol / 10.0; l(e, c*nd+2, 0) = vol * 3.0 / 10.0; l(e, c*nd+3, 0) = vol * 3.0 / 5.0; }
@@ -304,7 +318,7 @@ class CompFlowHIP {
   {
     std::lock_guard<std::mutex> lock(m_state->mtx);
     auto it = m_state->meshes.find(inpoel.data());
-    if (it == m_state->meshes.end()) throw Exception("CompFlowHIP: mesh not attached");
+    if (it == m_state->meshes.end()) throw Exception("qdg: mesh not attached");
     return it->second;
   }
 
@@ -323,6 +337,27 @@ class CompFlowHIP {
   InputDeck m_deck;
   std::vector<int32_t> m_bcset, m_bctype;
   std::shared_ptr<State> m_state;   // copies of the PDE object share the device state
+};
+
+}  // namespace detail
+
+//! Drop-in for dg::CompFlow (src/PDE/CompFlow/DGCompFlow.hpp:62-702)
+template <class Physics, class Problem>
+class CompFlowHIP : public detail::DeviceDG<QDG_PDE_COMPFLOW> {
+ public:
+  //! \param[in] c Equation system index (as dg::CompFlow; only system 0 is on the device)
+  //! \param[in] deck The values dg::CompFlow reads from g_inputdeck
+  explicit CompFlowHIP(ncomp_t c, const InputDeck& deck)
+    : detail::DeviceDG<QDG_PDE_COMPFLOW>(c, deck, Problem::type()) {}
+};
+
+//! Drop-in for dg::Transport with one scalar (src/PDE/Transport/DGTransport.hpp:50-360);
+//! deck.flux must be QDG_FLUX_UPWIND and deck.dt > 0
+template <class Physics, class Problem>
+class TransportHIP : public detail::DeviceDG<QDG_PDE_TRANSPORT> {
+ public:
+  explicit TransportHIP(ncomp_t c, const InputDeck& deck)
+    : detail::DeviceDG<QDG_PDE_TRANSPORT>(c, deck, Problem::type()) {}
 };
 
 }  // namespace dg

@@ -383,7 +383,7 @@ def run_transport_case(case, fix, nstep=None):
                         _p(m.y, c_f64p), _p(m.z, c_f64p), _p(U, c_f64p), C.c_double(0.0), C.c_int64(ne))
     Un, R = np.zeros_like(U), np.zeros_like(U)
     t, dt, rows = 0.0, case["dt"], []
-    for it in range(nstep or case["nstep"]):
+    for it in range(case["nstep"] if nstep is None else nstep):
         for stage in range(3):
             if stage == 0:
                 Un[:] = U
@@ -397,4 +397,4 @@ def run_transport_case(case, fix, nstep=None):
         s = L.orc_tr_diag_l2sum(C.c_int64(ndof), _p(m.geoElem, c_f64p), _p(U, c_f64p), C.c_int64(ne))
         t += dt
         rows.append([it + 1, t, dt, np.sqrt(s / m.meshvol)])
-    return {"mesh": m, "U": U, "diag": np.array(rows), "t": t}
+    return {"mesh": m, "U": U, "L": Lm, "diag": np.array(rows), "t": t}

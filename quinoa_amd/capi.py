@@ -13,11 +13,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # QDG_LIB selects an alternative build of the same library (kernel A/B runs)
 LIB_PATH = os.environ.get("QDG_LIB") or os.path.join(_HERE, "lib", "libqdg.so")
 
-FLUX = {"hllc": 0, "laxfriedrichs": 1}
+FLUX = {"hllc": 0, "laxfriedrichs": 1, "upwind": 2}
 LIMITER = {"nolimiter": 0, "wenop1": 1, "superbeep1": 2}
 PROBLEM = {"user_defined": 0, "sod_shocktube": 1, "sedov_blastwave": 2,
-           "vortical_flow": 3, "taylor_green": 4}
-BC_DIRICHLET, BC_SYMMETRY, BC_EXTRAPOLATE = 1, 2, 3
+           "vortical_flow": 3, "taylor_green": 4, "slot_cyl": 5}
+BC_DIRICHLET, BC_SYMMETRY, BC_EXTRAPOLATE, BC_INLET, BC_OUTLET = 1, 2, 3, 4, 5
+PDE = {"compflow": 0, "transport": 1}
 
 c_szp = C.POINTER(C.c_size_t)
 c_i32p = C.POINTER(C.c_int32)
@@ -35,7 +36,8 @@ class qdg_config(C.Structure):
                 ("bc_sideset", c_i32p), ("bc_type", c_i32p),
                 ("gamma", C.c_double), ("pstiff", C.c_double), ("cv", C.c_double),
                 ("cweight", C.c_double), ("alpha", C.c_double), ("beta", C.c_double),
-                ("p0", C.c_double), ("cfl", C.c_double), ("dt", C.c_double)]
+                ("p0", C.c_double), ("cfl", C.c_double), ("dt", C.c_double),
+                ("pde", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class qdg_bface(C.Structure):
@@ -161,22 +163,24 @@ def gen_geoelem(inpoel, coord):
 class Context:
     def __init__(self, ndof, flux="hllc", limiter="nolimiter", problem="sod_shocktube",
                  gamma=1.4, pstiff=0.0, cv=717.5, cweight=1.0, alpha=0.0, beta=0.0, p0=0.0,
-                 cfl=0.0, dt=0.0, bc_dirichlet=(), bc_sym=(), bc_extrapolate=(), device=0):
+                 cfl=0.0, dt=0.0, bc_dirichlet=(), bc_sym=(), bc_extrapolate=(), device=0,
+                 pde="compflow", bc_inlet=(), bc_outlet=()):
         L = lib()
-        ss = list(bc_dirichlet) + list(bc_sym) + list(bc_extrapolate)
+        ss = list(bc_dirichlet) + list(bc_sym) + list(bc_extrapolate) + list(bc_inlet) + list(bc_outlet)
         ty = [BC_DIRICHLET] * len(bc_dirichlet) + [BC_SYMMETRY] * len(bc_sym) + \
-             [BC_EXTRAPOLATE] * len(bc_extrapolate)
+             [BC_EXTRAPOLATE] * len(bc_extrapolate) + [BC_INLET] * len(bc_inlet) + \
+             [BC_OUTLET] * len(bc_outlet)
         self._ss, pss = _i32(np.array(ss or [0], dtype=np.int32))
         self._ty, pty = _i32(np.array(ty or [1], dtype=np.int32))
         self.cfg = qdg_config(struct_size=C.sizeof(qdg_config), device=device, ndof=ndof,
                               rdof=ndof, flux=FLUX[flux], limiter=LIMITER[limiter],
                               problem=PROBLEM[problem], nbc=len(ss), bc_sideset=pss, bc_type=pty,
                               gamma=gamma, pstiff=pstiff, cv=cv, cweight=cweight, alpha=alpha,
-                              beta=beta, p0=p0, cfl=cfl, dt=dt)
+                              beta=beta, p0=p0, cfl=cfl, dt=dt, pde=PDE[pde], reserved_=0)
         self.h = C.c_void_p()
         _chk(L.qdg_ctx_create(C.byref(self.cfg), C.byref(self.h)))
         self.ndof = ndof
-        self.nprop = 5 * ndof
+        self.nprop = (1 if pde == "transport" else 5) * ndof
 
     def set_stream(self, stream_ptr):
         _chk(lib().qdg_ctx_set_stream(self.h, C.c_void_p(stream_ptr)))

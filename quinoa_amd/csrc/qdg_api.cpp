@@ -135,15 +135,29 @@ static int check_cfg(const qdg_config* c)
     return fail("qdg_ctx_create: ndof must be one of 1,4,10");
   if (c->rdof != c->ndof)
     return fail("qdg_ctx_create: rdof != ndof (P0P1 reconstruction) is not supported");
-  if (c->flux != QDG_FLUX_HLLC && c->flux != QDG_FLUX_LAXFRIEDRICHS)
-    return fail("qdg_ctx_create: unknown flux");
   if (c->limiter < QDG_LIMITER_NONE || c->limiter > QDG_LIMITER_SUPERBEEP1)
     return fail("qdg_ctx_create: unknown limiter");
+  if (c->nbc < 0 || (c->nbc > 0 && (!c->bc_sideset || !c->bc_type)))
+    return fail("qdg_ctx_create: bad BC table");
+  if (c->pde == QDG_PDE_TRANSPORT) {
+    if (c->flux != QDG_FLUX_UPWIND) return fail("qdg_ctx_create: transport needs the upwind flux");
+    if (c->problem != QDG_PROBLEM_SLOT_CYL) return fail("qdg_ctx_create: unknown transport problem");
+    if (c->limiter != QDG_LIMITER_NONE) return fail("qdg_ctx_create: limiters are not supported for transport");
+    if (!(c->dt > 0.0))
+      return fail("qdg_ctx_create: transport needs a constant dt (dg::Transport::dt gives no CFL estimate)");
+    for (int i = 0; i < c->nbc; ++i) {
+      const int b = c->bc_type[i];
+      if (!(b == QDG_BC_DIRICHLET || b == QDG_BC_EXTRAPOLATE || b == QDG_BC_INLET || b == QDG_BC_OUTLET))
+        return fail("qdg_ctx_create: unknown transport BC type");
+    }
+    return 0;
+  }
+  if (c->pde != QDG_PDE_COMPFLOW) return fail("qdg_ctx_create: unknown pde");
+  if (c->flux != QDG_FLUX_HLLC && c->flux != QDG_FLUX_LAXFRIEDRICHS)
+    return fail("qdg_ctx_create: unknown flux");
   if (c->problem < QDG_PROBLEM_USER_DEFINED || c->problem > QDG_PROBLEM_TAYLOR_GREEN)
     return fail("qdg_ctx_create: unknown problem");
   if (!(c->gamma > 1.0)) return fail("qdg_ctx_create: gamma must be > 1");
-  if (c->nbc < 0 || (c->nbc > 0 && (!c->bc_sideset || !c->bc_type)))
-    return fail("qdg_ctx_create: bad BC table");
   for (int i = 0; i < c->nbc; ++i)
     if (c->bc_type[i] < QDG_BC_DIRICHLET || c->bc_type[i] > QDG_BC_EXTRAPOLATE)
       return fail("qdg_ctx_create: unknown BC type");
@@ -452,7 +466,8 @@ extern "C" int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t 
   std::unique_ptr<qdg_mesh> m(new qdg_mesh);
   m->ctx = ctx;
   m->ndof = ctx->cfg.ndof;
-  m->nprop = NCOMP * m->ndof;
+  const int ncomp = ctx->cfg.pde == QDG_PDE_TRANSPORT ? 1 : NCOMP;
+  m->nprop = ncomp * m->ndof;
   m->nie = nie; m->ne = ne; m->stride = stride;
   hipStream_t s = ctx->stream;
   HIPCHK(m->inpoel.upload(h_inpoel, s));
@@ -496,7 +511,7 @@ extern "C" int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t 
   HIPCHK(m->task_nb.upload(h_task_nb, s)); HIPCHK(m->task_f.upload(h_task_f, s));
   dm.ntile = ntile; dm.tile_off = m->tile_off.p; dm.task_a = m->task_a.p;
   dm.task_nb = m->task_nb.p; dm.task_f = m->task_f.p;
-  dm.blk0 = 0; dm.ninner = (int)ninner;
+  dm.blk0 = 0; dm.ninner = (int)ninner; dm.ncomp = ncomp;
   HIPCHK(hipStreamSynchronize(s));
   *out = m.release();
   return 0;
@@ -601,7 +616,7 @@ static int run_limiter(qdg_mesh* mesh, double*& Ucur, double* Ualt_in)
 static bool use_p1_fast(const qdg_mesh* mesh)
 {
   static const bool generic = std::getenv("QDG_GENERIC_RHS") != nullptr;
-  return mesh->ndof == 4 && !generic;
+  return mesh->ndof == 4 && mesh->dm.ncomp == NCOMP && !generic;
 }
 
 // tile / face-task kernel (each in-tile face evaluated once, LDS accumulation with
@@ -680,6 +695,10 @@ extern "C" int qdg_dt(qdg_mesh* mesh, const double* U_aos, double* mindt)
   QDG_TRY
   MESH_ENTER("qdg_dt");
   if (!U_aos || !mindt) return fail("qdg_dt: null argument");
+  if (mesh->dm.ncomp == 1) {        // dg::Transport::dt: no estimate (DGTransport.hpp:189-199)
+    *mindt = std::numeric_limits<double>::max();
+    return 0;
+  }
   if (int rc = scratch(mesh)) return rc;
   double* w = mesh->S1.p;
   if (int rc = host_to_planes(mesh, U_aos, w)) return rc;
@@ -1333,7 +1352,7 @@ extern "C" int qdg_rhs_algorithmic_bytes(qdg_mesh* mesh, double* bytes)
 {
   QDG_TRY
   if (!mesh || !bytes) return fail("qdg_rhs_algorithmic_bytes: null argument");
-  *bytes = (double)mesh->nie * (16.0 * NCOMP * mesh->ndof + 32.0) + 24.0 * (double)mesh->nnode_used;
+  *bytes = (double)mesh->nie * (16.0 * mesh->nprop + 32.0) + 24.0 * (double)mesh->nnode_used;
   return 0;
   QDG_CATCH
 }

@@ -73,6 +73,7 @@ struct DevMesh {
   // next to the halo, so a launch over the leading tiles never reads a ghost row.
   int blk0;
   int ninner;
+  int ncomp;        // 5: CompFlow, 1: scalar Transport (rows of ncomp*ndof doubles)
 };
 
 #ifndef QDG_TILE

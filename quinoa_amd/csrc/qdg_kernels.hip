@@ -1578,6 +1578,30 @@ __global__ __launch_bounds__(256) void k_init(DevMesh m, Phys ph, double t, doub
     for (int k = 0; k < NDOF; ++k) U[fidx(c * NDOF + k, e, NCOMP * NDOF)] = acc[c][k] / f[k];
 }
 
+// block reduction of the 15 diagnostics partials (sums 0..9, maxima 10..14) in a
+// fixed order; one row of `part` per workgroup
+__device__ __forceinline__ void diag_block_reduce(const double (&v)[15], double* __restrict__ part)
+{
+  __shared__ double sh[4][15];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 15; ++i) {
+    double x = v[i];
+    for (int off = 32; off > 0; off >>= 1) {
+      const double y = __shfl_down(x, off, 64);
+      x = (i < 10) ? x + y : fmax(x, y);
+    }
+    if (lane == 0) sh[wv][i] = x;
+  }
+  __syncthreads();
+  if (threadIdx.x < 15) {
+    const int i = threadIdx.x;
+    const double r = (i < 10) ? ((sh[0][i] + sh[1][i]) + (sh[2][i] + sh[3][i]))
+                              : fmax(fmax(sh[0][i], sh[1][i]), fmax(sh[2][i], sh[3][i]));
+    part[(size_t)blockIdx.x * 15 + i] = r;
+  }
+}
+
 // ElemDiagnostics::compute_diag, src/Inciter/ElemDiagnostics.cpp:116-215.
 // Per-block partial sums (deterministic two-pass reduction): 15 doubles/block.
 template <int NDOF, int PROB>
@@ -1615,24 +1639,7 @@ __global__ __launch_bounds__(256) void k_diag(DevMesh m, Phys ph, double t_new,
       }
     }
   }
-  __shared__ double sh[4][15];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-  for (int i = 0; i < 15; ++i) {
-    double x = v[i];
-    for (int off = 32; off > 0; off >>= 1) {
-      const double y = __shfl_down(x, off, 64);
-      x = (i < 10) ? x + y : fmax(x, y);
-    }
-    if (lane == 0) sh[wv][i] = x;
-  }
-  __syncthreads();
-  if (threadIdx.x < 15) {
-    const int i = threadIdx.x;
-    const double r = (i < 10) ? ((sh[0][i] + sh[1][i]) + (sh[2][i] + sh[3][i]))
-                              : fmax(fmax(sh[0][i], sh[1][i]), fmax(sh[2][i], sh[3][i]));
-    part[(size_t)blockIdx.x * 15 + i] = r;
-  }
+  diag_block_reduce(v, part);
 }
 
 __global__ void k_diag_final(const double* __restrict__ part, int nblk, double* __restrict__ out)
@@ -1646,6 +1653,259 @@ __global__ void k_diag_final(const double* __restrict__ part, int nblk, double* 
   }
   out[i] = r;
 }
+
+// ================================================================ scalar transport
+// dg::Transport (src/PDE/Transport/DGTransport.hpp:129-186) for ONE transported
+// scalar (BASELINE config 1: slot_cyl, DG-P0, Upwind): rows of NDOF doubles,
+// U[e*NDOF + k].  Same mesh layout, face codes and quadrature tables as CompFlow;
+// element-centric (every tet visits its 4 faces, R written once).
+namespace tr {
+
+// TransportProblemSlotCyl::solution (src/PDE/Transport/Problem/SlotCyl.cpp:30-110), c = 0
+__device__ double solution_slot_cyl(double x, double y, double t)
+{
+  const double T = t, R0 = 0.15, PI = 3.14159265358979323846;
+  double s = 0.0;
+  double x0 = 0.5, y0 = 0.25;
+  double r = sqrt((x0 - 0.5) * (x0 - 0.5) + (y0 - 0.5) * (y0 - 0.5));
+  const double kx = 0.5 + r * sin(T), ky = 0.5 - r * cos(T);
+  x0 = 0.25; y0 = 0.5;
+  r = sqrt((x0 - 0.5) * (x0 - 0.5) + (y0 - 0.5) * (y0 - 0.5));
+  const double hx = 0.5 + r * sin(T - PI / 2.0), hy = 0.5 - r * cos(T - PI / 2.0);
+  x0 = 0.5; y0 = 0.75;
+  r = sqrt((x0 - 0.5) * (x0 - 0.5) + (y0 - 0.5) * (y0 - 0.5));
+  const double cx = 0.5 + r * sin(T + PI), cy = 0.5 - r * cos(T + PI);
+  const double i1x = 0.525, i1y = cy - r * cos(asin(0.025 / r)), i2x = 0.525, i2y = 0.8,
+               i3x = 0.475, i3y = 0.8;
+  const double ct = cos(T), st = sin(T);
+  const double ri1x = 0.5 + ct * (i1x - 0.5) - st * (i1y - 0.5), ri1y = 0.5 + st * (i1x - 0.5) + ct * (i1y - 0.5);
+  const double ri2x = 0.5 + ct * (i2x - 0.5) - st * (i2y - 0.5), ri2y = 0.5 + st * (i2x - 0.5) + ct * (i2y - 0.5);
+  const double ri3x = 0.5 + ct * (i3x - 0.5) - st * (i3y - 0.5), ri3y = 0.5 + st * (i3x - 0.5) + ct * (i3y - 0.5);
+  const double v1x = ri2x - ri1x, v1y = ri2y - ri1y, v2x = ri3x - ri2x, v2y = ri3y - ri2y;
+  const double v1 = sqrt(v1x * v1x + v1y * v1y), v2 = sqrt(v2x * v2x + v2y * v2y);
+  r = sqrt((x - kx) * (x - kx) + (y - ky) * (y - ky)) / R0;          // cone
+  if (r < 1.0) s = 0.6 * (1.0 - r);
+  r = sqrt((x - hx) * (x - hx) + (y - hy) * (y - hy)) / R0;          // hump
+  if (r < 1.0) s = 0.2 * (1.0 + cos(PI * fmin(r, 1.0)));
+  r = sqrt((x - cx) * (x - cx) + (y - cy) * (y - cy)) / R0;          // slotted cylinder
+  const double d1 = (v1x * (y - ri1y) - (x - ri1x) * v1y) / v1;
+  const double d2 = (v2x * (y - ri2y) - (x - ri2x) * v2y) / v2;
+  if (r < 1.0 && (d1 > 0.05 || d1 < 0.0 || d2 < 0.0)) s = 0.6;
+  return s;
+}
+
+__device__ __forceinline__ double solution(int problem, double x, double y, double /*z*/, double t)
+{
+  return problem == 5 ? solution_slot_cyl(x, y, t) : 0.0;
+}
+
+// Problem::prescribedVelocity (SlotCyl.cpp:152-170): solid-body rotation about (0.5, 0.5)
+__device__ __forceinline__ void velocity(int /*problem*/, double x, double y, double /*z*/, double* v)
+{
+  v[0] = 0.5 - y; v[1] = x - 0.5; v[2] = 0.0;
+}
+
+// Upwind::flux, src/PDE/Integrate/Riemann/Upwind.hpp:35-55
+__device__ __forceinline__ double upwind(const double* fn, double ul, double ur, const double* v)
+{
+  const double swave = v[0] * fn[0] + v[1] * fn[1] + v[2] * fn[2];
+  const double splus = 0.5 * (swave + fabs(swave));
+  const double sminus = 0.5 * (swave - fabs(swave));
+  return splus * ul + sminus * ur;
+}
+
+template <int NDOF> __device__ __forceinline__ void load(const double* __restrict__ U, int e, double* u)
+{
+#pragma unroll
+  for (int k = 0; k < NDOF; ++k) u[k] = U[(size_t)e * NDOF + k];
+}
+template <int NDOF> __device__ __forceinline__ double state(const double* u, const double* B)
+{
+  double a = u[0];
+#pragma unroll
+  for (int k = 1; k < NDOF; ++k) a += u[k] * B[k];
+  return a;
+}
+
+// BC codes of the nbr plane: 1 Dirichlet, 3 Extrapolate, 4 Inlet, 5 Outlet
+// (DGTransport.hpp:163-168, 276-352)
+template <int NDOF>
+__global__ __launch_bounds__(256) void k_rhs(DevMesh m, Phys ph, double t,
+                                             const double* __restrict__ U, double* __restrict__ R)
+{
+  const int e = xcd_tile(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+  if (e >= m.nie) return;
+  const Tables<NDOF>& T = tab<NDOF>();
+  constexpr int NGF = Tables<NDOF>::NGF, NGV = Tables<NDOF>::NGV;
+  const int stride = m.stride;
+  double acc[NDOF], u[NDOF];
+#pragma unroll
+  for (int k = 0; k < NDOF; ++k) acc[k] = 0.0;
+  load<NDOF>(U, e, u);
+  ElemGeom g;
+  load_geom(m, e, g);
+#pragma unroll 1
+  for (int lf = 0; lf < 4; ++lf) {
+    const int nb = m.nbr[(size_t)lf * stride + e];
+    if (nb == -1) continue;                     // boundary face without a BC
+    const int info = m.finfo[(size_t)lf * stride + e];
+    const int f = m.fid[(size_t)lf * stride + e];
+    const double area = m.farea[f];
+    const double fn[3] = { m.fnx[f], m.fny[f], m.fnz[f] };
+    const bool own_left = (info >> 6) & 1;
+    double un[NDOF];
+    if (nb >= 0) load<NDOF>(U, nb, un);
+#pragma unroll 1
+    for (int ig = 0; ig < NGF; ++ig) {
+      const double s0 = T.fs[ig][0], s1 = T.fs[ig][1], s2 = T.fs[ig][2];
+      const double so = state<NDOF>(u, T.fB[lf][ig]);
+      double P[3], v[3], sn;
+      face_point(g, lf, s0, s1, s2, P);
+      if (nb >= 0) {
+        double xi, eta, zeta, Bn[NDOF];
+        nbr_ref_coords(info, s0, s1, s2, xi, eta, zeta);
+        eval_basis<NDOF>(xi, eta, zeta, Bn);
+        sn = state<NDOF>(un, Bn);
+      } else {
+        const int bc = -nb - 1;
+        sn = (bc == 4) ? 0.0 : (bc == 1) ? solution(ph.problem, P[0], P[1], P[2], t) : so;
+      }
+      velocity(ph.problem, P[0], P[1], P[2], v);
+      const double fl = own_left ? upwind(fn, so, sn, v) : upwind(fn, sn, so, v);
+      const double wt = (own_left ? -1.0 : 1.0) * T.fw[ig] * area;
+      acc[0] += wt * fl;
+#pragma unroll
+      for (int k = 1; k < NDOF; ++k) acc[k] += wt * fl * T.fB[lf][ig][k];
+    }
+  }
+  if constexpr (NDOF > 1) {        // volInt, src/PDE/Integrate/Volume.cpp:20-168
+    const double vol = m.vol[e];
+    double ji[3][3];
+    inverse_jacobian(g, ji);
+#pragma unroll 1
+    for (int ig = 0; ig < NGV; ++ig) {
+      const double xi = T.vc[ig][0], eta = T.vc[ig][1], zeta = T.vc[ig][2];
+      const double w0 = 1.0 - xi - eta - zeta;
+      double P[3], v[3];
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+        P[d] = g.p[0][d] * w0 + g.p[1][d] * xi + g.p[2][d] * eta + g.p[3][d] * zeta;
+      const double sc = state<NDOF>(u, T.vB[ig]);
+      velocity(ph.problem, P[0], P[1], P[2], v);
+      const double wt = T.vw[ig] * vol;
+#pragma unroll
+      for (int k = 1; k < NDOF; ++k) {
+        const double g0 = T.vdB[ig][0][k], g1 = T.vdB[ig][1][k], g2 = T.vdB[ig][2][k];
+        const double dx = g0 * ji[0][0] + g1 * ji[1][0] + g2 * ji[2][0];
+        const double dy = g0 * ji[0][1] + g1 * ji[1][1] + g2 * ji[2][1];
+        const double dz = g0 * ji[0][2] + g1 * ji[1][2] + g2 * ji[2][2];
+        acc[k] += wt * (v[0] * sc * dx + v[1] * sc * dy + v[2] * sc * dz);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NDOF; ++k) R[(size_t)e * NDOF + k] = acc[k];
+}
+
+template <int NDOF>
+__global__ __launch_bounds__(256) void k_init(DevMesh m, Phys ph, double t, double* __restrict__ U)
+{
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= m.nie) return;
+  const QuadTet& Q = c_qinit[order_index<NDOF>()];
+  ElemGeom g;
+  load_geom(m, e, g);
+  const double vol = m.vol[e];
+  double acc[NDOF];
+#pragma unroll
+  for (int k = 0; k < NDOF; ++k) acc[k] = 0.0;
+#pragma unroll 1
+  for (int ig = 0; ig < Q.ng; ++ig) {
+    const double xi = Q.c[ig][0], eta = Q.c[ig][1], zeta = Q.c[ig][2];
+    const double w0 = 1.0 - xi - eta - zeta;
+    double P[3], B[NDOF];
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+      P[d] = g.p[0][d] * w0 + g.p[1][d] * xi + g.p[2][d] * eta + g.p[3][d] * zeta;
+    eval_basis<NDOF>(xi, eta, zeta, B);
+    const double sv = solution(ph.problem, P[0], P[1], P[2], t);
+    const double wt = Q.w[ig] * vol;
+    acc[0] += wt * sv;
+#pragma unroll
+    for (int k = 1; k < NDOF; ++k) acc[k] += wt * sv * B[k];
+  }
+  const double f[10] = { vol, vol / 10.0, vol * 3.0 / 10.0, vol * 3.0 / 5.0, vol / 35.0,
+                         vol / 21.0, vol / 14.0, vol / 7.0, vol * 3.0 / 14.0, vol * 3.0 / 7.0 };
+#pragma unroll
+  for (int k = 0; k < NDOF; ++k) U[(size_t)e * NDOF + k] = acc[k] / f[k];
+}
+
+template <int NDOF>
+__global__ __launch_bounds__(256) void k_diag(DevMesh m, Phys ph, double t_new,
+                                              const double* __restrict__ U, double* __restrict__ part)
+{
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  double v[15];
+#pragma unroll
+  for (int i = 0; i < 15; ++i) v[i] = 0.0;
+  if (e < m.nie) {
+    const QuadTet& Q = c_qdiag[order_index<NDOF>()];
+    ElemGeom g;
+    load_geom(m, e, g);
+    const double vol = m.vol[e];
+    double u[NDOF];
+    load<NDOF>(U, e, u);
+#pragma unroll 1
+    for (int ig = 0; ig < Q.ng; ++ig) {
+      const double xi = Q.c[ig][0], eta = Q.c[ig][1], zeta = Q.c[ig][2];
+      const double w0 = 1.0 - xi - eta - zeta;
+      double P[3], B[NDOF];
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+        P[d] = g.p[0][d] * w0 + g.p[1][d] * xi + g.p[2][d] * eta + g.p[3][d] * zeta;
+      eval_basis<NDOF>(xi, eta, zeta, B);
+      const double uu = state<NDOF>(u, B);
+      const double d = uu - solution(ph.problem, P[0], P[1], P[2], t_new);
+      const double wt = Q.w[ig] * vol;
+      v[0] += wt * uu * uu;
+      v[5] += wt * d * d;
+      v[10] = fmax(v[10], fabs(d));
+    }
+  }
+  diag_block_reduce(v, part);
+}
+
+template <int NDOF>
+__global__ void k_mass(DevMesh m, double* __restrict__ L)
+{
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= m.ne) return;
+  const double vol = m.vol[e];
+  const double f[10] = { vol, vol / 10.0, vol * 3.0 / 10.0, vol * 3.0 / 5.0, vol / 35.0,
+                         vol / 21.0, vol / 14.0, vol / 7.0, vol * 3.0 / 14.0, vol * 3.0 / 7.0 };
+#pragma unroll
+  for (int k = 0; k < NDOF; ++k) L[(size_t)e * NDOF + k] = f[k];
+}
+
+template <int NDOF>
+__global__ __launch_bounds__(256) void k_rk(DevMesh m, double a, double b, const double* __restrict__ dt,
+                                            const double* __restrict__ Un, const double* __restrict__ R,
+                                            const double* U, double* Uout)
+{
+  constexpr double imf[10] = { 1.0, 10.0, 10.0 / 3.0, 5.0 / 3.0, 35.0, 21.0, 14.0, 7.0,
+                               14.0 / 3.0, 7.0 / 3.0 };
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)m.nie * NDOF) return;
+  const int e = (int)(i / NDOF);
+  const int k = (int)(i - (size_t)e * NDOF);
+  double f = imf[0];
+#pragma unroll
+  for (int j = 1; j < NDOF; ++j) f = (k == j) ? imf[j] : f;
+  const double dtv = dt[0] / m.vol[e];
+  Uout[i] = a * Un[i] + b * (U[i] + dtv * f * R[i]);
+}
+
+}  // namespace tr
 
 // ------------------------------------------------- host <-> device rows
 // Host rows (caller's element numbering) <-> device rows (device numbering):
@@ -1753,6 +2013,10 @@ void launch_rhs(int ndof, const DevMesh& m, const Phys& ph, double t, const doub
                 hipStream_t s)
 {
   if (m.nie == 0) return;
+  if (m.ncomp == 1) {
+    QDG_DISPATCH_NDOF(ndof, (tr::k_rhs<N><<<nblk(m.nie, 256), 256, 0, s>>>(m, ph, t, U, R)));
+    return;
+  }
   QDG_DISPATCH_NDOF(ndof, QDG_DISPATCH_PROB(ph.problem, (k_rhs<N, P><<<nblk(m.nie, 256), 256, 0, s>>>(m, ph, t, U, R))));
 }
 
@@ -1854,18 +2118,30 @@ void launch_rk(int ndof, const DevMesh& m, double a, double b, const double* dt,
                const double* R, const double* U, double* Uout, hipStream_t s)
 {
   if (m.nie == 0) return;
+  if (m.ncomp == 1) {
+    QDG_DISPATCH_NDOF(ndof, (tr::k_rk<N><<<(unsigned)(((size_t)m.nie * N + 255) / 256), 256, 0, s>>>(m, a, b, dt, Un, R, U, Uout)));
+    return;
+  }
   QDG_DISPATCH_NDOF(ndof, (k_rk<N><<<(unsigned)(((size_t)m.nie * NCOMP * N + 255) / 256), 256, 0, s>>>(m, a, b, dt, Un, R, U, Uout)));
 }
 
 void launch_mass(int ndof, const DevMesh& m, double* L, hipStream_t s)
 {
   if (m.ne == 0) return;
+  if (m.ncomp == 1) {
+    QDG_DISPATCH_NDOF(ndof, (tr::k_mass<N><<<nblk(m.ne, 256), 256, 0, s>>>(m, L)));
+    return;
+  }
   QDG_DISPATCH_NDOF(ndof, (k_mass<N><<<nblk(m.ne, 256), 256, 0, s>>>(m, L)));
 }
 
 void launch_init(int ndof, const DevMesh& m, const Phys& ph, double t, double* U, hipStream_t s)
 {
   if (m.nie == 0) return;
+  if (m.ncomp == 1) {
+    QDG_DISPATCH_NDOF(ndof, (tr::k_init<N><<<nblk(m.nie, 256), 256, 0, s>>>(m, ph, t, U)));
+    return;
+  }
   QDG_DISPATCH_NDOF(ndof, QDG_DISPATCH_PROB(ph.problem, (k_init<N, P><<<nblk(m.nie, 256), 256, 0, s>>>(m, ph, t, U))));
 }
 
@@ -1873,7 +2149,9 @@ void launch_diag(int ndof, const DevMesh& m, const Phys& ph, double t_new, const
                  double* part, double* out, hipStream_t s)
 {
   const int nb = nblk(m.nie, 256);
-  if (nb > 0)
+  if (nb > 0 && m.ncomp == 1) {
+    QDG_DISPATCH_NDOF(ndof, (tr::k_diag<N><<<nb, 256, 0, s>>>(m, ph, t_new, U, part)));
+  } else if (nb > 0)
     QDG_DISPATCH_NDOF(ndof, QDG_DISPATCH_PROB(ph.problem, (k_diag<N, P><<<nb, 256, 0, s>>>(m, ph, t_new, U, part))));
   k_diag_final<<<1, 64, 0, s>>>(part, nb, out);
 }

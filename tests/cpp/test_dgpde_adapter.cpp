@@ -89,10 +89,34 @@ int main(int argc, char** argv)
     try { qdg::Fields bad(1, 1); eq.limit(std::vector<std::size_t>{0, 1, 2, 3}, bad); }
     catch (const qdg::Exception&) { threw = true; }
 
+    // dg::Transport stand-in (BASELINE config 1 physics) on the same chare data
+    qdg::InputDeck tdeck;
+    tdeck.ndof = tdeck.rdof = 1;
+    tdeck.flux = QDG_FLUX_UPWIND;
+    tdeck.dt = 5.0e-4;
+    tdeck.bcdir = { "1", "2" }; tdeck.bcextrapolate = { "3", "4" };
+    tdeck.bcinlet = { "5" }; tdeck.bcoutlet = { "6" };
+    qdg::dg::TransportHIP<qdg::dg::Advection, qdg::dg::SlotCyl> tq(0, tdeck);
+    qdg::Fields Lt(nelem, 1), Ut(nelem, 1), Rt(nelem, 1), Ut2(nelem, 1);
+    std::vector<std::size_t> ndofel1(nelem, 1);
+    tq.lhs(geoElem, Lt);
+    tq.attach(geoFace, geoElem, fd, inpoel, coord);
+    tq.initialize(Lt, inpoel, coord, Ut, 0.0, nelem);
+    tq.rhs(0.0, geoFace, geoElem, fd, inpoel, coord, Ut, ndofel1, Rt);
+    const double tdt = tq.dt(coord, inpoel, fd, geoFace, geoElem, ndofel1, Ut);
+    qdg_mesh* tm = tq.handle(inpoel);
+    qdg::check(qdg_state_upload(tm, Ut.data().data()));
+    double tt = 0.0, tdts[2];
+    for (int s = 0; s < 2; ++s) { qdg::check(qdg_step(tm, tt, 1e300, &tdts[s])); tt += tdts[s]; }
+    qdg::check(qdg_state_download(tm, Ut2.data().data()));
+
     FILE* o = fopen(argv[2], "wb");
     wr(o, L.data()); wr(o, U.data()); wr(o, R.data()); wr(o, Ulim.data()); wr(o, U2.data());
     wr(o, std::vector<double>{ dt, dts[0], dts[1], threw ? 1.0 : 0.0 });
+    wr(o, Lt.data()); wr(o, Ut.data()); wr(o, Rt.data()); wr(o, Ut2.data());
+    wr(o, std::vector<double>{ tdt, tdts[0], tdts[1] });
     fclose(o);
+    tq.release(inpoel);
     eq.release(inpoel);
     printf("adapter ok: %zu tets, %zu faces, %zu boundary faces, dt=%.6e\n", nelem, fd.Nipfac(), nb, dt);
   } catch (const std::exception& e) {

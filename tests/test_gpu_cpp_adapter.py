@@ -46,7 +46,7 @@ def test_cpp_adapter_matches_oracle(tmp_path):
     out = tmp_path / "out.bin"
     r = subprocess.run([EXE, str(mesh), str(out)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
-    L, U, R, Ulim, U2, sc = _read_vecs(out)
+    L, U, R, Ulim, U2, sc, Lt, Ut, Rt, Ut2, tsc = _read_vecs(out)
     kw = dict(flux="hllc", limiter="superbeep1", problem="sod_shocktube", gamma=1.4)
     om = O.OracleMesh(coord, inpoel, ch["sidesets"])
     orc = O.Oracle(om, O.make_cfg(4, **kw), bc_sym=[3, 4, 5, 6], bc_extrapolate=[1, 2])
@@ -64,3 +64,18 @@ def test_cpp_adapter_matches_oracle(tmp_path):
         t += dt
     assert np.abs(U2 - Uo).max() <= 1e-10
     assert sc[3] == 1.0      # the bad call threw qdg::Exception
+
+    # TransportHIP (dg::Transport stand-in): slot_cyl DG-P0, all four BC kinds
+    import sys
+    tcase = dict(ndof=1, dt=5.0e-4, nstep=2, bc_dirichlet=[1, 2], bc_extrapolate=[3, 4],
+                 bc_inlet=[5], bc_outlet=[6])
+    tfix = {"coord": coord, "inpoel": inpoel, "ss_ids": np.array(ids)}
+    for sid in ids:
+        tfix["ss_tri_%d" % sid] = ch["sidesets"][sid]
+    r0 = O.run_transport_case(tcase, tfix, nstep=0)
+    assert np.abs(Lt - r0["L"]).max() <= 1e-15 * r0["L"].max()
+    assert np.abs(Ut - r0["U"]).max() <= 1e-13
+    assert tsc[0] == sys.float_info.max and tsc[1] == 5.0e-4 and tsc[2] == 5.0e-4
+    r2 = O.run_transport_case(tcase, tfix, nstep=2)
+    assert np.abs(Ut2 - r2["U"]).max() <= 1e-12
+    assert np.isfinite(Rt).all() and np.abs(Rt).max() > 0.0
