@@ -810,6 +810,14 @@ void orc_initialize(const orc_cfg* k, const double* L, const int64_t* inpoel,
   }
 }
 
+/* p-adaptive DG (scheme pdg): per-element number of DOFs, DG::m_ndof
+ * (src/Inciter/DG.cpp:927).  NULL = every element has k->ndof.  Set by
+ * orc_set_ndofel() around the calls of one pdg step (test infrastructure:
+ * a module-level pointer keeps the signatures of the uniform-order API). */
+static const int64_t* g_ndofel = 0;
+void orc_set_ndofel(const int64_t* ndofel) { g_ndofel = ndofel; }
+static int64_t nd_of(const orc_cfg* k, int64_t e) { return g_ndofel ? g_ndofel[e] : k->ndof; }
+
 /* src/PDE/Integrate/Surface.cpp:22-291 : interior-face Riemann flux integral */
 static void surf_int(const orc_cfg* k, int64_t nbfac, int64_t nfac,
                      const int32_t* esuf, const int64_t* inpofa,
@@ -819,15 +827,18 @@ static void surf_int(const orc_cfg* k, int64_t nbfac, int64_t nfac,
 {
   const int64_t ndof = k->ndof, rdof = k->rdof;
   const int64_t npu = NCOMP * rdof, npr = NCOMP * ndof;
-  const int ng = ng_fa(ndof);
-  const int64_t dof_e = (rdof > ndof) ? rdof : ndof;
   double cg[2][6], wg[6];
   int64_t f;
-  quad_tri(ng, cg, wg);
   for (f = nbfac; f < nfac; ++f) {
     const int64_t el = esuf[2 * f], er = esuf[2 * f + 1];
+    /* Surface.cpp:81-86: the larger of the two sides' point counts;
+     * :146-156: basis/state with each side's own number of DOFs */
+    const int64_t ndl = nd_of(k, el), ndr = nd_of(k, er);
+    const int ng = ng_fa(ndl) > ng_fa(ndr) ? ng_fa(ndl) : ng_fa(ndr);
+    const int64_t dof_el = (rdof > ndof) ? rdof : ndl, dof_er = (rdof > ndof) ? rdof : ndr;
     double pl[4][3], pr[4][3], pf[3][3], detl, detr, fn[3];
     int ig, c, i; int64_t j;
+    quad_tri(ng, cg, wg);
     elem_coords(inpoel, el, x, y, z, pl);
     elem_coords(inpoel, er, x, y, z, pr);
     detl = jacobian(pl[0], pl[1], pl[2], pl[3]);
@@ -841,21 +852,21 @@ static void surf_int(const orc_cfg* k, int64_t nbfac, int64_t nfac,
       double gp[3], xi, eta, zeta, Bl[10], Br[10], sl[5], sr[5], fl[5], wt;
       gp_tri(pf, cg[0][ig], cg[1][ig], gp);
       ref_coords(pl, detl, gp, &xi, &eta, &zeta);
-      eval_basis(dof_e, xi, eta, zeta, Bl);
+      eval_basis(dof_el, xi, eta, zeta, Bl);
       ref_coords(pr, detr, gp, &xi, &eta, &zeta);
-      eval_basis(dof_e, xi, eta, zeta, Br);
+      eval_basis(dof_er, xi, eta, zeta, Br);
       wt = wg[ig] * geoFace[7 * f];
-      eval_state(npu, rdof, dof_e, el, U, Bl, sl);
-      eval_state(npu, rdof, dof_e, er, U, Br, sr);
+      eval_state(npu, rdof, dof_el, el, U, Bl, sl);
+      eval_state(npu, rdof, dof_er, er, U, Br, sr);
       riemann(k, fn, sl, sr, fl);
-      /* update_rhs_fa, Surface.cpp:192-271 */
+      /* update_rhs_fa, Surface.cpp:192-271 (ndof_l, ndof_r = the sides' own counts) */
       for (c = 0; c < NCOMP; ++c) {
         double* rl = R + el * npr + c * ndof;
         double* rr = R + er * npr + c * ndof;
         rl[0] -= wt * fl[c];
         rr[0] += wt * fl[c];
-        for (j = 1; j < ndof; ++j) rl[j] -= wt * fl[c] * Bl[j];
-        for (j = 1; j < ndof; ++j) rr[j] += wt * fl[c] * Br[j];
+        for (j = 1; j < ndl; ++j) rl[j] -= wt * fl[c] * Bl[j];
+        for (j = 1; j < ndr; ++j) rr[j] += wt * fl[c] * Br[j];
       }
     }
   }
@@ -867,23 +878,24 @@ static void src_int(const orc_cfg* k, double t, const int64_t* inpoel,
                     const double* geoElem, int64_t nunk, double* R)
 {
   const int64_t ndof = k->ndof, npr = NCOMP * ndof;
-  const int ng = ng_vol(ndof);
   double cg[3][14], wg[14];
   int64_t e;
-  quad_tet(ng, cg, wg);
   for (e = 0; e < nunk; ++e) {
+    const int64_t nde = nd_of(k, e);           /* Source.cpp:54,81,88 */
+    const int ng = ng_vol(nde);
     double p[4][3]; int ig, c; int64_t j;
+    quad_tet(ng, cg, wg);
     elem_coords(inpoel, e, x, y, z, p);
     for (ig = 0; ig < ng; ++ig) {
       double gp[3], B[10], s[5], wt;
       gp_tet(p, cg[0][ig], cg[1][ig], cg[2][ig], gp);
-      eval_basis(ndof, cg[0][ig], cg[1][ig], cg[2][ig], B);
+      eval_basis(nde, cg[0][ig], cg[1][ig], cg[2][ig], B);
       prob_src(k, gp[0], gp[1], gp[2], t, s);
       wt = wg[ig] * geoElem[4 * e];
       for (c = 0; c < NCOMP; ++c) {
         double* r = R + e * npr + c * ndof;
         r[0] += wt * s[c];
-        for (j = 1; j < ndof; ++j) r[j] += wt * s[c] * B[j];
+        for (j = 1; j < nde; ++j) r[j] += wt * s[c] * B[j];
       }
     }
   }
@@ -895,26 +907,28 @@ static void vol_int(const orc_cfg* k, const int64_t* inpoel, const double* x,
                     int64_t nunk, const double* U, double* R)
 {
   const int64_t ndof = k->ndof, npu = NCOMP * k->rdof, npr = NCOMP * ndof;
-  const int ng = ng_vol(ndof);
   double cg[3][14], wg[14];
   int64_t e;
-  quad_tet(ng, cg, wg);
   for (e = 0; e < nunk; ++e) {
+    const int64_t nde = nd_of(k, e);           /* Volume.cpp:56-58 */
+    const int ng = ng_vol(nde);
     double p[4][3], ji[3][3], dBdx[3][10]; int ig, c; int64_t j;
+    if (nde <= 1) continue;
+    quad_tet(ng, cg, wg);
     elem_coords(inpoel, e, x, y, z, p);
     inverse_jacobian(p[0], p[1], p[2], p[3], ji);
     eval_dBdx_p1(ji, dBdx);
     for (ig = 0; ig < ng; ++ig) {
       double B[10], s[5], F[5][3], wt;
-      if (ndof > 4) eval_dBdx_p2(cg[0][ig], cg[1][ig], cg[2][ig], ji, dBdx);
-      eval_basis(ndof, cg[0][ig], cg[1][ig], cg[2][ig], B);
+      if (nde > 4) eval_dBdx_p2(cg[0][ig], cg[1][ig], cg[2][ig], ji, dBdx);
+      eval_basis(nde, cg[0][ig], cg[1][ig], cg[2][ig], B);
       wt = wg[ig] * geoElem[4 * e];
       /* reference passes ndof as the U stride here (Volume.cpp:100) */
-      eval_state(npu, ndof, ndof, e, U, B, s);
+      eval_state(npu, ndof, nde, e, U, B, s);
       euler_flux(k, s, F);
       for (c = 0; c < NCOMP; ++c) {
         double* r = R + e * npr + c * ndof;
-        for (j = 1; j < ndof; ++j)
+        for (j = 1; j < nde; ++j)
           r[j] += wt * (F[c][0] * dBdx[0][j] + F[c][1] * dBdx[1][j] + F[c][2] * dBdx[2][j]);
       }
     }
@@ -932,19 +946,20 @@ static void bnd_surf_int(const orc_cfg* k, const orc_bc* bc, int type,
 {
   const int64_t ndof = k->ndof, rdof = k->rdof;
   const int64_t npu = NCOMP * rdof, npr = NCOMP * ndof;
-  const int ng = ng_fa(ndof);
-  const int64_t dof_e = (rdof > ndof) ? rdof : ndof;
   double cg[2][6], wg[6];
   int64_t ic, is, q;
-  quad_tri(ng, cg, wg);
   for (ic = 0; ic < nconf; ++ic) {
     for (is = 0; is < bc->nset; ++is) {
       if (bc->set_id[is] != conf[ic]) continue;
       for (q = bc->set_off[is]; q < bc->set_off[is + 1]; ++q) {
         const int64_t f = bc->set_face[q];
         const int64_t el = esuf[2 * f];
+        const int64_t ndl = nd_of(k, el);          /* Boundary.cpp:94,143,165 */
+        const int ng = ng_fa(ndl);
+        const int64_t dof_e = (rdof > ndof) ? rdof : ndl;
         double pl[4][3], pf[3][3], detl, fn[3];
         int ig, c, i; int64_t j;
+        quad_tri(ng, cg, wg);
         elem_coords(inpoel, el, x, y, z, pl);
         detl = jacobian(pl[0], pl[1], pl[2], pl[3]);
         for (i = 0; i < 3; ++i) {
@@ -964,7 +979,7 @@ static void bnd_surf_int(const orc_cfg* k, const orc_bc* bc, int type,
           for (c = 0; c < NCOMP; ++c) {
             double* rl = R + el * npr + c * ndof;
             rl[0] -= wt * fl[c];
-            for (j = 1; j < ndof; ++j) rl[j] -= wt * fl[c] * Bl[j];
+            for (j = 1; j < ndl; ++j) rl[j] -= wt * fl[c] * Bl[j];
           }
         }
       }
@@ -998,17 +1013,19 @@ double orc_dt(const orc_cfg* k, int64_t nunk, int64_t nfac, const int32_t* esuf,
               const double* y, const double* z, const double* geoFace,
               const double* geoElem, const double* U)
 {
-  const int64_t ndof = k->ndof, rdof = k->rdof, npu = NCOMP * rdof;
-  const int ng = ng_fa(ndof);
+  const int64_t rdof = k->rdof, npu = NCOMP * rdof;
   double cg[2][6], wg[6], mindt = DBL_MAX;
   double* delt = (double*)calloc((size_t)nunk, sizeof(double));
   int64_t f, e;
-  quad_tri(ng, cg, wg);
   for (f = 0; f < nfac; ++f) {
     const int64_t el = esuf[2 * f];
     const int32_t er = esuf[2 * f + 1];
+    /* DGCompFlow.hpp:232-250: points = max of the two sides (interior), left side (boundary) */
+    const int64_t ndl = nd_of(k, el), ndr = er > -1 ? nd_of(k, er) : 1;
+    const int ng = (er > -1 && ng_fa(ndr) > ng_fa(ndl)) ? ng_fa(ndr) : ng_fa(ndl);
     double pl[4][3], pr[4][3], pf[3][3], detl, detr = 0.0, dSV_l = 0.0, dSV_r = 0.0;
     int ig, i;
+    quad_tri(ng, cg, wg);
     elem_coords(inpoel, el, x, y, z, pl);
     detl = jacobian(pl[0], pl[1], pl[2], pl[3]);
     if (er > -1) {
@@ -1023,9 +1040,9 @@ double orc_dt(const orc_cfg* k, int64_t nunk, int64_t nfac, const int32_t* esuf,
       double gp[3], xi, eta, zeta, B[10], s[5], rho, u, v, w, p, a, vn, wt;
       gp_tri(pf, cg[0][ig], cg[1][ig], gp);
       ref_coords(pl, detl, gp, &xi, &eta, &zeta);
-      eval_basis(ndof, xi, eta, zeta, B);
+      eval_basis(ndl, xi, eta, zeta, B);
       wt = wg[ig] * geoFace[7 * f];
-      eval_state(npu, rdof, ndof, el, U, B, s);
+      eval_state(npu, rdof, ndl, el, U, B, s);
       rho = s[0]; u = s[1] / rho; v = s[2] / rho; w = s[3] / rho;
       p = eos_pressure(k, rho, u, v, w, s[4]);
       a = eos_soundspeed(k, rho, p);
@@ -1033,8 +1050,8 @@ double orc_dt(const orc_cfg* k, int64_t nunk, int64_t nfac, const int32_t* esuf,
       dSV_l = wt * (fabs(vn) + a);
       if (er > -1) {
         ref_coords(pr, detr, gp, &xi, &eta, &zeta);
-        eval_basis(ndof, xi, eta, zeta, B);
-        eval_state(npu, rdof, ndof, er, U, B, s);
+        eval_basis(ndr, xi, eta, zeta, B);
+        eval_state(npu, rdof, ndr, er, U, B, s);
         rho = s[0]; u = s[1] / rho; v = s[2] / rho; w = s[3] / rho;
         p = eos_pressure(k, rho, u, v, w, s[4]);
         a = eos_soundspeed(k, rho, p);
@@ -1105,15 +1122,15 @@ void orc_superbee_p1(const orc_cfg* k, const int32_t* esuel, int64_t nielem,
                      const double* z, double* U)
 {
   const int64_t rdof = k->rdof, npu = NCOMP * rdof;
-  const int64_t dof_el = k->ndof;
   const double beta_lim = 2.0;
   const int ng = ng_fa(rdof);
   double cg[2][6], wg[6];
   int64_t e;
-  if (dof_el <= 1) return;
   quad_tri(ng, cg, wg);
   for (e = 0; e < nielem; ++e) {
+    const int64_t dof_el = nd_of(k, e);         /* Limiter.cpp:179-180 */
     double uMin[5], uMax[5], phi[5], p[4][3], detT; int c, is, lf, ig, i;
+    if (dof_el <= 1) continue;
     for (c = 0; c < NCOMP; ++c) uMin[c] = uMax[c] = U[e * npu + c * rdof];
     for (is = 0; is < 4; ++is) {
       const int32_t n = esuel[4 * e + is];
@@ -1196,22 +1213,23 @@ void orc_diag(const orc_cfg* k, double t_new, const int64_t* inpoel,
               const double* geoElem, const double* U, int64_t nielem,
               double* out)
 {
-  const int64_t ndof = k->ndof, rdof = k->rdof, npu = NCOMP * rdof;
-  const int ng = ng_diag(ndof);
+  const int64_t rdof = k->rdof, npu = NCOMP * rdof;
   double cg[3][14], wg[14];
   int64_t e; int i;
-  quad_tet(ng, cg, wg);
   for (i = 0; i < 15; ++i) out[i] = 0.0;
   for (e = 0; e < nielem; ++e) {
+    const int64_t nde = nd_of(k, e);            /* ElemDiagnostics.cpp:144,171,186 */
+    const int ng = ng_diag(nde);
     double p[4][3]; int ig, c;
+    quad_tet(ng, cg, wg);
     elem_coords(inpoel, e, x, y, z, p);
     for (ig = 0; ig < ng; ++ig) {
       double gp[3], B[10], s[5], u[5], wt;
       gp_tet(p, cg[0][ig], cg[1][ig], cg[2][ig], gp);
-      eval_basis(ndof, cg[0][ig], cg[1][ig], cg[2][ig], B);
+      eval_basis(nde, cg[0][ig], cg[1][ig], cg[2][ig], B);
       wt = wg[ig] * geoElem[4 * e];
       prob_solution(k, gp[0], gp[1], gp[2], t_new, s);
-      eval_state(npu, rdof, ndof, e, U, B, u);
+      eval_state(npu, rdof, nde, e, U, B, u);
       for (c = 0; c < NCOMP; ++c) {
         const double err = fabs(u[c] - s[c]);
         out[c] += wt * u[c] * u[c];
@@ -1251,6 +1269,103 @@ double orc_step(const orc_cfg* k, const orc_bc* bc, double t, double fixed_dt,
     orc_rhs(k, bc, t, nunk, nbfac, nfac, esuf, inpofa, inpoel, x, y, z, geoFace, geoElem, U, R);
     orc_rk_update(k, stage, dt, Un, R, L, U, nunk);
   }
+  return dt;
+}
+
+/* ---------------------------------------------------------------- p-adaptive DG
+ * (scheme pdg: ndof = rdof = 4, per-element m_ndof in {1,4}; Grammar.hpp:399-407) */
+
+/* DG::eval_ndof, src/Inciter/DG.cpp:1088-1163: an element that is P1 stays P1
+ * when the physical gradient of any component exceeds tolref, else becomes P0;
+ * P0 elements are left alone (they are raised again only by propagate_ndof) */
+void orc_eval_ndof(const orc_cfg* k, int64_t nielem, const int64_t* inpoel, const double* x,
+                   const double* y, const double* z, const double* U, double tolref,
+                   int64_t* ndofel)
+{
+  const int64_t rdof = k->rdof, npu = NCOMP * rdof;
+  int64_t e; int c;
+  for (e = 0; e < nielem; ++e) {
+    double p[4][3], ji[3][3]; int sign = 0;
+    if (ndofel[e] != 4) continue;
+    elem_coords(inpoel, e, x, y, z, p);
+    inverse_jacobian(p[0], p[1], p[2], p[3], ji);
+    for (c = 0; c < NCOMP; ++c) {
+      const double* u = U + e * npu + c * rdof;
+      const double d0 = 2 * u[1], d1 = u[1] + 3.0 * u[2], d2 = u[1] + u[2] + 4.0 * u[3];
+      const double gx = d0 * ji[0][0] + d1 * ji[1][0] + d2 * ji[2][0];
+      const double gy = d0 * ji[0][1] + d1 * ji[1][1] + d2 * ji[2][1];
+      const double gz = d0 * ji[0][2] + d1 * ji[1][2] + d2 * ji[2][2];
+      if (sqrt(gx * gx + gy * gy + gz * gz) > tolref) ++sign;
+    }
+    ndofel[e] = sign > 0 ? 4 : 1;
+  }
+}
+
+/* DG::propagate_ndof, DG.cpp:1284-1313: neighbours (across interior faces) of a
+ * P1 element become P1; Jacobi (decisions from the old vector) */
+void orc_propagate_ndof(int64_t nunk, int64_t nbfac, int64_t nfac, const int32_t* esuf,
+                        int64_t* ndofel)
+{
+  int64_t* nw = (int64_t*)malloc((size_t)nunk * sizeof(int64_t));
+  int64_t f;
+  memcpy(nw, ndofel, (size_t)nunk * sizeof(int64_t));
+  for (f = nbfac; f < nfac; ++f) {
+    const int64_t el = esuf[2 * f], er = esuf[2 * f + 1];
+    if (ndofel[el] == 4) nw[er] = 4;
+    if (ndofel[er] == 4) nw[el] = 4;
+  }
+  memcpy(ndofel, nw, (size_t)nunk * sizeof(int64_t));
+  free(nw);
+}
+
+/* DG::solve, DG.cpp:1451-1469: high-order DOFs of P0 elements are zeroed at stage 0 */
+void orc_pdg_zero(const orc_cfg* k, int64_t nunk, const int64_t* ndofel, double* U)
+{
+  const int64_t rdof = k->rdof, npu = NCOMP * rdof;
+  int64_t e; int c;
+  for (e = 0; e < nunk; ++e)
+    if (ndofel[e] == 1)
+      for (c = 0; c < NCOMP; ++c) {
+        double* u = U + e * npu + c * rdof;
+        u[1] = 0.0; u[2] = 0.0; u[3] = 0.0;
+      }
+}
+
+/* One pdg time step on a single partition, in the reference's order
+ * (DG::next: eval_ndof at stage 0 -> DG::lim: propagate_ndof at stage 0, limiter
+ * -> DG::dt -> DG::solve: zeroing at stage 0, Un = U, rhs, update).
+ * `ndofel` is DG::m_ndof, carried from step to step by the caller. */
+double orc_step_pdg(const orc_cfg* k, const orc_bc* bc, double t, double fixed_dt,
+                    double cfl, double tleft, double tolref, int64_t nunk, int64_t nbfac,
+                    int64_t nfac, const int32_t* esuel, const int32_t* esuf,
+                    const int64_t* inpofa, const int64_t* inpoel, const double* x,
+                    const double* y, const double* z, const double* geoFace,
+                    const double* geoElem, const double* L, double* U, double* Un,
+                    double* R, int64_t* ndofel)
+{
+  double dt = fixed_dt; int stage;
+  const int64_t* saved = g_ndofel;
+  g_ndofel = ndofel;
+  for (stage = 0; stage < 3; ++stage) {
+    if (stage == 0) {
+      orc_eval_ndof(k, nunk, inpoel, x, y, z, U, tolref, ndofel);
+      orc_propagate_ndof(nunk, nbfac, nfac, esuf, ndofel);
+    }
+    orc_limit(k, esuel, nunk, inpoel, x, y, z, U);
+    if (stage == 0) {
+      if (!(fixed_dt > 0.0)) {
+        const double dgp = (k->ndof == 4) ? 1.0 : (k->ndof == 10) ? 2.0 : 0.0;
+        dt = orc_dt(k, nunk, nfac, esuf, inpofa, inpoel, x, y, z, geoFace, geoElem, U);
+        dt *= cfl / (2.0 * dgp + 1.0);
+      }
+      if (dt > tleft) dt = tleft;
+      orc_pdg_zero(k, nunk, ndofel, U);
+      memcpy(Un, U, (size_t)(nunk * NCOMP * k->rdof) * sizeof(double));
+    }
+    orc_rhs(k, bc, t, nunk, nbfac, nfac, esuf, inpofa, inpoel, x, y, z, geoFace, geoElem, U, R);
+    orc_rk_update(k, stage, dt, Un, R, L, U, nunk);
+  }
+  g_ndofel = saved;
   return dt;
 }
 

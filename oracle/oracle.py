@@ -63,6 +63,7 @@ def lib():
         _LIB = C.CDLL(build())
         _LIB.orc_dt.restype = C.c_double
         _LIB.orc_step.restype = C.c_double
+        _LIB.orc_step_pdg.restype = C.c_double
         _LIB.orc_jacobian.restype = C.c_double
         _LIB.orc_gen_nipfac.restype = C.c_int64
     return _LIB
@@ -225,8 +226,12 @@ class ChunkMesh:
 class Oracle:
     """Reference time loop on one mesh chunk (CPU, AoS fields)."""
 
-    def __init__(self, mesh, cfg, bc_dirichlet=(), bc_sym=(), bc_extrapolate=()):
+    def __init__(self, mesh, cfg, bc_dirichlet=(), bc_sym=(), bc_extrapolate=(), pref=False,
+                 tolref=0.1):
         self.m, self.cfg, self.L_ = mesh, cfg, lib()
+        # p-adaptive DG (scheme pdg): DG::m_ndof, all elements start at ndof (DG.cpp:927)
+        self.pref, self.tolref = bool(pref), float(tolref)
+        self.ndofel = np.full(mesh.nelem, cfg.ndof, dtype=np.int64) if pref else None
         self._dir = np.array(list(bc_dirichlet) or [0], dtype=np.int64)
         self._sym = np.array(list(bc_sym) or [0], dtype=np.int64)
         self._ext = np.array(list(bc_extrapolate) or [0], dtype=np.int64)
@@ -238,6 +243,17 @@ class Oracle:
                      extrap=_p(self._ext, c_i64p))
         self.nprop = 5 * cfg.rdof
         self.npropr = 5 * cfg.ndof
+
+    class _Ndofel:
+        """operators see the per-element ndof while inside (orc_set_ndofel)"""
+        def __init__(self, o):
+            self.o = o
+        def __enter__(self):
+            if self.o.pref:
+                self.o.L_.orc_set_ndofel(_p(self.o.ndofel, c_i64p))
+        def __exit__(self, *a):
+            if self.o.pref:
+                self.o.L_.orc_set_ndofel(None)
 
     # --- single operators -------------------------------------------------
     def lhs(self):
@@ -257,16 +273,18 @@ class Oracle:
     def rhs(self, t, U):
         m = self.m
         R = np.zeros(m.nelem * self.npropr)
-        self.L_.orc_rhs(C.byref(self.cfg), C.byref(self.bc), C.c_double(t), C.c_int64(m.nelem),
-                        C.c_int64(m.nbfac), C.c_int64(m.nfac), _p(m.esuf, c_i32p),
-                        _p(m.inpofa, c_i64p), _p(m.inpoel.reshape(-1), c_i64p),
-                        _p(m.x, c_f64p), _p(m.y, c_f64p), _p(m.z, c_f64p),
-                        _p(m.geoFace, c_f64p), _p(m.geoElem, c_f64p), _p(U, c_f64p), _p(R, c_f64p))
+        with self._Ndofel(self):
+          self.L_.orc_rhs(C.byref(self.cfg), C.byref(self.bc), C.c_double(t), C.c_int64(m.nelem),
+                          C.c_int64(m.nbfac), C.c_int64(m.nfac), _p(m.esuf, c_i32p),
+                          _p(m.inpofa, c_i64p), _p(m.inpoel.reshape(-1), c_i64p),
+                          _p(m.x, c_f64p), _p(m.y, c_f64p), _p(m.z, c_f64p),
+                          _p(m.geoFace, c_f64p), _p(m.geoElem, c_f64p), _p(U, c_f64p), _p(R, c_f64p))
         return R
 
     def dt(self, U):
         m = self.m
-        return float(self.L_.orc_dt(C.byref(self.cfg), C.c_int64(m.nelem), C.c_int64(m.nfac),
+        with self._Ndofel(self):
+          return float(self.L_.orc_dt(C.byref(self.cfg), C.c_int64(m.nelem), C.c_int64(m.nfac),
                                     _p(m.esuf, c_i32p), _p(m.inpofa, c_i64p),
                                     _p(m.inpoel.reshape(-1), c_i64p), _p(m.x, c_f64p),
                                     _p(m.y, c_f64p), _p(m.z, c_f64p), _p(m.geoFace, c_f64p),
@@ -275,9 +293,10 @@ class Oracle:
     def limit(self, U):
         """In place, like the reference (src/Inciter/DG.cpp:1251-1260)."""
         m = self.m
-        self.L_.orc_limit(C.byref(self.cfg), _p(m.esuel, c_i32p), C.c_int64(self.nie),
-                          _p(m.inpoel.reshape(-1), c_i64p), _p(m.x, c_f64p), _p(m.y, c_f64p),
-                          _p(m.z, c_f64p), _p(U, c_f64p))
+        with self._Ndofel(self):
+            self.L_.orc_limit(C.byref(self.cfg), _p(m.esuel, c_i32p), C.c_int64(self.nie),
+                              _p(m.inpoel.reshape(-1), c_i64p), _p(m.x, c_f64p), _p(m.y, c_f64p),
+                              _p(m.z, c_f64p), _p(U, c_f64p))
         return U
 
     def rk_update(self, stage, dt, Un, R, Lm, U):
@@ -290,9 +309,10 @@ class Oracle:
         L2(u_c - analytic) x5 (Transporter.cpp:901-916)."""
         m = self.m
         out = np.zeros(15)
-        self.L_.orc_diag(C.byref(self.cfg), C.c_double(t_new), _p(m.inpoel.reshape(-1), c_i64p),
-                         _p(m.x, c_f64p), _p(m.y, c_f64p), _p(m.z, c_f64p),
-                         _p(m.geoElem, c_f64p), _p(U, c_f64p), C.c_int64(self.nie), _p(out, c_f64p))
+        with self._Ndofel(self):
+            self.L_.orc_diag(C.byref(self.cfg), C.c_double(t_new), _p(m.inpoel.reshape(-1), c_i64p),
+                             _p(m.x, c_f64p), _p(m.y, c_f64p), _p(m.z, c_f64p),
+                             _p(m.geoElem, c_f64p), _p(U, c_f64p), C.c_int64(self.nie), _p(out, c_f64p))
         return np.sqrt(out[:10] / m.meshvol), out[10:]
 
     def step(self, t, U, Lm, fixed_dt=0.0, cfl=0.0, tleft=1e300, work=None):
@@ -300,6 +320,15 @@ class Oracle:
         if work is None:
             work = (np.zeros_like(U), np.zeros(m.nelem * self.npropr))
         Un, R = work
+        if self.pref:
+            dt = self.L_.orc_step_pdg(
+                C.byref(self.cfg), C.byref(self.bc), C.c_double(t), C.c_double(fixed_dt),
+                C.c_double(cfl), C.c_double(tleft), C.c_double(self.tolref), C.c_int64(m.nelem),
+                C.c_int64(m.nbfac), C.c_int64(m.nfac), _p(m.esuel, c_i32p), _p(m.esuf, c_i32p),
+                _p(m.inpofa, c_i64p), _p(m.inpoel.reshape(-1), c_i64p), _p(m.x, c_f64p),
+                _p(m.y, c_f64p), _p(m.z, c_f64p), _p(m.geoFace, c_f64p), _p(m.geoElem, c_f64p),
+                _p(Lm, c_f64p), _p(U, c_f64p), _p(Un, c_f64p), _p(R, c_f64p), _p(self.ndofel, c_i64p))
+            return float(dt)
         dt = self.L_.orc_step(C.byref(self.cfg), C.byref(self.bc), C.c_double(t),
                               C.c_double(fixed_dt), C.c_double(cfl), C.c_double(tleft),
                               C.c_int64(m.nelem), C.c_int64(m.nbfac), C.c_int64(m.nfac),
@@ -331,12 +360,14 @@ def run_case(case, fix, nstep=None, on_step=None):
                    problem=case["problem"], gamma=case["gamma"],
                    alpha=case.get("alpha", 0.0), beta=case.get("beta", 0.0),
                    p0=case.get("p0", 0.0))
-    orc = Oracle(mesh, cfg, case["bc_dirichlet"], case["bc_sym"], case["bc_extrapolate"])
+    orc = Oracle(mesh, cfg, case["bc_dirichlet"], case["bc_sym"], case["bc_extrapolate"],
+                 pref=case.get("pref", False), tolref=case.get("tolref", 0.1))
     Lm = orc.lhs()
     U = orc.initialize(Lm, 0.0)
     t, it = 0.0, 0
     nstep = nstep or case["nstep"]
     diag_rows, fields, times = [], [orc.field_output(U)], [0.0]
+    ndofs = [orc.ndofel.copy()] if orc.pref else []
     work = (np.zeros_like(U), np.zeros(mesh.nelem * orc.npropr))
     while it < nstep:
         dt = orc.step(t, U, Lm, fixed_dt=case["dt"], cfl=case["cfl"], work=work)
@@ -348,11 +379,13 @@ def run_case(case, fix, nstep=None, on_step=None):
         if it % case["plot_interval"] == 0 or it == nstep:
             fields.append(orc.field_output(U))
             times.append(t)
+            if orc.pref:
+                ndofs.append(orc.ndofel.copy())
         if on_step:
             on_step(it, t, dt, U)
     return {"mesh": mesh, "oracle": orc, "U": U, "L": Lm, "t": t,
             "diag": np.array(diag_rows), "fields": np.array(fields),
-            "times": np.array(times)}
+            "times": np.array(times), "ndof": np.array(ndofs)}
 
 
 # ---------------------------------------------------------------- transport

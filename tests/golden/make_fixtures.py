@@ -114,7 +114,8 @@ def main():
             # serial runs keep the input ordering of tets and nodes
             assert np.array_equal(conn, inpoel), name
             assert np.abs(gcoord - coord).max() < 1e-14, name
-            keep = [i for i, n in enumerate(names) if n.endswith("_numerical")]
+            # numerical fields (+ the per-element ndof of p-adaptive runs)
+            keep = [i for i, n in enumerate(names) if n.endswith("_numerical") or n == "ndof"]
             out["exo_times"] = t
             out["exo_names"] = np.array([names[i] for i in keep])
             out["exo_vals"] = vals[:, keep, :]

@@ -13,7 +13,7 @@ from oracle import oracle as O
 from conftest import load_fixture
 
 # absolute tolerance on golden ExodusII element fields (full-precision f64)
-FIELD_ATOL = {"sod_dg": 1e-13, "sedov_dgp1": 5e-12, "vortical_flow_dg": 1e-12,
+FIELD_ATOL = {"sod_dg": 1e-13, "sedov_dgp1": 5e-12, "sedov_pdg": 5e-12, "vortical_flow_dg": 1e-12,
               "vortical_flow_dg_lf": 1e-12, "vortical_flow_dgp1": 1e-12,
               "vortical_flow_dgp1_lf": 1e-12, "taylor_green_dgp2": 1e-12,
               "taylor_green_dgp2_cfl": 1e-12}
@@ -36,6 +36,10 @@ def test_oracle_reproduces_reference_golden(name, cases):
         nvar = 5
     err = np.abs(r["fields"][:, :nvar] - fix["exo_vals"][:, :nvar]).max()
     assert err <= FIELD_ATOL[name], (name, err)
+    if case.get("pref"):
+        # p-adaptive run: the per-element number of DOFs the reference wrote out
+        assert np.array_equal(r["ndof"], fix["exo_vals"][:, 6].astype(np.int64))
+        assert 0 < (r["ndof"][-1] == 4).sum() < r["ndof"].shape[1]
     # --- diagnostics table: it, t, dt, L2(u_c) x5, L2(u_c - analytic) x5 ---
     gold = {int(row[0]): row for row in fix["diag"]}
     assert len(r["diag"]) == len(gold)
