@@ -100,7 +100,9 @@ typedef struct qdg_config {
   double cfl;                /* discr::cfl; used when dt <= 0 */
   double dt;                 /* discr::dt; > 0 selects constant time step */
   int32_t pde;               /* QDG_PDE_* */
-  int32_t reserved_;         /* 0 */
+  int32_t pref;              /* pref::pref: p-adaptive DG (scheme pdg; needs ndof = rdof = 4,
+                                Grammar.hpp:399-407): per-element ndof in {1,4} */
+  double tolref;             /* pref::tolref (default 0.1, InputDeck.hpp:232) */
 } qdg_config;
 
 /* flattened std::map<int, std::vector<std::size_t>> FaceData::m_bface */
@@ -160,6 +162,15 @@ int qdg_stage_rhs_update(qdg_mesh* mesh, int stage, double t);
  * scalar across chunks, then calls qdg_stage_update.  Stages 1,2: RHS only. */
 int qdg_stage_rhs_dt(qdg_mesh* mesh, int stage, double t, double tleft);
 int qdg_stage_update(qdg_mesh* mesh, int stage);
+/* p-adaptive DG (cfg.pref): the per-element number of DOFs DG::m_ndof lives on
+ * the device (all = ndof after upload / qdg_state_initialize).  qdg_stage_pdg is
+ * the stage-0 work of DG::next / DG::lim / DG::solve on it: eval_ndof
+ * (DG.cpp:1088-1163), propagate_ndof (:1284-1313), zeroing of the high-order DOFs
+ * of P0 elements (:1451-1469); call it before qdg_stage_limit of stage 0
+ * (qdg_step does).  get/set: nunk entries in the caller's element numbering. */
+int qdg_stage_pdg(qdg_mesh* mesh);
+int qdg_ndofel_get(qdg_mesh* mesh, size_t* ndofel);
+int qdg_ndofel_set(qdg_mesh* mesh, const size_t* ndofel);
 /* whole step on one chunk without ghosts: 3 x (limit, [dt], rhs, update);
  * returns the dt taken (host sync only when dt_taken != NULL) */
 int qdg_step(qdg_mesh* mesh, double t, double tleft, double* dt_taken);

@@ -172,6 +172,8 @@ struct InputDeck {
   real alpha = 0.0, beta = 0.0, p0 = 0.0;
   std::vector<std::string> bcdir, bcsym, bcextrapolate;   // side set id strings, as parsed
   std::vector<std::string> bcinlet, bcoutlet;              // transport only (DGTransport.hpp:163-168)
+  bool pref = false;                         // pref::pref (scheme pdg)
+  real tolref = 0.1;                         // pref::tolref
   int device = 0;
 };
 
@@ -212,7 +214,7 @@ class DeviceDG {
     }
     qdg_config cfg{};
     cfg.struct_size = (int32_t)sizeof(qdg_config);
-    cfg.pde = PDE;
+    cfg.pde = PDE; cfg.pref = deck.pref ? 1 : 0; cfg.tolref = deck.tolref;
     cfg.device = deck.device;
     cfg.ndof = (int32_t)deck.ndof; cfg.rdof = (int32_t)deck.rdof;
     cfg.flux = deck.flux; cfg.limiter = deck.limiter; cfg.problem = problem;
@@ -289,8 +291,8 @@ class DeviceDG {
            const std::vector<std::size_t>& inpoel, const Coords& coord, const Fields& U,
            const std::vector<std::size_t>& ndofel, Fields& R) const
   {
-    (void)ndofel;   // p-adaptive DG (pdg) is not on the device path yet
     attach(geoFace, geoElem, fd, inpoel, coord);
+    if (m_deck.pref) check(qdg_ndofel_set(handle(inpoel), ndofel.data()));   // p-adaptive DG
     check(qdg_rhs(handle(inpoel), t, U.data().data(), R.data().data()));
   }
 
@@ -299,8 +301,8 @@ class DeviceDG {
           const Fields& geoFace, const Fields& geoElem, const std::vector<std::size_t>& ndofel,
           const Fields& U) const
   {
-    (void)ndofel;
     attach(geoFace, geoElem, fd, inpoel, coord);
+    if (m_deck.pref) check(qdg_ndofel_set(handle(inpoel), ndofel.data()));
     real v = 0.0;
     check(qdg_dt(handle(inpoel), U.data().data(), &v));
     return v;
@@ -309,6 +311,12 @@ class DeviceDG {
   //! WENO_P1 / Superbee_P1 as DG::lim calls them (src/Inciter/DG.cpp:1251-1260)
   void limit(const std::vector<std::size_t>& inpoel, Fields& U) const
   { check(qdg_limit(handle(inpoel), U.data().data())); }
+  //! Superbee_P1 with the per-element ndof of p-adaptive DG (Limiter.cpp:155-180)
+  void limit(const std::vector<std::size_t>& inpoel, const std::vector<std::size_t>& ndofel, Fields& U) const
+  {
+    if (m_deck.pref) check(qdg_ndofel_set(handle(inpoel), ndofel.data()));
+    check(qdg_limit(handle(inpoel), U.data().data()));
+  }
 
   //! Problem::side via the configured BC lists (DGCompFlow.hpp:430-434)
   void side(std::unordered_set<int>& conf) const { for (int s : m_bcset) conf.insert(s); }

@@ -37,7 +37,7 @@ class qdg_config(C.Structure):
                 ("gamma", C.c_double), ("pstiff", C.c_double), ("cv", C.c_double),
                 ("cweight", C.c_double), ("alpha", C.c_double), ("beta", C.c_double),
                 ("p0", C.c_double), ("cfl", C.c_double), ("dt", C.c_double),
-                ("pde", C.c_int32), ("reserved_", C.c_int32)]
+                ("pde", C.c_int32), ("pref", C.c_int32), ("tolref", C.c_double)]
 
 
 class qdg_bface(C.Structure):
@@ -164,7 +164,7 @@ class Context:
     def __init__(self, ndof, flux="hllc", limiter="nolimiter", problem="sod_shocktube",
                  gamma=1.4, pstiff=0.0, cv=717.5, cweight=1.0, alpha=0.0, beta=0.0, p0=0.0,
                  cfl=0.0, dt=0.0, bc_dirichlet=(), bc_sym=(), bc_extrapolate=(), device=0,
-                 pde="compflow", bc_inlet=(), bc_outlet=()):
+                 pde="compflow", bc_inlet=(), bc_outlet=(), pref=False, tolref=0.1):
         L = lib()
         ss = list(bc_dirichlet) + list(bc_sym) + list(bc_extrapolate) + list(bc_inlet) + list(bc_outlet)
         ty = [BC_DIRICHLET] * len(bc_dirichlet) + [BC_SYMMETRY] * len(bc_sym) + \
@@ -176,7 +176,7 @@ class Context:
                               rdof=ndof, flux=FLUX[flux], limiter=LIMITER[limiter],
                               problem=PROBLEM[problem], nbc=len(ss), bc_sideset=pss, bc_type=pty,
                               gamma=gamma, pstiff=pstiff, cv=cv, cweight=cweight, alpha=alpha,
-                              beta=beta, p0=p0, cfl=cfl, dt=dt, pde=PDE[pde], reserved_=0)
+                              beta=beta, p0=p0, cfl=cfl, dt=dt, pde=PDE[pde], pref=1 if pref else 0, tolref=tolref)
         self.h = C.c_void_p()
         _chk(L.qdg_ctx_create(C.byref(self.cfg), C.byref(self.h)))
         self.ndof = ndof
@@ -271,6 +271,18 @@ class Mesh:
 
     def state_initialize(self, t=0.0):
         _chk(lib().qdg_state_initialize(self.h, C.c_double(t)))
+
+    def stage_pdg(self):
+        _chk(lib().qdg_stage_pdg(self.h))
+
+    def ndofel_get(self):
+        a = np.zeros(self.nunk, dtype=np.uint64)
+        _chk(lib().qdg_ndofel_get(self.h, a.ctypes.data_as(c_szp)))
+        return a.astype(np.int64)
+
+    def ndofel_set(self, ndofel):
+        a, pa = _sz(ndofel)
+        _chk(lib().qdg_ndofel_set(self.h, pa))
 
     def stage_limit(self):
         _chk(lib().qdg_stage_limit(self.h))

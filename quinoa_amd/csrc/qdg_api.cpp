@@ -96,6 +96,7 @@ struct qdg_mesh {
   double* Unp = nullptr;
   double* Upending = nullptr;     // output of a fused RHS+RK launch, adopted by qdg_stage_update
   DevBuf<double> S1, S2;          // scratch of the stateless operators (allocated on first use)
+  DevBuf<int> ndofel, ndofel2;    // p-adaptive DG: DG::m_ndof per device row (+ Jacobi copy)
   // halo
   size_t nnbr = 0, nsend = 0, nrecv = 0;
   std::vector<int32_t> nbr_rank;
@@ -145,6 +146,7 @@ static int check_cfg(const qdg_config* c)
     if (c->limiter != QDG_LIMITER_NONE) return fail("qdg_ctx_create: limiters are not supported for transport");
     if (!(c->dt > 0.0))
       return fail("qdg_ctx_create: transport needs a constant dt (dg::Transport::dt gives no CFL estimate)");
+    if (c->pref) return fail("qdg_ctx_create: p-adaptive DG is not supported for transport");
     for (int i = 0; i < c->nbc; ++i) {
       const int b = c->bc_type[i];
       if (!(b == QDG_BC_DIRICHLET || b == QDG_BC_EXTRAPOLATE || b == QDG_BC_INLET || b == QDG_BC_OUTLET))
@@ -153,6 +155,11 @@ static int check_cfg(const qdg_config* c)
     return 0;
   }
   if (c->pde != QDG_PDE_COMPFLOW) return fail("qdg_ctx_create: unknown pde");
+  if (c->pref) {
+    if (c->ndof != 4) return fail("qdg_ctx_create: p-adaptive DG needs ndof = rdof = 4");
+    if (c->limiter == QDG_LIMITER_WENOP1) return fail("qdg_ctx_create: p-adaptive DG with WENO is not supported");
+    if (!(c->tolref >= 0.0)) return fail("qdg_ctx_create: bad tolref");
+  }
   if (c->flux != QDG_FLUX_HLLC && c->flux != QDG_FLUX_LAXFRIEDRICHS)
     return fail("qdg_ctx_create: unknown flux");
   if (c->problem < QDG_PROBLEM_USER_DEFINED || c->problem > QDG_PROBLEM_TAYLOR_GREEN)
@@ -512,6 +519,12 @@ extern "C" int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t 
   dm.ntile = ntile; dm.tile_off = m->tile_off.p; dm.task_a = m->task_a.p;
   dm.task_nb = m->task_nb.p; dm.task_f = m->task_f.p;
   dm.blk0 = 0; dm.ninner = (int)ninner; dm.ncomp = ncomp;
+  dm.ndofel = nullptr;
+  if (ctx->cfg.pref) {
+    HIPCHK(m->ndofel.alloc(ne)); HIPCHK(m->ndofel2.alloc(ne));
+    launch_fill_int(m->ndofel.p, (int)ne, 4, s);
+    dm.ndofel = m->ndofel.p;
+  }
   HIPCHK(hipStreamSynchronize(s));
   *out = m.release();
   return 0;
@@ -616,15 +629,15 @@ static int run_limiter(qdg_mesh* mesh, double*& Ucur, double* Ualt_in)
 static bool use_p1_fast(const qdg_mesh* mesh)
 {
   static const bool generic = std::getenv("QDG_GENERIC_RHS") != nullptr;
-  return mesh->ndof == 4 && mesh->dm.ncomp == NCOMP && !generic;
+  return mesh->ndof == 4 && mesh->dm.ncomp == NCOMP && (!generic || mesh->dm.ndofel);
 }
 
 // tile / face-task kernel (each in-tile face evaluated once, LDS accumulation with
 // ds_add_f64) unless bitwise run-to-run reproducibility is requested
-static bool use_tile(const qdg_mesh*)
+static bool use_tile(const qdg_mesh* mesh)
 {
   static const bool det = std::getenv("QDG_DETERMINISTIC_RHS") != nullptr;
-  return !det;
+  return !det || mesh->dm.ndofel;      // p-adaptive DG exists in the tile kernel only
 }
 
 static void run_rhs(qdg_mesh* mesh, double t, const double* U, double* R)
@@ -752,6 +765,7 @@ extern "C" int qdg_state_initialize(qdg_mesh* mesh, double t)
   QDG_TRY
   MESH_ENTER("qdg_state_initialize");
   launch_init(mesh->ndof, mesh->dm, ctx->ph, t, mesh->Ucur, s);
+  if (mesh->dm.ndofel) launch_fill_int(mesh->ndofel.p, (int)mesh->ne, mesh->ndof, s);   // DG.cpp:927
   HIPCHK(hipGetLastError());
   return 0;
   QDG_CATCH
@@ -963,6 +977,61 @@ extern "C" int qdg_stage_update(qdg_mesh* mesh, int stage)
   QDG_CATCH
 }
 
+// ---------------------------------------------------------------- p-adaptive DG
+
+extern "C" int qdg_stage_pdg(qdg_mesh* mesh)
+{
+  QDG_TRY
+  MESH_ENTER("qdg_stage_pdg");
+  if (!mesh->dm.ndofel) return fail("qdg_stage_pdg: the context was not created with pref");
+  if (mesh->nnbr != 0) return fail("qdg_stage_pdg: partitioned meshes are not supported yet");
+  launch_pdg_eval(mesh->dm, mesh->Ucur, ctx->cfg.tolref, mesh->ndofel.p, s);        // DG::next
+  launch_pdg_propagate(mesh->dm, mesh->ndofel.p, mesh->ndofel2.p, s);               // DG::lim
+  HIPCHK(hipMemcpyAsync(mesh->ndofel.p, mesh->ndofel2.p, mesh->ne * sizeof(int),
+                        hipMemcpyDeviceToDevice, s));
+  launch_pdg_zero(mesh->dm, mesh->ndofel.p, mesh->Ucur, s);                          // DG::solve
+  HIPCHK(hipGetLastError());
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_ndofel_get(qdg_mesh* mesh, size_t* ndofel)
+{
+  QDG_TRY
+  MESH_ENTER("qdg_ndofel_get");
+  if (!ndofel) return fail("qdg_ndofel_get: null argument");
+  if (!mesh->dm.ndofel) {
+    for (size_t e = 0; e < mesh->ne; ++e) ndofel[e] = (size_t)mesh->ndof;
+    return 0;
+  }
+  std::vector<int> nd(mesh->ne), d2h(mesh->ne);
+  HIPCHK(hipMemcpyAsync(nd.data(), mesh->ndofel.p, mesh->ne * sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(d2h.data(), mesh->d2h.p, mesh->ne * sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  for (size_t d = 0; d < mesh->ne; ++d) ndofel[d2h[d]] = (size_t)nd[d];
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_ndofel_set(qdg_mesh* mesh, const size_t* ndofel)
+{
+  QDG_TRY
+  MESH_ENTER("qdg_ndofel_set");
+  if (!ndofel) return fail("qdg_ndofel_set: null argument");
+  if (!mesh->dm.ndofel) return fail("qdg_ndofel_set: the context was not created with pref");
+  std::vector<int> nd(mesh->ne), d2h(mesh->ne);
+  HIPCHK(hipMemcpy(d2h.data(), mesh->d2h.p, mesh->ne * sizeof(int), hipMemcpyDeviceToHost));
+  for (size_t d = 0; d < mesh->ne; ++d) {
+    const size_t v = ndofel[d2h[d]];
+    if (v != 1 && v != 4) return fail("qdg_ndofel_set: entries must be 1 or 4");
+    nd[d] = (int)v;
+  }
+  HIPCHK(hipMemcpyAsync(mesh->ndofel.p, nd.data(), mesh->ne * sizeof(int), hipMemcpyHostToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return 0;
+  QDG_CATCH
+}
+
 extern "C" int qdg_step(qdg_mesh* mesh, double t, double tleft, double* dt_taken)
 {
   QDG_TRY
@@ -971,6 +1040,7 @@ extern "C" int qdg_step(qdg_mesh* mesh, double t, double tleft, double* dt_taken
     return fail("qdg_step: this chunk has halo neighbours; drive the stages and the exchange "
                 "explicitly (qdg_stage_* + qdg_halo_*)");
   for (int stage = 0; stage < 3; ++stage) {
+    if (stage == 0 && mesh->dm.ndofel) if (int rc = qdg_stage_pdg(mesh)) return rc;
     if (int rc = qdg_stage_limit(mesh)) return rc;
     if (int rc = qdg_stage_rhs_dt(mesh, stage, t, tleft)) return rc;
     if (int rc = qdg_stage_update(mesh, stage)) return rc;
@@ -1266,6 +1336,9 @@ extern "C" int qdg_step_comm(qdg_mesh* mesh, qdg_comm* comm, double t, double tl
   QDG_TRY
   MESH_ENTER("qdg_step_comm");
   if (!comm) return fail("qdg_step_comm: null communicator");
+  if (mesh->dm.ndofel)
+    return fail("qdg_step_comm: p-adaptive DG on a partitioned mesh is not supported yet "
+                "(the ghosts' ndof would have to travel with comsol/comlim, DG.cpp:1032,1275)");
   const bool limited = ctx->cfg.limiter != QDG_LIMITER_NONE && mesh->ndof > 1;
   const bool overlap = can_overlap(mesh);
   hipStream_t cs = comm->cs;

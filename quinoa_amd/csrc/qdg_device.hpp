@@ -74,6 +74,8 @@ struct DevMesh {
   int blk0;
   int ninner;
   int ncomp;        // 5: CompFlow, 1: scalar Transport (rows of ncomp*ndof doubles)
+  // p-adaptive DG (scheme pdg): DG::m_ndof per device row, 1 or 4; null otherwise
+  const int* ndofel;
 };
 
 #ifndef QDG_TILE

@@ -968,7 +968,14 @@ __device__ __forceinline__ void vertex_basis(int v, double& b1, double& b2, doub
   b3 = (v == 3) ? 3.0 : -1.0;
 }
 
-template <bool WITH_DT, bool FUSE_RK, int PROB>
+// PDG (p-adaptive DG, scheme pdg): a tet with m.ndofel == 1 is a P0 element --
+// its state is its mean (Surface.cpp:146-156), only its mean is updated
+// (update_rhs_fa, Surface.cpp:234-271), it has no volume term (Volume.cpp:56)
+// and its source integral uses the 1-point rule (Source.cpp:54).  The face
+// quadrature keeps 3 points where the reference takes max(ng_l, ng_r)
+// (Surface.cpp:81-86): between two P0 tets both states are constant, so the 1-
+// and the 3-point sums agree to rounding.
+template <bool WITH_DT, bool FUSE_RK, int PROB, bool PDG>
 __global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1t(DevMesh m, Phys ph, double t,
                                                      const double* __restrict__ U,
                                                      double* __restrict__ R,
@@ -1012,6 +1019,12 @@ __global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1t(DevMesh m, Phys ph, doub
 #pragma unroll
       for (int c = 0; c < NCOMP; ++c) { r[c][0] = 1.0; r[c][1] = r[c][2] = r[c][3] = 0.0; }
     }
+    if constexpr (PDG) {
+      if (tid < nloc && m.ndofel[tile_e0 + tid] == 1) {
+#pragma unroll
+        for (int c = 0; c < NCOMP; ++c) r[c][1] = r[c][2] = r[c][3] = 0.0;
+      }
+    }
     double2* dn = reinterpret_cast<double2*>(nod + (size_t)tid * NPROP);
     double2* da = reinterpret_cast<double2*>(accN + (size_t)tid * NPROP);
     double v[4][NCOMP];
@@ -1030,9 +1043,13 @@ __global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1t(DevMesh m, Phys ph, doub
     if (WITH_DT) sdelt[tid] = 0.0;
   }
   double gnx[4], rnx[NCOMP][NDOF];
+  int ndnx = 4;                      // PDG: ndofel of the external neighbour
   if (ta[0] >= 0) {
     load_row<4>(m.fgeo, tf[0], gnx);
-    if (((ta[0] >> 17) & 3) == TASK_EXT) load_row<NPROP>(U, tn[0], &rnx[0][0]);
+    if (((ta[0] >> 17) & 3) == TASK_EXT) {
+      load_row<NPROP>(U, tn[0], &rnx[0][0]);
+      if constexpr (PDG) ndnx = m.ndofel[tn[0]];
+    }
   }
   __syncthreads();
 
@@ -1053,6 +1070,12 @@ __global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1t(DevMesh m, Phys ph, doub
     for (int c = 0; c < NCOMP; ++c)
 #pragma unroll
       for (int k = 0; k < NDOF; ++k) rex[c][k] = rnx[c][k];
+    if constexpr (PDG) {
+      if (ndnx == 1) {
+#pragma unroll
+        for (int c = 0; c < NCOMP; ++c) rex[c][1] = rex[c][2] = rex[c][3] = 0.0;
+      }
+    }
     {
       // prefetch the next task of this lane
       const int an = (q == 0) ? ta[1] : (q == 1) ? ta[2] : (q == 2) ? ta[3] : -1;
@@ -1060,7 +1083,10 @@ __global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1t(DevMesh m, Phys ph, doub
       const int nq = (q == 0) ? tn[1] : (q == 1) ? tn[2] : tn[3];
       if (an >= 0) {
         load_row<4>(m.fgeo, fq, gnx);
-        if (((an >> 17) & 3) == TASK_EXT) load_row<NPROP>(U, nq, &rnx[0][0]);
+        if (((an >> 17) & 3) == TASK_EXT) {
+          load_row<NPROP>(U, nq, &rnx[0][0]);
+          if constexpr (PDG) ndnx = m.ndofel[nq];
+        }
       }
     }
     const bool bnd = kind == TASK_BND;
@@ -1181,12 +1207,14 @@ __global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1t(DevMesh m, Phys ph, doub
   // other waves' last tasks)
   double u[NCOMP][NDOF], un[NCOMP][NDOF];
   double vol = 1.0;
+  bool p0 = false;                   // PDG: this tet is a P0 element
   ElemGeom g;
   if (tid < nloc) {
     const int e = tile_e0 + tid;
     const int stride = m.stride;
     load_row<NPROP>(U, e, &u[0][0]);          // modal row again (L1/L2 hit)
     if (FUSE_RK) load_row<NPROP>(Un, e, &un[0][0]);
+    if constexpr (PDG) p0 = m.ndofel[e] == 1;
     vol = m.vol[e];
     const int n0 = m.inpoel[e], n1 = m.inpoel[(size_t)stride + e], n2 = m.inpoel[(size_t)2 * stride + e],
               n3 = m.inpoel[(size_t)3 * stride + e];
@@ -1213,6 +1241,12 @@ __global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1t(DevMesh m, Phys ph, doub
         acc[c][1] = nv[1][c] - nv[0][c];
         acc[c][2] = 2.0 * nv[2][c] - nv[0][c] - nv[1][c];
         acc[c][3] = 3.0 * nv[3][c] - nv[0][c] - nv[1][c] - nv[2][c];
+      }
+    }
+    if constexpr (PDG) {
+      if (p0) {
+#pragma unroll
+        for (int c = 0; c < NCOMP; ++c) u[c][1] = u[c][2] = u[c][3] = 0.0;
       }
     }
     {
@@ -1246,23 +1280,34 @@ __global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1t(DevMesh m, Phys ph, doub
         for (int c = 0; c < NCOMP; ++c) acc[c][k] += Fs[c][0] * dx + Fs[c][1] * dy + Fs[c][2] * dz;
       }
     }
+    if constexpr (PDG) {
+      if (p0) {                        // no high-order update of a P0 element
+#pragma unroll
+        for (int c = 0; c < NCOMP; ++c) acc[c][1] = acc[c][2] = acc[c][3] = 0.0;
+      }
+    }
     if constexpr (prob_has_source<PROB>()) {
+      const int ngs = (PDG && p0) ? 1 : NGV;     // Source.cpp:54: NGvol(ndofel[e])
 #pragma unroll 1
-      for (int ig = 0; ig < NGV; ++ig) {
-        const double xi = T.vc[ig][0], eta = T.vc[ig][1], zeta = T.vc[ig][2];
+      for (int ig = 0; ig < ngs; ++ig) {
+        const bool one = PDG && p0;
+        const double xi = one ? 0.25 : T.vc[ig][0], eta = one ? 0.25 : T.vc[ig][1],
+                     zeta = one ? 0.25 : T.vc[ig][2];
         const double w0 = 1.0 - xi - eta - zeta;
         double P[3], s[NCOMP];
 #pragma unroll
         for (int d = 0; d < 3; ++d)
           P[d] = g.p[0][d] * w0 + g.p[1][d] * xi + g.p[2][d] * eta + g.p[3][d] * zeta;
         prob_src<PROB>(ph, P[0], P[1], P[2], t, s);
-        const double wt = T.vw[ig] * vol;
+        const double wt = (one ? 1.0 : T.vw[ig]) * vol;
 #pragma unroll
         for (int c = 0; c < NCOMP; ++c) {
           const double ws = wt * s[c];
           acc[c][0] += ws;
+          if (!one) {
 #pragma unroll
-          for (int k = 1; k < NDOF; ++k) acc[c][k] += ws * T.vB[ig][k];
+            for (int k = 1; k < NDOF; ++k) acc[c][k] += ws * T.vB[ig][k];
+          }
         }
       }
     }
@@ -1355,6 +1400,10 @@ __global__ __launch_bounds__(256) void k_superbee(DevMesh m, double* __restrict_
           phi[c] = fmin(phi[c], pg);
         }
       }
+    if (m.ndofel && m.ndofel[e] == 1) {    // pdg: P0 elements are not limited (Limiter.cpp:179-180)
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) phi[c] = 1.0;
+    }
 #pragma unroll
     for (int c = 0; c < NCOMP; ++c)
 #pragma unroll
@@ -1614,7 +1663,10 @@ __global__ __launch_bounds__(256) void k_diag(DevMesh m, Phys ph, double t_new,
 #pragma unroll
   for (int i = 0; i < 15; ++i) v[i] = 0.0;
   if (e < m.nie) {
-    const QuadTet& Q = c_qdiag[order_index<NDOF>()];
+    // pdg: NGdiag(ndofel[e]) points and the element's own number of modes
+    // (ElemDiagnostics.cpp:144,171,186)
+    const bool p0 = NDOF > 1 && m.ndofel && m.ndofel[e] == 1;
+    const QuadTet& Q = p0 ? c_qdiag[0] : c_qdiag[order_index<NDOF>()];
     ElemGeom g;
     load_geom(m, e, g);
     const double vol = m.vol[e];
@@ -1627,6 +1679,10 @@ __global__ __launch_bounds__(256) void k_diag(DevMesh m, Phys ph, double t_new,
       for (int d = 0; d < 3; ++d)
         P[d] = g.p[0][d] * w0 + g.p[1][d] * xi + g.p[2][d] * eta + g.p[3][d] * zeta;
       eval_basis<NDOF>(xi, eta, zeta, B);
+      if (p0) {
+#pragma unroll
+        for (int k = 1; k < NDOF; ++k) B[k] = 0.0;
+      }
       prob_solution<PROB>(ph, P[0], P[1], P[2], t_new, s);
       state_gather<NDOF>(U, m.stride, e, B, u);
       const double wt = Q.w[ig] * vol;
@@ -1652,6 +1708,68 @@ __global__ void k_diag_final(const double* __restrict__ part, int nblk, double* 
     r = (i < 10) ? r + y : fmax(r, y);
   }
   out[i] = r;
+}
+
+// ================================================================ p-adaptive DG
+// DG::eval_ndof (src/Inciter/DG.cpp:1088-1163): a P1 tet stays P1 when the
+// physical gradient of any conserved variable exceeds tolref, else becomes P0
+__global__ __launch_bounds__(256) void k_eval_ndof(DevMesh m, const double* __restrict__ U,
+                                                   double tolref, int* __restrict__ ndofel)
+{
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= m.nie) return;
+  if (ndofel[e] != 4) return;
+  ElemGeom g;
+  load_geom(m, e, g);
+  double ji[3][3], u[NCOMP][4];
+  inverse_jacobian(g, ji);
+  load_row<NCOMP * 4>(U, e, &u[0][0]);
+  int sign = 0;
+#pragma unroll
+  for (int c = 0; c < NCOMP; ++c) {
+    const double d0 = 2 * u[c][1], d1 = u[c][1] + 3.0 * u[c][2], d2 = u[c][1] + u[c][2] + 4.0 * u[c][3];
+    const double gx = d0 * ji[0][0] + d1 * ji[1][0] + d2 * ji[2][0];
+    const double gy = d0 * ji[0][1] + d1 * ji[1][1] + d2 * ji[2][1];
+    const double gz = d0 * ji[0][2] + d1 * ji[1][2] + d2 * ji[2][2];
+    if (sqrt(gx * gx + gy * gy + gz * gz) > tolref) ++sign;
+  }
+  ndofel[e] = sign > 0 ? 4 : 1;
+}
+
+// DG::propagate_ndof (DG.cpp:1284-1313), Jacobi: face neighbours of a P1 tet
+// become P1.  Ghost entries (rows >= nie) are the owners' values and are copied.
+__global__ __launch_bounds__(256) void k_propagate_ndof(DevMesh m, const int* __restrict__ in,
+                                                        int* __restrict__ out)
+{
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= m.ne) return;
+  int v = in[e];
+  if (e < m.nie && v != 4) {
+#pragma unroll
+    for (int lf = 0; lf < 4; ++lf) {
+      const int nb = m.nbr[(size_t)lf * m.stride + e];
+      if (nb >= 0 && in[nb] == 4) v = 4;
+    }
+  }
+  out[e] = v;
+}
+
+// DG::solve (DG.cpp:1451-1469): high-order DOFs of P0 tets are zeroed at stage 0
+__global__ __launch_bounds__(256) void k_pdg_zero(DevMesh m, const int* __restrict__ ndofel,
+                                                  double* __restrict__ U)
+{
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= m.ne || ndofel[e] != 1) return;
+#pragma unroll
+  for (int c = 0; c < NCOMP; ++c)
+#pragma unroll
+    for (int k = 1; k < 4; ++k) U[(size_t)e * (NCOMP * 4) + c * 4 + k] = 0.0;
+}
+
+__global__ void k_fill_int(int* __restrict__ p, int n, int v)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
 }
 
 // ================================================================ scalar transport
@@ -1965,6 +2083,12 @@ __global__ void k_halo_unpack(const double* __restrict__ slab, int nprop, int ni
 
 // ================================================================ launchers
 
+#define QDG_DISPATCH_PDG(m, CALL)                              \
+  do {                                                         \
+    if ((m).ndofel) { constexpr bool G = true; CALL; }         \
+    else { constexpr bool G = false; CALL; }                   \
+  } while (0)
+
 #define QDG_DISPATCH_NDOF(ndof, CALL)          \
   do {                                          \
     if ((ndof) == 1) { constexpr int N = 1; CALL; }       \
@@ -2048,9 +2172,9 @@ void launch_rhs_p1t(const DevMesh& m0, const Phys& ph, double t, const double* U
   const int nb = count < 0 ? m.ntile - first : count;
   if (nb > 0) {
     if (with_dt) {
-      QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1t<true, false, P><<<nb, TILE_BS, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr)));
+      QDG_DISPATCH_PDG(m, QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1t<true, false, P, G><<<nb, TILE_BS, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr))));
     } else {
-      QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1t<false, false, P><<<nb, TILE_BS, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr)));
+      QDG_DISPATCH_PDG(m, QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1t<false, false, P, G><<<nb, TILE_BS, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr))));
     }
   }
   if (with_dt && first + nb == m.ntile)
@@ -2066,7 +2190,7 @@ void launch_rhs_p1t_rk(const DevMesh& m0, const Phys& ph, double t, const double
   m.blk0 = first;
   const int nb = count < 0 ? m.ntile - first : count;
   if (nb <= 0) return;
-  QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1t<false, true, P><<<nb, TILE_BS, 0, s>>>(m, ph, t, U, Uout, nullptr, a, b, dt, Un)));
+  QDG_DISPATCH_PDG(m, QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1t<false, true, P, G><<<nb, TILE_BS, 0, s>>>(m, ph, t, U, Uout, nullptr, a, b, dt, Un))));
 }
 
 // P1 RHS with the SSP-RK3 update fused in: Uout = a*Un + b*(U + dt*R/L)
@@ -2186,6 +2310,27 @@ void launch_halo_unpack(const double* slab, int nprop, int /*stride*/, int nie, 
   if (nrecv == 0) return;
   const size_t n = (size_t)nrecv * nprop;
   k_halo_unpack<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(slab, nprop, nie, nrecv, U);
+}
+
+// p-adaptive DG: eval_ndof + propagate_ndof + zeroing (stage 0); ndofel/tmp are [ne] ints
+void launch_pdg_eval(const DevMesh& m, const double* U, double tolref, int* ndofel, hipStream_t s)
+{
+  if (m.nie == 0) return;
+  k_eval_ndof<<<nblk(m.nie, 256), 256, 0, s>>>(m, U, tolref, ndofel);
+}
+void launch_pdg_propagate(const DevMesh& m, const int* in, int* out, hipStream_t s)
+{
+  if (m.ne == 0) return;
+  k_propagate_ndof<<<nblk(m.ne, 256), 256, 0, s>>>(m, in, out);
+}
+void launch_pdg_zero(const DevMesh& m, const int* ndofel, double* U, hipStream_t s)
+{
+  if (m.ne == 0) return;
+  k_pdg_zero<<<nblk(m.ne, 256), 256, 0, s>>>(m, ndofel, U);
+}
+void launch_fill_int(int* p, int n, int v, hipStream_t s)
+{
+  if (n > 0) k_fill_int<<<nblk(n, 256), 256, 0, s>>>(p, n, v);
 }
 
 }  // namespace qdg

@@ -47,4 +47,10 @@ void launch_halo_pack(const double* U, int nprop, int stride, const int* send_el
 void launch_halo_unpack(const double* slab, int nprop, int stride, int nie, int nrecv, double* U,
                         hipStream_t s);
 
+// p-adaptive DG (DG::eval_ndof, propagate_ndof, zeroing of P0 high-order DOFs)
+void launch_pdg_eval(const DevMesh& m, const double* U, double tolref, int* ndofel, hipStream_t s);
+void launch_pdg_propagate(const DevMesh& m, const int* in, int* out, hipStream_t s);
+void launch_pdg_zero(const DevMesh& m, const int* ndofel, double* U, hipStream_t s);
+void launch_fill_int(int* p, int n, int v, hipStream_t s);
+
 }  // namespace qdg

@@ -26,17 +26,19 @@ def _setup(case, fix, dt=None, cfl=None):
                        p0=case.get("p0", 0.0), cfl=case["cfl"] if cfl is None else cfl,
                        dt=case["dt"] if dt is None else dt,
                        bc_dirichlet=case["bc_dirichlet"], bc_sym=case["bc_sym"],
-                       bc_extrapolate=case["bc_extrapolate"])
+                       bc_extrapolate=case["bc_extrapolate"],
+                       pref=case.get("pref", False), tolref=case.get("tolref", 0.1))
     mesh = dgmesh.upload(ctx, chunk)
     om = O.OracleMesh(fix["coord"], fix["inpoel"], ss)
     cfg = O.make_cfg(case["ndof"], flux=case["flux"], limiter=case["limiter"],
                      problem=case["problem"], gamma=case["gamma"], alpha=case.get("alpha", 0.0),
                      beta=case.get("beta", 0.0), p0=case.get("p0", 0.0))
-    orc = O.Oracle(om, cfg, case["bc_dirichlet"], case["bc_sym"], case["bc_extrapolate"])
+    orc = O.Oracle(om, cfg, case["bc_dirichlet"], case["bc_sym"], case["bc_extrapolate"],
+                   pref=case.get("pref", False), tolref=case.get("tolref", 0.1))
     return ctx, mesh, chunk, orc
 
 
-CASES = ["sod_dg", "sedov_dgp1", "vortical_flow_dg", "vortical_flow_dg_lf",
+CASES = ["sod_dg", "sedov_dgp1", "sedov_pdg", "vortical_flow_dg", "vortical_flow_dg_lf",
          "vortical_flow_dgp1", "vortical_flow_dgp1_lf", "taylor_green_dgp2",
          "taylor_green_dgp2_cfl"]
 
@@ -57,6 +59,11 @@ def test_operators_match_oracle(name, cases):
         U, t = U0.copy(), 0.0
         for _ in range(3):
             t += orc.step(t, U, Lm, fixed_dt=case["dt"], cfl=case["cfl"])
+        if case.get("pref"):
+            # p-adaptive: the stateless operators use the mesh handle's ndofel
+            assert 0 < (orc.ndofel == 1).sum() < len(orc.ndofel)
+            mesh.ndofel_set(orc.ndofel)
+            assert np.array_equal(mesh.ndofel_get(), orc.ndofel)
         R = orc.rhs(t, U)
         Rg = mesh.rhs(t, U)
         assert np.abs(Rg - R).max() <= 1e-11 * max(1.0, np.abs(R).max()), name
@@ -95,6 +102,8 @@ def test_time_stepping_matches_reference_golden(name, cases):
         err = (np.abs(np.array(fields)[:, :nvar] - gold) / scale).max()
         assert err <= TOL, (name, err)
         assert np.allclose(times, fix["exo_times"], rtol=1e-12, atol=1e-15)
+        if case.get("pref"):     # the reference's per-element ndof at the last output time
+            assert np.array_equal(mesh.ndofel_get(), fix["exo_vals"][-1, 6].astype(np.int64))
         g = {int(r[0]): r for r in fix["diag"]}
         for r in rows:
             for a, b in zip(r[1:13], g[int(r[0])][1:13]):
@@ -238,5 +247,29 @@ def test_tile_kernel_run_to_run_spread_is_rounding_only(cases):
             t += orc.step(t, U, orc.lhs(), cfl=case["cfl"])
         R1, R2 = mesh.rhs(t, U), mesh.rhs(t, U)
         assert np.abs(R1 - R2).max() <= 1e-13 * np.abs(R1).max()
+    finally:
+        mesh.close(); ctx.close()
+
+
+def test_pdg_full_dof_vector_and_ndof_match_oracle(cases):
+    """p-adaptive DG (scheme pdg): every step's dt, the per-element ndof and
+    all DOFs against the oracle."""
+    name = "sedov_pdg"
+    case, fix = cases[name], load_fixture(name)
+    ctx, mesh, chunk, orc = _setup(case, fix)
+    try:
+        mesh.state_initialize(0.0)
+        Lm = orc.lhs(); U = orc.initialize(Lm, 0.0)
+        t = 0.0
+        for it in range(case["nstep"]):
+            dtg = mesh.step(t)
+            dto = orc.step(t, U, Lm, cfl=case["cfl"])
+            assert abs(dtg - dto) <= 1e-11 * dto, it
+            assert np.array_equal(mesh.ndofel_get(), orc.ndofel), it
+            t += dto
+        Ug = mesh.state_download()
+        err = np.abs(Ug - U).max() / max(1.0, np.abs(U).max())
+        assert err <= TOL, err
+        assert (orc.ndofel == 1).sum() > 0 and (orc.ndofel == 4).sum() > 0
     finally:
         mesh.close(); ctx.close()
