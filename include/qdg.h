@@ -169,6 +169,11 @@ int qdg_stage_update(qdg_mesh* mesh, int stage);
  * of P0 elements (:1451-1469); call it before qdg_stage_limit of stage 0
  * (qdg_step does).  get/set: nunk entries in the caller's element numbering. */
 int qdg_stage_pdg(qdg_mesh* mesh);
+/* partitioned mesh: eval (DG::next) -> exchange ghosts (the slab rows carry the
+ * tets' ndof as one more column, like comsol/comlim DG.cpp:1032,1275) ->
+ * propagate + zeroing (DG::lim, DG::solve) */
+int qdg_stage_pdg_eval(qdg_mesh* mesh);
+int qdg_stage_pdg_propagate(qdg_mesh* mesh);
 int qdg_ndofel_get(qdg_mesh* mesh, size_t* ndofel);
 int qdg_ndofel_set(qdg_mesh* mesh, const size_t* ndofel);
 /* whole step on one chunk without ghosts: 3 x (limit, [dt], rhs, update);
@@ -184,7 +189,9 @@ int qdg_state_device_ptr(qdg_mesh* mesh, void** dptr, size_t* stride);
  * order the receiver stores its ghosts), recv ranges are contiguous ghost
  * rows.  Buffers are device memory owned by the mesh handle, one contiguous
  * slab per direction, element-major rows of nprop doubles (like the
- * reference's comsol payload u[j] = m_u[tet]). */
+ * reference's comsol payload u[j] = m_u[tet]); with p-adaptive DG (cfg.pref)
+ * nprop + 1 doubles, the last one the tet's ndof; qdg_halo_buffers reports
+ * the row size. */
 int qdg_halo_setup(qdg_mesh* mesh, size_t nnbr, const int32_t* nbr_rank,
                    const size_t* send_off, const size_t* send_elem,
                    const size_t* recv_off);

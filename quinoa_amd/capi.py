@@ -275,6 +275,12 @@ class Mesh:
     def stage_pdg(self):
         _chk(lib().qdg_stage_pdg(self.h))
 
+    def stage_pdg_eval(self):
+        _chk(lib().qdg_stage_pdg_eval(self.h))
+
+    def stage_pdg_propagate(self):
+        _chk(lib().qdg_stage_pdg_propagate(self.h))
+
     def ndofel_get(self):
         a = np.zeros(self.nunk, dtype=np.uint64)
         _chk(lib().qdg_ndofel_get(self.h, a.ctypes.data_as(c_szp)))

@@ -979,19 +979,40 @@ extern "C" int qdg_stage_update(qdg_mesh* mesh, int stage)
 
 // ---------------------------------------------------------------- p-adaptive DG
 
-extern "C" int qdg_stage_pdg(qdg_mesh* mesh)
+extern "C" int qdg_stage_pdg_eval(qdg_mesh* mesh)
 {
   QDG_TRY
-  MESH_ENTER("qdg_stage_pdg");
-  if (!mesh->dm.ndofel) return fail("qdg_stage_pdg: the context was not created with pref");
-  if (mesh->nnbr != 0) return fail("qdg_stage_pdg: partitioned meshes are not supported yet");
+  MESH_ENTER("qdg_stage_pdg_eval");
+  if (!mesh->dm.ndofel) return fail("qdg_stage_pdg_eval: the context was not created with pref");
   launch_pdg_eval(mesh->dm, mesh->Ucur, ctx->cfg.tolref, mesh->ndofel.p, s);        // DG::next
+  HIPCHK(hipGetLastError());
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_stage_pdg_propagate(qdg_mesh* mesh)
+{
+  QDG_TRY
+  MESH_ENTER("qdg_stage_pdg_propagate");
+  if (!mesh->dm.ndofel) return fail("qdg_stage_pdg_propagate: the context was not created with pref");
   launch_pdg_propagate(mesh->dm, mesh->ndofel.p, mesh->ndofel2.p, s);               // DG::lim
   HIPCHK(hipMemcpyAsync(mesh->ndofel.p, mesh->ndofel2.p, mesh->ne * sizeof(int),
                         hipMemcpyDeviceToDevice, s));
   launch_pdg_zero(mesh->dm, mesh->ndofel.p, mesh->Ucur, s);                          // DG::solve
   HIPCHK(hipGetLastError());
   return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_stage_pdg(qdg_mesh* mesh)
+{
+  QDG_TRY
+  if (!mesh) return fail("qdg_stage_pdg: null mesh");
+  if (mesh->nnbr != 0)
+    return fail("qdg_stage_pdg: this chunk has halo neighbours; call qdg_stage_pdg_eval, exchange "
+                "the ghosts, then qdg_stage_pdg_propagate");
+  if (int rc = qdg_stage_pdg_eval(mesh)) return rc;
+  return qdg_stage_pdg_propagate(mesh);
   QDG_CATCH
 }
 
@@ -1065,6 +1086,9 @@ extern "C" int qdg_diag(qdg_mesh* mesh, double t_new, double* out15)
 
 // ---------------------------------------------------------------- halo
 
+// doubles per slab row: the row of U, plus the tet's ndof with p-adaptive DG
+static size_t slab_w(const qdg_mesh* mesh) { return (size_t)mesh->nprop + (mesh->dm.ndofel ? 1 : 0); }
+
 extern "C" int qdg_halo_setup(qdg_mesh* mesh, size_t nnbr, const int32_t* nbr_rank,
                               const size_t* send_off, const size_t* send_elem,
                               const size_t* recv_off)
@@ -1092,8 +1116,8 @@ extern "C" int qdg_halo_setup(qdg_mesh* mesh, size_t nnbr, const int32_t* nbr_ra
     se[i] = h2d[send_elem[i]];
   }
   HIPCHK(mesh->send_elem.upload(se, s));
-  HIPCHK(mesh->send_slab.alloc(std::max<size_t>(1, mesh->nsend * mesh->nprop)));
-  HIPCHK(mesh->recv_slab.alloc(std::max<size_t>(1, mesh->nrecv * mesh->nprop)));
+  HIPCHK(mesh->send_slab.alloc(std::max<size_t>(1, mesh->nsend * slab_w(mesh))));
+  HIPCHK(mesh->recv_slab.alloc(std::max<size_t>(1, mesh->nrecv * slab_w(mesh))));
   mesh->send_ptr = mesh->send_slab.p;
   mesh->recv_ptr = mesh->recv_slab.p;
   return 0;
@@ -1105,7 +1129,7 @@ extern "C" int qdg_halo_buffers(qdg_mesh* mesh, void** send_dev, void** recv_dev
   QDG_TRY
   if (!mesh || !send_dev || !recv_dev || !row_bytes) return fail("qdg_halo_buffers: null argument");
   *send_dev = mesh->send_ptr; *recv_dev = mesh->recv_ptr;
-  *row_bytes = (size_t)mesh->nprop * sizeof(double);
+  *row_bytes = slab_w(mesh) * sizeof(double);
   return 0;
   QDG_CATCH
 }
@@ -1115,7 +1139,7 @@ extern "C" int qdg_halo_pack(qdg_mesh* mesh)
   QDG_TRY
   MESH_ENTER("qdg_halo_pack");
   launch_halo_pack(mesh->Ucur, mesh->nprop, (int)mesh->stride, mesh->send_elem.p, (int)mesh->nsend,
-                   mesh->send_ptr, s);
+                   mesh->send_ptr, s, mesh->dm.ndofel);
   HIPCHK(hipGetLastError());
   return 0;
   QDG_CATCH
@@ -1126,7 +1150,7 @@ extern "C" int qdg_halo_unpack(qdg_mesh* mesh)
   QDG_TRY
   MESH_ENTER("qdg_halo_unpack");
   launch_halo_unpack(mesh->recv_ptr, mesh->nprop, (int)mesh->stride, (int)mesh->nie,
-                     (int)mesh->nrecv, mesh->Ucur, s);
+                     (int)mesh->nrecv, mesh->Ucur, s, mesh->ndofel.p);
   HIPCHK(hipGetLastError());
   return 0;
   QDG_CATCH
@@ -1280,19 +1304,26 @@ static int exchange_on(qdg_mesh* mesh, qdg_comm* comm, hipStream_t s)
     if (mesh->nbr_rank[i] < 0 || mesh->nbr_rank[i] >= comm->nranks)
       return fail("qdg_halo_exchange: neighbour rank outside the communicator");
   RcclApi* a = rccl_api();
-  const size_t np = (size_t)mesh->nprop;
+  const size_t np = (size_t)mesh->nprop, w = slab_w(mesh);
+  const bool direct = w == np;       // ghost rows are contiguous per neighbour: received in place
   launch_halo_pack(mesh->Ucur, mesh->nprop, (int)mesh->stride, mesh->send_elem.p, (int)mesh->nsend,
-                   mesh->send_ptr, s);
+                   mesh->send_ptr, s, mesh->dm.ndofel);
   HIPCHK(hipGetLastError());
   RCCLCHK(a->GroupStart());
   for (size_t i = 0; i < mesh->nnbr; ++i) {
-    const size_t ns = (mesh->send_off[i + 1] - mesh->send_off[i]) * np;
-    const size_t nr = (mesh->recv_off[i + 1] - mesh->recv_off[i]) * np;
-    if (ns) RCCLCHK(a->Send(mesh->send_ptr + mesh->send_off[i] * np, ns, ncclDouble, mesh->nbr_rank[i], comm->comm, s));
-    // ghost rows are contiguous per neighbour: received in place, no unpack pass
-    if (nr) RCCLCHK(a->Recv(mesh->Ucur + (mesh->nie + mesh->recv_off[i]) * np, nr, ncclDouble, mesh->nbr_rank[i], comm->comm, s));
+    const size_t ns = (mesh->send_off[i + 1] - mesh->send_off[i]) * w;
+    const size_t nr = (mesh->recv_off[i + 1] - mesh->recv_off[i]) * w;
+    double* dst = direct ? mesh->Ucur + (mesh->nie + mesh->recv_off[i]) * np
+                         : mesh->recv_ptr + mesh->recv_off[i] * w;
+    if (ns) RCCLCHK(a->Send(mesh->send_ptr + mesh->send_off[i] * w, ns, ncclDouble, mesh->nbr_rank[i], comm->comm, s));
+    if (nr) RCCLCHK(a->Recv(dst, nr, ncclDouble, mesh->nbr_rank[i], comm->comm, s));
   }
   RCCLCHK(a->GroupEnd());
+  if (!direct) {                     // p-adaptive DG: rows carry the ndof column
+    launch_halo_unpack(mesh->recv_ptr, mesh->nprop, (int)mesh->stride, (int)mesh->nie,
+                       (int)mesh->nrecv, mesh->Ucur, s, mesh->ndofel.p);
+    HIPCHK(hipGetLastError());
+  }
   return 0;
 }
 
@@ -1326,7 +1357,7 @@ extern "C" int qdg_stage_dt_allreduce(qdg_mesh* mesh, qdg_comm* comm)
 static bool can_overlap(const qdg_mesh* mesh)
 {
   static const bool on = std::getenv("QDG_OVERLAP") != nullptr;
-  return on && mesh->nnbr > 0 && use_p1_fast(mesh) && use_tile(mesh) &&
+  return on && mesh->nnbr > 0 && !mesh->dm.ndofel && use_p1_fast(mesh) && use_tile(mesh) &&
          mesh->ctx->cfg.limiter != QDG_LIMITER_WENOP1 && mesh->dm.ninner / TILE > 0 &&
          mesh->dm.ninner / 256 > 0;
 }
@@ -1336,17 +1367,17 @@ extern "C" int qdg_step_comm(qdg_mesh* mesh, qdg_comm* comm, double t, double tl
   QDG_TRY
   MESH_ENTER("qdg_step_comm");
   if (!comm) return fail("qdg_step_comm: null communicator");
-  if (mesh->dm.ndofel)
-    return fail("qdg_step_comm: p-adaptive DG on a partitioned mesh is not supported yet "
-                "(the ghosts' ndof would have to travel with comsol/comlim, DG.cpp:1032,1275)");
   const bool limited = ctx->cfg.limiter != QDG_LIMITER_NONE && mesh->ndof > 1;
   const bool overlap = can_overlap(mesh);
   hipStream_t cs = comm->cs;
   for (int stage = 0; stage < 3; ++stage) {
     if (!overlap) {
+      const bool pdg0 = stage == 0 && mesh->dm.ndofel;
+      if (pdg0) if (int rc = qdg_stage_pdg_eval(mesh)) return rc;          // DG::next: eval_ndof
       if (int rc = exchange_on(mesh, comm, s)) return rc;                 // DG::next -> comsol
+      if (pdg0) if (int rc = qdg_stage_pdg_propagate(mesh)) return rc;     // DG::lim: propagate_ndof
       if (int rc = qdg_stage_limit(mesh)) return rc;                       // DG::lim
-      if (limited) if (int rc = exchange_on(mesh, comm, s)) return rc;    // -> comlim
+      if (limited || pdg0) if (int rc = exchange_on(mesh, comm, s)) return rc;   // -> comlim
       if (int rc = qdg_stage_rhs_dt(mesh, stage, t, tleft)) return rc;     // DG::dt, DG::solve
       if (stage == 0) if (int rc = qdg_stage_dt_allreduce(mesh, comm)) return rc;
       if (int rc = qdg_stage_update(mesh, stage)) return rc;

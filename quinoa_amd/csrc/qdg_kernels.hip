@@ -2063,22 +2063,29 @@ __global__ void k_copy_rows(const double* __restrict__ src, double* __restrict__
 // slab row j = U[send_elem[j]] (element-major rows of nprop doubles)
 __global__ void k_halo_pack(const double* __restrict__ U, int nprop,
                             const int* __restrict__ send_elem, int nsend,
-                            double* __restrict__ slab)
+                            double* __restrict__ slab, const int* __restrict__ ndofel)
 {
+  // with p-adaptive DG the tet's ndof travels as one more column of its row
+  // (DG.cpp:1032,1275: ndof is piggy-backed on comsol / comlim)
+  const int w = nprop + (ndofel ? 1 : 0);
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (size_t)nsend * nprop) return;
-  const int j = (int)(i / nprop), p = (int)(i - (size_t)j * nprop);
-  slab[i] = U[(size_t)send_elem[j] * nprop + p];
+  if (i >= (size_t)nsend * w) return;
+  const int j = (int)(i / w), p = (int)(i - (size_t)j * w);
+  const int e = send_elem[j];
+  slab[i] = (p < nprop) ? U[(size_t)e * nprop + p] : (double)ndofel[e];
 }
 
 // DG::lim / DG::dt receive side (DG.cpp:1239-1247, 1372-1380): ghost rows
 // [nie, nie+nrecv) are contiguous, so unpacking is one contiguous copy
 __global__ void k_halo_unpack(const double* __restrict__ slab, int nprop, int nie, int nrecv,
-                              double* __restrict__ U)
+                              double* __restrict__ U, int* __restrict__ ndofel)
 {
+  const int w = nprop + (ndofel ? 1 : 0);
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (size_t)nrecv * nprop) return;
-  U[(size_t)nie * nprop + i] = slab[i];
+  if (i >= (size_t)nrecv * w) return;
+  const int j = (int)(i / w), p = (int)(i - (size_t)j * w);
+  if (p < nprop) U[(size_t)(nie + j) * nprop + p] = slab[i];
+  else ndofel[nie + j] = (int)slab[i];
 }
 
 // ================================================================ launchers
@@ -2297,19 +2304,19 @@ void launch_soa2aos(const double* soa, int nprop, const int* d2h, int n0, int n1
 }
 
 void launch_halo_pack(const double* U, int nprop, int /*stride*/, const int* send_elem, int nsend,
-                      double* slab, hipStream_t s)
+                      double* slab, hipStream_t s, const int* ndofel)
 {
   if (nsend == 0) return;
-  const size_t n = (size_t)nsend * nprop;
-  k_halo_pack<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(U, nprop, send_elem, nsend, slab);
+  const size_t n = (size_t)nsend * (nprop + (ndofel ? 1 : 0));
+  k_halo_pack<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(U, nprop, send_elem, nsend, slab, ndofel);
 }
 
 void launch_halo_unpack(const double* slab, int nprop, int /*stride*/, int nie, int nrecv, double* U,
-                        hipStream_t s)
+                        hipStream_t s, int* ndofel)
 {
   if (nrecv == 0) return;
-  const size_t n = (size_t)nrecv * nprop;
-  k_halo_unpack<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(slab, nprop, nie, nrecv, U);
+  const size_t n = (size_t)nrecv * (nprop + (ndofel ? 1 : 0));
+  k_halo_unpack<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(slab, nprop, nie, nrecv, U, ndofel);
 }
 
 // p-adaptive DG: eval_ndof + propagate_ndof + zeroing (stage 0); ndofel/tmp are [ne] ints

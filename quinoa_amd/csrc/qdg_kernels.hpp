@@ -42,10 +42,11 @@ void launch_aos2soa(const double* aos, int nprop, const int* d2h, int n0, int n1
                     double* soa, hipStream_t s);
 void launch_soa2aos(const double* soa, int nprop, const int* d2h, int n0, int n1, int stride,
                     double* aos, hipStream_t s);
+// ndofel != null (p-adaptive DG): slab rows are nprop + 1 doubles, the last one the tet's ndof
 void launch_halo_pack(const double* U, int nprop, int stride, const int* send_elem, int nsend,
-                      double* slab, hipStream_t s);
+                      double* slab, hipStream_t s, const int* ndofel = nullptr);
 void launch_halo_unpack(const double* slab, int nprop, int stride, int nie, int nrecv, double* U,
-                        hipStream_t s);
+                        hipStream_t s, int* ndofel = nullptr);
 
 // p-adaptive DG (DG::eval_ndof, propagate_ndof, zeroing of P0 high-order DOFs)
 void launch_pdg_eval(const DevMesh& m, const double* U, double tolref, int* ndofel, hipStream_t s);

@@ -49,8 +49,8 @@ class TorchComm:
         dist, torch = self.dist, self.torch
         ops, keep = [], []
         for i, q in enumerate(drv.nbr_rank):
-            s0, s1 = drv.send_off[i] * drv.nprop, drv.send_off[i + 1] * drv.nprop
-            r0, r1 = drv.recv_off[i] * drv.nprop, drv.recv_off[i + 1] * drv.nprop
+            s0, s1 = drv.send_off[i] * drv.roww, drv.send_off[i + 1] * drv.roww
+            r0, r1 = drv.recv_off[i] * drv.roww, drv.recv_off[i + 1] * drv.roww
             if self.backend == "nccl":
                 sb, rb = drv.send_slab[s0:s1], drv.recv_slab[r0:r1]
             else:
@@ -121,6 +121,7 @@ class DGDriver:
         self.ctx, self.mesh = ctx, mesh
         self.comm = comm or SerialComm()
         self.nprop = mesh.nprop
+        self.pref = bool(ctx.cfg.pref)
         self.nbr_rank = list(nbr_rank)
         self.limiter_active = ctx.cfg.limiter != 0 and ctx.ndof > 1
         self.send_slab = self.recv_slab = self.dt_buf = None
@@ -134,10 +135,12 @@ class DGDriver:
             mesh.halo_setup(self.nbr_rank, send_lists, recv_counts)
             self.send_off, self.recv_off = mesh.send_off, mesh.recv_off
             ns, nr = mesh.halo_sizes()
+            # doubles per slab row (nprop, + 1 for the tet's ndof with p-adaptive DG)
+            self.roww = mesh.halo_buffers()[2] // 8
             # torch owns the slabs and the dt scalar so that the communication
             # library sees ordinary device tensors; the kernels write into them
-            self.send_slab = torch.zeros(max(1, ns * self.nprop), dtype=torch.float64, device=dev)
-            self.recv_slab = torch.zeros(max(1, nr * self.nprop), dtype=torch.float64, device=dev)
+            self.send_slab = torch.zeros(max(1, ns * self.roww), dtype=torch.float64, device=dev)
+            self.recv_slab = torch.zeros(max(1, nr * self.roww), dtype=torch.float64, device=dev)
             self.dt_buf = torch.zeros(1, dtype=torch.float64, device=dev)
             mesh.halo_use_buffers(self.send_slab.data_ptr(), self.recv_slab.data_ptr())
             mesh.stage_dt_use_buffer(self.dt_buf.data_ptr())
@@ -157,10 +160,15 @@ class DGDriver:
             m.step_comm(self.comm.comm, t, tleft)
             return
         for stage in range(3):
-            self.exchange()                      # comsol
+            if self.pref and stage == 0:
+                m.stage_pdg_eval()               # DG::next: eval_ndof
+            self.exchange()                      # comsol (rows + ndof)
+            if self.pref and stage == 0:
+                m.stage_pdg_propagate()          # DG::lim: propagate_ndof (+ zeroing of DG::solve)
             m.stage_limit()
-            if self.limiter_active:
-                self.exchange()                  # comlim (a no-op copy without a limiter)
+            if self.limiter_active or (self.pref and stage == 0):
+                self.exchange()                  # comlim (a no-op copy without a limiter;
+                                                 # with pdg it carries the propagated ndof)
             # rhs; at stage 0 it also yields the local dt (the reference computes
             # dt first, DG.cpp:1360-1430, from the same state; R does not depend on dt)
             m.stage_rhs_dt(stage, t, tleft)

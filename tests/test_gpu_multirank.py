@@ -18,7 +18,7 @@ BC = dict(bc_sym=[3, 4, 5, 6], bc_extrapolate=[1, 2])
 NSTEP = 4
 
 
-def _run(rank, world, port, parts, out):
+def _run(rank, world, port, parts, out, pref=False):
     import torch
     import torch.distributed as dist
     from quinoa_amd import capi, dg, dgmesh, meshgen
@@ -32,7 +32,7 @@ def _run(rank, world, port, parts, out):
     try:
         ch = meshgen.kuhn_box_chunk(NX, NY, NZ, parts=parts, rank=rank)
         ck = dgmesh.build_chunk(ch["coord"], ch["inpoel"], ch["nielem"], ch["sidesets"])
-        ctx = capi.Context(4, cfl=0.3, device=0, **KW, **BC)
+        ctx = capi.Context(4, cfl=0.3, device=0, pref=pref, tolref=0.1, **KW, **BC)
         mesh = dgmesh.upload(ctx, ck)
         drv = dg.DGDriver(ctx, mesh, ch["nbr_rank"], ch["send_lists"], ch["recv_counts"], comm)
         mesh.state_initialize(0.0)
@@ -41,7 +41,8 @@ def _run(rank, world, port, parts, out):
             drv.step(t)
             t += drv.dt_taken()
         U = mesh.state_download().reshape(-1, 20)[:ck.nielem]
-        np.savez(out % rank, gid=ch["gid"][:ck.nielem], U=U, t=t)
+        np.savez(out % rank, gid=ch["gid"][:ck.nielem], U=U, t=t,
+                 ndof=mesh.ndofel_get()[:ck.nielem])
         mesh.close(); ctx.close()
     finally:
         if world > 1:
@@ -53,18 +54,26 @@ def _free_port():
     return p
 
 
-def test_two_ranks_on_one_gpu_equal_single_chunk(tmp_path):
+@pytest.mark.parametrize("pref", [False, True])
+def test_two_ranks_on_one_gpu_equal_single_chunk(tmp_path, pref):
+    """pref: p-adaptive DG -- the tets' ndof travels with the halo rows and
+    propagate_ndof crosses the chunk boundary; the ndof field must be identical."""
     import torch.multiprocessing as mp
     out1 = str(tmp_path / "single%d.npz")
     out2 = str(tmp_path / "rank%d.npz")
-    mp.spawn(_run, args=(1, 0, (1, 1, 1), out1), nprocs=1, join=True)
-    mp.spawn(_run, args=(2, _free_port(), (2, 1, 1), out2), nprocs=2, join=True)
+    mp.spawn(_run, args=(1, 0, (1, 1, 1), out1, pref), nprocs=1, join=True)
+    mp.spawn(_run, args=(2, _free_port(), (2, 1, 1), out2, pref), nprocs=2, join=True)
     s = np.load(out1 % 0)
     ref = np.zeros((NX * NY * NZ * 6, 20))
     ref[s["gid"]] = s["U"]
+    nref = np.zeros(NX * NY * NZ * 6, dtype=np.int64)
+    nref[s["gid"]] = s["ndof"]
+    if pref:
+        assert 0 < (nref == 1).sum() < nref.size      # both orders present
     n = 0
     for r in range(2):
         d = np.load(out2 % r)
+        assert np.array_equal(d["ndof"], nref[d["gid"]]), r
         assert abs(float(d["t"]) - float(s["t"])) <= 1e-12 * float(s["t"])
         err = np.abs(d["U"] - ref[d["gid"]]).max() / np.abs(ref).max()
         assert err <= 1e-10, (r, err)     # north_star: same fields as the 1-GPU run to <= 1e-10
@@ -72,12 +81,12 @@ def test_two_ranks_on_one_gpu_equal_single_chunk(tmp_path):
     assert n == ref.shape[0]
 
 
-def _self_halo_run(kind, out):
+def _self_halo_run(kind, out, pref=False):
     """chunk 0 of a 2x1x1 cut whose neighbour is this rank itself"""
     from quinoa_amd import capi, dg, dgmesh, meshgen
     ch = meshgen.kuhn_box_chunk(NX, NY, NZ, parts=(2, 1, 1), rank=0)
     ck = dgmesh.build_chunk(ch["coord"], ch["inpoel"], ch["nielem"], ch["sidesets"])
-    ctx = capi.Context(4, cfl=0.3, device=0, **KW, **BC)
+    ctx = capi.Context(4, cfl=0.3, device=0, pref=pref, tolref=0.1, **KW, **BC)
     mesh = dgmesh.upload(ctx, ck)
     if kind == "rccl_overlap":
         os.environ["QDG_OVERLAP"] = "1"          # read once per process by libqdg
@@ -90,7 +99,7 @@ def _self_halo_run(kind, out):
         drv.step(t)
         t += drv.dt_taken()
     U = mesh.state_download().reshape(-1, 20)
-    np.savez(out, U=U, t=t, nie=ck.nielem)
+    np.savez(out, U=U, t=t, nie=ck.nielem, ndof=mesh.ndofel_get())
     mesh.close()
     if kind != "copy":
         comm.close()
@@ -120,5 +129,18 @@ def test_rccl_transport_self_halo(tmp_path):
         assert err <= 1e-12, (kind, err)
 
 
-def _self_halo_run_spawn(_, kind, out):
-    _self_halo_run(kind, out)
+def _self_halo_run_spawn(_, kind, out, pref=False):
+    _self_halo_run(kind, out, pref)
+
+
+def test_rccl_transport_self_halo_pdg(tmp_path):
+    """same, p-adaptive DG: slab rows carry the ndof column through ncclSend/ncclRecv"""
+    import torch.multiprocessing as mp
+    outs = {}
+    for kind in ("copy", "rccl"):
+        outs[kind] = str(tmp_path / (kind + ".npz"))
+        mp.spawn(_self_halo_run_spawn, args=(kind, outs[kind], True), nprocs=1, join=True)
+    a, b = np.load(outs["copy"]), np.load(outs["rccl"])
+    assert np.array_equal(a["ndof"], b["ndof"]) and (a["ndof"] == 1).any() and (a["ndof"] == 4).any()
+    assert abs(float(a["t"]) - float(b["t"])) <= 1e-13 * float(a["t"])
+    assert np.abs(a["U"] - b["U"]).max() / np.abs(a["U"]).max() <= 1e-12
