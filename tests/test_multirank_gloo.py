@@ -37,7 +37,7 @@ class _CpuDriver:
     """what TorchComm needs from a driver, with host tensors"""
 
     def __init__(self, ch, nprop):
-        self.nprop = nprop
+        self.nprop = self.roww = nprop      # roww: doubles per slab row (no ndof column here)
         self.nbr_rank = ch["nbr_rank"]
         self.send_lists = ch["send_lists"]
         self.send_off = np.concatenate([[0], np.cumsum([len(s) for s in ch["send_lists"]])]).astype(np.int64)
