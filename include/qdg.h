@@ -181,6 +181,13 @@ int qdg_ndofel_set(qdg_mesh* mesh, const size_t* ndofel);
 int qdg_step(qdg_mesh* mesh, double t, double tleft, double* dt_taken);
 /* sum_e sum_g wt*u^2, wt*(u-s)^2, max|u-s| per component (15 doubles) */
 int qdg_diag(qdg_mesh* mesh, double t_new, double* out15);
+/* Problem::fieldOutput on the device, numerical fields from the cell means of the
+ * resident state (CompFlow: density, x/y/z-velocity, specific_total_energy,
+ * pressure -- SodShocktube.cpp:139-237 and siblings; Transport: the scalar):
+ * out[f*nielem + e], e in the caller's element numbering, f < qdg_field_count */
+int qdg_field_count(qdg_mesh* mesh, size_t* nfield);
+const char* qdg_field_name(qdg_mesh* mesh, size_t f);
+int qdg_field_output(qdg_mesh* mesh, double* out);
 /* device pointer/stride of the resident SoA state, for zero-copy plumbing */
 int qdg_state_device_ptr(qdg_mesh* mesh, void** dptr, size_t* stride);
 

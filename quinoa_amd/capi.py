@@ -272,6 +272,16 @@ class Mesh:
     def state_initialize(self, t=0.0):
         _chk(lib().qdg_state_initialize(self.h, C.c_double(t)))
 
+    def field_output(self):
+        """numerical output fields [nfield, nielem] and their names"""
+        n = C.c_size_t()
+        _chk(lib().qdg_field_count(self.h, C.byref(n)))
+        out = np.zeros((n.value, self.nielem))
+        _chk(lib().qdg_field_output(self.h, out.ctypes.data_as(c_f64p)))
+        lib().qdg_field_name.restype = C.c_char_p
+        lib().qdg_field_name.argtypes = [C.c_void_p, C.c_size_t]
+        return out, [lib().qdg_field_name(self.h, i).decode() for i in range(n.value)]
+
     def stage_pdg(self):
         _chk(lib().qdg_stage_pdg(self.h))
 

@@ -97,6 +97,7 @@ struct qdg_mesh {
   double* Upending = nullptr;     // output of a fused RHS+RK launch, adopted by qdg_stage_update
   DevBuf<double> S1, S2;          // scratch of the stateless operators (allocated on first use)
   DevBuf<int> ndofel, ndofel2;    // p-adaptive DG: DG::m_ndof per device row (+ Jacobi copy)
+  DevBuf<double> fout;            // field output staging (allocated on first use)
   // halo
   size_t nnbr = 0, nsend = 0, nrecv = 0;
   std::vector<int32_t> nbr_rank;
@@ -767,6 +768,40 @@ extern "C" int qdg_state_initialize(qdg_mesh* mesh, double t)
   launch_init(mesh->ndof, mesh->dm, ctx->ph, t, mesh->Ucur, s);
   if (mesh->dm.ndofel) launch_fill_int(mesh->ndofel.p, (int)mesh->ne, mesh->ndof, s);   // DG.cpp:927
   HIPCHK(hipGetLastError());
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_field_count(qdg_mesh* mesh, size_t* nfield)
+{
+  QDG_TRY
+  if (!mesh || !nfield) return fail("qdg_field_count: null argument");
+  *nfield = mesh->dm.ncomp == 1 ? 1 : 6;
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" const char* qdg_field_name(qdg_mesh* mesh, size_t f)
+{
+  static const char* cf[6] = { "density_numerical", "x-velocity_numerical", "y-velocity_numerical",
+                               "z-velocity_numerical", "specific_total_energy_numerical",
+                               "pressure_numerical" };
+  if (!mesh) return "";
+  if (mesh->dm.ncomp == 1) return f == 0 ? "c0_numerical" : "";
+  return f < 6 ? cf[f] : "";
+}
+
+extern "C" int qdg_field_output(qdg_mesh* mesh, double* out)
+{
+  QDG_TRY
+  MESH_ENTER("qdg_field_output");
+  if (!out) return fail("qdg_field_output: null out");
+  const size_t nf = mesh->dm.ncomp == 1 ? 1 : 6, n = nf * mesh->nie;
+  if (mesh->fout.n < n) HIPCHK(mesh->fout.alloc(n));
+  launch_field_output(mesh->ndof, mesh->dm, ctx->ph, mesh->Ucur, mesh->fout.p, s);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out, mesh->fout.p, n * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
   return 0;
   QDG_CATCH
 }

@@ -1710,6 +1710,26 @@ __global__ void k_diag_final(const double* __restrict__ part, int nblk, double* 
   out[i] = r;
 }
 
+// ================================================================ field output
+// Problem::fieldOutput, numerical fields from the cell means
+// (src/PDE/CompFlow/Problem/SodShocktube.cpp:160-237: density, x/y/z velocity,
+// specific total energy, pressure; Transport: the scalar's mean).  out is
+// [nfield][nie] in the CALLER's element numbering.
+__global__ __launch_bounds__(256) void k_field_output(DevMesh m, Phys ph, int ndof,
+                                                      const double* __restrict__ U,
+                                                      double* __restrict__ out)
+{
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= m.nie) return;
+  const size_t h = (size_t)m.d2h[e], n = (size_t)m.nie;
+  const double* u = U + (size_t)e * m.ncomp * ndof;
+  if (m.ncomp == 1) { out[h] = u[0]; return; }
+  const double r = u[0], vx = u[ndof] / r, vy = u[2 * ndof] / r, vz = u[3 * ndof] / r, re = u[4 * ndof];
+  out[h] = r; out[n + h] = vx; out[2 * n + h] = vy; out[3 * n + h] = vz;
+  out[4 * n + h] = re / r;
+  out[5 * n + h] = eos_pressure(ph, r, vx, vy, vz, re);
+}
+
 // ================================================================ p-adaptive DG
 // DG::eval_ndof (src/Inciter/DG.cpp:1088-1163): a P1 tet stays P1 when the
 // physical gradient of any conserved variable exceeds tolref, else becomes P0
@@ -2317,6 +2337,13 @@ void launch_halo_unpack(const double* slab, int nprop, int /*stride*/, int nie, 
   if (nrecv == 0) return;
   const size_t n = (size_t)nrecv * (nprop + (ndofel ? 1 : 0));
   k_halo_unpack<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(slab, nprop, nie, nrecv, U, ndofel);
+}
+
+void launch_field_output(int ndof, const DevMesh& m, const Phys& ph, const double* U, double* out,
+                         hipStream_t s)
+{
+  if (m.nie == 0) return;
+  k_field_output<<<nblk(m.nie, 256), 256, 0, s>>>(m, ph, ndof, U, out);
 }
 
 // p-adaptive DG: eval_ndof + propagate_ndof + zeroing (stage 0); ndofel/tmp are [ne] ints

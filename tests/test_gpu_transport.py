@@ -40,6 +40,8 @@ def test_slot_cyl_config1_matches_reference_golden_and_oracle(cases):
             t += dt
             rows.append([it + 1, t, np.sqrt(mesh.diag(t)[0] / chunk.meshvol)])
         U = mesh.state_download()
+        fo, names = mesh.field_output()
+        assert names == ["c0_numerical"] and np.array_equal(fo[0], U)
     finally:
         mesh.close(); ctx.close()
     # reference diag table (iteration, time, dt, L2(c0)): 6 printed digits
