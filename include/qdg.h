@@ -72,7 +72,9 @@ enum { QDG_PROBLEM_USER_DEFINED = 0, QDG_PROBLEM_SOD_SHOCKTUBE = 1,
        QDG_PROBLEM_SEDOV_BLASTWAVE = 2, QDG_PROBLEM_VORTICAL_FLOW = 3,
        QDG_PROBLEM_TAYLOR_GREEN = 4,
        /* Transport problem policies (src/PDE/Transport/Problem/SlotCyl.cpp:30-170) */
-       QDG_PROBLEM_SLOT_CYL = 5 };
+       QDG_PROBLEM_SLOT_CYL = 5,
+       /* more CompFlow policies (RotatedSodShocktube.cpp:28-45, NLEnergyGrowth.cpp:28-190) */
+       QDG_PROBLEM_ROTATED_SOD_SHOCKTUBE = 6, QDG_PROBLEM_NL_ENERGY_GROWTH = 7 };
 /* BC state functions (src/PDE/CompFlow/DGCompFlow.hpp:649-701) */
 enum { QDG_BC_DIRICHLET = 1, QDG_BC_SYMMETRY = 2, QDG_BC_EXTRAPOLATE = 3,
        /* Transport only (src/PDE/Transport/DGTransport.hpp:163-168, 276-352) */
@@ -103,6 +105,7 @@ typedef struct qdg_config {
   int32_t pref;              /* pref::pref: p-adaptive DG (scheme pdg; needs ndof = rdof = 4,
                                 Grammar.hpp:399-407): per-element ndof in {1,4} */
   double tolref;             /* pref::tolref (default 0.1, InputDeck.hpp:232) */
+  double betax, betay, betaz, r0, ce, kappa;   /* nl_energy_growth parameters (with alpha) */
 } qdg_config;
 
 /* flattened std::map<int, std::vector<std::size_t>> FaceData::m_bface */

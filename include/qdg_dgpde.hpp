@@ -170,6 +170,7 @@ struct InputDeck {
   real cfl = 0.0, dt = 0.0;                  // discr::cfl | dt
   real gamma = 1.4, pstiff = 0.0, cv = 717.5;
   real alpha = 0.0, beta = 0.0, p0 = 0.0;
+  real betax = 0.0, betay = 0.0, betaz = 0.0, r0 = 0.0, ce = 0.0, kappa = 0.0;   // nl_energy_growth
   std::vector<std::string> bcdir, bcsym, bcextrapolate;   // side set id strings, as parsed
   std::vector<std::string> bcinlet, bcoutlet;              // transport only (DGTransport.hpp:163-168)
   bool pref = false;                         // pref::pref (scheme pdg)
@@ -187,6 +188,8 @@ struct SodShocktube   { static int type() noexcept { return QDG_PROBLEM_SOD_SHOC
 struct SedovBlastwave { static int type() noexcept { return QDG_PROBLEM_SEDOV_BLASTWAVE; } };
 struct VorticalFlow   { static int type() noexcept { return QDG_PROBLEM_VORTICAL_FLOW; } };
 struct TaylorGreen    { static int type() noexcept { return QDG_PROBLEM_TAYLOR_GREEN; } };
+struct RotatedSodShocktube { static int type() noexcept { return QDG_PROBLEM_ROTATED_SOD_SHOCKTUBE; } };
+struct NLEnergyGrowth { static int type() noexcept { return QDG_PROBLEM_NL_ENERGY_GROWTH; } };
 // Transport (src/PDE/Transport/Physics/DGAdvection.hpp, Problem/SlotCyl.hpp)
 struct Advection { };
 struct SlotCyl        { static int type() noexcept { return QDG_PROBLEM_SLOT_CYL; } };
@@ -222,6 +225,8 @@ class DeviceDG {
     cfg.bc_sideset = m_bcset.data(); cfg.bc_type = m_bctype.data();
     cfg.gamma = deck.gamma; cfg.pstiff = deck.pstiff; cfg.cv = deck.cv; cfg.cweight = deck.cweight;
     cfg.alpha = deck.alpha; cfg.beta = deck.beta; cfg.p0 = deck.p0; cfg.cfl = deck.cfl; cfg.dt = deck.dt;
+    cfg.betax = deck.betax; cfg.betay = deck.betay; cfg.betaz = deck.betaz;
+    cfg.r0 = deck.r0; cfg.ce = deck.ce; cfg.kappa = deck.kappa;
     check(qdg_ctx_create(&cfg, &m_state->ctx));
   }
 

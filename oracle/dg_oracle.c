@@ -35,7 +35,8 @@
 enum { ORC_FLUX_HLLC = 0, ORC_FLUX_LAXFRIEDRICHS = 1 };
 enum { ORC_LIM_NONE = 0, ORC_LIM_WENOP1 = 1, ORC_LIM_SUPERBEEP1 = 2 };
 enum { ORC_PROB_USER = 0, ORC_PROB_SOD = 1, ORC_PROB_SEDOV = 2,
-       ORC_PROB_VORTICAL = 3, ORC_PROB_TAYLOR_GREEN = 4 };
+       ORC_PROB_VORTICAL = 3, ORC_PROB_TAYLOR_GREEN = 4,
+       ORC_PROB_ROTATED_SOD = 6, ORC_PROB_NLEG = 7 };
 
 typedef struct {
   int64_t ndof, rdof;    /* src/Control/Inciter/InputDeck/Grammar.hpp:378-406 */
@@ -45,7 +46,8 @@ typedef struct {
   int32_t pad_;
   double cweight;        /* InputDeck.hpp:210 */
   double gamma, pstiff, cv; /* Grammar.hpp:154-175 (pstiff 0, cv 717.5) */
-  double alpha, beta, p0;   /* vortical_flow parameters */
+  double alpha, beta, p0;   /* vortical_flow parameters (alpha: also nl_energy_growth) */
+  double betax, betay, betaz, r0, ce, kappa;   /* nl_energy_growth parameters */
 } orc_cfg;
 
 /* boundary-condition description: side sets of the mesh + configured lists */
@@ -453,11 +455,42 @@ static void euler_flux(const orc_cfg* k, const double* s, double F[5][3])
 
 /* Problem::solution -- src/PDE/CompFlow/Problem/SodShocktube.cpp:28-78,
  * SedovBlastwave.cpp:28-75, VorticalFlow.cpp:28-64, TaylorGreen.cpp:28-62 */
+/* src/Base/Vector.cpp:77-131 */
+static void rot_x(double* v, double a)
+{ const double y = cos(a) * v[1] - sin(a) * v[2], z = sin(a) * v[1] + cos(a) * v[2]; v[1] = y; v[2] = z; }
+static void rot_y(double* v, double a)
+{ const double x = cos(a) * v[0] + sin(a) * v[2], z = -sin(a) * v[0] + cos(a) * v[2]; v[0] = x; v[2] = z; }
+static void rot_z(double* v, double a)
+{ const double x = cos(a) * v[0] - sin(a) * v[1], y = sin(a) * v[0] + cos(a) * v[1]; v[0] = x; v[1] = y; }
+
+/* NLEnergyGrowth.cpp:28-60 */
+static double nleg_hx(const orc_cfg* k, double x, double y, double z)
+{ return cos(k->betax * M_PI * x) * cos(k->betay * M_PI * y) * cos(k->betaz * M_PI * z); }
+static double nleg_ec(const orc_cfg* k, double t, double h, double p)
+{ return pow(-3.0 * (k->ce + k->kappa * h * h * t), p); }
+
 static void prob_solution(const orc_cfg* k, double x, double y, double z,
                           double t, double* s)
 {
-  (void)t;
   switch (k->problem) {
+  case ORC_PROB_ROTATED_SOD: {
+    /* RotatedSodShocktube.cpp:38-44: rotate back by -45 degrees about Z, Y, X, then Sod */
+    const double a = -45.0 * M_PI / 180.0;
+    double c[3] = { x, y, z }, r, p;
+    rot_z(c, a); rot_y(c, a); rot_x(c, a);
+    if (c[0] < 0.5) { r = 1.0; p = 1.0; } else { r = 0.125; p = 0.1; }
+    s[0] = r; s[1] = r * 0.0; s[2] = r * 0.0; s[3] = r * 0.0;
+    s[4] = eos_totalenergy(k, r, 0.0, 0.0, 0.0, p);
+    break; }
+  case ORC_PROB_NLEG: {
+    /* NLEnergyGrowth.cpp:62-101 */
+    const double gx = 1.0 - x * x - y * y - z * z;
+    const double h = nleg_hx(k, x, y, z);
+    const double ft = exp(-k->alpha * t);
+    const double r = k->r0 + ft * gx;
+    s[0] = r; s[1] = 0.0; s[2] = 0.0; s[3] = 0.0;
+    s[4] = r * nleg_ec(k, t, h, -1.0 / 3.0);
+    break; }
   case ORC_PROB_SOD: {
     double r, p;
     if (x < 0.5) { r = 1.0; p = 1.0; } else { r = 0.125; p = 0.1; }
@@ -500,8 +533,31 @@ void orc_solution(const orc_cfg* k, double x, double y, double z, double t, doub
 static void prob_src(const orc_cfg* k, double x, double y, double z, double t,
                      double* r)
 {
-  (void)t;
   switch (k->problem) {
+  case ORC_PROB_NLEG: {
+    /* NLEnergyGrowth.cpp:124-190 */
+    const double a = k->alpha, bx = k->betax, by = k->betay, bz = k->betaz, g = k->gamma;
+    const double gx = 1.0 - x * x - y * y - z * z;
+    const double dg[3] = { -2.0 * x, -2.0 * y, -2.0 * z };
+    const double h = nleg_hx(k, x, y, z);
+    const double dh[3] = { -bx * M_PI * sin(bx * M_PI * x) * cos(by * M_PI * y) * cos(bz * M_PI * z),
+                           -by * M_PI * cos(bx * M_PI * x) * sin(by * M_PI * y) * cos(bz * M_PI * z),
+                           -bz * M_PI * cos(bx * M_PI * x) * cos(by * M_PI * y) * sin(bz * M_PI * z) };
+    const double ft = exp(-a * t), dfdt = -a * ft;
+    const double rho = k->r0 + ft * gx;
+    const double drdx[3] = { ft * dg[0], ft * dg[1], ft * dg[2] };
+    const double drdt = gx * dfdt;
+    const double ie = nleg_ec(k, t, h, -1.0 / 3.0);
+    const double dedx[3] = { 2.0 * pow(ie, 4.0) * k->kappa * h * dh[0] * t,
+                             2.0 * pow(ie, 4.0) * k->kappa * h * dh[1] * t,
+                             2.0 * pow(ie, 4.0) * k->kappa * h * dh[2] * t };
+    const double dedt = k->kappa * h * h * pow(ie, 4.0);
+    r[0] = drdt;
+    r[1] = (g - 1.0) * (rho * dedx[0] + ie * drdx[0]);
+    r[2] = (g - 1.0) * (rho * dedx[1] + ie * drdx[1]);
+    r[3] = (g - 1.0) * (rho * dedx[2] + ie * drdx[2]);
+    r[4] = rho * dedt + ie * drdt;
+    break; }
   case ORC_PROB_VORTICAL: {
     const double a = k->alpha, b = k->beta, g = k->gamma;
     double s[5];

@@ -20,7 +20,8 @@ _LIB = None
 FLUX = {"hllc": 0, "laxfriedrichs": 1}
 LIMITER = {"nolimiter": 0, "wenop1": 1, "superbeep1": 2}
 PROBLEM = {"user_defined": 0, "sod_shocktube": 1, "sedov_blastwave": 2,
-           "vortical_flow": 3, "taylor_green": 4}
+           "vortical_flow": 3, "taylor_green": 4, "rotated_sod_shocktube": 6,
+           "nl_energy_growth": 7}
 
 c_i64p = C.POINTER(C.c_int64)
 c_i32p = C.POINTER(C.c_int32)
@@ -33,7 +34,9 @@ class Cfg(C.Structure):
                 ("pad_", C.c_int32), ("cweight", C.c_double),
                 ("gamma", C.c_double), ("pstiff", C.c_double),
                 ("cv", C.c_double), ("alpha", C.c_double),
-                ("beta", C.c_double), ("p0", C.c_double)]
+                ("beta", C.c_double), ("p0", C.c_double),
+                ("betax", C.c_double), ("betay", C.c_double), ("betaz", C.c_double),
+                ("r0", C.c_double), ("ce", C.c_double), ("kappa", C.c_double)]
 
 
 class Bc(C.Structure):
@@ -85,11 +88,18 @@ def _p(a, t):
 
 def make_cfg(ndof, rdof=None, flux="hllc", limiter="nolimiter",
              problem="sod_shocktube", gamma=1.4, pstiff=0.0, cv=717.5,
-             cweight=1.0, alpha=0.0, beta=0.0, p0=0.0):
-    return Cfg(ndof=ndof, rdof=rdof or ndof, flux=FLUX[flux],
+             cweight=1.0, alpha=0.0, beta=0.0, p0=0.0, betax=0.0, betay=0.0, betaz=0.0,
+             r0=0.0, ce=0.0, kappa=0.0):
+    return Cfg(betax=betax, betay=betay, betaz=betaz, r0=r0, ce=ce, kappa=kappa,
+               ndof=ndof, rdof=rdof or ndof, flux=FLUX[flux],
                limiter=LIMITER[limiter], problem=PROBLEM[problem], pad_=0,
                cweight=cweight, gamma=gamma, pstiff=pstiff, cv=cv,
                alpha=alpha, beta=beta, p0=p0)
+
+
+def nleg_params(case):
+    """nl_energy_growth parameters of a tests/golden case (0 when absent)"""
+    return {k: case.get(k, 0.0) for k in ("betax", "betay", "betaz", "r0", "ce", "kappa")}
 
 
 def regen_boundary_faces(inpoel, sidesets):
@@ -359,7 +369,7 @@ def run_case(case, fix, nstep=None, on_step=None):
     cfg = make_cfg(case["ndof"], flux=case["flux"], limiter=case["limiter"],
                    problem=case["problem"], gamma=case["gamma"],
                    alpha=case.get("alpha", 0.0), beta=case.get("beta", 0.0),
-                   p0=case.get("p0", 0.0))
+                   p0=case.get("p0", 0.0), **nleg_params(case))
     orc = Oracle(mesh, cfg, case["bc_dirichlet"], case["bc_sym"], case["bc_extrapolate"],
                  pref=case.get("pref", False), tolref=case.get("tolref", 0.1))
     Lm = orc.lhs()

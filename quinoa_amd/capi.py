@@ -16,7 +16,8 @@ LIB_PATH = os.environ.get("QDG_LIB") or os.path.join(_HERE, "lib", "libqdg.so")
 FLUX = {"hllc": 0, "laxfriedrichs": 1, "upwind": 2}
 LIMITER = {"nolimiter": 0, "wenop1": 1, "superbeep1": 2}
 PROBLEM = {"user_defined": 0, "sod_shocktube": 1, "sedov_blastwave": 2,
-           "vortical_flow": 3, "taylor_green": 4, "slot_cyl": 5}
+           "vortical_flow": 3, "taylor_green": 4, "slot_cyl": 5,
+           "rotated_sod_shocktube": 6, "nl_energy_growth": 7}
 BC_DIRICHLET, BC_SYMMETRY, BC_EXTRAPOLATE, BC_INLET, BC_OUTLET = 1, 2, 3, 4, 5
 PDE = {"compflow": 0, "transport": 1}
 
@@ -37,7 +38,9 @@ class qdg_config(C.Structure):
                 ("gamma", C.c_double), ("pstiff", C.c_double), ("cv", C.c_double),
                 ("cweight", C.c_double), ("alpha", C.c_double), ("beta", C.c_double),
                 ("p0", C.c_double), ("cfl", C.c_double), ("dt", C.c_double),
-                ("pde", C.c_int32), ("pref", C.c_int32), ("tolref", C.c_double)]
+                ("pde", C.c_int32), ("pref", C.c_int32), ("tolref", C.c_double),
+                ("betax", C.c_double), ("betay", C.c_double), ("betaz", C.c_double),
+                ("r0", C.c_double), ("ce", C.c_double), ("kappa", C.c_double)]
 
 
 class qdg_bface(C.Structure):
@@ -164,7 +167,8 @@ class Context:
     def __init__(self, ndof, flux="hllc", limiter="nolimiter", problem="sod_shocktube",
                  gamma=1.4, pstiff=0.0, cv=717.5, cweight=1.0, alpha=0.0, beta=0.0, p0=0.0,
                  cfl=0.0, dt=0.0, bc_dirichlet=(), bc_sym=(), bc_extrapolate=(), device=0,
-                 pde="compflow", bc_inlet=(), bc_outlet=(), pref=False, tolref=0.1):
+                 pde="compflow", bc_inlet=(), bc_outlet=(), pref=False, tolref=0.1,
+                 betax=0.0, betay=0.0, betaz=0.0, r0=0.0, ce=0.0, kappa=0.0):
         L = lib()
         ss = list(bc_dirichlet) + list(bc_sym) + list(bc_extrapolate) + list(bc_inlet) + list(bc_outlet)
         ty = [BC_DIRICHLET] * len(bc_dirichlet) + [BC_SYMMETRY] * len(bc_sym) + \
@@ -176,7 +180,8 @@ class Context:
                               rdof=ndof, flux=FLUX[flux], limiter=LIMITER[limiter],
                               problem=PROBLEM[problem], nbc=len(ss), bc_sideset=pss, bc_type=pty,
                               gamma=gamma, pstiff=pstiff, cv=cv, cweight=cweight, alpha=alpha,
-                              beta=beta, p0=p0, cfl=cfl, dt=dt, pde=PDE[pde], pref=1 if pref else 0, tolref=tolref)
+                              beta=beta, p0=p0, cfl=cfl, dt=dt, pde=PDE[pde], pref=1 if pref else 0, tolref=tolref,
+                              betax=betax, betay=betay, betaz=betaz, r0=r0, ce=ce, kappa=kappa)
         self.h = C.c_void_p()
         _chk(L.qdg_ctx_create(C.byref(self.cfg), C.byref(self.h)))
         self.ndof = ndof

@@ -163,7 +163,8 @@ static int check_cfg(const qdg_config* c)
   }
   if (c->flux != QDG_FLUX_HLLC && c->flux != QDG_FLUX_LAXFRIEDRICHS)
     return fail("qdg_ctx_create: unknown flux");
-  if (c->problem < QDG_PROBLEM_USER_DEFINED || c->problem > QDG_PROBLEM_TAYLOR_GREEN)
+  if (c->problem < QDG_PROBLEM_USER_DEFINED || c->problem > QDG_PROBLEM_NL_ENERGY_GROWTH ||
+      c->problem == QDG_PROBLEM_SLOT_CYL)
     return fail("qdg_ctx_create: unknown problem");
   if (!(c->gamma > 1.0)) return fail("qdg_ctx_create: gamma must be > 1");
   for (int i = 0; i < c->nbc; ++i)
@@ -198,6 +199,8 @@ extern "C" int qdg_ctx_create(const qdg_config* cfg, qdg_ctx** out)
   c->device = cfg->device;
   c->ph.gamma = cfg->gamma; c->ph.pstiff = cfg->pstiff; c->ph.cweight = cfg->cweight;
   c->ph.alpha = cfg->alpha; c->ph.beta = cfg->beta; c->ph.p0 = cfg->p0;
+  c->ph.betax = cfg->betax; c->ph.betay = cfg->betay; c->ph.betaz = cfg->betaz;
+  c->ph.r0 = cfg->r0; c->ph.ce = cfg->ce; c->ph.kappa = cfg->kappa;
   c->ph.flux = cfg->flux; c->ph.problem = cfg->problem; c->ph.limiter = cfg->limiter;
   HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   c->own_stream = true;

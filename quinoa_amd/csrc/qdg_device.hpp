@@ -93,6 +93,7 @@ enum { TASK_INT = 0, TASK_EXT = 1, TASK_BND = 2 };
 struct Phys {
   double gamma, pstiff, cweight;
   double alpha, beta, p0;
+  double betax, betay, betaz, r0, ce, kappa;   // nl_energy_growth
   int flux, problem, limiter;
 };
 

@@ -313,11 +313,40 @@ __device__ __forceinline__ void riemann(const Phys& ph, const double* fn, const 
 // Problem::solution (device functor per ProblemType):
 // SodShocktube.cpp:28-78, SedovBlastwave.cpp:28-75, VorticalFlow.cpp:28-64,
 // TaylorGreen.cpp:28-62 under src/PDE/CompFlow/Problem/
+// NLEnergyGrowth.cpp:28-60
+__device__ __forceinline__ double nleg_hx(const Phys& ph, double x, double y, double z)
+{
+  const double pi = 3.14159265358979323846;
+  return cos(ph.betax * pi * x) * cos(ph.betay * pi * y) * cos(ph.betaz * pi * z);
+}
+__device__ __forceinline__ double nleg_ec(const Phys& ph, double t, double h, double p)
+{
+  return pow(-3.0 * (ph.ce + ph.kappa * h * h * t), p);
+}
+
 template <int PROB>
 __device__ __forceinline__ void prob_solution(const Phys& ph, double x, double y, double z,
-                                              double /*t*/, double* s)
+                                              double t, double* s)
 {
-  if constexpr (PROB == 1) {
+  if constexpr (PROB == 6) {
+    // RotatedSodShocktube.cpp:38-44: rotate back by -45 degrees about Z, Y, X (Vector.cpp:77-131)
+    const double a = -45.0 * 3.14159265358979323846 / 180.0, ca = cos(a), sa = sin(a);
+    double c0 = ca * x - sa * y, c1 = sa * x + ca * y, c2 = z;          // rotateZ
+    { const double n0 = ca * c0 + sa * c2, n2 = -sa * c0 + ca * c2; c0 = n0; c2 = n2; }   // rotateY
+    { const double n1 = ca * c1 - sa * c2, n2 = sa * c1 + ca * c2; c1 = n1; c2 = n2; }    // rotateX
+    (void)c1; (void)c2;
+    const bool l = c0 < 0.5;
+    const double r = l ? 1.0 : 0.125, p = l ? 1.0 : 0.1;
+    s[0] = r; s[1] = 0.0; s[2] = 0.0; s[3] = 0.0;
+    s[4] = eos_totalenergy(ph, r, 0.0, 0.0, 0.0, p);
+  } else if constexpr (PROB == 7) {
+    // NLEnergyGrowth.cpp:62-101
+    const double gx = 1.0 - x * x - y * y - z * z;
+    const double h = nleg_hx(ph, x, y, z);
+    const double r = ph.r0 + exp(-ph.alpha * t) * gx;
+    s[0] = r; s[1] = 0.0; s[2] = 0.0; s[3] = 0.0;
+    s[4] = r * nleg_ec(ph, t, h, -1.0 / 3.0);
+  } else if constexpr (PROB == 1) {
     const bool l = x < 0.5;
     const double r = l ? 1.0 : 0.125, p = l ? 1.0 : 0.1;
     s[0] = r; s[1] = 0.0; s[2] = 0.0; s[3] = 0.0;
@@ -344,12 +373,33 @@ __device__ __forceinline__ void prob_solution(const Phys& ph, double x, double y
 }
 
 // Problem::src: VorticalFlow.cpp:80-115, TaylorGreen.cpp:77-90 (zero otherwise)
-template <int PROB> constexpr bool prob_has_source() { return PROB == 3 || PROB == 4; }
+template <int PROB> constexpr bool prob_has_source() { return PROB == 3 || PROB == 4 || PROB == 7; }
 template <int PROB>
 __device__ __forceinline__ void prob_src(const Phys& ph, double x, double y, double z,
-                                         double /*t*/, double* r)
+                                         double t, double* r)
 {
-  if constexpr (PROB == 3) {
+  if constexpr (PROB == 7) {
+    // NLEnergyGrowth.cpp:124-190
+    const double pi = 3.14159265358979323846;
+    const double a = ph.alpha, bx = ph.betax, by = ph.betay, bz = ph.betaz, g = ph.gamma;
+    const double gx = 1.0 - x * x - y * y - z * z;
+    const double dg[3] = { -2.0 * x, -2.0 * y, -2.0 * z };
+    const double h = nleg_hx(ph, x, y, z);
+    const double dh[3] = { -bx * pi * sin(bx * pi * x) * cos(by * pi * y) * cos(bz * pi * z),
+                           -by * pi * cos(bx * pi * x) * sin(by * pi * y) * cos(bz * pi * z),
+                           -bz * pi * cos(bx * pi * x) * cos(by * pi * y) * sin(bz * pi * z) };
+    const double ft = exp(-a * t), dfdt = -a * ft;
+    const double rho = ph.r0 + ft * gx;
+    const double drdt = gx * dfdt;
+    const double ie = nleg_ec(ph, t, h, -1.0 / 3.0);
+    const double ie4 = pow(ie, 4.0);
+    const double dedt = ph.kappa * h * h * ie4;
+    r[0] = drdt;
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+      r[1 + d] = (g - 1.0) * (rho * (2.0 * ie4 * ph.kappa * h * dh[d] * t) + ie * (ft * dg[d]));
+    r[4] = rho * dedt + ie * drdt;
+  } else if constexpr (PROB == 3) {
     const double a = ph.alpha, b = ph.beta;
     double s[5];
     prob_solution<3>(ph, x, y, z, 0.0, s);
@@ -830,7 +880,7 @@ __global__ __launch_bounds__(256, QDG_P1_WAVES) void k_rhs_p1(DevMesh m, Phys ph
 
   // ---- faces ----------------------------------------------------------------
   double delt = 0.0;
-  constexpr bool HAS_DIRICHLET = (PROB == 3 || PROB == 4 || PROB == 0);
+  constexpr bool HAS_DIRICHLET = (PROB == 3 || PROB == 4 || PROB == 0 || PROB == 7);
 #pragma unroll 1
   for (int lf = 0; lf < 4; ++lf) {
     const int nb = (lf == 0) ? nb0 : (lf == 1) ? nb1 : (lf == 2) ? nb2 : nb3;
@@ -1054,7 +1104,7 @@ __global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1t(DevMesh m, Phys ph, doub
   __syncthreads();
 
   // ---- phase 1: one lane per face task ------------------------------------------
-  constexpr bool HAS_DIRICHLET = (PROB == 3 || PROB == 4 || PROB == 0);
+  constexpr bool HAS_DIRICHLET = (PROB == 3 || PROB == 4 || PROB == 0 || PROB == 7);
   if ((t1 - t0) > TILE_BS * MAXT) __builtin_trap();   // cannot happen: <= 4*TILE tasks per tile
 #pragma unroll 1
   for (int q = 0; q < MAXT; ++q) {
@@ -2130,6 +2180,8 @@ __global__ void k_halo_unpack(const double* __restrict__ slab, int nprop, int ni
       case 2: { constexpr int P = 2; CALL; } break;         \
       case 3: { constexpr int P = 3; CALL; } break;         \
       case 4: { constexpr int P = 4; CALL; } break;         \
+      case 6: { constexpr int P = 6; CALL; } break;         \
+      case 7: { constexpr int P = 7; CALL; } break;         \
       default: { constexpr int P = 0; CALL; } break;        \
     }                                                       \
   } while (0)

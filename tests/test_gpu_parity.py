@@ -27,18 +27,19 @@ def _setup(case, fix, dt=None, cfl=None):
                        dt=case["dt"] if dt is None else dt,
                        bc_dirichlet=case["bc_dirichlet"], bc_sym=case["bc_sym"],
                        bc_extrapolate=case["bc_extrapolate"],
-                       pref=case.get("pref", False), tolref=case.get("tolref", 0.1))
+                       pref=case.get("pref", False), tolref=case.get("tolref", 0.1),
+                       **O.nleg_params(case))
     mesh = dgmesh.upload(ctx, chunk)
     om = O.OracleMesh(fix["coord"], fix["inpoel"], ss)
     cfg = O.make_cfg(case["ndof"], flux=case["flux"], limiter=case["limiter"],
                      problem=case["problem"], gamma=case["gamma"], alpha=case.get("alpha", 0.0),
-                     beta=case.get("beta", 0.0), p0=case.get("p0", 0.0))
+                     beta=case.get("beta", 0.0), p0=case.get("p0", 0.0), **O.nleg_params(case))
     orc = O.Oracle(om, cfg, case["bc_dirichlet"], case["bc_sym"], case["bc_extrapolate"],
                    pref=case.get("pref", False), tolref=case.get("tolref", 0.1))
     return ctx, mesh, chunk, orc
 
 
-CASES = ["sod_dg", "sedov_dgp1", "sedov_pdg", "vortical_flow_dg", "vortical_flow_dg_lf",
+CASES = ["sod_dg", "rotated_sod_dg", "nleg_dgp2", "sedov_dgp1", "sedov_pdg", "vortical_flow_dg", "vortical_flow_dg_lf",
          "vortical_flow_dgp1", "vortical_flow_dgp1_lf", "taylor_green_dgp2",
          "taylor_green_dgp2_cfl"]
 

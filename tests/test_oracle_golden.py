@@ -13,7 +13,7 @@ from oracle import oracle as O
 from conftest import load_fixture
 
 # absolute tolerance on golden ExodusII element fields (full-precision f64)
-FIELD_ATOL = {"sod_dg": 1e-13, "sedov_dgp1": 5e-12, "sedov_pdg": 5e-12, "vortical_flow_dg": 1e-12,
+FIELD_ATOL = {"sod_dg": 1e-13, "rotated_sod_dg": 1e-13, "nleg_dgp2": 1e-12, "sedov_dgp1": 5e-12, "sedov_pdg": 5e-12, "vortical_flow_dg": 1e-12,
               "vortical_flow_dg_lf": 1e-12, "vortical_flow_dgp1": 1e-12,
               "vortical_flow_dgp1_lf": 1e-12, "taylor_green_dgp2": 1e-12,
               "taylor_green_dgp2_cfl": 1e-12}
