@@ -1432,13 +1432,22 @@ double orc_step_pdg(const orc_cfg* k, const orc_bc* bc, double t, double fixed_d
  * Upwind.hpp:35-55) and the Problem's prescribed velocity.
  * ===================================================================== */
 
-enum { ORC_TR_SLOT_CYL = 1 };
+enum { ORC_TR_SLOT_CYL = 1, ORC_TR_CYL_ADVECT = 2, ORC_TR_GAUSS_HUMP = 3 };
 enum { TR_BC_EXTRAPOLATE = 0, TR_BC_INLET = 1, TR_BC_OUTLET = 2, TR_BC_DIRICHLET = 3 };
 
 /* TransportProblemSlotCyl::solution, src/PDE/Transport/Problem/SlotCyl.cpp:30-110 (ncomp = 1) */
 static double tr_solution(int problem, double x, double y, double z, double t)
 {
-  (void)z; (void)problem;
+  (void)z;
+  if (problem == ORC_TR_CYL_ADVECT) {       /* CylAdvect.cpp:28-60: square wave of radius 0.2 */
+    const double x0 = 0.25 + 0.1 * t, y0 = 0.25 + 0.1 * t;
+    const double r = sqrt((x - x0) * (x - x0) + (y - y0) * (y - y0));
+    return r < 0.2 ? 1.0 : 0.0;
+  }
+  if (problem == ORC_TR_GAUSS_HUMP) {       /* GaussHump.cpp:28-56 */
+    const double x0 = 0.25 + 0.1 * t, y0 = 0.25 + 0.1 * t;
+    return 1.0 * exp(-((x - x0) * (x - x0) + (y - y0) * (y - y0)) / (2.0 * 0.005));
+  }
   {
     const double T = t;          /* t + 2*pi/ncomp*c with c = 0 */
     const double R0 = 0.15;
@@ -1480,9 +1489,16 @@ static double tr_solution(int problem, double x, double y, double z, double t)
 /* TransportProblemSlotCyl::prescribedVelocity, SlotCyl.cpp:152-170 */
 static void tr_velocity(int problem, double x, double y, double z, double* v)
 {
-  (void)problem; (void)z;
+  (void)z;
+  if (problem == ORC_TR_CYL_ADVECT || problem == ORC_TR_GAUSS_HUMP) {
+    v[0] = 0.1; v[1] = 0.1; v[2] = 0.0;    /* CylAdvect.cpp:114-129, GaussHump.cpp:110-125 */
+    return;
+  }
   v[0] = 0.5 - y; v[1] = x - 0.5; v[2] = 0.0;
 }
+
+/* per-element number of modes of the scalar (p-adaptive transport), else ndof */
+static int64_t tr_nd(int64_t ndof, int64_t e) { return g_ndofel ? g_ndofel[e] : ndof; }
 
 /* Upwind::flux, Upwind.hpp:35-55 (one component) */
 static double tr_upwind(const double* fn, double ul, double ur, const double* v)
@@ -1493,6 +1509,13 @@ static double tr_upwind(const double* fn, double ul, double ur, const double* v)
   return splus * ul + sminus * ur;
 }
 
+static double tr_state_n(const double* U, int64_t e, int64_t ndof, int64_t dof_el, const double* B)
+{
+  const double* u = U + e * ndof;
+  double a = u[0]; int64_t k;
+  for (k = 1; k < dof_el; ++k) a += u[k] * B[k];
+  return a;
+}
 static double tr_state(const double* U, int64_t e, int64_t ndof, const double* B)
 {
   const double* u = U + e * ndof;
@@ -1545,16 +1568,17 @@ void orc_tr_rhs(int problem, int64_t ndof, const orc_bc* bc, const int32_t* bcty
                 const double* z, const double* geoFace, const double* geoElem, const double* U,
                 double* R)
 {
-  const int ngf = ng_fa(ndof), ngv = ng_vol(ndof);
   double cf[2][6], wf[6], cv[3][14], wv[14];
   int64_t f, e, k, is, q; int ig, i, type;
-  quad_tri(ngf, cf, wf);
   memset(R, 0, (size_t)(nunk * ndof) * sizeof(double));
-  /* surfInt */
+  /* surfInt (per-element modes with p-adaptive DG: Surface.cpp:81-86,146-156,234-271) */
   for (f = nbfac; f < nfac; ++f) {
     const int64_t el = esuf[2 * f], er = esuf[2 * f + 1];
+    const int64_t ndl = tr_nd(ndof, el), ndr = tr_nd(ndof, er);
+    const int ngf = ng_fa(ndl) > ng_fa(ndr) ? ng_fa(ndl) : ng_fa(ndr);
     double pl[4][3], pr[4][3], pf[3][3], detl, detr;
     const double* fn = geoFace + 7 * f + 1;
+    quad_tri(ngf, cf, wf);
     elem_coords(inpoel, el, x, y, z, pl);
     elem_coords(inpoel, er, x, y, z, pr);
     detl = jacobian(pl[0], pl[1], pl[2], pl[3]);
@@ -1563,34 +1587,36 @@ void orc_tr_rhs(int problem, int64_t ndof, const orc_bc* bc, const int32_t* bcty
     for (ig = 0; ig < ngf; ++ig) {
       double gp[3], xi, eta, zeta, Bl[10], Br[10], v[3], fl, wt;
       gp_tri(pf, cf[0][ig], cf[1][ig], gp);
-      ref_coords(pl, detl, gp, &xi, &eta, &zeta); eval_basis(ndof, xi, eta, zeta, Bl);
-      ref_coords(pr, detr, gp, &xi, &eta, &zeta); eval_basis(ndof, xi, eta, zeta, Br);
+      ref_coords(pl, detl, gp, &xi, &eta, &zeta); eval_basis(ndl, xi, eta, zeta, Bl);
+      ref_coords(pr, detr, gp, &xi, &eta, &zeta); eval_basis(ndr, xi, eta, zeta, Br);
       wt = wf[ig] * geoFace[7 * f];
       tr_velocity(problem, gp[0], gp[1], gp[2], v);
-      fl = tr_upwind(fn, tr_state(U, el, ndof, Bl), tr_state(U, er, ndof, Br), v);
+      fl = tr_upwind(fn, tr_state_n(U, el, ndof, ndl, Bl), tr_state_n(U, er, ndof, ndr, Br), v);
       R[el * ndof] -= wt * fl; R[er * ndof] += wt * fl;
-      for (k = 1; k < ndof; ++k) { R[el * ndof + k] -= wt * fl * Bl[k]; R[er * ndof + k] += wt * fl * Br[k]; }
+      for (k = 1; k < ndl; ++k) R[el * ndof + k] -= wt * fl * Bl[k];
+      for (k = 1; k < ndr; ++k) R[er * ndof + k] += wt * fl * Br[k];
     }
   }
   /* volInt */
-  if (ndof > 1) {
+  for (e = 0; e < nunk; ++e) {
+    const int64_t nde = tr_nd(ndof, e);
+    const int ngv = ng_vol(nde);
+    double p[4][3], ji[3][3], dBdx[3][10];
+    if (nde <= 1) continue;
     quad_tet(ngv, cv, wv);
-    for (e = 0; e < nunk; ++e) {
-      double p[4][3], ji[3][3], dBdx[3][10];
-      elem_coords(inpoel, e, x, y, z, p);
-      inverse_jacobian(p[0], p[1], p[2], p[3], ji);
-      eval_dBdx_p1(ji, dBdx);
-      for (ig = 0; ig < ngv; ++ig) {
-        double B[10], gp[3], v[3], s, wt;
-        if (ndof > 4) eval_dBdx_p2(cv[0][ig], cv[1][ig], cv[2][ig], ji, dBdx);
-        gp_tet(p, cv[0][ig], cv[1][ig], cv[2][ig], gp);
-        eval_basis(ndof, cv[0][ig], cv[1][ig], cv[2][ig], B);
-        wt = wv[ig] * geoElem[4 * e];
-        s = tr_state(U, e, ndof, B);
-        tr_velocity(problem, gp[0], gp[1], gp[2], v);
-        for (k = 1; k < ndof; ++k)
-          R[e * ndof + k] += wt * (v[0] * s * dBdx[0][k] + v[1] * s * dBdx[1][k] + v[2] * s * dBdx[2][k]);
-      }
+    elem_coords(inpoel, e, x, y, z, p);
+    inverse_jacobian(p[0], p[1], p[2], p[3], ji);
+    eval_dBdx_p1(ji, dBdx);
+    for (ig = 0; ig < ngv; ++ig) {
+      double B[10], gp[3], v[3], sc, wt;
+      if (nde > 4) eval_dBdx_p2(cv[0][ig], cv[1][ig], cv[2][ig], ji, dBdx);
+      gp_tet(p, cv[0][ig], cv[1][ig], cv[2][ig], gp);
+      eval_basis(nde, cv[0][ig], cv[1][ig], cv[2][ig], B);
+      wt = wv[ig] * geoElem[4 * e];
+      sc = tr_state_n(U, e, ndof, nde, B);
+      tr_velocity(problem, gp[0], gp[1], gp[2], v);
+      for (k = 1; k < nde; ++k)
+        R[e * ndof + k] += wt * (v[0] * sc * dBdx[0][k] + v[1] * sc * dBdx[1][k] + v[2] * sc * dBdx[2][k]);
     }
   }
   /* bndSurfInt per BC type in the reference's order */
@@ -1600,9 +1626,12 @@ void orc_tr_rhs(int problem, int64_t ndof, const orc_bc* bc, const int32_t* bcty
       for (q = bc->set_off[is]; q < bc->set_off[is + 1]; ++q) {
         double pl[4][3], pf[3][3], detl;
         const double* fn;
-        int64_t el;
+        int64_t el, ndl; int ngf;
         f = bc->set_face[q];
         el = esuf[2 * f];
+        ndl = tr_nd(ndof, el);
+        ngf = ng_fa(ndl);
+        quad_tri(ngf, cf, wf);
         fn = geoFace + 7 * f + 1;
         elem_coords(inpoel, el, x, y, z, pl);
         detl = jacobian(pl[0], pl[1], pl[2], pl[3]);
@@ -1610,18 +1639,154 @@ void orc_tr_rhs(int problem, int64_t ndof, const orc_bc* bc, const int32_t* bcty
         for (ig = 0; ig < ngf; ++ig) {
           double gp[3], xi, eta, zeta, Bl[10], v[3], ul, ur, fl, wt;
           gp_tri(pf, cf[0][ig], cf[1][ig], gp);
-          ref_coords(pl, detl, gp, &xi, &eta, &zeta); eval_basis(ndof, xi, eta, zeta, Bl);
+          ref_coords(pl, detl, gp, &xi, &eta, &zeta); eval_basis(ndl, xi, eta, zeta, Bl);
           wt = wf[ig] * geoFace[7 * f];
-          ul = tr_state(U, el, ndof, Bl);
+          ul = tr_state_n(U, el, ndof, ndl, Bl);
           ur = (type == TR_BC_INLET) ? 0.0
              : (type == TR_BC_DIRICHLET) ? tr_solution(problem, gp[0], gp[1], gp[2], t) : ul;
           tr_velocity(problem, gp[0], gp[1], gp[2], v);
           fl = tr_upwind(fn, ul, ur, v);
           R[el * ndof] -= wt * fl;
-          for (k = 1; k < ndof; ++k) R[el * ndof + k] -= wt * fl * Bl[k];
+          for (k = 1; k < ndl; ++k) R[el * ndof + k] -= wt * fl * Bl[k];
         }
       }
     }
+}
+
+/* Superbee_P1 (src/PDE/Limiter.cpp:155-316) for one scalar */
+void orc_tr_superbee(int64_t ndof, const int32_t* esuel, int64_t nielem, const int64_t* inpoel,
+                     const double* x, const double* y, const double* z, double* U)
+{
+  const int ng = ng_fa(ndof);
+  double cg[2][6], wg[6];
+  int64_t e;
+  if (ndof <= 1) return;
+  quad_tri(ng, cg, wg);
+  for (e = 0; e < nielem; ++e) {
+    const int64_t dof_el = tr_nd(ndof, e);
+    double uMin, uMax, phi = 1.0, p[4][3], detT, u0; int is, lf, ig, i;
+    if (dof_el <= 1) continue;
+    u0 = uMin = uMax = U[e * ndof];
+    for (is = 0; is < 4; ++is) {
+      const int32_t n = esuel[4 * e + is];
+      double v;
+      if (n == -1) continue;
+      v = U[(int64_t)n * ndof];
+      if (v < uMin) uMin = v;
+      if (v > uMax) uMax = v;
+    }
+    elem_coords(inpoel, e, x, y, z, p);
+    detT = jacobian(p[0], p[1], p[2], p[3]);
+    for (lf = 0; lf < 4; ++lf) {
+      double pf[3][3];
+      for (i = 0; i < 3; ++i) {
+        const int64_t n = inpoel[4 * e + LPOFA[lf][i]];
+        pf[i][0] = x[n]; pf[i][1] = y[n]; pf[i][2] = z[n];
+      }
+      for (ig = 0; ig < ng; ++ig) {
+        double gp[3], xi, eta, zeta, B[10], uNeg, pg, t1, t2;
+        gp_tri(pf, cg[0][ig], cg[1][ig], gp);
+        ref_coords(p, detT, gp, &xi, &eta, &zeta);
+        eval_basis(ndof, xi, eta, zeta, B);
+        uNeg = tr_state_n(U, e, ndof, dof_el, B) - u0;
+        if (uNeg > 1.0e-14)       pg = fmin(1.0, (uMax - u0) / (2.0 * uNeg));
+        else if (uNeg < -1.0e-14) pg = fmin(1.0, (uMin - u0) / (2.0 * uNeg));
+        else                      pg = 1.0;
+        t1 = fmin(2.0 * pg, 1.0);
+        t2 = fmin(pg, 2.0);
+        pg = fmax(0.0, fmax(t1, t2));
+        phi = fmin(phi, pg);
+      }
+    }
+    U[e * ndof + 1] *= phi; U[e * ndof + 2] *= phi; U[e * ndof + 3] *= phi;
+  }
+}
+
+/* WENO_P1 (src/PDE/Limiter.cpp:29-153) for one scalar: Jacobi over the P1 modes */
+void orc_tr_weno(int64_t ndof, double cweight, const int32_t* esuel, int64_t nielem, double* U)
+{
+  double* lim = (double*)malloc((size_t)nielem * 3 * sizeof(double));
+  int64_t e; int is, d;
+  if (ndof <= 1) { free(lim); return; }
+  for (e = 0; e < nielem; ++e) {
+    double g[5][3], w[5], wtot = 0.0;
+    for (d = 0; d < 3; ++d) g[0][d] = U[e * ndof + 1 + d];
+    for (is = 1; is < 5; ++is) {
+      const int32_t n = esuel[4 * e + is - 1];
+      for (d = 0; d < 3; ++d) g[is][d] = (n == -1) ? 0.0 : U[(int64_t)n * ndof + 1 + d];
+    }
+    for (is = 0; is < 5; ++is) {
+      const double wst = (is == 0) ? cweight : (esuel[4 * e + is - 1] == -1 ? 0.0 : 1.0);
+      const double osc = sqrt(g[is][0] * g[is][0] + g[is][1] * g[is][1] + g[is][2] * g[is][2]);
+      w[is] = wst * pow(1.0e-8 + osc, -2.0);
+      wtot += w[is];
+    }
+    for (d = 0; d < 3; ++d) {
+      double a = 0.0;
+      for (is = 0; is < 5; ++is) a += (w[is] / wtot) * g[is][d];
+      lim[3 * e + d] = a;
+    }
+  }
+  for (e = 0; e < nielem; ++e)
+    for (d = 0; d < 3; ++d) U[e * ndof + 1 + d] = lim[3 * e + d];
+  free(lim);
+}
+
+/* DG::eval_ndof (DG.cpp:1088-1163) and the zeroing of DG::solve (:1451-1469), one scalar */
+void orc_tr_eval_ndof(int64_t ndof, int64_t nielem, const int64_t* inpoel, const double* x,
+                      const double* y, const double* z, const double* U, double tolref,
+                      int64_t* ndofel)
+{
+  int64_t e;
+  for (e = 0; e < nielem; ++e) {
+    double p[4][3], ji[3][3];
+    const double* u = U + e * ndof;
+    double d0, d1, d2, gx, gy, gz;
+    if (ndofel[e] != 4) continue;
+    elem_coords(inpoel, e, x, y, z, p);
+    inverse_jacobian(p[0], p[1], p[2], p[3], ji);
+    d0 = 2 * u[1]; d1 = u[1] + 3.0 * u[2]; d2 = u[1] + u[2] + 4.0 * u[3];
+    gx = d0 * ji[0][0] + d1 * ji[1][0] + d2 * ji[2][0];
+    gy = d0 * ji[0][1] + d1 * ji[1][1] + d2 * ji[2][1];
+    gz = d0 * ji[0][2] + d1 * ji[1][2] + d2 * ji[2][2];
+    ndofel[e] = sqrt(gx * gx + gy * gy + gz * gz) > tolref ? 4 : 1;
+  }
+}
+void orc_tr_pdg_zero(int64_t ndof, int64_t nunk, const int64_t* ndofel, double* U)
+{
+  int64_t e;
+  for (e = 0; e < nunk; ++e)
+    if (ndofel[e] == 1) { U[e * ndof + 1] = 0.0; U[e * ndof + 2] = 0.0; U[e * ndof + 3] = 0.0; }
+}
+
+/* ElemDiagnostics::compute_diag (ElemDiagnostics.cpp:116-215), one scalar:
+ * out = { sum wt*u^2, sum wt*(u-s)^2, max|u-s| } with NGdiag(ndofel[e]) points */
+void orc_tr_diag(int problem, int64_t ndof, double t_new, const int64_t* inpoel, const double* x,
+                 const double* y, const double* z, const double* geoElem, const double* U,
+                 int64_t nielem, double* out)
+{
+  double cg[3][14], wg[14];
+  int64_t e; int ig;
+  out[0] = out[1] = out[2] = 0.0;
+  for (e = 0; e < nielem; ++e) {
+    const int64_t nde = tr_nd(ndof, e);
+    const int ng = ng_diag(nde);
+    double p[4][3];
+    quad_tet(ng, cg, wg);
+    elem_coords(inpoel, e, x, y, z, p);
+    for (ig = 0; ig < ng; ++ig) {
+      double gp[3], B[10], u, sv, wt, err;
+      gp_tet(p, cg[0][ig], cg[1][ig], cg[2][ig], gp);
+      eval_basis(nde, cg[0][ig], cg[1][ig], cg[2][ig], B);
+      wt = wg[ig] * geoElem[4 * e];
+      sv = tr_solution(problem, gp[0], gp[1], gp[2], t_new);
+      u = tr_state_n(U, e, ndof, nde, B);
+      err = fabs(u - sv);
+      out[0] += wt * u * u;
+      out[1] += wt * (u - sv) * (u - sv);
+      if (err > out[2]) out[2] = err;
+    }
+  }
 }
 
 /* SSP-RK3 stage for one scalar (DG.cpp:1478-1488) */

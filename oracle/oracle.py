@@ -399,15 +399,23 @@ def run_case(case, fix, nstep=None, on_step=None):
 
 
 # ---------------------------------------------------------------- transport
+TR_PROBLEM = {"slot_cyl": 1, "cyl_advect": 2, "gauss_hump": 3}
+
+
 def run_transport_case(case, fix, nstep=None):
-    """BASELINE config 1: Transport slot_cyl DG (dg::Transport with Upwind flux,
-    src/PDE/Transport/DGTransport.hpp:129-186) on one chunk, fixed dt."""
+    """dg::Transport with one scalar (src/PDE/Transport/DGTransport.hpp:129-186,
+    Upwind flux) on one chunk, fixed dt, in the DG chare's stage order: limiter
+    (WENO_P1 / Superbee_P1 with ncomp = 1), rhs, SSP-RK3; with scheme pdg also
+    eval_ndof / propagate_ndof / zeroing at stage 0.  BASELINE config 1 is the
+    slot_cyl DG-P0 case."""
     L = lib()
-    L.orc_tr_diag_l2sum.restype = C.c_double
     m = OracleMesh(fix["coord"], fix["inpoel"],
                    {int(s): fix["ss_tri_%d" % s] for s in fix["ss_ids"]})
     ndof = case["ndof"]
     ne = m.nelem
+    prob = C.c_int(TR_PROBLEM[case.get("problem", "slot_cyl")])
+    limiter = case.get("limiter", "nolimiter")
+    pref, tolref = bool(case.get("pref", False)), float(case.get("tolref", 0.1))
     # BC type per side set in the bface map (DGTransport.hpp:163-168 order)
     types = {"bc_extrapolate": 0, "bc_inlet": 1, "bc_outlet": 2, "bc_dirichlet": 3}
     bctype = np.full(len(m._set_id), -1, dtype=np.int32)
@@ -419,25 +427,55 @@ def run_transport_case(case, fix, nstep=None):
             set_face=_p(m._set_face, c_i64p), ndir=0, nsym=0, nextrap=0,
             dir=_p(zero, c_i64p), sym=_p(zero, c_i64p), extrap=_p(zero, c_i64p))
     inp = m.inpoel.reshape(-1)
+    mesh_args = (_p(inp, c_i64p), _p(m.x, c_f64p), _p(m.y, c_f64p), _p(m.z, c_f64p))
     Lm = np.zeros(ne * ndof)
     L.orc_tr_mass(C.c_int64(ndof), _p(m.geoElem, c_f64p), C.c_int64(ne), _p(Lm, c_f64p))
     U = np.zeros(ne * ndof)
-    L.orc_tr_initialize(C.c_int(1), C.c_int64(ndof), _p(Lm, c_f64p), _p(inp, c_i64p), _p(m.x, c_f64p),
+    L.orc_tr_initialize(prob, C.c_int64(ndof), _p(Lm, c_f64p), _p(inp, c_i64p), _p(m.x, c_f64p),
                         _p(m.y, c_f64p), _p(m.z, c_f64p), _p(U, c_f64p), C.c_double(0.0), C.c_int64(ne))
+    ndofel = np.full(ne, ndof, dtype=np.int64)
     Un, R = np.zeros_like(U), np.zeros_like(U)
     t, dt, rows = 0.0, case["dt"], []
-    for it in range(case["nstep"] if nstep is None else nstep):
-        for stage in range(3):
-            if stage == 0:
-                Un[:] = U
-            L.orc_tr_rhs(C.c_int(1), C.c_int64(ndof), C.byref(bc), _p(bctype, c_i32p), C.c_double(t),
-                         C.c_int64(ne), C.c_int64(m.nbfac), C.c_int64(m.nfac), _p(m.esuf, c_i32p),
-                         _p(m.inpofa, c_i64p), _p(inp, c_i64p), _p(m.x, c_f64p), _p(m.y, c_f64p),
-                         _p(m.z, c_f64p), _p(m.geoFace, c_f64p), _p(m.geoElem, c_f64p), _p(U, c_f64p),
-                         _p(R, c_f64p))
-            L.orc_tr_rk_update(C.c_int64(ndof), C.c_int(stage), C.c_double(dt), _p(Un, c_f64p),
-                               _p(R, c_f64p), _p(Lm, c_f64p), _p(U, c_f64p), C.c_int64(ne))
-        s = L.orc_tr_diag_l2sum(C.c_int64(ndof), _p(m.geoElem, c_f64p), _p(U, c_f64p), C.c_int64(ne))
-        t += dt
-        rows.append([it + 1, t, dt, np.sqrt(s / m.meshvol)])
-    return {"mesh": m, "U": U, "L": Lm, "diag": np.array(rows), "t": t}
+    nstep = case["nstep"] if nstep is None else nstep
+    plot = case.get("plot_interval", 1)
+    means = lambda: U.reshape(ne, ndof)[:, 0].copy()
+    fields, times, ndofs = [means()], [0.0], [ndofel.copy()]
+    if pref:
+        L.orc_set_ndofel(_p(ndofel, c_i64p))
+    try:
+        for it in range(nstep):
+            for stage in range(3):
+                if pref and stage == 0:
+                    L.orc_tr_eval_ndof(C.c_int64(ndof), C.c_int64(ne), *mesh_args, _p(U, c_f64p),
+                                       C.c_double(tolref), _p(ndofel, c_i64p))
+                    L.orc_propagate_ndof(C.c_int64(ne), C.c_int64(m.nbfac), C.c_int64(m.nfac),
+                                         _p(m.esuf, c_i32p), _p(ndofel, c_i64p))
+                if limiter == "superbeep1":
+                    L.orc_tr_superbee(C.c_int64(ndof), _p(m.esuel, c_i32p), C.c_int64(ne), *mesh_args,
+                                      _p(U, c_f64p))
+                elif limiter == "wenop1":
+                    L.orc_tr_weno(C.c_int64(ndof), C.c_double(case.get("cweight", 1.0)),
+                                  _p(m.esuel, c_i32p), C.c_int64(ne), _p(U, c_f64p))
+                if stage == 0:
+                    if pref:
+                        L.orc_tr_pdg_zero(C.c_int64(ndof), C.c_int64(ne), _p(ndofel, c_i64p), _p(U, c_f64p))
+                    Un[:] = U
+                L.orc_tr_rhs(prob, C.c_int64(ndof), C.byref(bc), _p(bctype, c_i32p), C.c_double(t),
+                             C.c_int64(ne), C.c_int64(m.nbfac), C.c_int64(m.nfac), _p(m.esuf, c_i32p),
+                             _p(m.inpofa, c_i64p), *mesh_args, _p(m.geoFace, c_f64p),
+                             _p(m.geoElem, c_f64p), _p(U, c_f64p), _p(R, c_f64p))
+                L.orc_tr_rk_update(C.c_int64(ndof), C.c_int(stage), C.c_double(dt), _p(Un, c_f64p),
+                                   _p(R, c_f64p), _p(Lm, c_f64p), _p(U, c_f64p), C.c_int64(ne))
+            t += dt
+            if (it + 1) % case.get("diag_interval", 1) == 0:
+                out = np.zeros(3)
+                L.orc_tr_diag(prob, C.c_int64(ndof), C.c_double(t), *mesh_args, _p(m.geoElem, c_f64p),
+                              _p(U, c_f64p), C.c_int64(ne), _p(out, c_f64p))
+                rows.append([it + 1, t, dt, np.sqrt(out[0] / m.meshvol), np.sqrt(out[1] / m.meshvol), out[2]])
+            if (it + 1) % plot == 0 or it + 1 == nstep:
+                fields.append(means()); times.append(t); ndofs.append(ndofel.copy())
+    finally:
+        if pref:
+            L.orc_set_ndofel(None)
+    return {"mesh": m, "U": U, "L": Lm, "diag": np.array(rows), "t": t, "fields": np.array(fields),
+            "times": np.array(times), "ndof": np.array(ndofs)}

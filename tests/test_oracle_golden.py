@@ -103,3 +103,27 @@ def test_oracle_reproduces_transport_slot_cyl_config1(cases):
     assert abs(r["t"] - float(fix["chunk_time_last"][0])) < 1e-14
     err = np.abs(r["U"][oa] - fix["chunk_c0_last"][ob]).max()
     assert err <= 1e-13, err
+
+
+TRANSPORT_CASES = ["cyl_advect_dg", "cyl_advect_dgp1", "cyl_advect_dgp1_weno", "gauss_hump_dgp1",
+                   "gauss_hump_dgp2", "gauss_hump_pdg"]
+
+
+@pytest.mark.parametrize("name", TRANSPORT_CASES)
+def test_oracle_reproduces_transport_goldens(name, cases):
+    """More dg::Transport regression baselines of the reference (CylAdvect,
+    GaussHump: DG-P0/P1/P2, Superbee, WENO, p-adaptive): golden cell values,
+    per-element ndof, and the diag tables (L2, L2 error, Linf error)."""
+    case, fix = cases[name], load_fixture(name)
+    r = O.run_transport_case(case, fix)
+    if "exo_vals" in fix:
+        assert np.allclose(r["times"], fix["exo_times"], rtol=0, atol=1e-15)
+        assert np.abs(r["fields"] - fix["exo_vals"][:, 0]).max() <= 1e-13
+        if case.get("pref"):
+            assert np.array_equal(r["ndof"], fix["exo_vals"][:, 1].astype(np.int64))
+            assert 0 < (r["ndof"][-1] == 4).sum() < r["ndof"].shape[1]
+    assert len(r["diag"]) == len(fix["diag"])
+    for row, g in zip(r["diag"], fix["diag"]):
+        assert int(row[0]) == int(g[0])
+        for a, b in zip(row[1:len(g)], g[1:]):
+            assert abs(a - b) <= DIAG_RTOL * abs(b) + 1e-13, (name, int(row[0]), a, b)
