@@ -74,15 +74,18 @@ enum { QDG_PROBLEM_USER_DEFINED = 0, QDG_PROBLEM_SOD_SHOCKTUBE = 1,
        /* Transport problem policies (src/PDE/Transport/Problem/SlotCyl.cpp:30-170) */
        QDG_PROBLEM_SLOT_CYL = 5,
        /* more CompFlow policies (RotatedSodShocktube.cpp:28-45, NLEnergyGrowth.cpp:28-190) */
-       QDG_PROBLEM_ROTATED_SOD_SHOCKTUBE = 6, QDG_PROBLEM_NL_ENERGY_GROWTH = 7 };
+       QDG_PROBLEM_ROTATED_SOD_SHOCKTUBE = 6, QDG_PROBLEM_NL_ENERGY_GROWTH = 7,
+       /* more Transport policies (CylAdvect.cpp:28-129, GaussHump.cpp:28-125) */
+       QDG_PROBLEM_CYL_ADVECT = 8, QDG_PROBLEM_GAUSS_HUMP = 9 };
 /* BC state functions (src/PDE/CompFlow/DGCompFlow.hpp:649-701) */
 enum { QDG_BC_DIRICHLET = 1, QDG_BC_SYMMETRY = 2, QDG_BC_EXTRAPOLATE = 3,
        /* Transport only (src/PDE/Transport/DGTransport.hpp:163-168, 276-352) */
        QDG_BC_INLET = 4, QDG_BC_OUTLET = 5 };
 /* which DGPDE: dg::CompFlow (5 conserved variables, DGCompFlow.hpp) or dg::Transport
  * with one transported scalar (DGTransport.hpp:129-186; BASELINE config 1).
- * Transport: flux UPWIND, problem SLOT_CYL, BCs Dirichlet/Extrapolate/Inlet/Outlet,
- * constant dt only (dg::Transport::dt returns max, DGTransport.hpp:189-199), no limiter;
+ * Transport: flux UPWIND, problems SLOT_CYL / CYL_ADVECT / GAUSS_HUMP, BCs Dirichlet/
+ * Extrapolate/Inlet/Outlet, constant dt only (dg::Transport::dt returns max,
+ * DGTransport.hpp:189-199), limiters and p-adaptive DG as for CompFlow;
  * rows of every field are ndof doubles. */
 enum { QDG_PDE_COMPFLOW = 0, QDG_PDE_TRANSPORT = 1 };
 

@@ -193,6 +193,8 @@ struct NLEnergyGrowth { static int type() noexcept { return QDG_PROBLEM_NL_ENERG
 // Transport (src/PDE/Transport/Physics/DGAdvection.hpp, Problem/SlotCyl.hpp)
 struct Advection { };
 struct SlotCyl        { static int type() noexcept { return QDG_PROBLEM_SLOT_CYL; } };
+struct CylAdvect      { static int type() noexcept { return QDG_PROBLEM_CYL_ADVECT; } };
+struct GaussHump      { static int type() noexcept { return QDG_PROBLEM_GAUSS_HUMP; } };
 
 namespace detail {
 

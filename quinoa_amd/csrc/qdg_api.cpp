@@ -143,11 +143,16 @@ static int check_cfg(const qdg_config* c)
     return fail("qdg_ctx_create: bad BC table");
   if (c->pde == QDG_PDE_TRANSPORT) {
     if (c->flux != QDG_FLUX_UPWIND) return fail("qdg_ctx_create: transport needs the upwind flux");
-    if (c->problem != QDG_PROBLEM_SLOT_CYL) return fail("qdg_ctx_create: unknown transport problem");
-    if (c->limiter != QDG_LIMITER_NONE) return fail("qdg_ctx_create: limiters are not supported for transport");
+    if (!(c->problem == QDG_PROBLEM_SLOT_CYL || c->problem == QDG_PROBLEM_CYL_ADVECT ||
+          c->problem == QDG_PROBLEM_GAUSS_HUMP))
+      return fail("qdg_ctx_create: unknown transport problem");
     if (!(c->dt > 0.0))
       return fail("qdg_ctx_create: transport needs a constant dt (dg::Transport::dt gives no CFL estimate)");
-    if (c->pref) return fail("qdg_ctx_create: p-adaptive DG is not supported for transport");
+    if (c->pref) {
+      if (c->ndof != 4) return fail("qdg_ctx_create: p-adaptive DG needs ndof = rdof = 4");
+      if (c->limiter == QDG_LIMITER_WENOP1) return fail("qdg_ctx_create: p-adaptive DG with WENO is not supported");
+      if (!(c->tolref >= 0.0)) return fail("qdg_ctx_create: bad tolref");
+    }
     for (int i = 0; i < c->nbc; ++i) {
       const int b = c->bc_type[i];
       if (!(b == QDG_BC_DIRICHLET || b == QDG_BC_EXTRAPOLATE || b == QDG_BC_INLET || b == QDG_BC_OUTLET))
@@ -164,7 +169,7 @@ static int check_cfg(const qdg_config* c)
   if (c->flux != QDG_FLUX_HLLC && c->flux != QDG_FLUX_LAXFRIEDRICHS)
     return fail("qdg_ctx_create: unknown flux");
   if (c->problem < QDG_PROBLEM_USER_DEFINED || c->problem > QDG_PROBLEM_NL_ENERGY_GROWTH ||
-      c->problem == QDG_PROBLEM_SLOT_CYL)
+      c->problem == QDG_PROBLEM_SLOT_CYL)   /* 8, 9: transport */
     return fail("qdg_ctx_create: unknown problem");
   if (!(c->gamma > 1.0)) return fail("qdg_ctx_create: gamma must be > 1");
   for (int i = 0; i < c->nbc; ++i)

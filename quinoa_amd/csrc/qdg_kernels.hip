@@ -1190,9 +1190,15 @@ __global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1t(DevMesh m, Phys ph, doub
 #pragma unroll
       for (int c = 0; c < NCOMP; ++c) W[j][c] = 0.0;
 
+    // PDG: a Dirichlet face of a P0 tet takes NGfa(1) = 1 point (Boundary.cpp:94) --
+    // the analytic state varies along the face, so the count must match
+    bool one = false;
+    if constexpr (PDG && HAS_DIRICHLET) one = bnd && bc == 1 && m.ndofel[tile_e0 + el] == 1;
+    const int ngl = one ? 1 : NGF;
 #pragma unroll QDG_TILE_GP_UNROLL
-    for (int ig = 0; ig < NGF; ++ig) {
-      const double s0 = T.fs[ig][0], s1 = T.fs[ig][1], s2 = T.fs[ig][2];
+    for (int ig = 0; ig < ngl; ++ig) {
+      const double s0 = one ? 1.0 / 3.0 : T.fs[ig][0], s1 = one ? 1.0 / 3.0 : T.fs[ig][1],
+                   s2 = one ? 1.0 / 3.0 : T.fs[ig][2];
       double so[NCOMP], sn[NCOMP], fl[NCOMP];
 #pragma unroll
       for (int c = 0; c < NCOMP; ++c) {
@@ -1214,7 +1220,7 @@ __global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1t(DevMesh m, Phys ph, doub
       Prim ql, qr;
       primitives(ph, fn, L, ql);
       primitives(ph, fn, Rr, qr);
-      const double wq = T.fw[ig] * area;
+      const double wq = (one ? 1.0 : T.fw[ig]) * area;
       if (WITH_DT) {
         const double dl = wq * (fabs(ql.vn) + ql.a);
         const double dr = bnd ? 0.0 : wq * (fabs(qr.vn) + qr.a);
@@ -1791,13 +1797,12 @@ __global__ __launch_bounds__(256) void k_eval_ndof(DevMesh m, const double* __re
   if (ndofel[e] != 4) return;
   ElemGeom g;
   load_geom(m, e, g);
-  double ji[3][3], u[NCOMP][4];
+  double ji[3][3];
   inverse_jacobian(g, ji);
-  load_row<NCOMP * 4>(U, e, &u[0][0]);
   int sign = 0;
-#pragma unroll
-  for (int c = 0; c < NCOMP; ++c) {
-    const double d0 = 2 * u[c][1], d1 = u[c][1] + 3.0 * u[c][2], d2 = u[c][1] + u[c][2] + 4.0 * u[c][3];
+  for (int c = 0; c < m.ncomp; ++c) {
+    const double* u = U + ((size_t)e * m.ncomp + c) * 4;
+    const double d0 = 2 * u[1], d1 = u[1] + 3.0 * u[2], d2 = u[1] + u[2] + 4.0 * u[3];
     const double gx = d0 * ji[0][0] + d1 * ji[1][0] + d2 * ji[2][0];
     const double gy = d0 * ji[0][1] + d1 * ji[1][1] + d2 * ji[2][1];
     const double gz = d0 * ji[0][2] + d1 * ji[1][2] + d2 * ji[2][2];
@@ -1830,10 +1835,9 @@ __global__ __launch_bounds__(256) void k_pdg_zero(DevMesh m, const int* __restri
 {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= m.ne || ndofel[e] != 1) return;
+  for (int c = 0; c < m.ncomp; ++c)
 #pragma unroll
-  for (int c = 0; c < NCOMP; ++c)
-#pragma unroll
-    for (int k = 1; k < 4; ++k) U[(size_t)e * (NCOMP * 4) + c * 4 + k] = 0.0;
+    for (int k = 1; k < 4; ++k) U[((size_t)e * m.ncomp + c) * 4 + k] = 0.0;
 }
 
 __global__ void k_fill_int(int* __restrict__ p, int n, int v)
@@ -1882,15 +1886,23 @@ __device__ double solution_slot_cyl(double x, double y, double t)
   return s;
 }
 
+// problem ids: 5 slot_cyl, 8 cyl_advect (CylAdvect.cpp:28-60), 9 gauss_hump (GaussHump.cpp:28-56)
 __device__ __forceinline__ double solution(int problem, double x, double y, double /*z*/, double t)
 {
-  return problem == 5 ? solution_slot_cyl(x, y, t) : 0.0;
+  if (problem == 5) return solution_slot_cyl(x, y, t);
+  const double x0 = 0.25 + 0.1 * t, y0 = 0.25 + 0.1 * t;
+  const double d2 = (x - x0) * (x - x0) + (y - y0) * (y - y0);
+  if (problem == 8) return sqrt(d2) < 0.2 ? 1.0 : 0.0;
+  if (problem == 9) return 1.0 * exp(-d2 / (2.0 * 0.005));
+  return 0.0;
 }
 
-// Problem::prescribedVelocity (SlotCyl.cpp:152-170): solid-body rotation about (0.5, 0.5)
-__device__ __forceinline__ void velocity(int /*problem*/, double x, double y, double /*z*/, double* v)
+// Problem::prescribedVelocity: SlotCyl.cpp:152-170 solid-body rotation about (0.5, 0.5);
+// CylAdvect.cpp:114-129, GaussHump.cpp:110-125 constant (0.1, 0.1, 0)
+__device__ __forceinline__ void velocity(int problem, double x, double y, double /*z*/, double* v)
 {
-  v[0] = 0.5 - y; v[1] = x - 0.5; v[2] = 0.0;
+  if (problem == 5) { v[0] = 0.5 - y; v[1] = x - 0.5; v[2] = 0.0; }
+  else { v[0] = 0.1; v[1] = 0.1; v[2] = 0.0; }
 }
 
 // Upwind::flux, src/PDE/Integrate/Riemann/Upwind.hpp:35-55
@@ -1916,7 +1928,11 @@ template <int NDOF> __device__ __forceinline__ double state(const double* u, con
 }
 
 // BC codes of the nbr plane: 1 Dirichlet, 3 Extrapolate, 4 Inlet, 5 Outlet
-// (DGTransport.hpp:163-168, 276-352)
+// (DGTransport.hpp:163-168, 276-352).  With p-adaptive DG (m.ndofel) a P0 tet
+// contributes its mean only, gets no high-order update and no volume term, and
+// a face uses NGfa(max of the two sides) points (Surface.cpp:81-86; Boundary.cpp:94):
+// the velocity and the Dirichlet state vary along the face, so the point count
+// must match the reference's exactly.
 template <int NDOF>
 __global__ __launch_bounds__(256) void k_rhs(DevMesh m, Phys ph, double t,
                                              const double* __restrict__ U, double* __restrict__ R)
@@ -1926,10 +1942,16 @@ __global__ __launch_bounds__(256) void k_rhs(DevMesh m, Phys ph, double t,
   const Tables<NDOF>& T = tab<NDOF>();
   constexpr int NGF = Tables<NDOF>::NGF, NGV = Tables<NDOF>::NGV;
   const int stride = m.stride;
+  const bool pdg = NDOF == 4 && m.ndofel != nullptr;
+  const bool p0 = pdg && m.ndofel[e] == 1;
   double acc[NDOF], u[NDOF];
 #pragma unroll
   for (int k = 0; k < NDOF; ++k) acc[k] = 0.0;
   load<NDOF>(U, e, u);
+  if (p0) {
+#pragma unroll
+    for (int k = 1; k < NDOF; ++k) u[k] = 0.0;
+  }
   ElemGeom g;
   load_geom(m, e, g);
 #pragma unroll 1
@@ -1942,11 +1964,29 @@ __global__ __launch_bounds__(256) void k_rhs(DevMesh m, Phys ph, double t,
     const double fn[3] = { m.fnx[f], m.fny[f], m.fnz[f] };
     const bool own_left = (info >> 6) & 1;
     double un[NDOF];
-    if (nb >= 0) load<NDOF>(U, nb, un);
+    bool p0n = true;
+    if (nb >= 0) {
+      load<NDOF>(U, nb, un);
+      p0n = pdg && m.ndofel[nb] == 1;
+      if (p0n) {
+#pragma unroll
+        for (int k = 1; k < NDOF; ++k) un[k] = 0.0;
+      }
+    }
+    const bool one = pdg && p0 && p0n;          // NGfa(1) = 1: the face centroid, weight 1
+    const int ng = one ? 1 : NGF;
+    const int own_code = lpofa(lf, 0) | (lpofa(lf, 1) << 2) | (lpofa(lf, 2) << 4);
 #pragma unroll 1
-    for (int ig = 0; ig < NGF; ++ig) {
-      const double s0 = T.fs[ig][0], s1 = T.fs[ig][1], s2 = T.fs[ig][2];
-      const double so = state<NDOF>(u, T.fB[lf][ig]);
+    for (int ig = 0; ig < ng; ++ig) {
+      const double s0 = one ? 1.0 / 3.0 : T.fs[ig][0], s1 = one ? 1.0 / 3.0 : T.fs[ig][1],
+                   s2 = one ? 1.0 / 3.0 : T.fs[ig][2];
+      double Bo[NDOF];
+      {
+        double xi, eta, zeta;
+        nbr_ref_coords(own_code, s0, s1, s2, xi, eta, zeta);
+        eval_basis<NDOF>(xi, eta, zeta, Bo);
+      }
+      const double so = state<NDOF>(u, Bo);
       double P[3], v[3], sn;
       face_point(g, lf, s0, s1, s2, P);
       if (nb >= 0) {
@@ -1960,39 +2000,118 @@ __global__ __launch_bounds__(256) void k_rhs(DevMesh m, Phys ph, double t,
       }
       velocity(ph.problem, P[0], P[1], P[2], v);
       const double fl = own_left ? upwind(fn, so, sn, v) : upwind(fn, sn, so, v);
-      const double wt = (own_left ? -1.0 : 1.0) * T.fw[ig] * area;
+      const double wt = (own_left ? -1.0 : 1.0) * (one ? 1.0 : T.fw[ig]) * area;
       acc[0] += wt * fl;
+      if (!p0) {
 #pragma unroll
-      for (int k = 1; k < NDOF; ++k) acc[k] += wt * fl * T.fB[lf][ig][k];
+        for (int k = 1; k < NDOF; ++k) acc[k] += wt * fl * Bo[k];
+      }
     }
   }
   if constexpr (NDOF > 1) {        // volInt, src/PDE/Integrate/Volume.cpp:20-168
-    const double vol = m.vol[e];
-    double ji[3][3];
-    inverse_jacobian(g, ji);
+    if (!p0) {
+      const double vol = m.vol[e];
+      double ji[3][3];
+      inverse_jacobian(g, ji);
 #pragma unroll 1
-    for (int ig = 0; ig < NGV; ++ig) {
-      const double xi = T.vc[ig][0], eta = T.vc[ig][1], zeta = T.vc[ig][2];
-      const double w0 = 1.0 - xi - eta - zeta;
-      double P[3], v[3];
+      for (int ig = 0; ig < NGV; ++ig) {
+        const double xi = T.vc[ig][0], eta = T.vc[ig][1], zeta = T.vc[ig][2];
+        const double w0 = 1.0 - xi - eta - zeta;
+        double P[3], v[3];
 #pragma unroll
-      for (int d = 0; d < 3; ++d)
-        P[d] = g.p[0][d] * w0 + g.p[1][d] * xi + g.p[2][d] * eta + g.p[3][d] * zeta;
-      const double sc = state<NDOF>(u, T.vB[ig]);
-      velocity(ph.problem, P[0], P[1], P[2], v);
-      const double wt = T.vw[ig] * vol;
+        for (int d = 0; d < 3; ++d)
+          P[d] = g.p[0][d] * w0 + g.p[1][d] * xi + g.p[2][d] * eta + g.p[3][d] * zeta;
+        const double sc = state<NDOF>(u, T.vB[ig]);
+        velocity(ph.problem, P[0], P[1], P[2], v);
+        const double wt = T.vw[ig] * vol;
 #pragma unroll
-      for (int k = 1; k < NDOF; ++k) {
-        const double g0 = T.vdB[ig][0][k], g1 = T.vdB[ig][1][k], g2 = T.vdB[ig][2][k];
-        const double dx = g0 * ji[0][0] + g1 * ji[1][0] + g2 * ji[2][0];
-        const double dy = g0 * ji[0][1] + g1 * ji[1][1] + g2 * ji[2][1];
-        const double dz = g0 * ji[0][2] + g1 * ji[1][2] + g2 * ji[2][2];
-        acc[k] += wt * (v[0] * sc * dx + v[1] * sc * dy + v[2] * sc * dz);
+        for (int k = 1; k < NDOF; ++k) {
+          const double g0 = T.vdB[ig][0][k], g1 = T.vdB[ig][1][k], g2 = T.vdB[ig][2][k];
+          const double dx = g0 * ji[0][0] + g1 * ji[1][0] + g2 * ji[2][0];
+          const double dy = g0 * ji[0][1] + g1 * ji[1][1] + g2 * ji[2][1];
+          const double dz = g0 * ji[0][2] + g1 * ji[1][2] + g2 * ji[2][2];
+          acc[k] += wt * (v[0] * sc * dx + v[1] * sc * dy + v[2] * sc * dz);
+        }
       }
     }
   }
 #pragma unroll
   for (int k = 0; k < NDOF; ++k) R[(size_t)e * NDOF + k] = acc[k];
+}
+
+// Superbee_P1 (src/PDE/Limiter.cpp:155-316) for one scalar; in place (only
+// neighbour means are read and a mean never changes)
+template <int NDOF>
+__global__ __launch_bounds__(256) void k_superbee(DevMesh m, double* __restrict__ U)
+{
+  const int e = xcd_tile(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+  if (e >= m.nie) return;
+  if constexpr (NDOF > 1) {
+    if (m.ndofel && m.ndofel[e] == 1) return;        // Limiter.cpp:179-180
+    const Tables<NDOF>& T = tab<NDOF>();
+    constexpr int NGF = Tables<NDOF>::NGF;
+    double u[NDOF];
+    load<NDOF>(U, e, u);
+    double uMin = u[0], uMax = u[0], phi = 1.0;
+#pragma unroll
+    for (int lf = 0; lf < 4; ++lf) {
+      const int nb = m.nbr[(size_t)lf * m.stride + e];
+      if (nb < 0) continue;
+      const double v = U[(size_t)nb * NDOF];
+      uMin = fmin(uMin, v); uMax = fmax(uMax, v);
+    }
+#pragma unroll 1
+    for (int lf = 0; lf < 4; ++lf)
+#pragma unroll
+      for (int ig = 0; ig < NGF; ++ig) {
+        const double uNeg = state<NDOF>(u, T.fB[lf][ig]) - u[0];
+        double pg;
+        if (uNeg > 1.0e-14)       pg = fmin(1.0, (uMax - u[0]) / (2.0 * uNeg));
+        else if (uNeg < -1.0e-14) pg = fmin(1.0, (uMin - u[0]) / (2.0 * uNeg));
+        else                      pg = 1.0;
+        pg = fmax(0.0, fmax(fmin(2.0 * pg, 1.0), fmin(pg, 2.0)));
+        phi = fmin(phi, pg);
+      }
+#pragma unroll
+    for (int k = 1; k < 4; ++k) U[(size_t)e * NDOF + k] = phi * u[k];
+  }
+}
+
+// WENO_P1 (src/PDE/Limiter.cpp:29-153) for one scalar: Jacobi, Uin -> modes 1-3 of Uout
+template <int NDOF>
+__global__ __launch_bounds__(256) void k_weno(DevMesh m, double cweight, const double* __restrict__ Uin,
+                                              double* __restrict__ Uout)
+{
+  const int e = xcd_tile(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+  if (e >= m.nie) return;
+  if constexpr (NDOF > 1) {
+    double g[5][3], wd[5], wtot = 0.0;
+    int nb[4];
+#pragma unroll
+    for (int lf = 0; lf < 4; ++lf) nb[lf] = m.nbr[(size_t)lf * m.stride + e];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) g[0][d] = Uin[(size_t)e * NDOF + 1 + d];
+#pragma unroll
+    for (int is = 1; is < 5; ++is)
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+        g[is][d] = (nb[is - 1] >= 0) ? Uin[(size_t)nb[is - 1] * NDOF + 1 + d] : 0.0;
+#pragma unroll
+    for (int is = 0; is < 5; ++is) {
+      const double wst = (is == 0) ? cweight : (nb[is - (is > 0)] >= 0 ? 1.0 : 0.0);
+      const double osc = sqrt(g[is][0] * g[is][0] + g[is][1] * g[is][1] + g[is][2] * g[is][2]);
+      const double q = 1.0e-8 + osc;
+      wd[is] = wst / (q * q);
+      wtot += wd[is];
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      double a = 0.0;
+#pragma unroll
+      for (int is = 0; is < 5; ++is) a += (wd[is] / wtot) * g[is][d];
+      Uout[(size_t)e * NDOF + 1 + d] = a;
+    }
+  }
 }
 
 template <int NDOF>
@@ -2037,12 +2156,17 @@ __global__ __launch_bounds__(256) void k_diag(DevMesh m, Phys ph, double t_new,
 #pragma unroll
   for (int i = 0; i < 15; ++i) v[i] = 0.0;
   if (e < m.nie) {
-    const QuadTet& Q = c_qdiag[order_index<NDOF>()];
+    const bool p0 = NDOF > 1 && m.ndofel && m.ndofel[e] == 1;   // ElemDiagnostics.cpp:144
+    const QuadTet& Q = p0 ? c_qdiag[0] : c_qdiag[order_index<NDOF>()];
     ElemGeom g;
     load_geom(m, e, g);
     const double vol = m.vol[e];
     double u[NDOF];
     load<NDOF>(U, e, u);
+    if (p0) {
+#pragma unroll
+      for (int k = 1; k < NDOF; ++k) u[k] = 0.0;
+    }
 #pragma unroll 1
     for (int ig = 0; ig < Q.ng; ++ig) {
       const double xi = Q.c[ig][0], eta = Q.c[ig][1], zeta = Q.c[ig][2];
@@ -2285,6 +2409,10 @@ void launch_rhs_p1_rk(const DevMesh& m, const Phys& ph, double t, const double* 
 void launch_superbee(int ndof, const DevMesh& m0, double* U, hipStream_t s, int first, int count)
 {
   if (m0.nie == 0 || ndof == 1) return;
+  if (m0.ncomp == 1) {
+    if (first == 0) QDG_DISPATCH_NDOF(ndof, (tr::k_superbee<N><<<nblk(m0.nie, 256), 256, 0, s>>>(m0, U)));
+    return;
+  }
   DevMesh m = m0;
   m.blk0 = first;
   const int nb = count < 0 ? (int)nblk(m.nie, 256) - first : count;
@@ -2296,6 +2424,10 @@ void launch_weno(int ndof, const DevMesh& m, double cweight, const double* Uin, 
                  hipStream_t s)
 {
   if (m.nie == 0 || ndof == 1) return;
+  if (m.ncomp == 1) {
+    QDG_DISPATCH_NDOF(ndof, (tr::k_weno<N><<<nblk(m.nie, 256), 256, 0, s>>>(m, cweight, Uin, Uout)));
+    return;
+  }
   QDG_DISPATCH_NDOF(ndof, (k_weno<N><<<nblk(m.nie, 256), 256, 0, s>>>(m, cweight, Uin, Uout)));
 }
 

@@ -16,7 +16,10 @@ def _gpu(case, fix, ndof):
     from quinoa_amd import capi, dgmesh
     ss = {int(s): fix["ss_tri_%d" % s] for s in fix["ss_ids"]}
     chunk = dgmesh.build_chunk(fix["coord"], fix["inpoel"], None, ss)
-    ctx = capi.Context(ndof, pde="transport", flux="upwind", problem="slot_cyl", dt=case["dt"],
+    ctx = capi.Context(ndof, pde="transport", flux="upwind", problem=case.get("problem", "slot_cyl"),
+                       dt=case["dt"], limiter=case.get("limiter", "nolimiter"),
+                       cweight=case.get("cweight", 1.0), pref=case.get("pref", False),
+                       tolref=case.get("tolref", 0.1),
                        bc_dirichlet=case["bc_dirichlet"], bc_extrapolate=case["bc_extrapolate"],
                        bc_inlet=case["bc_inlet"], bc_outlet=case["bc_outlet"])
     return ctx, dgmesh.upload(ctx, chunk), chunk
@@ -88,3 +91,43 @@ def test_transport_config_errors():
         capi.Context(1, pde="transport", flux="upwind", problem="slot_cyl", cfl=0.3)
     with pytest.raises(capi.QdgError, match="upwind"):
         capi.Context(1, pde="transport", flux="hllc", problem="slot_cyl", dt=1e-3)
+
+
+MORE = ["cyl_advect_dg", "cyl_advect_dgp1", "cyl_advect_dgp1_weno", "gauss_hump_dgp1",
+        "gauss_hump_dgp2", "gauss_hump_pdg"]
+
+
+@pytest.mark.parametrize("name", MORE)
+def test_transport_regression_cases_match_reference_golden(name, cases):
+    """CylAdvect / GaussHump (DG-P0/P1/P2, Superbee, WENO, p-adaptive) resident on
+    the GPU vs the reference's golden cell values, ndof field and diag tables
+    (L2, L2 error, Linf error), and the full DOF vector vs the oracle."""
+    case, fix = cases[name], load_fixture(name)
+    ctx, mesh, chunk = _gpu(case, fix, case["ndof"])
+    try:
+        mesh.state_initialize(0.0)
+        t, rows = 0.0, []
+        fields, times, ndofs = [mesh.field_output()[0][0]], [0.0], [mesh.ndofel_get()]
+        for it in range(case["nstep"]):
+            t += mesh.step(t)
+            if (it + 1) % case["diag_interval"] == 0:
+                d = mesh.diag(t)
+                rows.append([it + 1, t, case["dt"], np.sqrt(d[0] / chunk.meshvol),
+                             np.sqrt(d[5] / chunk.meshvol), d[10]])
+            if (it + 1) % case["plot_interval"] == 0 or it + 1 == case["nstep"]:
+                fields.append(mesh.field_output()[0][0]); times.append(t); ndofs.append(mesh.ndofel_get())
+        U = mesh.state_download()
+    finally:
+        mesh.close(); ctx.close()
+    if "exo_vals" in fix:
+        assert np.allclose(times, fix["exo_times"], rtol=1e-12, atol=1e-15)
+        assert np.abs(np.array(fields) - fix["exo_vals"][:, 0]).max() <= 1e-10     # north_star bar
+        if case.get("pref"):
+            assert np.array_equal(np.array(ndofs), fix["exo_vals"][:, 1].astype(np.int64))
+    for row, g in zip(rows, fix["diag"]):
+        assert int(row[0]) == int(g[0])
+        for a, b in zip(row[1:len(g)], g[1:]):
+            assert abs(a - b) <= 6e-7 * abs(b) + 1e-13, (name, int(row[0]), a, b)
+    r = O.run_transport_case(case, fix)
+    # all DOFs; WENO's (1e-8 + |grad|)^-2 weights amplify rounding (measured 1.8e-11)
+    assert np.abs(U - r["U"]).max() <= 1e-10 * max(1.0, np.abs(r["U"]).max())
