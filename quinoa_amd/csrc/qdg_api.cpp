@@ -982,6 +982,14 @@ extern "C" int qdg_stage_rhs_dt(qdg_mesh* mesh, int stage, double t, double tlef
       launch_rhs_p1(mesh->dm, ctx->ph, t, mesh->Ucur, mesh->R.p, true, mesh->blockmin.p, scale,
                     tleft, mesh->dtraw.p, mesh->dt_ptr, s);
     if (ev) HIPCHK(hipEventRecord(ev->second, s));
+  } else if (cfl_dt && mesh->dm.ncomp == NCOMP) {
+    // P0 / P2 (and the generic P1 path): the CFL sum comes out of the same face loop
+    const double p = (mesh->ndof == 4) ? 1.0 : (mesh->ndof == 10) ? 2.0 : 0.0;
+    const double scale = ctx->cfg.cfl / (2.0 * p + 1.0);     // DG.cpp:1404-1418
+    if (int rc = prof_begin(mesh, &ev)) return rc;
+    launch_rhs_dt(mesh->ndof, mesh->dm, ctx->ph, t, mesh->Ucur, mesh->R.p, mesh->blockmin.p, scale,
+                  tleft, mesh->dtraw.p, mesh->dt_ptr, s);
+    if (ev) HIPCHK(hipEventRecord(ev->second, s));
   } else {
     if (cfl_dt) if (int rc = qdg_stage_dt(mesh, tleft)) return rc;
     if (int rc = prof_begin(mesh, &ev)) return rc;

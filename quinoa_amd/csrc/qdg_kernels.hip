@@ -537,127 +537,6 @@ __device__ __forceinline__ void inverse_jacobian(const ElemGeom& g, double (&ji)
   ji[2][2] =  (bx * cy - cx * by) * id;
 }
 
-// ------------------------------------------------------------- RHS kernel
-// dg::CompFlow::rhs (src/PDE/CompFlow/DGCompFlow.hpp:130-195) for interior
-// tets: surfInt + bndSurfInt (per local face), volInt, srcInt.
-template <int NDOF, int PROB>
-__global__ __launch_bounds__(256) void k_rhs(DevMesh m, Phys ph, double t,
-                                             const double* __restrict__ U,
-                                             double* __restrict__ R)
-{
-  const int e = xcd_tile(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
-  if (e >= m.nie) return;
-  const Tables<NDOF>& T = tab<NDOF>();
-  constexpr int NGF = Tables<NDOF>::NGF, NGV = Tables<NDOF>::NGV;
-  const int stride = m.stride;
-
-  double acc[NCOMP][NDOF];
-#pragma unroll
-  for (int c = 0; c < NCOMP; ++c)
-#pragma unroll
-    for (int k = 0; k < NDOF; ++k) acc[c][k] = 0.0;
-
-  ElemGeom g;
-  load_geom(m, e, g);
-
-  // ---- faces ------------------------------------------------------------
-#pragma unroll 1
-  for (int lf = 0; lf < 4; ++lf) {
-    const int nb = m.nbr[(size_t)lf * stride + e];
-    if (nb == -1) continue;                     // boundary face without a BC
-    const int info = m.finfo[(size_t)lf * stride + e];
-    const int f = m.fid[(size_t)lf * stride + e];
-    const double area = m.farea[f];
-    const double fn[3] = { m.fnx[f], m.fny[f], m.fnz[f] };
-    const bool own_left = (info >> 6) & 1;
-#pragma unroll 1
-    for (int ig = 0; ig < NGF; ++ig) {
-      const double s0 = T.fs[ig][0], s1 = T.fs[ig][1], s2 = T.fs[ig][2];
-      double so[NCOMP], sn[NCOMP], fl[NCOMP];
-      state_gather<NDOF>(U, stride, e, T.fB[lf][ig], so);
-      if (nb >= 0) {
-        double xi, eta, zeta, Bn[NDOF];
-        nbr_ref_coords(info, s0, s1, s2, xi, eta, zeta);
-        eval_basis<NDOF>(xi, eta, zeta, Bn);
-        state_gather<NDOF>(U, stride, nb, Bn, sn);
-      } else {
-        double P[3];
-        face_point(g, lf, s0, s1, s2, P);
-        bc_state<PROB>(ph, -nb - 1, so, P[0], P[1], P[2], t, fn, sn);
-      }
-      if (own_left) riemann(ph, fn, so, sn, fl);
-      else          riemann(ph, fn, sn, so, fl);
-      const double wt = (own_left ? -1.0 : 1.0) * T.fw[ig] * area;
-#pragma unroll
-      for (int c = 0; c < NCOMP; ++c) {
-        const double wf = wt * fl[c];
-        acc[c][0] += wf;
-#pragma unroll
-        for (int k = 1; k < NDOF; ++k) acc[c][k] += wf * T.fB[lf][ig][k];
-      }
-    }
-  }
-
-  const double vol = m.vol[e];
-
-  // ---- volume integral, src/PDE/Integrate/Volume.cpp:20-168 -------------
-  if constexpr (NDOF > 1) {
-    double ji[3][3];
-    inverse_jacobian(g, ji);
-#pragma unroll 1
-    for (int ig = 0; ig < NGV; ++ig) {
-      double s[NCOMP];
-      state_gather<NDOF>(U, stride, e, T.vB[ig], s);
-      const double ir = 1.0 / s[0];
-      const double u = s[1] * ir, v = s[2] * ir, w = s[3] * ir;
-      const double p = eos_pressure(ph, s[0], u, v, w, s[4]);
-      const double wt = T.vw[ig] * vol;
-      // Euler flux F[c][d], src/PDE/CompFlow/DGCompFlow.hpp:599-635
-      const double F[NCOMP][3] = {
-        { s[1], s[2], s[3] },
-        { s[1] * u + p, s[2] * u, s[3] * u },
-        { s[1] * v, s[2] * v + p, s[3] * v },
-        { s[1] * w, s[2] * w, s[3] * w + p },
-        { u * (s[4] + p), v * (s[4] + p), w * (s[4] + p) } };
-#pragma unroll
-      for (int k = 1; k < NDOF; ++k) {
-        // dB_k/dx_d = sum_j dB_k/dxi_j * jacInv[j][d]   (Basis.cpp:77-265)
-        const double g0 = T.vdB[ig][0][k], g1 = T.vdB[ig][1][k], g2 = T.vdB[ig][2][k];
-        const double dx = g0 * ji[0][0] + g1 * ji[1][0] + g2 * ji[2][0];
-        const double dy = g0 * ji[0][1] + g1 * ji[1][1] + g2 * ji[2][1];
-        const double dz = g0 * ji[0][2] + g1 * ji[1][2] + g2 * ji[2][2];
-#pragma unroll
-        for (int c = 0; c < NCOMP; ++c)
-          acc[c][k] += wt * (F[c][0] * dx + F[c][1] * dy + F[c][2] * dz);
-      }
-    }
-  }
-
-  // ---- source integral, src/PDE/Integrate/Source.cpp:21-141 -------------
-  if constexpr (prob_has_source<PROB>()) {
-#pragma unroll 1
-    for (int ig = 0; ig < NGV; ++ig) {
-      const double xi = T.vc[ig][0], eta = T.vc[ig][1], zeta = T.vc[ig][2];
-      const double w0 = 1.0 - xi - eta - zeta;
-      double P[3], s[NCOMP];
-#pragma unroll
-      for (int d = 0; d < 3; ++d)
-        P[d] = g.p[0][d] * w0 + g.p[1][d] * xi + g.p[2][d] * eta + g.p[3][d] * zeta;
-      prob_src<PROB>(ph, P[0], P[1], P[2], t, s);
-      const double wt = T.vw[ig] * vol;
-#pragma unroll
-      for (int c = 0; c < NCOMP; ++c) {
-        const double ws = wt * s[c];
-        acc[c][0] += ws;
-#pragma unroll
-        for (int k = 1; k < NDOF; ++k) acc[c][k] += ws * T.vB[ig][k];
-      }
-    }
-  }
-
-  store_row<NCOMP * NDOF>(R, e, &acc[0][0]);
-}
-
 // ------------------------------------------------------- fast fp64 helpers
 // 1/x and sqrt(x) from the hardware seeds (v_rcp_f64 / v_rsq_f64) plus Newton
 // steps: ~1 ulp, without the div_scale/div_fixup range handling of the full
@@ -752,6 +631,164 @@ __device__ __forceinline__ void flux_lf_q(const double* fn, const double* L, con
 #pragma unroll
   for (int c = 0; c < 5; ++c) flx[c] = 0.5 * (fl[c] + fr[c] - lambda * (R[c] - L[c]));
 }
+
+// ------------------------------------------------------------- RHS kernel
+// dg::CompFlow::rhs (src/PDE/CompFlow/DGCompFlow.hpp:130-195) for interior
+// tets: surfInt + bndSurfInt (per local face), volInt, srcInt.
+// Rows are read ONCE into registers: the tet's own row before the face loop, a
+// neighbour's row once per face (P2: 3 x 100 VGPRs of rows and accumulators --
+// the kernel is built for one wave per SIMD, where a wave may hold 512 registers).
+// WITH_DT (stage 0 with a CFL time step): dg::CompFlow::dt needs |vn|+a of both
+// sides at every face Gauss point -- what the Riemann solver has just computed;
+// the per-workgroup minimum of vol/delt goes to blockmin (k_dt_final finishes).
+template <int NDOF, int PROB, bool WITH_DT>
+__global__ __launch_bounds__(256, (NDOF > 4 ? 1 : 2)) void k_rhs(DevMesh m, Phys ph, double t,
+                                             const double* __restrict__ U,
+                                             double* __restrict__ R,
+                                             double* __restrict__ blockmin)
+{
+  const int e0 = xcd_tile(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+  const bool active = e0 < m.nie;
+  if (!WITH_DT && !active) return;
+  const int e = active ? e0 : m.nie - 1;       // WITH_DT: every lane reaches the reduction
+  double delt = 0.0;
+  const Tables<NDOF>& T = tab<NDOF>();
+  constexpr int NGF = Tables<NDOF>::NGF, NGV = Tables<NDOF>::NGV;
+  const int stride = m.stride;
+
+  double acc[NCOMP][NDOF], u[NCOMP][NDOF];
+#pragma unroll
+  for (int c = 0; c < NCOMP; ++c)
+#pragma unroll
+    for (int k = 0; k < NDOF; ++k) acc[c][k] = 0.0;
+  load_dofs<NDOF>(U, stride, e, u);
+
+  ElemGeom g;
+  load_geom(m, e, g);
+
+  // ---- faces ------------------------------------------------------------
+#pragma unroll 1
+  for (int lf = 0; lf < 4; ++lf) {
+    const int nb = m.nbr[(size_t)lf * stride + e];
+    if (nb == -1) continue;                     // boundary face without a BC
+    const int info = m.finfo[(size_t)lf * stride + e];
+    const int f = m.fid[(size_t)lf * stride + e];
+    const double area = m.farea[f];
+    const double fn[3] = { m.fnx[f], m.fny[f], m.fnz[f] };
+    const bool own_left = (info >> 6) & 1;
+    double un[NCOMP][NDOF];
+    if (nb >= 0) load_dofs<NDOF>(U, stride, nb, un);
+#pragma unroll 1
+    for (int ig = 0; ig < NGF; ++ig) {
+      const double s0 = T.fs[ig][0], s1 = T.fs[ig][1], s2 = T.fs[ig][2];
+      double so[NCOMP], sn[NCOMP], fl[NCOMP];
+      state_from<NDOF>(u, T.fB[lf][ig], so);
+      if (nb >= 0) {
+        double xi, eta, zeta, Bn[NDOF];
+        nbr_ref_coords(info, s0, s1, s2, xi, eta, zeta);
+        eval_basis<NDOF>(xi, eta, zeta, Bn);
+        state_from<NDOF>(un, Bn, sn);
+      } else {
+        double P[3];
+        face_point(g, lf, s0, s1, s2, P);
+        bc_state<PROB>(ph, -nb - 1, so, P[0], P[1], P[2], t, fn, sn);
+      }
+      double L[NCOMP], Rr[NCOMP];
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) { L[c] = own_left ? so[c] : sn[c]; Rr[c] = own_left ? sn[c] : so[c]; }
+      Prim ql, qr;
+      primitives(ph, fn, L, ql);
+      primitives(ph, fn, Rr, qr);
+      const double wq = T.fw[ig] * area;
+      if (WITH_DT) {
+        // std::max(dSV_l, dSV_r) as (a < b) ? b : a in (face-left, face-right) order
+        const double dl = wq * (fabs(ql.vn) + ql.a);
+        const double dr = (nb < 0) ? 0.0 : wq * (fabs(qr.vn) + qr.a);
+        delt += (dl < dr) ? dr : dl;
+      }
+      if (ph.flux == 1) flux_lf_q(fn, L, Rr, ql, qr, fl);
+      else flux_hllc_q(fn, L, Rr, ql, qr, fl);
+      const double wt = (own_left ? -1.0 : 1.0) * wq;
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) {
+        const double wf = wt * fl[c];
+        acc[c][0] += wf;
+#pragma unroll
+        for (int k = 1; k < NDOF; ++k) acc[c][k] += wf * T.fB[lf][ig][k];
+      }
+    }
+  }
+
+  const double vol = m.vol[e];
+
+  // ---- volume integral, src/PDE/Integrate/Volume.cpp:20-168 -------------
+  if constexpr (NDOF > 1) {
+    double ji[3][3];
+    inverse_jacobian(g, ji);
+#pragma unroll 1
+    for (int ig = 0; ig < NGV; ++ig) {
+      double s[NCOMP];
+      state_from<NDOF>(u, T.vB[ig], s);
+      const double ir = fast_rcp(s[0]);
+      const double u = s[1] * ir, v = s[2] * ir, w = s[3] * ir;
+      const double p = eos_pressure(ph, s[0], u, v, w, s[4]);
+      const double wt = T.vw[ig] * vol;
+      // Euler flux F[c][d], src/PDE/CompFlow/DGCompFlow.hpp:599-635
+      const double F[NCOMP][3] = {
+        { s[1], s[2], s[3] },
+        { s[1] * u + p, s[2] * u, s[3] * u },
+        { s[1] * v, s[2] * v + p, s[3] * v },
+        { s[1] * w, s[2] * w, s[3] * w + p },
+        { u * (s[4] + p), v * (s[4] + p), w * (s[4] + p) } };
+#pragma unroll
+      for (int k = 1; k < NDOF; ++k) {
+        // dB_k/dx_d = sum_j dB_k/dxi_j * jacInv[j][d]   (Basis.cpp:77-265)
+        const double g0 = T.vdB[ig][0][k], g1 = T.vdB[ig][1][k], g2 = T.vdB[ig][2][k];
+        const double dx = g0 * ji[0][0] + g1 * ji[1][0] + g2 * ji[2][0];
+        const double dy = g0 * ji[0][1] + g1 * ji[1][1] + g2 * ji[2][1];
+        const double dz = g0 * ji[0][2] + g1 * ji[1][2] + g2 * ji[2][2];
+#pragma unroll
+        for (int c = 0; c < NCOMP; ++c)
+          acc[c][k] += wt * (F[c][0] * dx + F[c][1] * dy + F[c][2] * dz);
+      }
+    }
+  }
+
+  // ---- source integral, src/PDE/Integrate/Source.cpp:21-141 -------------
+  if constexpr (prob_has_source<PROB>()) {
+#pragma unroll 1
+    for (int ig = 0; ig < NGV; ++ig) {
+      const double xi = T.vc[ig][0], eta = T.vc[ig][1], zeta = T.vc[ig][2];
+      const double w0 = 1.0 - xi - eta - zeta;
+      double P[3], s[NCOMP];
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+        P[d] = g.p[0][d] * w0 + g.p[1][d] * xi + g.p[2][d] * eta + g.p[3][d] * zeta;
+      prob_src<PROB>(ph, P[0], P[1], P[2], t, s);
+      const double wt = T.vw[ig] * vol;
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) {
+        const double ws = wt * s[c];
+        acc[c][0] += ws;
+#pragma unroll
+        for (int k = 1; k < NDOF; ++k) acc[c][k] += ws * T.vB[ig][k];
+      }
+    }
+  }
+
+  if (active) store_row<NCOMP * NDOF>(R, e, &acc[0][0]);
+  if (WITH_DT) {
+    double dte = active ? m.vol[e] / delt : DBL_MAX;
+    for (int off = 32; off > 0; off >>= 1) dte = fmin(dte, __shfl_down(dte, off, 64));
+    __shared__ double wmin[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) wmin[wv] = dte;
+    __syncthreads();
+    if (threadIdx.x == 0)
+      blockmin[blockIdx.x] = fmin(fmin(wmin[0], wmin[1]), fmin(wmin[2], wmin[3]));
+  }
+}
+
 
 // ------------------------------------------------- DG-P1 RHS (headline kernel)
 // Same algorithm as k_rhs<4>, specialised for throughput:
@@ -2344,7 +2381,18 @@ void launch_rhs(int ndof, const DevMesh& m, const Phys& ph, double t, const doub
     QDG_DISPATCH_NDOF(ndof, (tr::k_rhs<N><<<nblk(m.nie, 256), 256, 0, s>>>(m, ph, t, U, R)));
     return;
   }
-  QDG_DISPATCH_NDOF(ndof, QDG_DISPATCH_PROB(ph.problem, (k_rhs<N, P><<<nblk(m.nie, 256), 256, 0, s>>>(m, ph, t, U, R))));
+  QDG_DISPATCH_NDOF(ndof, QDG_DISPATCH_PROB(ph.problem, (k_rhs<N, P, false><<<nblk(m.nie, 256), 256, 0, s>>>(m, ph, t, U, R, nullptr))));
+}
+
+// generic RHS with the CFL time step fused in (stage 0): dt = min(vol/delt) * scale, capped to tleft
+void launch_rhs_dt(int ndof, const DevMesh& m, const Phys& ph, double t, const double* U, double* R,
+                   double* blockmin, double scale, double tleft, double* out_raw, double* out_dt,
+                   hipStream_t s)
+{
+  const int nb = nblk(m.nie, 256);
+  if (nb == 0) return;
+  QDG_DISPATCH_NDOF(ndof, QDG_DISPATCH_PROB(ph.problem, (k_rhs<N, P, true><<<nb, 256, 0, s>>>(m, ph, t, U, R, blockmin))));
+  k_dt_final<<<1, 256, 0, s>>>(blockmin, nb, scale, tleft, out_raw, out_dt);
 }
 
 // P1 fast path; with_dt: also reduce min(vol/delt) into out_raw/out_dt

@@ -11,6 +11,9 @@ hipError_t upload_tables(const Tables<1>& t1, const Tables<4>& t4, const Tables<
 
 void launch_rhs(int ndof, const DevMesh& m, const Phys& ph, double t, const double* U, double* R,
                 hipStream_t s);
+void launch_rhs_dt(int ndof, const DevMesh& m, const Phys& ph, double t, const double* U, double* R,
+                   double* blockmin, double scale, double tleft, double* out_raw, double* out_dt,
+                   hipStream_t s);
 void launch_rhs_p1(const DevMesh& m, const Phys& ph, double t, const double* U, double* R,
                    bool with_dt, double* blockmin, double scale, double tleft, double* out_raw,
                    double* out_dt, hipStream_t s);

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Resident RHS/step timing of any order on the synthetic box (for DESIGN.md's
+per-order table; bench.py stays on the BASELINE workload).
+Usage (GPU box): python tools/rhs_rate.py <ndof> [nx] [limiter] [problem]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+from quinoa_amd import capi, dgmesh, meshgen  # noqa: E402
+
+ndof = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+nx = int(sys.argv[2]) if len(sys.argv) > 2 else 55
+limiter = sys.argv[3] if len(sys.argv) > 3 else "nolimiter"
+problem = sys.argv[4] if len(sys.argv) > 4 else "sod_shocktube"
+ch = meshgen.kuhn_box(nx, nx, nx)
+t0 = time.perf_counter()
+chunk = dgmesh.build_chunk(ch["coord"], ch["inpoel"], None, ch["sidesets"])
+t1 = time.perf_counter()
+kw = dict(bc_extrapolate=[1, 2], bc_sym=[3, 4, 5, 6]) if problem in ("sod_shocktube",) else \
+    dict(bc_dirichlet=[1, 2, 3, 4, 5, 6])
+ctx = capi.Context(ndof, flux="hllc", limiter=limiter, problem=problem, gamma=1.4, cfl=0.3,
+                   alpha=0.1, beta=1.0, p0=10.0, **kw)
+mesh = dgmesh.upload(ctx, chunk)
+t2 = time.perf_counter()
+mesh.state_initialize(0.0)
+for _ in range(3):
+    mesh.step(0.0, want_dt=False)
+ctx.synchronize()
+mesh.profile_enable(True)
+n = 10
+t3 = time.perf_counter()
+for _ in range(n):
+    mesh.step(0.0, want_dt=False)
+ctx.synchronize()
+el = (time.perf_counter() - t3) / n
+nl, ms = mesh.profile_read()
+alg = mesh.rhs_algorithmic_bytes()
+print("ndof %d %s %s: %d tets; host FaceData+geometry %.2f s, upload %.2f s; step %.3f ms = %.0f M elem-updates/s; "
+      "RHS %.4f ms/launch = %.0f GB/s algorithmic (%.1f %% of 8 TB/s)"
+      % (ndof, limiter, problem, chunk.nielem, t1 - t0, t2 - t1, el * 1e3, chunk.nielem * 3 / el / 1e6,
+         ms / nl, alg / (ms / nl * 1e-3) / 1e9, alg / (ms / nl * 1e-3) / 8e12 * 100))
+mesh.close(); ctx.close()
