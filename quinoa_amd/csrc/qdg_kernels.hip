@@ -28,6 +28,9 @@
 #ifndef QDG_SQRT_NR
 #define QDG_SQRT_NR 1   // Goldschmidt steps after v_rsq_f64 (plus one residual correction)
 #endif
+#ifndef QDG_TILE_WAVES
+#define QDG_TILE_WAVES 2
+#endif
 #ifndef QDG_TILE_GP_UNROLL
 #define QDG_TILE_GP_UNROLL 1
 #endif
@@ -1047,6 +1050,9 @@ __global__ __launch_bounds__(256, QDG_P1_WAVES) void k_rhs_p1(DevMesh m, Phys ph
 // The LDS accumulation uses ds_add_f64: the order in which the (at most four)
 // face contributions of a tet arrive is not fixed, so R can differ in the last
 // bit from run to run; QDG_DETERMINISTIC_RHS=1 selects k_rhs_p1 instead.
+// LDS index of (tet, vertex, component) in the tile kernels' nodal arrays
+#define LIDX(e, v, c) ((((v) * NCOMP) + (c)) * TILE + (e))
+
 __device__ __forceinline__ void vertex_basis(int v, double& b1, double& b2, double& b3)
 {
   // B1 = 2xi+eta+zeta-1, B2 = 3eta+zeta-1, B3 = 4zeta-1 at reference vertex v
@@ -1063,7 +1069,7 @@ __device__ __forceinline__ void vertex_basis(int v, double& b1, double& b2, doub
 // (Surface.cpp:81-86): between two P0 tets both states are constant, so the 1-
 // and the 3-point sums agree to rounding.
 template <bool WITH_DT, bool FUSE_RK, int PROB, bool PDG>
-__global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1t(DevMesh m, Phys ph, double t,
+__global__ __launch_bounds__(TILE_BS, QDG_TILE_WAVES) void k_rhs_p1t(DevMesh m, Phys ph, double t,
                                                      const double* __restrict__ U,
                                                      double* __restrict__ R,
                                                      double* __restrict__ blockmin,
@@ -1112,8 +1118,6 @@ __global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1t(DevMesh m, Phys ph, doub
         for (int c = 0; c < NCOMP; ++c) r[c][1] = r[c][2] = r[c][3] = 0.0;
       }
     }
-    double2* dn = reinterpret_cast<double2*>(nod + (size_t)tid * NPROP);
-    double2* da = reinterpret_cast<double2*>(accN + (size_t)tid * NPROP);
     double v[4][NCOMP];
 #pragma unroll
     for (int c = 0; c < NCOMP; ++c) {
@@ -1124,9 +1128,12 @@ __global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1t(DevMesh m, Phys ph, doub
       v[2][c] = a + 2.0 * r[c][2];
       v[3][c] = r[c][0] + 3.0 * r[c][3];
     }
-    const double* vf = &v[0][0];
+    // LDS planes [vertex][component][tet]: lanes of a wave work on different tets at the
+    // same (vertex, component), so tet-fastest storage is free of bank conflicts
 #pragma unroll
-    for (int i = 0; i < NPROP / 2; ++i) { dn[i] = make_double2(vf[2 * i], vf[2 * i + 1]); da[i] = make_double2(0.0, 0.0); }
+    for (int vx = 0; vx < 4; ++vx)
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) { nod[LIDX(tid, vx, c)] = v[vx][c]; accN[LIDX(tid, vx, c)] = 0.0; }
     if (WITH_DT) sdelt[tid] = 0.0;
   }
   double gnx[4], rnx[NCOMP][NDOF];
@@ -1185,16 +1192,14 @@ __global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1t(DevMesh m, Phys ph, doub
     for (int j = 0; j < 3; ++j) { no[j] = lpofa(lf, j); nn[j] = (code >> (2 * j)) & 3; }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      const double* p = nod + ((size_t)el * 4 + no[j]) * NCOMP;
 #pragma unroll
-      for (int c = 0; c < NCOMP; ++c) Vo[j][c] = p[c];
+      for (int c = 0; c < NCOMP; ++c) Vo[j][c] = nod[LIDX(el, no[j], c)];
     }
     if (kind == TASK_INT) {
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
-        const double* p = nod + ((size_t)pl * 4 + nn[j]) * NCOMP;
 #pragma unroll
-        for (int c = 0; c < NCOMP; ++c) Vn[j][c] = p[c];
+        for (int c = 0; c < NCOMP; ++c) Vn[j][c] = nod[LIDX(pl, nn[j], c)];
       }
     } else if (kind == TASK_EXT) {
 #pragma unroll
@@ -1278,19 +1283,17 @@ __global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1t(DevMesh m, Phys ph, doub
       const double sg = own_left ? -1.0 : 1.0;
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
-        double* ao = accN + ((size_t)el * 4 + no[j]) * NCOMP;
 #pragma unroll
         for (int c = 0; c < NCOMP; ++c)
-          __hip_atomic_fetch_add(ao + c, sg * W[j][c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_add(accN + LIDX(el, no[j], c), sg * W[j][c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
       if (WITH_DT) __hip_atomic_fetch_add(sdelt + el, dsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       if (kind == TASK_INT) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-          double* ap = accN + ((size_t)pl * 4 + nn[j]) * NCOMP;
 #pragma unroll
           for (int c = 0; c < NCOMP; ++c)
-            __hip_atomic_fetch_add(ap + c, -sg * W[j][c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(accN + LIDX(pl, nn[j], c), -sg * W[j][c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         if (WITH_DT) __hip_atomic_fetch_add(sdelt + pl, dsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
@@ -1327,7 +1330,10 @@ __global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1t(DevMesh m, Phys ph, doub
     {
       // R[c][k] = sum_v accN[v][c] * B_k(vertex v)
       double nv[4][NCOMP];
-      lds_row<NPROP>(accN, tid, &nv[0][0]);
+#pragma unroll
+      for (int vx = 0; vx < 4; ++vx)
+#pragma unroll
+        for (int c = 0; c < NCOMP; ++c) nv[vx][c] = accN[LIDX(tid, vx, c)];
 #pragma unroll
       for (int c = 0; c < NCOMP; ++c) {
         acc[c][0] = (nv[0][c] + nv[1][c]) + (nv[2][c] + nv[3][c]);
