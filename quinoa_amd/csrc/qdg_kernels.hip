@@ -1480,6 +1480,14 @@ __global__ __launch_bounds__(256) void k_superbee(DevMesh m, double* __restrict_
         }
       }
     }
+    // Limiter.cpp:283-301: phi = min over the face points of f(phi_gp),
+    // phi_gp = min(1, (uMax|uMin - u0) / (2 uNeg)), f(p) = max(0, max(min(2p,1), min(p,2))).
+    // f is non-decreasing, so phi = f(min phi_gp): the smallest ratio a/b is
+    // tracked by cross-multiplication (a, b >= 0) and divided once per component
+    // instead of once per point (|uNeg| <= 1e-14 -> phi_gp = 1: skipped).
+    double ra[NCOMP], rb[NCOMP];
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c) { ra[c] = 1.0; rb[c] = 1.0; }
 #pragma unroll 1
     for (int lf = 0; lf < 4; ++lf)
 #pragma unroll
@@ -1488,17 +1496,19 @@ __global__ __launch_bounds__(256) void k_superbee(DevMesh m, double* __restrict_
         state_from<NDOF>(u, T.fB[lf][ig], s);
 #pragma unroll
         for (int c = 0; c < NCOMP; ++c) {
-          // Limiter.cpp:283-301 without the three-way branch: one numerator
-          // select, one reciprocal (|uNeg| <= 1e-14 -> phi_gp = 1)
           const double uNeg = s[c] - u[c][0];
-          const double num = (uNeg > 0.0 ? uMax[c] : uMin[c]) - u[c][0];
-          const bool flat = fabs(uNeg) <= 1.0e-14;
-          double pg = fmin(1.0, num * fast_rcp(2.0 * (flat ? 1.0 : uNeg)));
-          pg = flat ? 1.0 : pg;
-          pg = fmax(0.0, fmax(fmin(2.0 * pg, 1.0), fmin(pg, 2.0)));
-          phi[c] = fmin(phi[c], pg);
+          const double a = (uNeg > 0.0) ? (uMax[c] - u[c][0]) : (u[c][0] - uMin[c]);
+          const double b = 2.0 * fabs(uNeg);
+          const bool take = (fabs(uNeg) > 1.0e-14) && (a * rb[c] < ra[c] * b);
+          ra[c] = take ? a : ra[c];
+          rb[c] = take ? b : rb[c];
         }
       }
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c) {
+      const double pg = fmin(1.0, ra[c] * fast_rcp(rb[c]));
+      phi[c] = fmax(0.0, fmax(fmin(2.0 * pg, 1.0), fmin(pg, 2.0)));
+    }
     if (m.ndofel && m.ndofel[e] == 1) {    // pdg: P0 elements are not limited (Limiter.cpp:179-180)
 #pragma unroll
       for (int c = 0; c < NCOMP; ++c) phi[c] = 1.0;
