@@ -2322,6 +2322,17 @@ __global__ void k_halo_pack(const double* __restrict__ U, int nprop,
   slab[i] = (p < nprop) ? U[(size_t)e * nprop + p] : (double)ndofel[e];
 }
 
+// the common case (even row length, no ndof column): 16-byte chunks
+__global__ __launch_bounds__(256) void k_halo_pack2(const double2* __restrict__ U, int nchunk,
+                                                    const int* __restrict__ send_elem, int nsend,
+                                                    double2* __restrict__ slab)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nsend * nchunk) return;
+  const int j = i / nchunk, p = i - j * nchunk;
+  slab[i] = U[(size_t)send_elem[j] * nchunk + p];
+}
+
 // DG::lim / DG::dt receive side (DG.cpp:1239-1247, 1372-1380): ghost rows
 // [nie, nie+nrecv) are contiguous, so unpacking is one contiguous copy
 __global__ void k_halo_unpack(const double* __restrict__ slab, int nprop, int nie, int nrecv,
@@ -2575,6 +2586,13 @@ void launch_halo_pack(const double* U, int nprop, int /*stride*/, const int* sen
                       double* slab, hipStream_t s, const int* ndofel)
 {
   if (nsend == 0) return;
+  if (!ndofel && nprop % 2 == 0) {
+    const int nchunk = nprop / 2;
+    const size_t n2 = (size_t)nsend * nchunk;
+    k_halo_pack2<<<(unsigned)((n2 + 255) / 256), 256, 0, s>>>(reinterpret_cast<const double2*>(U), nchunk,
+                                                              send_elem, nsend, reinterpret_cast<double2*>(slab));
+    return;
+  }
   const size_t n = (size_t)nsend * (nprop + (ndofel ? 1 : 0));
   k_halo_pack<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(U, nprop, send_elem, nsend, slab, ndofel);
 }
