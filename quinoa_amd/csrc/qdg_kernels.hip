@@ -673,7 +673,10 @@ __global__ __launch_bounds__(256, (NDOF > 4 ? 1 : 2)) void k_rhs(DevMesh m, Phys
 #pragma unroll 1
   for (int lf = 0; lf < 4; ++lf) {
     const int nb = m.nbr[(size_t)lf * stride + e];
-    if (nb == -1) continue;                     // boundary face without a BC
+    // boundary face without a BC: no flux, but dg::CompFlow::dt still counts it
+    // (its face loop runs over all faces, DGCompFlow.hpp:226)
+    if (nb == -1 && !WITH_DT) continue;
+    const double wsel = (nb == -1) ? 0.0 : 1.0;
     const int info = m.finfo[(size_t)lf * stride + e];
     const int f = m.fid[(size_t)lf * stride + e];
     const double area = m.farea[f];
@@ -711,7 +714,7 @@ __global__ __launch_bounds__(256, (NDOF > 4 ? 1 : 2)) void k_rhs(DevMesh m, Phys
       }
       if (ph.flux == 1) flux_lf_q(fn, L, Rr, ql, qr, fl);
       else flux_hllc_q(fn, L, Rr, ql, qr, fl);
-      const double wt = (own_left ? -1.0 : 1.0) * wq;
+      const double wt = (own_left ? -1.0 : 1.0) * wq * wsel;
 #pragma unroll
       for (int c = 0; c < NCOMP; ++c) {
         const double wf = wt * fl[c];

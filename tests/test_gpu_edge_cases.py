@@ -1,0 +1,115 @@
+"""Edge cases of the HIP path through the C ABI: tiny and ragged meshes (one tet,
+two tets, a tile boundary cut through the element range), faces without a
+configured BC, and malformed input that must be rejected on the host before any
+kernel sees it."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+KW = dict(flux="hllc", problem="sod_shocktube", gamma=1.4)
+
+
+def _tets(n):
+    """n tets glued in a strip along x (each shares a face with the next)"""
+    if n == 1:
+        coord = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], dtype=float)
+        return coord, np.array([[0, 1, 2, 3]])
+    from quinoa_amd import meshgen
+    ch = meshgen.kuhn_box(1, 1, 1)
+    return ch["coord"], ch["inpoel"][:n] if n <= 6 else None
+
+
+def _run_rhs(coord, inpoel, sidesets, ndof, limiter="nolimiter", bc=None):
+    from quinoa_amd import capi, dgmesh
+    bc = bc or {}
+    chunk = dgmesh.build_chunk(coord, inpoel, None, sidesets)
+    ctx = capi.Context(ndof, limiter=limiter, cfl=0.3, **KW, **bc)
+    mesh = dgmesh.upload(ctx, chunk)
+    om = O.OracleMesh(coord, inpoel, sidesets)
+    orc = O.Oracle(om, O.make_cfg(ndof, limiter=limiter, **KW), bc.get("bc_dirichlet", ()),
+                   bc.get("bc_sym", ()), bc.get("bc_extrapolate", ()))
+    try:
+        rng = np.random.default_rng(5)
+        Lm = orc.lhs()
+        U = orc.initialize(Lm, 0.0)
+        U += 1e-3 * rng.normal(size=U.shape)          # populate all modes
+        R, Rg = orc.rhs(0.0, U), mesh.rhs(0.0, U)
+        assert np.abs(Rg - R).max() <= 1e-11 * max(1.0, np.abs(R).max())
+        assert abs(mesh.dt(U) - orc.dt(U)) <= 1e-12 * orc.dt(U)
+        if limiter != "nolimiter" and ndof > 1:
+            assert np.abs(mesh.limit(U) - orc.limit(U.copy())).max() <= 1e-12
+        mesh.state_upload(U)
+        t = 0.0
+        for _ in range(2):
+            dtg = mesh.step(t)
+            dto = orc.step(t, U, Lm, cfl=0.3)
+            assert abs(dtg - dto) <= 1e-11 * dto
+            t += dto
+        assert np.abs(mesh.state_download() - U).max() <= 1e-10 * max(1.0, np.abs(U).max())
+    finally:
+        mesh.close(); ctx.close()
+
+
+@pytest.mark.parametrize("ndof", [1, 4, 10])
+def test_single_tet_all_faces_on_the_boundary(ndof):
+    coord, inpoel = _tets(1)
+    tri = np.array([[1, 2, 3], [2, 0, 3], [3, 0, 1], [0, 2, 1]])
+    # two faces extrapolate, one symmetry, one without any BC (no flux through it)
+    _run_rhs(coord, inpoel, {1: tri[:2], 2: tri[2:3], 3: tri[3:]}, ndof,
+             limiter="superbeep1" if ndof == 4 else "nolimiter",
+             bc=dict(bc_extrapolate=[1], bc_sym=[2]))
+
+
+@pytest.mark.parametrize("ndof", [1, 4])
+def test_six_tets_no_bc_configured(ndof):
+    """one Kuhn cube: interior faces only matter, every boundary face is left without a BC"""
+    from quinoa_amd import meshgen
+    ch = meshgen.kuhn_box(1, 1, 1)
+    _run_rhs(ch["coord"], ch["inpoel"], ch["sidesets"], ndof)
+
+
+def test_ragged_last_tile_and_last_workgroup():
+    """element count = 248 * k + small and 256 * k' + small: the last tile of the tile
+    kernel and the last workgroup of the 256-wide kernels are nearly empty"""
+    from quinoa_amd import meshgen
+    ch = meshgen.kuhn_box(7, 6, 1)                  # 252 tets: one full tile + 4, one workgroup - 4
+    assert ch["inpoel"].shape[0] == 252
+    _run_rhs(ch["coord"], ch["inpoel"], ch["sidesets"], 4, limiter="superbeep1",
+             bc=dict(bc_extrapolate=[1, 2], bc_sym=[3, 4, 5, 6]))
+    ch = meshgen.kuhn_box(43, 1, 1)                 # 258 tets: 256 + 2
+    assert ch["inpoel"].shape[0] == 258
+    _run_rhs(ch["coord"], ch["inpoel"], ch["sidesets"], 4, limiter="superbeep1",
+             bc=dict(bc_extrapolate=[1, 2], bc_sym=[3, 4, 5, 6]))
+
+
+def test_malformed_meshes_are_rejected_on_the_host():
+    from quinoa_amd import capi, dgmesh, meshgen
+    ch = meshgen.kuhn_box(2, 2, 2)
+    chunk = dgmesh.build_chunk(ch["coord"], ch["inpoel"], None, ch["sidesets"])
+    ctx = capi.Context(4, cfl=0.3, **KW)
+    try:
+        def upload(**over):
+            a = dict(nielem=chunk.nielem, inpoel=chunk.inpoel, coord=chunk.coord, esuf=chunk.esuf,
+                     esuel=chunk.esuel, inpofa=chunk.inpofa, geoFace=chunk.geoFace,
+                     geoElem=chunk.geoElem, bface=chunk.bface, nbfac=chunk.nbfac)
+            a.update(over)
+            return capi.Mesh(ctx, a["nielem"], a["inpoel"], a["coord"], a["esuf"], a["esuel"],
+                             a["inpofa"], a["geoFace"], a["geoElem"], a["bface"], a["nbfac"])
+        upload().close()                                           # the good one goes through
+        bad = chunk.inpoel.copy(); bad[3, 2] = chunk.coord.shape[0] + 7
+        with pytest.raises(capi.QdgError, match="inpoel"):
+            upload(inpoel=bad)
+        bad = chunk.esuel.copy(); bad[5] = chunk.nunk + 3
+        with pytest.raises(capi.QdgError, match="esuel"):
+            upload(esuel=bad)
+        bad = chunk.geoElem.copy(); bad[4 * 7] = -1.0
+        with pytest.raises(capi.QdgError, match="volume"):
+            upload(geoElem=bad)
+        bad = chunk.esuf.copy(); bad[2 * (chunk.nbfac + 1) + 1] = bad[2 * (chunk.nbfac + 1)]
+        with pytest.raises(capi.QdgError):
+            upload(esuf=bad)
+    finally:
+        ctx.close()
