@@ -962,6 +962,14 @@ extern "C" int qdg_stage_rhs_dt(qdg_mesh* mesh, int stage, double t, double tlef
                        mesh->dt_ptr, mesh->Unp, s);
     if (ev) HIPCHK(hipEventRecord(ev->second, s));
     mesh->Upending = out;
+  } else if (stage > 0 && mesh->dm.ncomp == NCOMP) {
+    // P0 / P2 (and the generic P1 path): the same fusion in the generic kernel
+    double* out = free_buf(mesh, mesh->Ucur, mesh->Unp);
+    if (int rc = prof_begin(mesh, &ev)) return rc;
+    launch_rhs_rk(mesh->ndof, mesh->dm, ctx->ph, t, mesh->Ucur, out, RK[0][stage], RK[1][stage],
+                  mesh->dt_ptr, mesh->Unp, s);
+    if (ev) HIPCHK(hipEventRecord(ev->second, s));
+    mesh->Upending = out;
   } else if (cfl_dt && use_p1_fast(mesh)) {
     const double scale = ctx->cfg.cfl / 3.0;     // cfl/(2p+1), p = 1 (DG.cpp:1404-1418)
     if (int rc = prof_begin(mesh, &ev)) return rc;

@@ -644,12 +644,18 @@ __device__ __forceinline__ void flux_lf_q(const double* fn, const double* L, con
 // WITH_DT (stage 0 with a CFL time step): dg::CompFlow::dt needs |vn|+a of both
 // sides at every face Gauss point -- what the Riemann solver has just computed;
 // the per-workgroup minimum of vol/delt goes to blockmin (k_dt_final finishes).
-template <int NDOF, int PROB, bool WITH_DT>
+// MODE 0: R = rhs(U); 1: + CFL time step (stage 0); 2: the SSP-RK3 update fused in,
+// R <- a*Un + b*(U + dt*rhs/L) (stages 1, 2: dt is known, the RHS never goes to memory)
+template <int NDOF, int PROB, int MODE>
 __global__ __launch_bounds__(256, (NDOF > 4 ? 1 : 2)) void k_rhs(DevMesh m, Phys ph, double t,
                                              const double* __restrict__ U,
                                              double* __restrict__ R,
-                                             double* __restrict__ blockmin)
+                                             double* __restrict__ blockmin,
+                                             double rk_a, double rk_b,
+                                             const double* __restrict__ dtp,
+                                             const double* __restrict__ Un)
 {
+  constexpr bool WITH_DT = MODE == 1, FUSE_RK = MODE == 2;
   const int e0 = xcd_tile(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   const bool active = e0 < m.nie;
   if (!WITH_DT && !active) return;
@@ -782,6 +788,21 @@ __global__ __launch_bounds__(256, (NDOF > 4 ? 1 : 2)) void k_rhs(DevMesh m, Phys
     }
   }
 
+  if constexpr (FUSE_RK) {
+    constexpr double imf[10] = { 1.0, 10.0, 10.0 / 3.0, 5.0 / 3.0, 35.0, 21.0, 14.0, 7.0,
+                                 14.0 / 3.0, 7.0 / 3.0 };
+    const double dtv = dtp[0] / m.vol[e];
+    // Un row streamed component by component (the own row u is still in registers)
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c) {
+      double un[NDOF];
+#pragma unroll
+      for (int k = 0; k < NDOF; ++k) un[k] = Un[(size_t)e * (NCOMP * NDOF) + c * NDOF + k];
+#pragma unroll
+      for (int k = 0; k < NDOF; ++k)
+        acc[c][k] = rk_a * un[k] + rk_b * (u[c][k] + dtv * imf[k] * acc[c][k]);
+    }
+  }
   if (active) store_row<NCOMP * NDOF>(R, e, &acc[0][0]);
   if (WITH_DT) {
     double dte = active ? m.vol[e] / delt : DBL_MAX;
@@ -2411,7 +2432,7 @@ void launch_rhs(int ndof, const DevMesh& m, const Phys& ph, double t, const doub
     QDG_DISPATCH_NDOF(ndof, (tr::k_rhs<N><<<nblk(m.nie, 256), 256, 0, s>>>(m, ph, t, U, R)));
     return;
   }
-  QDG_DISPATCH_NDOF(ndof, QDG_DISPATCH_PROB(ph.problem, (k_rhs<N, P, false><<<nblk(m.nie, 256), 256, 0, s>>>(m, ph, t, U, R, nullptr))));
+  QDG_DISPATCH_NDOF(ndof, QDG_DISPATCH_PROB(ph.problem, (k_rhs<N, P, 0><<<nblk(m.nie, 256), 256, 0, s>>>(m, ph, t, U, R, nullptr, 0.0, 0.0, nullptr, nullptr))));
 }
 
 // generic RHS with the CFL time step fused in (stage 0): dt = min(vol/delt) * scale, capped to tleft
@@ -2421,8 +2442,17 @@ void launch_rhs_dt(int ndof, const DevMesh& m, const Phys& ph, double t, const d
 {
   const int nb = nblk(m.nie, 256);
   if (nb == 0) return;
-  QDG_DISPATCH_NDOF(ndof, QDG_DISPATCH_PROB(ph.problem, (k_rhs<N, P, true><<<nb, 256, 0, s>>>(m, ph, t, U, R, blockmin))));
+  QDG_DISPATCH_NDOF(ndof, QDG_DISPATCH_PROB(ph.problem, (k_rhs<N, P, 1><<<nb, 256, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr))));
   k_dt_final<<<1, 256, 0, s>>>(blockmin, nb, scale, tleft, out_raw, out_dt);
+}
+
+// generic RHS with the SSP-RK3 update fused in (stages 1, 2): Uout = a*Un + b*(U + dt*R/L)
+void launch_rhs_rk(int ndof, const DevMesh& m, const Phys& ph, double t, const double* U, double* Uout,
+                   double a, double b, const double* dt, const double* Un, hipStream_t s)
+{
+  const int nb = nblk(m.nie, 256);
+  if (nb == 0) return;
+  QDG_DISPATCH_NDOF(ndof, QDG_DISPATCH_PROB(ph.problem, (k_rhs<N, P, 2><<<nb, 256, 0, s>>>(m, ph, t, U, Uout, nullptr, a, b, dt, Un))));
 }
 
 // P1 fast path; with_dt: also reduce min(vol/delt) into out_raw/out_dt

@@ -14,6 +14,8 @@ void launch_rhs(int ndof, const DevMesh& m, const Phys& ph, double t, const doub
 void launch_rhs_dt(int ndof, const DevMesh& m, const Phys& ph, double t, const double* U, double* R,
                    double* blockmin, double scale, double tleft, double* out_raw, double* out_dt,
                    hipStream_t s);
+void launch_rhs_rk(int ndof, const DevMesh& m, const Phys& ph, double t, const double* U, double* Uout,
+                   double a, double b, const double* dt, const double* Un, hipStream_t s);
 void launch_rhs_p1(const DevMesh& m, const Phys& ph, double t, const double* U, double* R,
                    bool with_dt, double* blockmin, double scale, double tleft, double* out_raw,
                    double* out_dt, hipStream_t s);
