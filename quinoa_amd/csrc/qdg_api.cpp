@@ -625,8 +625,7 @@ static int run_limiter(qdg_mesh* mesh, double*& Ucur, double* Ualt_in)
       launch_superbee(mesh->ndof, mesh->dm, Ucur, s);
     }
   } else if (ctx->cfg.limiter == QDG_LIMITER_WENOP1) {
-    launch_copy_planes(Ucur, Ualt, mesh->nprop, (int)mesh->ne, (int)mesh->stride, s);
-    launch_weno(mesh->ndof, mesh->dm, ctx->ph.cweight, Ucur, Ualt, s);
+    launch_weno(mesh->ndof, mesh->dm, ctx->ph.cweight, Ucur, Ualt, s);    // writes every row of Ualt
     std::swap(Ucur, Ualt);
   }
   HIPCHK(hipGetLastError());

@@ -1554,42 +1554,49 @@ __global__ __launch_bounds__(256) void k_weno(DevMesh m, double cweight,
                                               const double* __restrict__ Uin,
                                               double* __restrict__ Uout)
 {
+  // every row of Uout is written here (own row with modes 1-3 replaced; ghost rows
+  // copied), so the Jacobi sweep needs no separate copy of the state
   const int e = xcd_tile(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
-  if (e >= m.nie) return;
+  if (e >= m.ne) return;
+  double r[NCOMP][NDOF];
+  load_row<NCOMP * NDOF>(Uin, e, &r[0][0]);
   if constexpr (NDOF > 1) {
-    const int stride = m.stride;
-    int nb[4];
+    if (e < m.nie) {
+      const int stride = m.stride;
+      int nb[4];
 #pragma unroll
-    for (int lf = 0; lf < 4; ++lf) nb[lf] = m.nbr[(size_t)lf * stride + e];
-#pragma unroll 1
-    for (int c = 0; c < NCOMP; ++c) {
-      double g[5][3], wd[5], wtot = 0.0;
+      for (int lf = 0; lf < 4; ++lf) nb[lf] = m.nbr[(size_t)lf * stride + e];
 #pragma unroll
-      for (int d = 0; d < 3; ++d) g[0][d] = Uin[fidx(c * NDOF + 1 + d, e, NCOMP * NDOF)];
+      for (int c = 0; c < NCOMP; ++c) {
+        double g[5][3], wd[5], wtot = 0.0;
 #pragma unroll
-      for (int is = 1; is < 5; ++is) {
-        const int n = nb[is - 1];
+        for (int d = 0; d < 3; ++d) g[0][d] = r[c][1 + d];
 #pragma unroll
-        for (int d = 0; d < 3; ++d)
-          g[is][d] = (n >= 0) ? Uin[fidx(c * NDOF + 1 + d, n, NCOMP * NDOF)] : 0.0;
-      }
+        for (int is = 1; is < 5; ++is) {
+          const int n = nb[is - 1];
 #pragma unroll
-      for (int is = 0; is < 5; ++is) {
-        const double wst = (is == 0) ? cweight : (nb[is - (is > 0)] >= 0 ? 1.0 : 0.0);
-        const double osc = sqrt(g[is][0] * g[is][0] + g[is][1] * g[is][1] + g[is][2] * g[is][2]);
-        const double q = 1.0e-8 + osc;
-        wd[is] = wst / (q * q);
-        wtot += wd[is];
-      }
+          for (int d = 0; d < 3; ++d)
+            g[is][d] = (n >= 0) ? Uin[fidx(c * NDOF + 1 + d, n, NCOMP * NDOF)] : 0.0;
+        }
 #pragma unroll
-      for (int d = 0; d < 3; ++d) {
-        double a = 0.0;
+        for (int is = 0; is < 5; ++is) {
+          const double wst = (is == 0) ? cweight : (nb[is - (is > 0)] >= 0 ? 1.0 : 0.0);
+          const double osc = sqrt(g[is][0] * g[is][0] + g[is][1] * g[is][1] + g[is][2] * g[is][2]);
+          const double q = 1.0e-8 + osc;
+          wd[is] = wst / (q * q);
+          wtot += wd[is];
+        }
 #pragma unroll
-        for (int is = 0; is < 5; ++is) a += (wd[is] / wtot) * g[is][d];
-        Uout[fidx(c * NDOF + 1 + d, e, NCOMP * NDOF)] = a;
+        for (int d = 0; d < 3; ++d) {
+          double a = 0.0;
+#pragma unroll
+          for (int is = 0; is < 5; ++is) a += (wd[is] / wtot) * g[is][d];
+          r[c][1 + d] = a;
+        }
       }
     }
   }
+  store_row<NCOMP * NDOF>(Uout, e, &r[0][0]);
 }
 
 // ------------------------------------------------------------- time step
@@ -2154,42 +2161,49 @@ __global__ __launch_bounds__(256) void k_superbee(DevMesh m, double* __restrict_
   }
 }
 
-// WENO_P1 (src/PDE/Limiter.cpp:29-153) for one scalar: Jacobi, Uin -> modes 1-3 of Uout
+// WENO_P1 (src/PDE/Limiter.cpp:29-153) for one scalar: Jacobi, Uin -> Uout (all rows)
 template <int NDOF>
 __global__ __launch_bounds__(256) void k_weno(DevMesh m, double cweight, const double* __restrict__ Uin,
                                               double* __restrict__ Uout)
 {
   const int e = xcd_tile(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
-  if (e >= m.nie) return;
+  if (e >= m.ne) return;
+  double r[NDOF];
+  load<NDOF>(Uin, e, r);
   if constexpr (NDOF > 1) {
-    double g[5][3], wd[5], wtot = 0.0;
-    int nb[4];
+    if (e < m.nie) {
+      double g[5][3], wd[5], wtot = 0.0;
+      int nb[4];
 #pragma unroll
-    for (int lf = 0; lf < 4; ++lf) nb[lf] = m.nbr[(size_t)lf * m.stride + e];
+      for (int lf = 0; lf < 4; ++lf) nb[lf] = m.nbr[(size_t)lf * m.stride + e];
 #pragma unroll
-    for (int d = 0; d < 3; ++d) g[0][d] = Uin[(size_t)e * NDOF + 1 + d];
+      for (int d = 0; d < 3; ++d) g[0][d] = r[1 + d];
 #pragma unroll
-    for (int is = 1; is < 5; ++is)
+      for (int is = 1; is < 5; ++is)
 #pragma unroll
-      for (int d = 0; d < 3; ++d)
-        g[is][d] = (nb[is - 1] >= 0) ? Uin[(size_t)nb[is - 1] * NDOF + 1 + d] : 0.0;
+        for (int d = 0; d < 3; ++d)
+          g[is][d] = (nb[is - 1] >= 0) ? Uin[(size_t)nb[is - 1] * NDOF + 1 + d] : 0.0;
 #pragma unroll
-    for (int is = 0; is < 5; ++is) {
-      const double wst = (is == 0) ? cweight : (nb[is - (is > 0)] >= 0 ? 1.0 : 0.0);
-      const double osc = sqrt(g[is][0] * g[is][0] + g[is][1] * g[is][1] + g[is][2] * g[is][2]);
-      const double q = 1.0e-8 + osc;
-      wd[is] = wst / (q * q);
-      wtot += wd[is];
-    }
+      for (int is = 0; is < 5; ++is) {
+        const double wst = (is == 0) ? cweight : (nb[is - (is > 0)] >= 0 ? 1.0 : 0.0);
+        const double osc = sqrt(g[is][0] * g[is][0] + g[is][1] * g[is][1] + g[is][2] * g[is][2]);
+        const double q = 1.0e-8 + osc;
+        wd[is] = wst / (q * q);
+        wtot += wd[is];
+      }
 #pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      double a = 0.0;
+      for (int d = 0; d < 3; ++d) {
+        double a = 0.0;
 #pragma unroll
-      for (int is = 0; is < 5; ++is) a += (wd[is] / wtot) * g[is][d];
-      Uout[(size_t)e * NDOF + 1 + d] = a;
+        for (int is = 0; is < 5; ++is) a += (wd[is] / wtot) * g[is][d];
+        r[1 + d] = a;
+      }
     }
   }
+#pragma unroll
+  for (int k = 0; k < NDOF; ++k) Uout[(size_t)e * NDOF + k] = r[k];
 }
+
 
 template <int NDOF>
 __global__ __launch_bounds__(256) void k_init(DevMesh m, Phys ph, double t, double* __restrict__ U)
@@ -2531,12 +2545,12 @@ void launch_superbee(int ndof, const DevMesh& m0, double* U, hipStream_t s, int 
 void launch_weno(int ndof, const DevMesh& m, double cweight, const double* Uin, double* Uout,
                  hipStream_t s)
 {
-  if (m.nie == 0 || ndof == 1) return;
+  if (m.ne == 0 || ndof == 1) return;
   if (m.ncomp == 1) {
-    QDG_DISPATCH_NDOF(ndof, (tr::k_weno<N><<<nblk(m.nie, 256), 256, 0, s>>>(m, cweight, Uin, Uout)));
+    QDG_DISPATCH_NDOF(ndof, (tr::k_weno<N><<<nblk(m.ne, 256), 256, 0, s>>>(m, cweight, Uin, Uout)));
     return;
   }
-  QDG_DISPATCH_NDOF(ndof, (k_weno<N><<<nblk(m.nie, 256), 256, 0, s>>>(m, cweight, Uin, Uout)));
+  QDG_DISPATCH_NDOF(ndof, (k_weno<N><<<nblk(m.ne, 256), 256, 0, s>>>(m, cweight, Uin, Uout)));
 }
 
 void launch_copy_planes(const double* src, double* dst, int nprop, int n, int /*stride*/, hipStream_t s)
