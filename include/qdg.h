@@ -76,7 +76,9 @@ enum { QDG_PROBLEM_USER_DEFINED = 0, QDG_PROBLEM_SOD_SHOCKTUBE = 1,
        /* more CompFlow policies (RotatedSodShocktube.cpp:28-45, NLEnergyGrowth.cpp:28-190) */
        QDG_PROBLEM_ROTATED_SOD_SHOCKTUBE = 6, QDG_PROBLEM_NL_ENERGY_GROWTH = 7,
        /* more Transport policies (CylAdvect.cpp:28-129, GaussHump.cpp:28-125) */
-       QDG_PROBLEM_CYL_ADVECT = 8, QDG_PROBLEM_GAUSS_HUMP = 9 };
+       QDG_PROBLEM_CYL_ADVECT = 8, QDG_PROBLEM_GAUSS_HUMP = 9,
+       /* CompFlow RayleighTaylor.cpp:28-175 (alpha, betax/y/z, p0, r0, kappa) */
+       QDG_PROBLEM_RAYLEIGH_TAYLOR = 10 };
 /* BC state functions (src/PDE/CompFlow/DGCompFlow.hpp:649-701) */
 enum { QDG_BC_DIRICHLET = 1, QDG_BC_SYMMETRY = 2, QDG_BC_EXTRAPOLATE = 3,
        /* Transport only (src/PDE/Transport/DGTransport.hpp:163-168, 276-352) */

@@ -190,6 +190,7 @@ struct VorticalFlow   { static int type() noexcept { return QDG_PROBLEM_VORTICAL
 struct TaylorGreen    { static int type() noexcept { return QDG_PROBLEM_TAYLOR_GREEN; } };
 struct RotatedSodShocktube { static int type() noexcept { return QDG_PROBLEM_ROTATED_SOD_SHOCKTUBE; } };
 struct NLEnergyGrowth { static int type() noexcept { return QDG_PROBLEM_NL_ENERGY_GROWTH; } };
+struct RayleighTaylor { static int type() noexcept { return QDG_PROBLEM_RAYLEIGH_TAYLOR; } };
 // Transport (src/PDE/Transport/Physics/DGAdvection.hpp, Problem/SlotCyl.hpp)
 struct Advection { };
 struct SlotCyl        { static int type() noexcept { return QDG_PROBLEM_SLOT_CYL; } };

@@ -36,7 +36,7 @@ enum { ORC_FLUX_HLLC = 0, ORC_FLUX_LAXFRIEDRICHS = 1 };
 enum { ORC_LIM_NONE = 0, ORC_LIM_WENOP1 = 1, ORC_LIM_SUPERBEEP1 = 2 };
 enum { ORC_PROB_USER = 0, ORC_PROB_SOD = 1, ORC_PROB_SEDOV = 2,
        ORC_PROB_VORTICAL = 3, ORC_PROB_TAYLOR_GREEN = 4,
-       ORC_PROB_ROTATED_SOD = 6, ORC_PROB_NLEG = 7 };
+       ORC_PROB_ROTATED_SOD = 6, ORC_PROB_NLEG = 7, ORC_PROB_RAYLEIGH_TAYLOR = 10 };
 
 typedef struct {
   int64_t ndof, rdof;    /* src/Control/Inciter/InputDeck/Grammar.hpp:378-406 */
@@ -482,6 +482,16 @@ static void prob_solution(const orc_cfg* k, double x, double y, double z,
     s[0] = r; s[1] = r * 0.0; s[2] = r * 0.0; s[3] = r * 0.0;
     s[4] = eos_totalenergy(k, r, 0.0, 0.0, 0.0, p);
     break; }
+  case ORC_PROB_RAYLEIGH_TAYLOR: {
+    /* RayleighTaylor.cpp:28-62 (alpha, betax/y/z, p0, r0, kappa) */
+    const double gx = k->betax * x * x + k->betay * y * y + k->betaz * z * z;
+    const double r = k->r0 - gx, p = k->p0 + k->alpha * gx;
+    const double ft = cos(k->kappa * M_PI * t);
+    const double u = ft * z * sin(M_PI * x), v = ft * z * cos(M_PI * y);
+    const double w = ft * (-0.5 * M_PI * z * z * (cos(M_PI * x) - sin(M_PI * y)));
+    s[0] = r; s[1] = r * u; s[2] = r * v; s[3] = r * w;
+    s[4] = eos_totalenergy(k, r, u, v, w, p);
+    break; }
   case ORC_PROB_NLEG: {
     /* NLEnergyGrowth.cpp:62-101 */
     const double gx = 1.0 - x * x - y * y - z * z;
@@ -534,6 +544,38 @@ static void prob_src(const orc_cfg* k, double x, double y, double z, double t,
                      double* r)
 {
   switch (k->problem) {
+  case ORC_PROB_RAYLEIGH_TAYLOR: {
+    /* RayleighTaylor.cpp:95-175 */
+    const double a = k->alpha, bx = k->betax, by = k->betay, bz = k->betaz, kp = k->kappa, g = k->gamma;
+    double s[5];
+    prob_solution(k, x, y, z, t, s);
+    {
+      const double rho = s[0], u = s[1] / s[0], v = s[2] / s[0], w = s[3] / s[0], E = s[4] / s[0];
+      const double p = k->p0 + a * (bx * x * x + by * y * y + bz * z * z);
+      const double drdx[3] = { -2.0 * bx * x, -2.0 * by * y, -2.0 * bz * z };
+      const double dpdx[3] = { 2.0 * a * bx * x, 2.0 * a * by * y, 2.0 * a * bz * z };
+      const double ft = cos(kp * M_PI * t);
+      const double dudx[3] = { ft * M_PI * z * cos(M_PI * x), 0.0, ft * sin(M_PI * x) };
+      const double dvdx[3] = { 0.0, -ft * M_PI * z * sin(M_PI * y), ft * cos(M_PI * y) };
+      const double dwdx[3] = { ft * M_PI * 0.5 * M_PI * z * z * sin(M_PI * x),
+                               ft * M_PI * 0.5 * M_PI * z * z * cos(M_PI * y),
+                               -ft * M_PI * z * (cos(M_PI * x) - sin(M_PI * y)) };
+      double dedx[3]; int d;
+      const double dudt = -kp * M_PI * sin(kp * M_PI * t) * z * sin(M_PI * x);
+      const double dvdt = -kp * M_PI * sin(kp * M_PI * t) * z * cos(M_PI * y);
+      const double dwdt = kp * M_PI * sin(kp * M_PI * t) / 2 * M_PI * z * z * (cos(M_PI * x) - sin(M_PI * y));
+      const double dedt = u * dudt + v * dvdt + w * dwdt;
+      for (d = 0; d < 3; ++d)
+        dedx[d] = dpdx[d] / rho / (g - 1.0) - p / (g - 1.0) / rho / rho * drdx[d]
+                + u * dudx[d] + v * dvdx[d] + w * dwdx[d];
+      r[0] = u * drdx[0] + v * drdx[1] + w * drdx[2];
+      r[1] = rho * dudt + u * r[0] + dpdx[0] + s[1] * dudx[0] + s[2] * dudx[1] + s[3] * dudx[2];
+      r[2] = rho * dvdt + v * r[0] + dpdx[1] + s[1] * dvdx[0] + s[2] * dvdx[1] + s[3] * dvdx[2];
+      r[3] = rho * dwdt + w * r[0] + dpdx[2] + s[1] * dwdx[0] + s[2] * dwdx[1] + s[3] * dwdx[2];
+      r[4] = rho * dedt + E * r[0] + s[1] * dedx[0] + s[2] * dedx[1] + s[3] * dedx[2]
+           + u * dpdx[0] + v * dpdx[1] + w * dpdx[2];
+    }
+    break; }
   case ORC_PROB_NLEG: {
     /* NLEnergyGrowth.cpp:124-190 */
     const double a = k->alpha, bx = k->betax, by = k->betay, bz = k->betaz, g = k->gamma;

@@ -21,7 +21,7 @@ FLUX = {"hllc": 0, "laxfriedrichs": 1}
 LIMITER = {"nolimiter": 0, "wenop1": 1, "superbeep1": 2}
 PROBLEM = {"user_defined": 0, "sod_shocktube": 1, "sedov_blastwave": 2,
            "vortical_flow": 3, "taylor_green": 4, "rotated_sod_shocktube": 6,
-           "nl_energy_growth": 7}
+           "nl_energy_growth": 7, "rayleigh_taylor": 10}
 
 c_i64p = C.POINTER(C.c_int64)
 c_i32p = C.POINTER(C.c_int32)

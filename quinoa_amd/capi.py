@@ -17,7 +17,8 @@ FLUX = {"hllc": 0, "laxfriedrichs": 1, "upwind": 2}
 LIMITER = {"nolimiter": 0, "wenop1": 1, "superbeep1": 2}
 PROBLEM = {"user_defined": 0, "sod_shocktube": 1, "sedov_blastwave": 2,
            "vortical_flow": 3, "taylor_green": 4, "slot_cyl": 5,
-           "rotated_sod_shocktube": 6, "nl_energy_growth": 7, "cyl_advect": 8, "gauss_hump": 9}
+           "rotated_sod_shocktube": 6, "nl_energy_growth": 7, "cyl_advect": 8, "gauss_hump": 9,
+           "rayleigh_taylor": 10}
 BC_DIRICHLET, BC_SYMMETRY, BC_EXTRAPOLATE, BC_INLET, BC_OUTLET = 1, 2, 3, 4, 5
 PDE = {"compflow": 0, "transport": 1}
 

@@ -168,8 +168,9 @@ static int check_cfg(const qdg_config* c)
   }
   if (c->flux != QDG_FLUX_HLLC && c->flux != QDG_FLUX_LAXFRIEDRICHS)
     return fail("qdg_ctx_create: unknown flux");
-  if (c->problem < QDG_PROBLEM_USER_DEFINED || c->problem > QDG_PROBLEM_NL_ENERGY_GROWTH ||
-      c->problem == QDG_PROBLEM_SLOT_CYL)   /* 8, 9: transport */
+  if (!((c->problem >= QDG_PROBLEM_USER_DEFINED && c->problem <= QDG_PROBLEM_TAYLOR_GREEN) ||
+        c->problem == QDG_PROBLEM_ROTATED_SOD_SHOCKTUBE || c->problem == QDG_PROBLEM_NL_ENERGY_GROWTH ||
+        c->problem == QDG_PROBLEM_RAYLEIGH_TAYLOR))   /* 5, 8, 9: transport */
     return fail("qdg_ctx_create: unknown problem");
   if (!(c->gamma > 1.0)) return fail("qdg_ctx_create: gamma must be > 1");
   for (int i = 0; i < c->nbc; ++i)

@@ -342,6 +342,16 @@ __device__ __forceinline__ void prob_solution(const Phys& ph, double x, double y
     const double r = l ? 1.0 : 0.125, p = l ? 1.0 : 0.1;
     s[0] = r; s[1] = 0.0; s[2] = 0.0; s[3] = 0.0;
     s[4] = eos_totalenergy(ph, r, 0.0, 0.0, 0.0, p);
+  } else if constexpr (PROB == 10) {
+    // RayleighTaylor.cpp:28-62
+    const double pi = 3.14159265358979323846;
+    const double gx = ph.betax * x * x + ph.betay * y * y + ph.betaz * z * z;
+    const double r = ph.r0 - gx, p = ph.p0 + ph.alpha * gx;
+    const double ft = cos(ph.kappa * pi * t);
+    const double u = ft * z * sin(pi * x), v = ft * z * cos(pi * y);
+    const double w = ft * (-0.5 * pi * z * z * (cos(pi * x) - sin(pi * y)));
+    s[0] = r; s[1] = r * u; s[2] = r * v; s[3] = r * w;
+    s[4] = eos_totalenergy(ph, r, u, v, w, p);
   } else if constexpr (PROB == 7) {
     // NLEnergyGrowth.cpp:62-101
     const double gx = 1.0 - x * x - y * y - z * z;
@@ -376,12 +386,42 @@ __device__ __forceinline__ void prob_solution(const Phys& ph, double x, double y
 }
 
 // Problem::src: VorticalFlow.cpp:80-115, TaylorGreen.cpp:77-90 (zero otherwise)
-template <int PROB> constexpr bool prob_has_source() { return PROB == 3 || PROB == 4 || PROB == 7; }
+template <int PROB> constexpr bool prob_has_source() { return PROB == 3 || PROB == 4 || PROB == 7 || PROB == 10; }
 template <int PROB>
 __device__ __forceinline__ void prob_src(const Phys& ph, double x, double y, double z,
                                          double t, double* r)
 {
-  if constexpr (PROB == 7) {
+  if constexpr (PROB == 10) {
+    // RayleighTaylor.cpp:95-175
+    const double pi = 3.14159265358979323846;
+    const double a = ph.alpha, bx = ph.betax, by = ph.betay, bz = ph.betaz, kp = ph.kappa, g = ph.gamma;
+    double s[5];
+    prob_solution<10>(ph, x, y, z, t, s);
+    const double rho = s[0], u = s[1] / s[0], v = s[2] / s[0], w = s[3] / s[0], E = s[4] / s[0];
+    const double p = ph.p0 + a * (bx * x * x + by * y * y + bz * z * z);
+    const double drdx[3] = { -2.0 * bx * x, -2.0 * by * y, -2.0 * bz * z };
+    const double dpdx[3] = { 2.0 * a * bx * x, 2.0 * a * by * y, 2.0 * a * bz * z };
+    const double ft = cos(kp * pi * t), st = sin(kp * pi * t);
+    const double dudx[3] = { ft * pi * z * cos(pi * x), 0.0, ft * sin(pi * x) };
+    const double dvdx[3] = { 0.0, -ft * pi * z * sin(pi * y), ft * cos(pi * y) };
+    const double dwdx[3] = { ft * pi * 0.5 * pi * z * z * sin(pi * x), ft * pi * 0.5 * pi * z * z * cos(pi * y),
+                             -ft * pi * z * (cos(pi * x) - sin(pi * y)) };
+    const double dudt = -kp * pi * st * z * sin(pi * x);
+    const double dvdt = -kp * pi * st * z * cos(pi * y);
+    const double dwdt = kp * pi * st / 2 * pi * z * z * (cos(pi * x) - sin(pi * y));
+    const double dedt = u * dudt + v * dvdt + w * dwdt;
+    double dedx[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+      dedx[d] = dpdx[d] / rho / (g - 1.0) - p / (g - 1.0) / rho / rho * drdx[d]
+              + u * dudx[d] + v * dvdx[d] + w * dwdx[d];
+    r[0] = u * drdx[0] + v * drdx[1] + w * drdx[2];
+    r[1] = rho * dudt + u * r[0] + dpdx[0] + s[1] * dudx[0] + s[2] * dudx[1] + s[3] * dudx[2];
+    r[2] = rho * dvdt + v * r[0] + dpdx[1] + s[1] * dvdx[0] + s[2] * dvdx[1] + s[3] * dvdx[2];
+    r[3] = rho * dwdt + w * r[0] + dpdx[2] + s[1] * dwdx[0] + s[2] * dwdx[1] + s[3] * dwdx[2];
+    r[4] = rho * dedt + E * r[0] + s[1] * dedx[0] + s[2] * dedx[1] + s[3] * dedx[2]
+         + u * dpdx[0] + v * dpdx[1] + w * dpdx[2];
+  } else if constexpr (PROB == 7) {
     // NLEnergyGrowth.cpp:124-190
     const double pi = 3.14159265358979323846;
     const double a = ph.alpha, bx = ph.betax, by = ph.betay, bz = ph.betaz, g = ph.gamma;
@@ -944,7 +984,7 @@ __global__ __launch_bounds__(256, QDG_P1_WAVES) void k_rhs_p1(DevMesh m, Phys ph
 
   // ---- faces ----------------------------------------------------------------
   double delt = 0.0;
-  constexpr bool HAS_DIRICHLET = (PROB == 3 || PROB == 4 || PROB == 0 || PROB == 7);
+  constexpr bool HAS_DIRICHLET = (PROB == 3 || PROB == 4 || PROB == 0 || PROB == 7 || PROB == 10);
 #pragma unroll 1
   for (int lf = 0; lf < 4; ++lf) {
     const int nb = (lf == 0) ? nb0 : (lf == 1) ? nb1 : (lf == 2) ? nb2 : nb3;
@@ -1172,7 +1212,7 @@ __global__ __launch_bounds__(TILE_BS, QDG_TILE_WAVES) void k_rhs_p1t(DevMesh m, 
   __syncthreads();
 
   // ---- phase 1: one lane per face task ------------------------------------------
-  constexpr bool HAS_DIRICHLET = (PROB == 3 || PROB == 4 || PROB == 0 || PROB == 7);
+  constexpr bool HAS_DIRICHLET = (PROB == 3 || PROB == 4 || PROB == 0 || PROB == 7 || PROB == 10);
   if ((t1 - t0) > TILE_BS * MAXT) __builtin_trap();   // cannot happen: <= 4*TILE tasks per tile
 #pragma unroll 1
   for (int q = 0; q < MAXT; ++q) {
@@ -2408,6 +2448,7 @@ __global__ void k_halo_unpack(const double* __restrict__ slab, int nprop, int ni
       case 4: { constexpr int P = 4; CALL; } break;         \
       case 6: { constexpr int P = 6; CALL; } break;         \
       case 7: { constexpr int P = 7; CALL; } break;         \
+      case 10: { constexpr int P = 10; CALL; } break;       \
       default: { constexpr int P = 0; CALL; } break;        \
     }                                                       \
   } while (0)
