@@ -1,3 +1,10 @@
+"""Per-phase wave timing of the element-centric P1 RHS kernel (k_rhs_p1) from
+s_memtime stamps compiled in with -DQDG_STAMPS (debug build, not the product):
+
+  cd quinoa_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DQDG_STAMPS \
+      -o ../lib/libqdg_stamps.so qdg_kernels.hip qdg_api.cpp qdg_meshdata.cpp -ldl
+  QDG_DETERMINISTIC_RHS=1 python tools/stamps.py        # on the GPU box
+"""
 import ctypes as C, os, sys, numpy as np
 sys.path.insert(0, '.')
 os.environ["QDG_LIB"] = os.path.abspath("quinoa_amd/lib/libqdg_stamps.so")
