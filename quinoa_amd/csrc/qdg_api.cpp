@@ -478,6 +478,13 @@ extern "C" int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t 
       for (const Task& k : tt) { h_task_a.push_back(k.a); h_task_nb.push_back(k.nb); h_task_f.push_back(k.f); }
       h_tile_off[t + 1] = (int)h_task_a.size();
     }
+    if (std::getenv("QDG_UPLOAD_STATS")) {
+      size_t cnt[3] = { 0, 0, 0 };
+      for (int a : h_task_a) ++cnt[(a >> 17) & 3];
+      std::fprintf(stderr, "qdg upload: %zu tets, %d tiles, tasks per tet: interior-in-tile %.3f, "
+                   "to other tiles/ghosts %.3f, boundary %.3f\n", nie, ntile, (double)cnt[TASK_INT] / nie,
+                   (double)cnt[TASK_EXT] / nie, (double)cnt[TASK_BND] / nie);
+    }
   }
 
   std::unique_ptr<qdg_mesh> m(new qdg_mesh);
