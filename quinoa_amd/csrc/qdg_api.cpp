@@ -74,6 +74,14 @@ struct qdg_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  ~qdg_ctx()
+  {
+    if (own_stream && stream) {
+      (void)hipSetDevice(device);
+      (void)hipStreamSynchronize(stream);
+      (void)hipStreamDestroy(stream);
+    }
+  }
 };
 
 struct qdg_mesh {
@@ -229,10 +237,7 @@ extern "C" int qdg_ctx_create(const qdg_config* cfg, qdg_ctx** out)
 extern "C" int qdg_ctx_destroy(qdg_ctx* ctx)
 {
   QDG_TRY
-  if (!ctx) return 0;
-  (void)hipSetDevice(ctx->device);
-  if (ctx->own_stream && ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
-  delete ctx;
+  delete ctx;      // ~qdg_ctx drains and destroys the stream it owns
   return 0;
   QDG_CATCH
 }
@@ -242,7 +247,12 @@ extern "C" int qdg_ctx_set_stream(qdg_ctx* ctx, void* s)
   QDG_TRY
   if (!ctx) return fail("qdg_ctx_set_stream: null ctx");
   HIPCHK(hipSetDevice(ctx->device));
-  if (ctx->own_stream && ctx->stream) { HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(hipStreamDestroy(ctx->stream)); }
+  if (ctx->own_stream && ctx->stream) {
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const hipStream_t old = ctx->stream;
+    ctx->stream = nullptr; ctx->own_stream = false;
+    HIPCHK(hipStreamDestroy(old));
+  }
   ctx->stream = (hipStream_t)s;
   ctx->own_stream = false;
   return 0;
@@ -410,7 +420,6 @@ extern "C" int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t 
   const size_t stride = (ne + 63) / 64 * 64;
   std::vector<int> h_inpoel(4 * stride, 0), h_nbr(4 * stride, -1), h_finfo(4 * stride, 0), h_fid(4 * stride, 0);
   std::vector<double> h_vol(stride, 1.0);
-  const bool debug_self_nbr = std::getenv("QDG_DEBUG_SELF_NBR") != nullptr;
   std::vector<int> fmap(nfac, -1);
   int nfd = 0;
   for (size_t d = 0; d < ne; ++d) {
@@ -427,8 +436,7 @@ extern "C" int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t 
       if (nb < 0) {
         h_nbr[lf * stride + d] = -(1 + bcface[f]);
       } else {
-        // QDG_DEBUG_SELF_NBR: timing experiment only (wrong results): every gather hits the own row
-        h_nbr[lf * stride + d] = debug_self_nbr ? (int)d : h2d[nb];
+        h_nbr[lf * stride + d] = h2d[nb];
         for (int j = 0; j < 3; ++j) {
           const size_t g = inpoel[4 * h + LPOFA[lf][j]];
           int m = -1;
@@ -1274,24 +1282,25 @@ struct RcclApi {
 
 RcclApi* rccl_api()
 {
-  static RcclApi api;
-  static bool tried = false;
-  if (tried) return &api;
-  tried = true;
-  const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
-  for (const char* n : names) {
-    api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-    if (api.handle) break;
-  }
-  if (!api.handle) { api.error = std::string("cannot load librccl: ") + dlerror(); return &api; }
+  // resolved once; thread-safe (function-local static initialised by a lambda)
+  static RcclApi* const instance = [] {
+    static RcclApi api;
+    const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+    for (const char* n : names) {
+      api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+      if (api.handle) break;
+    }
+    if (!api.handle) { api.error = std::string("cannot load librccl: ") + dlerror(); return &api; }
 #define QDG_RCCL_SYM(f)                                                        \
-  api.f = reinterpret_cast<decltype(api.f)>(dlsym(api.handle, "nccl" #f));     \
-  if (!api.f) { api.error = "librccl lacks nccl" #f; return &api; }
-  QDG_RCCL_SYM(GetUniqueId) QDG_RCCL_SYM(CommInitRank) QDG_RCCL_SYM(CommDestroy)
-  QDG_RCCL_SYM(GetErrorString) QDG_RCCL_SYM(GroupStart) QDG_RCCL_SYM(GroupEnd)
-  QDG_RCCL_SYM(Send) QDG_RCCL_SYM(Recv) QDG_RCCL_SYM(AllReduce)
+    api.f = reinterpret_cast<decltype(api.f)>(dlsym(api.handle, "nccl" #f));   \
+    if (!api.f) { api.error = "librccl lacks nccl" #f; return &api; }
+    QDG_RCCL_SYM(GetUniqueId) QDG_RCCL_SYM(CommInitRank) QDG_RCCL_SYM(CommDestroy)
+    QDG_RCCL_SYM(GetErrorString) QDG_RCCL_SYM(GroupStart) QDG_RCCL_SYM(GroupEnd)
+    QDG_RCCL_SYM(Send) QDG_RCCL_SYM(Recv) QDG_RCCL_SYM(AllReduce)
 #undef QDG_RCCL_SYM
-  return &api;
+    return &api;
+  }();
+  return instance;
 }
 }  // namespace
 
