@@ -273,6 +273,18 @@ int qdg_bnd_faces(size_t nelem, const size_t* inpoel, size_t ntri,
                   const size_t* tri, const int32_t* tri_set, size_t* nbfac,
                   size_t* triinpoel, int32_t* face_set);
 
+/* -- mesh-derived data generated on the device (first step) -----
+ * The same arrays as qdg_gen_esuel / nipfac / inpofa / belem / esuf / geoface /
+ * geoelem above (src/Inciter/FaceData.cpp:19-41, src/Mesh/DerivedData.cpp:937-1491),
+ * same content and order, computed by sort/scan kernels on the context's GPU and
+ * copied back.  Capacities: esuel 4*nelem, inpofa 3*(nbfac+2*nelem),
+ * esuf 2*(nbfac+2*nelem), belem nbfac, geoFace 7*(nbfac+2*nelem), geoElem 4*nelem;
+ * *nipfac returns the number of faces (boundary + interior). */
+int qdg_dev_facedata(qdg_ctx* ctx, size_t nelem, size_t nnode, const size_t* inpoel,
+                     const double* x, const double* y, const double* z, size_t nbfac,
+                     const size_t* triinpoel, int* esuel, size_t* nipfac, size_t* inpofa,
+                     int* esuf, size_t* belem, double* geoFace, double* geoElem);
+
 #ifdef __cplusplus
 }
 #endif

@@ -414,6 +414,34 @@ class Mesh:
             self.h = C.c_void_p()
 
 
+def dev_facedata(ctx, inpoel, coord, triinpoel):
+    """FaceData arrays and geometry of one chunk generated on the GPU
+    (qdg_dev_facedata): dict with esuel, nipfac, inpofa, esuf, belem, geoFace, geoElem."""
+    inpoel = np.ascontiguousarray(inpoel, dtype=np.uint64).reshape(-1)
+    coord = np.ascontiguousarray(coord, dtype=np.float64)
+    tri = np.ascontiguousarray(triinpoel, dtype=np.uint64).reshape(-1)
+    nelem, nnode, nbfac = inpoel.size // 4, coord.shape[0], tri.size // 3
+    nfmax = nbfac + 2 * nelem
+    x, y, z = (np.ascontiguousarray(coord[:, d]) for d in range(3))
+    esuel = np.zeros(4 * nelem, dtype=np.int32)
+    inpofa = np.zeros(3 * nfmax, dtype=np.uint64)
+    esuf = np.zeros(2 * nfmax, dtype=np.int32)
+    belem = np.zeros(max(1, nbfac), dtype=np.uint64)
+    geoFace = np.zeros(7 * nfmax)
+    geoElem = np.zeros(4 * nelem)
+    nip = C.c_size_t()
+    trip = tri if nbfac else np.zeros(3, dtype=np.uint64)
+    _chk(lib().qdg_dev_facedata(ctx.h, C.c_size_t(nelem), C.c_size_t(nnode), inpoel.ctypes.data_as(c_szp),
+                                x.ctypes.data_as(c_f64p), y.ctypes.data_as(c_f64p), z.ctypes.data_as(c_f64p),
+                                C.c_size_t(nbfac), trip.ctypes.data_as(c_szp), esuel.ctypes.data_as(c_i32p),
+                                C.byref(nip), inpofa.ctypes.data_as(c_szp), esuf.ctypes.data_as(c_i32p),
+                                belem.ctypes.data_as(c_szp), geoFace.ctypes.data_as(c_f64p),
+                                geoElem.ctypes.data_as(c_f64p)))
+    n = nip.value
+    return dict(esuel=esuel, nipfac=n, inpofa=inpofa[:3 * n], esuf=esuf[:2 * n], belem=belem[:nbfac],
+                geoFace=geoFace[:7 * n], geoElem=geoElem)
+
+
 class Comm:
     """RCCL communicator of libqdg (qdg_comm_*): one rank per GPU."""
 

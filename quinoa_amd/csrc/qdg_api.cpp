@@ -131,6 +131,12 @@ struct qdg_mesh {
   }
 };
 
+namespace qdg {
+// for the other translation units of the library (qdg_devmesh.hip)
+int ctx_device(const qdg_ctx* ctx) { return ctx->device; }
+hipStream_t ctx_stream(const qdg_ctx* ctx) { return ctx->stream; }
+}  // namespace qdg
+
 // ---------------------------------------------------------------- misc
 
 extern "C" const char* qdg_last_error(void) { return g_err.c_str(); }

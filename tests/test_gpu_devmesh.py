@@ -1,0 +1,97 @@
+"""Mesh-derived data generated on the GPU (qdg_dev_facedata: sort/scan kernels)
+against the host mirror of inciter::FaceData / DerivedData -- integer arrays bit
+for bit, geometry to rounding -- and against the reference's known answers."""
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_fixture
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare(ctx, inpoel, coord, sidesets):
+    from quinoa_amd import capi
+    bface, tri = capi.bnd_faces(inpoel, sidesets)
+    fd = capi.FaceData(inpoel, bface, tri)
+    g = capi.dev_facedata(ctx, inpoel, coord, tri)
+    assert g["nipfac"] == fd.nipfac
+    assert np.array_equal(g["esuel"], fd.esuel)
+    assert np.array_equal(g["inpofa"], fd.inpofa.astype(np.uint64))
+    assert np.array_equal(g["esuf"], fd.esuf)
+    assert np.array_equal(g["belem"], np.asarray(fd.belem, dtype=np.uint64))
+    gf = capi.gen_geoface(fd.nipfac, fd.inpofa, coord)
+    ge = capi.gen_geoelem(inpoel, coord)
+    assert np.abs(g["geoFace"] - gf).max() <= 1e-14 * max(1.0, np.abs(gf).max())
+    assert np.abs(g["geoElem"] - ge).max() <= 1e-14 * max(1.0, np.abs(ge).max())
+    return g
+
+
+def test_device_facedata_equals_host_on_reference_meshes(cases):
+    from quinoa_amd import capi
+    ctx = capi.Context(1, cfl=0.3)
+    try:
+        for name in ("sod_dg", "sedov_dgp1", "taylor_green_dgp2", "slot_cyl_dg"):
+            fix = load_fixture(name)
+            ss = {int(s): fix["ss_tri_%d" % s] for s in fix["ss_ids"]}
+            _compare(ctx, fix["inpoel"], fix["coord"], ss)
+    finally:
+        ctx.close()
+
+
+def test_device_facedata_known_answers_and_tiny_meshes():
+    """the reference's unit-test mesh (tests/unit/Mesh/TestDerivedData.cpp) and 1-/6-tet meshes"""
+    from quinoa_amd import capi, meshgen
+    ka = json.load(open(os.path.join(ROOT, "tests", "golden", "derived_data_ka.json")))
+    ctx = capi.Context(1, cfl=0.3)
+    try:
+        # TestDerivedData.cpp:2767 (genInpofa) and :2429 (genEsuf): mesh + boundary triangles
+        d = ka["genInpofa"]
+        inpoel = (np.array(d["inpoel_1based"], dtype=np.int64) - 1).reshape(-1, 4)
+        tri = (np.array(d["triinpoel_1based"], dtype=np.int64) - 1).reshape(-1, 3)
+        nnode = int(inpoel.max()) + 1
+        coord = np.random.default_rng(1).normal(size=(nnode, 3))
+        g = capi.dev_facedata(ctx, inpoel, coord, tri)
+        assert np.array_equal(g["inpofa"].astype(np.int64), np.array(d["correct_inpofa_1based"]) - 1)
+        d = ka["genEsuf"]
+        inpoel2 = (np.array(d["inpoel_1based"], dtype=np.int64) - 1).reshape(-1, 4)
+        if np.array_equal(inpoel2, inpoel) and d["nbfac"] == len(tri):
+            assert g["nipfac"] == d["nipfac"]
+            assert np.array_equal(g["esuf"], np.array(d["correct_esuf_1based"], dtype=np.int32) - 1)
+        one = np.array([[0, 1, 2, 3]])
+        c1 = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], dtype=float)
+        g = capi.dev_facedata(ctx, one, c1, np.array([[1, 2, 3], [2, 0, 3], [3, 0, 1], [0, 2, 1]]))
+        assert g["nipfac"] == 4 and (g["esuel"] == -1).all() and (g["esuf"][1::2] == -1).all()
+        assert abs(g["geoElem"][0] - 1.0 / 6.0) < 1e-15
+        ch = meshgen.kuhn_box(1, 1, 1)
+        _compare(ctx, ch["inpoel"], ch["coord"], ch["sidesets"])
+    finally:
+        ctx.close()
+
+
+def test_device_facedata_full_size_and_timing():
+    """998 250 tets: identical to the host mirror; the timing is printed for DESIGN.md"""
+    from quinoa_amd import capi, meshgen
+    ch = meshgen.kuhn_box(55, 55, 55)
+    ctx = capi.Context(1, cfl=0.3)
+    try:
+        t0 = time.perf_counter()
+        bface, tri = capi.bnd_faces(ch["inpoel"], ch["sidesets"])
+        fd = capi.FaceData(ch["inpoel"], bface, tri)
+        gf = capi.gen_geoface(fd.nipfac, fd.inpofa, ch["coord"])
+        ge = capi.gen_geoelem(ch["inpoel"], ch["coord"])
+        t1 = time.perf_counter()
+        capi.dev_facedata(ctx, ch["inpoel"], ch["coord"], tri)      # warm-up (module load)
+        t2 = time.perf_counter()
+        g = capi.dev_facedata(ctx, ch["inpoel"], ch["coord"], tri)
+        t3 = time.perf_counter()
+        print("\nFaceData + geometry of 998250 tets: host %.2f s (incl. bnd_faces), device %.3f s "
+              "(incl. PCIe both ways)" % (t1 - t0, t3 - t2))
+        assert np.array_equal(g["esuel"], fd.esuel) and np.array_equal(g["esuf"], fd.esuf)
+        assert np.array_equal(g["inpofa"], fd.inpofa.astype(np.uint64))
+        assert np.abs(g["geoFace"] - gf).max() <= 1e-14 and np.abs(g["geoElem"] - ge).max() <= 1e-14
+    finally:
+        ctx.close()
