@@ -82,6 +82,8 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    import __graft_entry__
+    __graft_entry__.ensure_built()          # no-op when libqdg.so is there
     import numpy as np
     import torch
     from quinoa_amd import capi, dg, dgmesh, meshgen

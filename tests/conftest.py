@@ -14,6 +14,9 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a fresh checkout has no built artefacts: build them once (no-op otherwise)
+    import __graft_entry__
+    __graft_entry__.ensure_built()
 
 
 @pytest.fixture(scope="session")
