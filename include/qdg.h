@@ -129,6 +129,11 @@ int qdg_ctx_destroy(qdg_ctx* ctx);
 /* run all kernels of this context on an existing HIP stream (hipStream_t) */
 int qdg_ctx_set_stream(qdg_ctx* ctx, void* hip_stream);
 int qdg_ctx_synchronize(qdg_ctx* ctx);
+/* Problem::solution at n points (DGPDE::analyticSolution, src/PDE/DGPDE.hpp:141-144;
+ * also the Dirichlet state and the initial condition): out[i*ncomp + c], ncomp = 5
+ * (CompFlow) or 1 (Transport); evaluated by the device functors of the context's problem */
+int qdg_solution(qdg_ctx* ctx, size_t n, const double* x, const double* y, const double* z,
+                 double t, double* out);
 
 /* Upload one mesh chunk.  nielem interior tets, nunk >= nielem incl. ghosts
  * (rows [nielem,nunk) of every field are ghosts filled by the halo exchange);

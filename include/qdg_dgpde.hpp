@@ -326,6 +326,49 @@ class DeviceDG {
     check(qdg_limit(handle(inpoel), U.data().data()));
   }
 
+  //! DGPDE::analyticSolution (src/PDE/DGPDE.hpp:141-144): the Problem's solution at a point
+  std::vector<real> analyticSolution(real xi, real yi, real zi, real t) const
+  {
+    std::vector<real> s(PDE == QDG_PDE_TRANSPORT ? 1 : 5);
+    check(qdg_solution(m_state->ctx, 1, &xi, &yi, &zi, t, s.data()));
+    return s;
+  }
+
+  //! DGPDE::fieldNames (numerical fields; SodShocktube.cpp:139-158 and siblings)
+  std::vector<std::string> fieldNames() const
+  {
+    if (PDE == QDG_PDE_TRANSPORT) return { "c0_numerical" };
+    return { "density_numerical", "x-velocity_numerical", "y-velocity_numerical", "z-velocity_numerical",
+             "specific_total_energy_numerical", "pressure_numerical" };
+  }
+
+  //! DGPDE::names: labels of the integral variables in the diagnostics file
+  std::vector<std::string> names() const
+  {
+    if (PDE == QDG_PDE_TRANSPORT) return { "c0" };
+    return { "r", "ru", "rv", "rw", "re" };
+  }
+
+  //! DGPDE::fieldOutput (src/PDE/DGPDE.hpp:126-131): numerical fields from the cell means of U
+  //! (host-side like the reference's, SodShocktube.cpp:160-237; no device data involved)
+  std::vector<std::vector<real>> fieldOutput(real /*t*/, const Fields& /*geoElem*/, const Fields& U) const
+  {
+    const std::size_t n = U.nunk(), nd = m_deck.ndof;
+    if (PDE == QDG_PDE_TRANSPORT) {
+      std::vector<std::vector<real>> out(1, std::vector<real>(n));
+      for (std::size_t e = 0; e < n; ++e) out[0][e] = U(e, 0, 0);
+      return out;
+    }
+    std::vector<std::vector<real>> out(6, std::vector<real>(n));
+    for (std::size_t e = 0; e < n; ++e) {
+      const real r = U(e, 0, 0), u = U(e, nd, 0) / r, v = U(e, 2 * nd, 0) / r, w = U(e, 3 * nd, 0) / r,
+                 re = U(e, 4 * nd, 0);
+      out[0][e] = r; out[1][e] = u; out[2][e] = v; out[3][e] = w; out[4][e] = re / r;
+      out[5][e] = (re - 0.5 * r * (u * u + v * v + w * w) - m_deck.pstiff) * (m_deck.gamma - 1.0) - m_deck.pstiff;
+    }
+    return out;
+  }
+
   //! Problem::side via the configured BC lists (DGCompFlow.hpp:430-434)
   void side(std::unordered_set<int>& conf) const { for (int s : m_bcset) conf.insert(s); }
 

@@ -188,6 +188,17 @@ class Context:
         self.ndof = ndof
         self.nprop = (1 if pde == "transport" else 5) * ndof
 
+    def solution(self, pts, t):
+        """Problem::solution at points [n,3] -> [n, ncomp]"""
+        pts = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 3)
+        n = pts.shape[0]
+        x, y, z = (np.ascontiguousarray(pts[:, d]) for d in range(3))
+        nc = self.nprop // self.ndof
+        out = np.zeros((n, nc))
+        _chk(lib().qdg_solution(self.h, C.c_size_t(n), x.ctypes.data_as(c_f64p), y.ctypes.data_as(c_f64p),
+                                z.ctypes.data_as(c_f64p), C.c_double(t), out.ctypes.data_as(c_f64p)))
+        return out
+
     def set_stream(self, stream_ptr):
         _chk(lib().qdg_ctx_set_stream(self.h, C.c_void_p(stream_ptr)))
 

@@ -275,6 +275,29 @@ extern "C" int qdg_ctx_synchronize(qdg_ctx* ctx)
   QDG_CATCH
 }
 
+extern "C" int qdg_solution(qdg_ctx* ctx, size_t n, const double* x, const double* y, const double* z,
+                            double t, double* out)
+{
+  QDG_TRY
+  if (!ctx || (n && (!x || !y || !z || !out))) return fail("qdg_solution: null argument");
+  if (n > (size_t)INT32_MAX / 8) return fail("qdg_solution: too many points for one call");
+  if (n == 0) return 0;
+  HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const int ncomp = ctx->cfg.pde == QDG_PDE_TRANSPORT ? 1 : NCOMP;
+  DevBuf<double> d;
+  HIPCHK(d.alloc((3 + (size_t)ncomp) * n));
+  HIPCHK(hipMemcpyAsync(d.p, x, n * 8, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(d.p + n, y, n * 8, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(d.p + 2 * n, z, n * 8, hipMemcpyHostToDevice, s));
+  launch_solution(ncomp, ctx->ph, (int)n, d.p, d.p + n, d.p + 2 * n, t, d.p + 3 * n, s);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out, d.p + 3 * n, (size_t)ncomp * n * 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return 0;
+  QDG_CATCH
+}
+
 // ---------------------------------------------------------------- upload
 
 static inline uint64_t spread21(uint64_t v)

@@ -1890,6 +1890,23 @@ __global__ void k_diag_final(const double* __restrict__ part, int nblk, double* 
   out[i] = r;
 }
 
+// ================================================================ Problem::solution
+// analytic / initial solution at arbitrary points (DGPDE::analyticSolution,
+// src/PDE/DGPDE.hpp:141-144): out[i*ncomp + c]
+template <int PROB>
+__global__ __launch_bounds__(256) void k_solution(Phys ph, int n, const double* __restrict__ x,
+                                                  const double* __restrict__ y,
+                                                  const double* __restrict__ z, double t,
+                                                  double* __restrict__ out)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s[NCOMP];
+  prob_solution<PROB>(ph, x[i], y[i], z[i], t, s);
+#pragma unroll
+  for (int c = 0; c < NCOMP; ++c) out[(size_t)i * NCOMP + c] = s[c];
+}
+
 // ================================================================ field output
 // Problem::fieldOutput, numerical fields from the cell means
 // (src/PDE/CompFlow/Problem/SodShocktube.cpp:160-237: density, x/y/z velocity,
@@ -2691,6 +2708,23 @@ void launch_halo_unpack(const double* slab, int nprop, int /*stride*/, int nie, 
   if (nrecv == 0) return;
   const size_t n = (size_t)nrecv * (nprop + (ndofel ? 1 : 0));
   k_halo_unpack<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(slab, nprop, nie, nrecv, U, ndofel);
+}
+
+__global__ __launch_bounds__(256) void k_tr_solution(int problem, int n, const double* __restrict__ x,
+                                                     const double* __restrict__ y,
+                                                     const double* __restrict__ z, double t,
+                                                     double* __restrict__ out)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = tr::solution(problem, x[i], y[i], z[i], t);
+}
+
+void launch_solution(int ncomp, const Phys& ph, int n, const double* x, const double* y, const double* z,
+                     double t, double* out, hipStream_t s)
+{
+  if (n == 0) return;
+  if (ncomp == 1) { k_tr_solution<<<nblk(n, 256), 256, 0, s>>>(ph.problem, n, x, y, z, t, out); return; }
+  QDG_DISPATCH_PROB(ph.problem, (k_solution<P><<<nblk(n, 256), 256, 0, s>>>(ph, n, x, y, z, t, out)));
 }
 
 void launch_field_output(int ndof, const DevMesh& m, const Phys& ph, const double* U, double* out,

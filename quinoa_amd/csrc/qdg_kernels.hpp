@@ -53,6 +53,8 @@ void launch_halo_pack(const double* U, int nprop, int stride, const int* send_el
 void launch_halo_unpack(const double* slab, int nprop, int stride, int nie, int nrecv, double* U,
                         hipStream_t s, int* ndofel = nullptr);
 
+void launch_solution(int ncomp, const Phys& ph, int n, const double* x, const double* y, const double* z,
+                     double t, double* out, hipStream_t s);
 void launch_field_output(int ndof, const DevMesh& m, const Phys& ph, const double* U, double* out,
                          hipStream_t s);
 // p-adaptive DG (DG::eval_ndof, propagate_ndof, zeroing of P0 high-order DOFs)

@@ -89,6 +89,15 @@ int main(int argc, char** argv)
     try { qdg::Fields bad(1, 1); eq.limit(std::vector<std::size_t>{0, 1, 2, 3}, bad); }
     catch (const qdg::Exception&) { threw = true; }
 
+    // output-side DGPDE members: fieldNames / names / fieldOutput / analyticSolution
+    const auto fnames = eq.fieldNames();
+    const auto dnames = eq.names();
+    const auto fout = eq.fieldOutput(0.0, geoElem, U2);
+    const auto asol = eq.analyticSolution(0.25, 0.5, 0.5, 0.0);      // Sod, left state
+    if (fnames.size() != 6 || fout.size() != 6 || dnames.size() != 5 || asol.size() != 5 ||
+        fnames[5] != "pressure_numerical" || fout[0].size() != nelem)
+      throw std::runtime_error("output-side DGPDE members: wrong shapes");
+
     // dg::Transport stand-in (BASELINE config 1 physics) on the same chare data
     qdg::InputDeck tdeck;
     tdeck.ndof = tdeck.rdof = 1;
@@ -115,6 +124,7 @@ int main(int argc, char** argv)
     wr(o, std::vector<double>{ dt, dts[0], dts[1], threw ? 1.0 : 0.0 });
     wr(o, Lt.data()); wr(o, Ut.data()); wr(o, Rt.data()); wr(o, Ut2.data());
     wr(o, std::vector<double>{ tdt, tdts[0], tdts[1] });
+    wr(o, fout[0]); wr(o, fout[5]); wr(o, asol);
     fclose(o);
     tq.release(inpoel);
     eq.release(inpoel);

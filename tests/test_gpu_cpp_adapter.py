@@ -46,7 +46,7 @@ def test_cpp_adapter_matches_oracle(tmp_path):
     out = tmp_path / "out.bin"
     r = subprocess.run([EXE, str(mesh), str(out)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
-    L, U, R, Ulim, U2, sc, Lt, Ut, Rt, Ut2, tsc = _read_vecs(out)
+    L, U, R, Ulim, U2, sc, Lt, Ut, Rt, Ut2, tsc, f_rho, f_p, asol = _read_vecs(out)
     kw = dict(flux="hllc", limiter="superbeep1", problem="sod_shocktube", gamma=1.4)
     om = O.OracleMesh(coord, inpoel, ch["sidesets"])
     orc = O.Oracle(om, O.make_cfg(4, **kw), bc_sym=[3, 4, 5, 6], bc_extrapolate=[1, 2])
@@ -79,3 +79,8 @@ def test_cpp_adapter_matches_oracle(tmp_path):
     r2 = O.run_transport_case(tcase, tfix, nstep=2)
     assert np.abs(Ut2 - r2["U"]).max() <= 1e-12
     assert np.isfinite(Rt).all() and np.abs(Rt).max() > 0.0
+
+    # output-side members: fieldOutput on the final state, analyticSolution (Sod left state)
+    fo = orc.field_output(U2)
+    assert np.abs(f_rho - fo[0]).max() <= 1e-14 and np.abs(f_p - fo[5]).max() <= 1e-13
+    assert np.allclose(asol, [1.0, 0.0, 0.0, 0.0, 1.0 / 0.4], rtol=1e-15, atol=0.0)

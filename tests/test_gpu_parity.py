@@ -349,3 +349,26 @@ def test_rayleigh_taylor_problem_matches_oracle(cases, ndof):
         assert np.abs(np.sqrt(d[:10] / chunk.meshvol) - l2).max() <= 1e-10
     finally:
         mesh.close(); ctx.close()
+
+
+@pytest.mark.parametrize("name", ["sedov_dgp1", "vortical_flow_dgp1", "taylor_green_dgp2", "nleg_dgp2"])
+def test_problem_solution_at_points_matches_oracle(name, cases):
+    """qdg_solution (DGPDE::analyticSolution / the Dirichlet state) vs the oracle's
+    Problem::solution at random points and times"""
+    import ctypes as C
+    case, fix = cases[name], load_fixture(name)
+    ctx, mesh, chunk, orc = _setup(case, fix)
+    try:
+        rng = np.random.default_rng(11)
+        pts = rng.uniform(0.0, 1.0, size=(200, 3))
+        for t in (0.0, 0.37):
+            got = ctx.solution(pts, t)
+            ref = np.zeros((200, 5))
+            for i, p in enumerate(pts):
+                s = np.zeros(5)
+                orc.L_.orc_solution(C.byref(orc.cfg), C.c_double(p[0]), C.c_double(p[1]), C.c_double(p[2]),
+                                    C.c_double(t), s.ctypes.data_as(O.c_f64p))
+                ref[i] = s
+            assert np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+    finally:
+        mesh.close(); ctx.close()
