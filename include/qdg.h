@@ -290,6 +290,15 @@ int qdg_dev_facedata(qdg_ctx* ctx, size_t nelem, size_t nnode, const size_t* inp
                      const size_t* triinpoel, int* esuel, size_t* nipfac, size_t* inpofa,
                      int* esuf, size_t* belem, double* geoFace, double* geoElem);
 
+/* One call from connectivity to a mesh handle, for a chunk WITHOUT ghosts (serial run,
+ * or the re-build after mesh refinement, DG::resizePostAMR src/Inciter/DG.cpp:1536-1612):
+ * boundary faces regenerated from the side-set triangles (qdg_bnd_faces), FaceData and
+ * geometry on the device (qdg_dev_facedata), then qdg_mesh_upload.  tri_set[i] is the side
+ * set id of triangle i. */
+int qdg_mesh_from_connectivity(qdg_ctx* ctx, size_t nelem, size_t nnode, const size_t* inpoel,
+                               const double* x, const double* y, const double* z, size_t ntri,
+                               const size_t* tri, const int32_t* tri_set, qdg_mesh** out);
+
 #ifdef __cplusplus
 }
 #endif

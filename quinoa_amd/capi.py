@@ -425,6 +425,31 @@ class Mesh:
             self.h = C.c_void_p()
 
 
+def mesh_from_connectivity(ctx, inpoel, coord, sidesets):
+    """qdg_mesh_from_connectivity: a Mesh handle for a chunk without ghosts straight from
+    (inpoel, coord, {side set id: triangles}); FaceData and geometry are made on the GPU."""
+    inpoel = np.ascontiguousarray(inpoel, dtype=np.uint64).reshape(-1)
+    coord = np.ascontiguousarray(coord, dtype=np.float64)
+    ids = sorted(sidesets)
+    tri = np.concatenate([np.asarray(sidesets[s_], dtype=np.uint64).reshape(-1, 3) for s_ in ids]) \
+        if ids else np.zeros((0, 3), dtype=np.uint64)
+    tset = np.concatenate([np.full(len(sidesets[s_]), s_, np.int32) for s_ in ids]) \
+        if ids else np.zeros(0, np.int32)
+    tri = np.ascontiguousarray(tri.reshape(-1) if tri.size else np.zeros(3, np.uint64))
+    tset = np.ascontiguousarray(tset if tset.size else np.zeros(1, np.int32))
+    x, y, z = (np.ascontiguousarray(coord[:, d]) for d in range(3))
+    m = Mesh.__new__(Mesh)
+    m.ctx, m.nunk, m.nielem, m.nprop = ctx, inpoel.size // 4, inpoel.size // 4, ctx.nprop
+    m.h = C.c_void_p()
+    ntri = sum(len(sidesets[s_]) for s_ in ids)
+    _chk(lib().qdg_mesh_from_connectivity(ctx.h, C.c_size_t(m.nunk), C.c_size_t(coord.shape[0]),
+                                          inpoel.ctypes.data_as(c_szp), x.ctypes.data_as(c_f64p),
+                                          y.ctypes.data_as(c_f64p), z.ctypes.data_as(c_f64p),
+                                          C.c_size_t(ntri), tri.ctypes.data_as(c_szp),
+                                          tset.ctypes.data_as(c_i32p), C.byref(m.h)))
+    return m
+
+
 def dev_facedata(ctx, inpoel, coord, triinpoel):
     """FaceData arrays and geometry of one chunk generated on the GPU
     (qdg_dev_facedata): dict with esuel, nipfac, inpofa, esuf, belem, geoFace, geoElem."""

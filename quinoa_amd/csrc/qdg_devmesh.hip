@@ -12,6 +12,7 @@
 //   binary search in the sorted keys;  geometry is one thread per face / tet.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <string>
@@ -286,5 +287,44 @@ extern "C" int qdg_dev_facedata(qdg_ctx* ctx, size_t nelem, size_t nnode, const 
   if (herr == 2) return fail("qdg_dev_facedata: a boundary face is not a face of any tet");
   *nipfac_out = nipfac;
   return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_mesh_from_connectivity(qdg_ctx* ctx, size_t nelem, size_t nnode, const size_t* inpoel,
+                                          const double* x, const double* y, const double* z,
+                                          size_t ntri, const size_t* tri, const int32_t* tri_set,
+                                          qdg_mesh** out)
+{
+  QDG_TRY
+  if (!ctx || !out || !inpoel || !x || !y || !z) return fail("qdg_mesh_from_connectivity: null argument");
+  if (ntri > 0 && (!tri || !tri_set)) return fail("qdg_mesh_from_connectivity: null side-set arrays");
+  *out = nullptr;
+  // boundary faces in the reference's order (Partitioner.cpp:357-393), grouped by side set
+  std::vector<size_t> triinpoel(3 * std::max<size_t>(ntri, 1));
+  std::vector<int32_t> fset(std::max<size_t>(ntri, 1));
+  size_t nbfac = 0;
+  if (ntri)
+    if (int rc = qdg_bnd_faces(nelem, inpoel, ntri, tri, tri_set, &nbfac, triinpoel.data(), fset.data()))
+      return rc;
+  const size_t nfmax = nbfac + 2 * nelem;
+  std::vector<int> esuel(4 * nelem), esuf(2 * nfmax);
+  std::vector<size_t> inpofa(3 * nfmax), belem(std::max<size_t>(nbfac, 1));
+  std::vector<double> geoFace(7 * nfmax), geoElem(4 * nelem);
+  size_t nipfac = 0;
+  if (int rc = qdg_dev_facedata(ctx, nelem, nnode, inpoel, x, y, z, nbfac, triinpoel.data(), esuel.data(),
+                                &nipfac, inpofa.data(), esuf.data(), belem.data(), geoFace.data(),
+                                geoElem.data()))
+    return rc;
+  // FaceData::m_bface: side set id -> boundary face ids (faces come grouped by ascending id)
+  std::vector<int32_t> ids; std::vector<size_t> off{ 0 }, faces(std::max<size_t>(nbfac, 1));
+  for (size_t f = 0; f < nbfac; ++f) {
+    if (ids.empty() || ids.back() != fset[f]) { if (!ids.empty()) off.push_back(f); ids.push_back(fset[f]); }
+    faces[f] = f;
+  }
+  off.push_back(nbfac);
+  if (ids.empty()) { ids.push_back(0); off.assign({ 0, 0 }); }
+  qdg_bface bf{ nbfac ? ids.size() : 0, ids.data(), off.data(), faces.data() };
+  return qdg_mesh_upload(ctx, nelem, nelem, nnode, inpoel, x, y, z, nbfac, nipfac, esuf.data(),
+                         esuel.data(), inpofa.data(), geoFace.data(), geoElem.data(), &bf, out);
   QDG_CATCH
 }

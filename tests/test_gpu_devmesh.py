@@ -95,3 +95,29 @@ def test_device_facedata_full_size_and_timing():
         assert np.abs(g["geoFace"] - gf).max() <= 1e-14 and np.abs(g["geoElem"] - ge).max() <= 1e-14
     finally:
         ctx.close()
+
+
+def test_mesh_from_connectivity_equals_the_hand_assembled_chunk(cases):
+    """qdg_mesh_from_connectivity (boundary faces + device FaceData + upload in one call)
+    gives the same operator results as the chunk assembled from host FaceData"""
+    from quinoa_amd import capi, dgmesh
+    case, fix = cases["sedov_dgp1"], load_fixture("sedov_dgp1")
+    ss = {int(s): fix["ss_tri_%d" % s] for s in fix["ss_ids"]}
+    kw = dict(flux=case["flux"], limiter=case["limiter"], problem=case["problem"], gamma=case["gamma"],
+              cfl=case["cfl"], bc_sym=case["bc_sym"], bc_extrapolate=case["bc_extrapolate"])
+    ctx = capi.Context(4, **kw)
+    try:
+        a = dgmesh.upload(ctx, dgmesh.build_chunk(fix["coord"], fix["inpoel"], None, ss))
+        b = capi.mesh_from_connectivity(ctx, fix["inpoel"], fix["coord"], ss)
+        for m in (a, b):
+            m.state_initialize(0.0)
+        t = 0.0
+        for _ in range(3):
+            dta, dtb = a.step(t), b.step(t)
+            assert abs(dta - dtb) <= 1e-14 * dta
+            t += dta
+        Ua, Ub = a.state_download(), b.state_download()
+        assert np.abs(Ua - Ub).max() <= 1e-12 * np.abs(Ua).max()
+        a.close(); b.close()
+    finally:
+        ctx.close()
