@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -16,7 +17,9 @@
 #include <limits>
 #include <memory>
 #include <numeric>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/qdg.h"
@@ -37,6 +40,21 @@ int fail(const std::string& m) { g_err = m; return 1; }
     if (e_ != hipSuccess)                                                         \
       return ::qdg::fail(std::string(#call) + ": " + hipGetErrorString(e_));      \
   } while (0)
+
+// run fn(begin, end) over [0, n) on the host's cores (mesh set-up loops)
+template <class F> static void parallel_for(size_t n, F&& fn, size_t serial_below = 65536)
+{
+  unsigned nt = std::thread::hardware_concurrency();
+  nt = std::max(1u, std::min(nt, 16u));
+  if (n < serial_below || nt == 1) { fn((size_t)0, n); return; }
+  std::vector<std::thread> th;
+  const size_t chunk = (n + nt - 1) / nt;
+  for (unsigned t = 0; t < nt; ++t) {
+    const size_t b = std::min(n, t * chunk), e = std::min(n, b + chunk);
+    if (b < e) th.emplace_back([&fn, b, e] { fn(b, e); });
+  }
+  for (auto& t : th) t.join();
+}
 
 // owning device buffer
 template <class T> struct DevBuf {
@@ -329,6 +347,17 @@ extern "C" int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t 
   HIPCHK(hipSetDevice(ctx->device));
   const size_t nie = nielem, ne = nunk;
 
+  // QDG_UPLOAD_STATS=1: wall time of the host sections below, on stderr
+  const bool stats = std::getenv("QDG_UPLOAD_STATS") != nullptr;
+  auto tprev = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!stats) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "qdg upload: %-34s %7.1f ms\n", what,
+                 std::chrono::duration<double, std::milli>(now - tprev).count());
+    tprev = now;
+  };
+
   // ---- validate connectivity before anything reaches a kernel -----------
   for (size_t i = 0; i < 4 * ne; ++i)
     if (inpoel[i] >= nnode) return fail("qdg_mesh_upload: inpoel entry out of range");
@@ -337,6 +366,7 @@ extern "C" int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t 
   for (size_t e = 0; e < ne; ++e)
     if (!(geoElem[4 * e] > 0.0)) return fail("qdg_mesh_upload: non-positive element volume");
 
+  lap("validation");
   // ---- device order of interior tets: Morton curve of the centroids ------
   std::vector<int> d2h(ne), h2d(ne);
   std::iota(d2h.begin(), d2h.end(), 0);
@@ -373,6 +403,7 @@ extern "C" int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t 
   }
   for (size_t d = 0; d < ne; ++d) h2d[d2h[d]] = (int)d;
 
+  lap("curve order");
   // ---- nodes renumbered by first touch in device order -------------------
   std::vector<int> nnew(nnode, -1);
   int ncount = 0;
@@ -385,6 +416,7 @@ extern "C" int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t 
   for (size_t n = 0; n < nnode; ++n)
     if (nnew[n] >= 0) { hx[nnew[n]] = x[n]; hy[nnew[n]] = y[n]; hz[nnew[n]] = z[n]; }
 
+  lap("node renumbering");
   // ---- (host element, local face) -> reference face id --------------------
   std::vector<int> rface(4 * nie, -1);
   for (size_t f = 0; f < nfac; ++f) {
@@ -422,6 +454,7 @@ extern "C" int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t 
     if (rface[i] < 0) return fail("qdg_mesh_upload: element face without an entry in esuf "
                                   "(every boundary face must be listed in [0,nbfac))");
 
+  lap("face ids per (tet, local face)");
   // ---- BC type of every boundary face -------------------------------------
   // reference: bndSurfInt over the configured side sets of each BC type
   // (src/PDE/Integrate/Boundary.cpp:84-90); faces of unconfigured sets get no flux
@@ -449,34 +482,46 @@ extern "C" int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t 
   const size_t stride = (ne + 63) / 64 * 64;
   std::vector<int> h_inpoel(4 * stride, 0), h_nbr(4 * stride, -1), h_finfo(4 * stride, 0), h_fid(4 * stride, 0);
   std::vector<double> h_vol(stride, 1.0);
+  // device face numbering: by first touch in device element order (serial, cheap) ...
   std::vector<int> fmap(nfac, -1);
   int nfd = 0;
-  for (size_t d = 0; d < ne; ++d) {
+  for (size_t d = 0; d < nie; ++d) {
     const size_t h = d2h[d];
-    for (int i = 0; i < 4; ++i) h_inpoel[i * stride + d] = nnew[inpoel[4 * h + i]];
-    h_vol[d] = geoElem[4 * h];
-    if (d >= nie) continue;
     for (int lf = 0; lf < 4; ++lf) {
       const int f = rface[4 * h + lf];
       if (fmap[f] < 0) fmap[f] = nfd++;
-      h_fid[lf * stride + d] = fmap[f];
-      const int nb = esuel[4 * h + lf];
-      int info = ((size_t)esuf[2 * f] == h) ? (1 << 6) : 0;
-      if (nb < 0) {
-        h_nbr[lf * stride + d] = -(1 + bcface[f]);
-      } else {
-        h_nbr[lf * stride + d] = h2d[nb];
-        for (int j = 0; j < 3; ++j) {
-          const size_t g = inpoel[4 * h + LPOFA[lf][j]];
-          int m = -1;
-          for (int q = 0; q < 4; ++q) if (inpoel[4 * (size_t)nb + q] == g) m = q;
-          if (m < 0) return fail("qdg_mesh_upload: neighbour does not share the face nodes (bad esuel/inpoel)");
-          info |= m << (2 * j);
-        }
-      }
-      h_finfo[lf * stride + d] = info;
     }
   }
+  // ... everything else per device row, on all cores
+  std::atomic<int> bad_nbr{0};
+  parallel_for(ne, [&](size_t d0, size_t d1) {
+    for (size_t d = d0; d < d1; ++d) {
+      const size_t h = d2h[d];
+      for (int i = 0; i < 4; ++i) h_inpoel[i * stride + d] = nnew[inpoel[4 * h + i]];
+      h_vol[d] = geoElem[4 * h];
+      if (d >= nie) continue;
+      for (int lf = 0; lf < 4; ++lf) {
+        const int f = rface[4 * h + lf];
+        h_fid[lf * stride + d] = fmap[f];
+        const int nb = esuel[4 * h + lf];
+        int info = ((size_t)esuf[2 * f] == h) ? (1 << 6) : 0;
+        if (nb < 0) {
+          h_nbr[lf * stride + d] = -(1 + bcface[f]);
+        } else {
+          h_nbr[lf * stride + d] = h2d[nb];
+          for (int j = 0; j < 3; ++j) {
+            const size_t g = inpoel[4 * h + LPOFA[lf][j]];
+            int m = -1;
+            for (int q = 0; q < 4; ++q) if (inpoel[4 * (size_t)nb + q] == g) m = q;
+            if (m < 0) { bad_nbr = 1; m = 0; }
+            info |= m << (2 * j);
+          }
+        }
+        h_finfo[lf * stride + d] = info;
+      }
+    }
+  });
+  if (bad_nbr) return fail("qdg_mesh_upload: neighbour does not share the face nodes (bad esuel/inpoel)");
   std::vector<double> h_area(std::max(nfd, 1)), h_nx(std::max(nfd, 1)), h_ny(std::max(nfd, 1)), h_nz(std::max(nfd, 1));
   for (size_t f = 0; f < nfac; ++f)
     if (fmap[f] >= 0) {
@@ -486,14 +531,15 @@ extern "C" int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t 
       h_nz[fmap[f]] = geoFace[7 * f + 3];
     }
 
+  lap("device arrays (host side)");
   // ---- face tasks per tile (k_rhs_p1t) -----------------------------------------
   const int ntile = (int)((nie + TILE - 1) / TILE);
   std::vector<int> h_tile_off(ntile + 1, 0), h_task_a, h_task_nb, h_task_f;
-  h_task_a.reserve(3 * nie); h_task_nb.reserve(3 * nie); h_task_f.reserve(3 * nie);
   {
     struct Task { int key, a, nb, f; };
-    std::vector<Task> tt;
-    for (int t = 0; t < ntile; ++t) {
+    // tasks of tile t in its (kind, local face) order; two passes over the tiles on all
+    // cores: count, then fill at the tile's offset
+    auto tile_tasks = [&](int t, std::vector<Task>& tt) {
       const size_t e0 = (size_t)t * TILE, e1 = std::min(nie, e0 + TILE);
       tt.clear();
       for (size_t d = e0; d < e1; ++d)
@@ -512,10 +558,24 @@ extern "C" int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t 
         }
       // same kind / local face next to each other: fewer divergent branches per wave
       std::stable_sort(tt.begin(), tt.end(), [](const Task& p, const Task& q) { return p.key < q.key; });
-      for (const Task& k : tt) { h_task_a.push_back(k.a); h_task_nb.push_back(k.nb); h_task_f.push_back(k.f); }
-      h_tile_off[t + 1] = (int)h_task_a.size();
-    }
-    if (std::getenv("QDG_UPLOAD_STATS")) {
+    };
+    parallel_for((size_t)ntile, [&](size_t t0, size_t t1) {
+      std::vector<Task> tt;
+      for (size_t t = t0; t < t1; ++t) { tile_tasks((int)t, tt); h_tile_off[t + 1] = (int)tt.size(); }
+    }, 256);
+    for (int t = 0; t < ntile; ++t) h_tile_off[t + 1] += h_tile_off[t];
+    const size_t ntask = (size_t)h_tile_off[ntile];
+    h_task_a.resize(ntask); h_task_nb.resize(ntask); h_task_f.resize(ntask);
+    parallel_for((size_t)ntile, [&](size_t t0, size_t t1) {
+      std::vector<Task> tt;
+      for (size_t t = t0; t < t1; ++t) {
+        tile_tasks((int)t, tt);
+        size_t o = (size_t)h_tile_off[t];
+        for (const Task& k : tt) { h_task_a[o] = k.a; h_task_nb[o] = k.nb; h_task_f[o] = k.f; ++o; }
+      }
+    }, 256);
+    lap("face tasks per tile");
+    if (stats) {
       size_t cnt[3] = { 0, 0, 0 };
       for (int a : h_task_a) ++cnt[(a >> 17) & 3];
       std::fprintf(stderr, "qdg upload: %zu tets, %d tiles, tasks per tet: interior-in-tile %.3f, "
@@ -580,6 +640,7 @@ extern "C" int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t 
     dm.ndofel = m->ndofel.p;
   }
   HIPCHK(hipStreamSynchronize(s));
+  lap("allocation + copies to the device");
   *out = m.release();
   return 0;
   QDG_CATCH
