@@ -336,6 +336,12 @@ class Mesh:
         _chk(lib().qdg_stage_dt_device_ptr(self.h, C.byref(p)))
         return p.value
 
+    def state_device_ptr(self):
+        """(device pointer, row stride) of the resident state, for zero-copy plumbing"""
+        p, st = C.c_void_p(), C.c_size_t()
+        _chk(lib().qdg_state_device_ptr(self.h, C.byref(p), C.byref(st)))
+        return p.value, st.value
+
     def stage_rhs_update(self, stage, t):
         _chk(lib().qdg_stage_rhs_update(self.h, C.c_int(stage), C.c_double(t)))
 

@@ -372,3 +372,32 @@ def test_problem_solution_at_points_matches_oracle(name, cases):
             assert np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
     finally:
         mesh.close(); ctx.close()
+
+
+@pytest.mark.parametrize("name", ["sedov_dgp1", "taylor_green_dgp2_cfl", "sod_dg"])
+def test_explicit_stage_api_equals_qdg_step(name, cases):
+    """The per-stage entry points a DG chare would call one by one (qdg_stage_limit,
+    qdg_stage_dt + get/set for the host-side min-reduction, qdg_stage_rhs_update in its
+    in-place form) give the same state as the fused qdg_step."""
+    case, fix = cases[name], load_fixture(name)
+    ctx, mesh, chunk, orc = _setup(case, fix)
+    ctx2, mesh2, _, _ = _setup(case, fix)
+    try:
+        mesh.state_initialize(0.0); mesh2.state_initialize(0.0)
+        assert mesh.state_device_ptr()[0] not in (None, 0)
+        t = 0.0
+        for _ in range(3):
+            dt = mesh.step(t)
+            for stage in range(3):
+                mesh2.stage_limit()
+                if stage == 0:
+                    mesh2.stage_dt()
+                    d = mesh2.stage_dt_get()          # what DG::dt contributes to the min-reduction
+                    assert abs(d - dt) <= 1e-12 * dt
+                    mesh2.stage_dt_set(d)             # the reduced value comes back
+                mesh2.stage_rhs_update(stage, t)
+            t += dt
+        U1, U2 = mesh.state_download(), mesh2.state_download()
+        assert np.abs(U1 - U2).max() <= 1e-12 * max(1.0, np.abs(U1).max())
+    finally:
+        mesh.close(); ctx.close(); mesh2.close(); ctx2.close()
