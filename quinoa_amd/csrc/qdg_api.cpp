@@ -1217,6 +1217,29 @@ extern "C" int qdg_ndofel_set(qdg_mesh* mesh, const size_t* ndofel)
   QDG_CATCH
 }
 
+// Stage-0 update fused with the limiter of stage 1 (k_upd_superbee): DG-P1 CompFlow with
+// Superbee, uniform order.  QDG_NO_FUSED_UPDATE=1 keeps the two kernels (A/B runs).
+static bool can_fuse_update_limit(const qdg_mesh* mesh)
+{
+  static const bool off = std::getenv("QDG_NO_FUSED_UPDATE") != nullptr;
+  return !off && use_p1_fast(mesh) && mesh->ctx->cfg.limiter == QDG_LIMITER_SUPERBEEP1 && !mesh->dm.ndofel;
+}
+
+// after qdg_stage_rhs_dt(stage 0): U1 = Superbee(U0 + dt R / L) into a free buffer; the
+// ghost rows of that buffer must already hold the neighbours' U1 (exchange_upd)
+static int stage0_update_and_limit(qdg_mesh* mesh)
+{
+  qdg_ctx* ctx = mesh->ctx;
+  hipStream_t s = ctx->stream;
+  if (!mesh->Unp || mesh->Unp != mesh->Ucur || mesh->Upending)
+    return fail("stage0_update_and_limit: not after a stage-0 RHS");
+  double* out = free_buf(mesh, mesh->Ucur, mesh->Unp);
+  launch_upd_superbee(mesh->dm, mesh->dt_ptr, mesh->Ucur, mesh->R.p, out, s);
+  HIPCHK(hipGetLastError());
+  mesh->Ucur = out;                   // Unp keeps pointing at the stage-0 state
+  return 0;
+}
+
 extern "C" int qdg_step(qdg_mesh* mesh, double t, double tleft, double* dt_taken)
 {
   QDG_TRY
@@ -1224,11 +1247,13 @@ extern "C" int qdg_step(qdg_mesh* mesh, double t, double tleft, double* dt_taken
   if (mesh->nnbr != 0)
     return fail("qdg_step: this chunk has halo neighbours; drive the stages and the exchange "
                 "explicitly (qdg_stage_* + qdg_halo_*)");
+  const bool fuse = can_fuse_update_limit(mesh);
   for (int stage = 0; stage < 3; ++stage) {
     if (stage == 0 && mesh->dm.ndofel) if (int rc = qdg_stage_pdg(mesh)) return rc;
-    if (int rc = qdg_stage_limit(mesh)) return rc;
+    if (!(fuse && stage == 1)) if (int rc = qdg_stage_limit(mesh)) return rc;   // stage 1: done below
     if (int rc = qdg_stage_rhs_dt(mesh, stage, t, tleft)) return rc;
-    if (int rc = qdg_stage_update(mesh, stage)) return rc;
+    if (fuse && stage == 0) { if (int rc = stage0_update_and_limit(mesh)) return rc; }
+    else if (int rc = qdg_stage_update(mesh, stage)) return rc;
   }
   if (dt_taken) return qdg_stage_dt_get(mesh, dt_taken);
   return 0;
@@ -1492,6 +1517,29 @@ static int exchange_on(qdg_mesh* mesh, qdg_comm* comm, hipStream_t s)
   return 0;
 }
 
+// the comsol exchange of stage 1 when the stage-0 update is fused into the limiter:
+// the send rows U1 = U0 + dt R / L are formed by the pack kernel, the neighbours' rows
+// land in the ghost rows of `out`, the buffer the fused kernel is about to fill
+static int exchange_upd(qdg_mesh* mesh, qdg_comm* comm, hipStream_t s, double* out)
+{
+  if (mesh->nnbr == 0) return 0;
+  if (!comm) return fail("qdg_step_comm: null communicator");
+  RcclApi* a = rccl_api();
+  const size_t np = (size_t)mesh->nprop;
+  launch_halo_pack_upd(mesh->Ucur, mesh->R.p, mesh->dt_ptr, mesh->vol.p, mesh->send_elem.p,
+                       (int)mesh->nsend, mesh->send_ptr, s);
+  HIPCHK(hipGetLastError());
+  RCCLCHK(a->GroupStart());
+  for (size_t i = 0; i < mesh->nnbr; ++i) {
+    const size_t ns = (mesh->send_off[i + 1] - mesh->send_off[i]) * np;
+    const size_t nr = (mesh->recv_off[i + 1] - mesh->recv_off[i]) * np;
+    if (ns) RCCLCHK(a->Send(mesh->send_ptr + mesh->send_off[i] * np, ns, ncclDouble, mesh->nbr_rank[i], comm->comm, s));
+    if (nr) RCCLCHK(a->Recv(out + (mesh->nie + mesh->recv_off[i]) * np, nr, ncclDouble, mesh->nbr_rank[i], comm->comm, s));
+  }
+  RCCLCHK(a->GroupEnd());
+  return 0;
+}
+
 extern "C" int qdg_halo_exchange(qdg_mesh* mesh, qdg_comm* comm)
 {
   QDG_TRY
@@ -1534,18 +1582,25 @@ extern "C" int qdg_step_comm(qdg_mesh* mesh, qdg_comm* comm, double t, double tl
   if (!comm) return fail("qdg_step_comm: null communicator");
   const bool limited = ctx->cfg.limiter != QDG_LIMITER_NONE && mesh->ndof > 1;
   const bool overlap = can_overlap(mesh);
+  const bool fuse = !overlap && can_fuse_update_limit(mesh);
   hipStream_t cs = comm->cs;
   for (int stage = 0; stage < 3; ++stage) {
     if (!overlap) {
       const bool pdg0 = stage == 0 && mesh->dm.ndofel;
+      const bool fused1 = fuse && stage == 1;        // comsol + limiter of stage 1 ran with the update
       if (pdg0) if (int rc = qdg_stage_pdg_eval(mesh)) return rc;          // DG::next: eval_ndof
-      if (int rc = exchange_on(mesh, comm, s)) return rc;                 // DG::next -> comsol
+      if (!fused1) if (int rc = exchange_on(mesh, comm, s)) return rc;    // DG::next -> comsol
       if (pdg0) if (int rc = qdg_stage_pdg_propagate(mesh)) return rc;     // DG::lim: propagate_ndof
-      if (int rc = qdg_stage_limit(mesh)) return rc;                       // DG::lim
+      if (!fused1) if (int rc = qdg_stage_limit(mesh)) return rc;          // DG::lim
       if (limited || pdg0) if (int rc = exchange_on(mesh, comm, s)) return rc;   // -> comlim
       if (int rc = qdg_stage_rhs_dt(mesh, stage, t, tleft)) return rc;     // DG::dt, DG::solve
       if (stage == 0) if (int rc = qdg_stage_dt_allreduce(mesh, comm)) return rc;
-      if (int rc = qdg_stage_update(mesh, stage)) return rc;
+      if (fuse && stage == 0) {
+        // update of stage 0 + comsol + limiter of stage 1 in one pass over the state
+        double* out = free_buf(mesh, mesh->Ucur, mesh->Unp);
+        if (int rc = exchange_upd(mesh, comm, s, out)) return rc;
+        if (int rc = stage0_update_and_limit(mesh)) return rc;
+      } else if (int rc = qdg_stage_update(mesh, stage)) return rc;
       continue;
     }
     HIPCHK(hipEventRecord(comm->ev_ready, s));

@@ -1504,6 +1504,42 @@ __global__ __launch_bounds__(TILE_BS, QDG_TILE_WAVES) void k_rhs_p1t(DevMesh m, 
 // ------------------------------------------------------------- limiters
 // Superbee_P1, src/PDE/Limiter.cpp:155-316: only neighbour MEANS are read, so
 // the in-place update is order independent.
+// Limiter.cpp:283-301: phi = min over the face points of f(phi_gp),
+// phi_gp = min(1, (uMax|uMin - u0) / (2 uNeg)), f(p) = max(0, max(min(2p,1), min(p,2))).
+// f is non-decreasing, so phi = f(min phi_gp): the smallest ratio a/b is tracked by
+// cross-multiplication (a, b >= 0) and divided once per component instead of once
+// per point (|uNeg| <= 1e-14 -> phi_gp = 1: skipped).
+template <int NDOF>
+__device__ __forceinline__ void superbee_phi(const Tables<NDOF>& T, const double (&u)[NCOMP][NDOF],
+                                             const double* uMin, const double* uMax, double* phi)
+{
+  constexpr int NGF = Tables<NDOF>::NGF;
+  double ra[NCOMP], rb[NCOMP];
+#pragma unroll
+  for (int c = 0; c < NCOMP; ++c) { ra[c] = 1.0; rb[c] = 1.0; }
+#pragma unroll 1
+  for (int lf = 0; lf < 4; ++lf)
+#pragma unroll
+    for (int ig = 0; ig < NGF; ++ig) {
+      double s[NCOMP];
+      state_from<NDOF>(u, T.fB[lf][ig], s);
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) {
+        const double uNeg = s[c] - u[c][0];
+        const double a = (uNeg > 0.0) ? (uMax[c] - u[c][0]) : (u[c][0] - uMin[c]);
+        const double b = 2.0 * fabs(uNeg);
+        const bool take = (fabs(uNeg) > 1.0e-14) && (a * rb[c] < ra[c] * b);
+        ra[c] = take ? a : ra[c];
+        rb[c] = take ? b : rb[c];
+      }
+    }
+#pragma unroll
+  for (int c = 0; c < NCOMP; ++c) {
+    const double pg = fmin(1.0, ra[c] * fast_rcp(rb[c]));
+    phi[c] = fmax(0.0, fmax(fmin(2.0 * pg, 1.0), fmin(pg, 2.0)));
+  }
+}
+
 template <int NDOF>
 __global__ __launch_bounds__(256) void k_superbee(DevMesh m, double* __restrict__ U)
 {
@@ -1544,35 +1580,7 @@ __global__ __launch_bounds__(256) void k_superbee(DevMesh m, double* __restrict_
         }
       }
     }
-    // Limiter.cpp:283-301: phi = min over the face points of f(phi_gp),
-    // phi_gp = min(1, (uMax|uMin - u0) / (2 uNeg)), f(p) = max(0, max(min(2p,1), min(p,2))).
-    // f is non-decreasing, so phi = f(min phi_gp): the smallest ratio a/b is
-    // tracked by cross-multiplication (a, b >= 0) and divided once per component
-    // instead of once per point (|uNeg| <= 1e-14 -> phi_gp = 1: skipped).
-    double ra[NCOMP], rb[NCOMP];
-#pragma unroll
-    for (int c = 0; c < NCOMP; ++c) { ra[c] = 1.0; rb[c] = 1.0; }
-#pragma unroll 1
-    for (int lf = 0; lf < 4; ++lf)
-#pragma unroll
-      for (int ig = 0; ig < NGF; ++ig) {
-        double s[NCOMP];
-        state_from<NDOF>(u, T.fB[lf][ig], s);
-#pragma unroll
-        for (int c = 0; c < NCOMP; ++c) {
-          const double uNeg = s[c] - u[c][0];
-          const double a = (uNeg > 0.0) ? (uMax[c] - u[c][0]) : (u[c][0] - uMin[c]);
-          const double b = 2.0 * fabs(uNeg);
-          const bool take = (fabs(uNeg) > 1.0e-14) && (a * rb[c] < ra[c] * b);
-          ra[c] = take ? a : ra[c];
-          rb[c] = take ? b : rb[c];
-        }
-      }
-#pragma unroll
-    for (int c = 0; c < NCOMP; ++c) {
-      const double pg = fmin(1.0, ra[c] * fast_rcp(rb[c]));
-      phi[c] = fmax(0.0, fmax(fmin(2.0 * pg, 1.0), fmin(pg, 2.0)));
-    }
+    superbee_phi<NDOF>(T, u, uMin, uMax, phi);
     if (m.ndofel && m.ndofel[e] == 1) {    // pdg: P0 elements are not limited (Limiter.cpp:179-180)
 #pragma unroll
       for (int c = 0; c < NCOMP; ++c) phi[c] = 1.0;
@@ -1585,6 +1593,111 @@ __global__ __launch_bounds__(256) void k_superbee(DevMesh m, double* __restrict_
     // stored its limited rows: safe, Superbee never changes a mean.
     tile_store_rows<NPROP>(U, tile_e0, m.nie, lds, &u[0][0]);
   }
+}
+
+// Stage-0 RK update fused with the limiter of stage 1 (DG-P1 CompFlow, Superbee):
+//   Uout = Superbee( U0 + dt * R / L )        (DG.cpp:1478-1488 with a = 0, b = 1, then Limiter.cpp:155-316)
+// U1 never goes to memory unlimited: one kernel reads U0 and R and writes the limited
+// U1 (saves a full write + read of the state per time step).  Means of neighbours outside
+// the 256-row tile are formed on the fly from U0 and R; ghost neighbours (rows >= nie) are
+// read from Uout, where the halo exchange has already put the owners' U1.
+template <int NDOF>
+__global__ __launch_bounds__(256) void k_upd_superbee(DevMesh m, const double* __restrict__ dtp,
+                                                      const double* __restrict__ U0,
+                                                      const double* __restrict__ R,
+                                                      double* __restrict__ Uout)
+{
+  static_assert(NDOF == 4, "fused update + Superbee exists for DG-P1");
+  const Tables<NDOF>& T = tab<NDOF>();
+  constexpr int NPROP = NCOMP * NDOF, NCH = NPROP / 2;     // 16-byte chunks per row
+  __shared__ double lds[256 * NPROP];
+  __shared__ double sdtv[256];
+  const int tid = threadIdx.x;
+  const int tile_e0 = (m.blk0 + xcd_tile(blockIdx.x, gridDim.x)) * 256;
+  const int e0 = tile_e0 + tid;
+  const bool active = e0 < m.nie;
+  const int e = active ? e0 : m.nie - 1;
+  const int stride = m.stride;
+  const double dt = dtp[0];
+  sdtv[tid] = dt / m.vol[e];                       // the row's dt / vol, as k_rk forms it
+  __syncthreads();
+  // the tile's rows of U1 = U0 + dt R / L go to LDS in one coalesced pass over both arrays
+  {
+    const double2* su = reinterpret_cast<const double2*>(U0 + (size_t)tile_e0 * NPROP);
+    const double2* sr = reinterpret_cast<const double2*>(R + (size_t)tile_e0 * NPROP);
+    double2* dst = reinterpret_cast<double2*>(lds);
+    const int nvalid = (m.nie - tile_e0 < 256 ? m.nie - tile_e0 : 256) * NCH;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const int i = j * 256 + tid;
+      double2 v = make_double2(1.0, 1.0);
+      if (i < nvalid) {
+        const double2 a = su[i], b = sr[i];
+        const int row = i / NCH, hi = (i - row * NCH) & 1;     // chunk holds modes (0,1) or (2,3)
+        const double dtv = sdtv[row];
+        const double f0 = hi ? 10.0 / 3.0 : 1.0, f1 = hi ? 5.0 / 3.0 : 10.0;
+        v = make_double2(a.x + dtv * f0 * b.x, a.y + dtv * f1 * b.y);
+      }
+      dst[i] = v;
+    }
+  }
+  __syncthreads();
+  double u[NCOMP][NDOF];
+  lds_row<NPROP>(lds, tid, &u[0][0]);
+  double uMin[NCOMP], uMax[NCOMP], phi[NCOMP];
+#pragma unroll
+  for (int c = 0; c < NCOMP; ++c) { uMin[c] = uMax[c] = u[c][0]; phi[c] = 1.0; }
+#pragma unroll
+  for (int lf = 0; lf < 4; ++lf) {
+    const int nb = m.nbr[(size_t)lf * stride + e];
+    if (nb < 0) continue;
+    const int rr = nb - tile_e0;
+    if ((unsigned)rr < 256u) {
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) {
+        const double v = lds[(size_t)rr * NPROP + c * NDOF];
+        uMin[c] = fmin(uMin[c], v); uMax[c] = fmax(uMax[c], v);
+      }
+    } else if (nb >= m.nie) {                   // ghost: the owner's U1 mean, already exchanged
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) {
+        const double v = Uout[fidx(c * NDOF, nb, NPROP)];
+        uMin[c] = fmin(uMin[c], v); uMax[c] = fmax(uMax[c], v);
+      }
+    } else {
+      const double dtn = dt / m.vol[nb];
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) {
+        const double v = U0[fidx(c * NDOF, nb, NPROP)] + dtn * 1.0 * R[fidx(c * NDOF, nb, NPROP)];
+        uMin[c] = fmin(uMin[c], v); uMax[c] = fmax(uMax[c], v);
+      }
+    }
+  }
+  superbee_phi<NDOF>(T, u, uMin, uMax, phi);
+#pragma unroll
+  for (int c = 0; c < NCOMP; ++c)
+#pragma unroll
+    for (int k = 1; k < 4; ++k) u[c][k] = phi[c] * u[c][k];
+  tile_store_rows<NPROP>(Uout, tile_e0, m.nie, lds, &u[0][0]);
+}
+
+// send side of the same fusion: slab row j = U0[e] + dt * R[e] / L[e], e = send_elem[j]
+__global__ __launch_bounds__(256) void k_halo_pack_upd(const double* __restrict__ U0,
+                                                       const double* __restrict__ R,
+                                                       const double* __restrict__ dtp,
+                                                       const double* __restrict__ vol,
+                                                       const int* __restrict__ send_elem, int nsend,
+                                                       double* __restrict__ slab)
+{
+  constexpr int NPROP = NCOMP * 4;
+  constexpr double imf[4] = { 1.0, 10.0, 10.0 / 3.0, 5.0 / 3.0 };
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nsend * NPROP) return;
+  const int j = i / NPROP, p = i - j * NPROP, k = p & 3;
+  const int e = send_elem[j];
+  const double dtv = dtp[0] / vol[e];
+  const double f = (k == 0) ? imf[0] : (k == 1) ? imf[1] : (k == 2) ? imf[2] : imf[3];
+  slab[i] = U0[(size_t)e * NPROP + p] + dtv * f * R[(size_t)e * NPROP + p];
 }
 
 // WENO_P1, src/PDE/Limiter.cpp:29-153 (Jacobi: reads Uin, writes modes 1-3 of
@@ -2598,6 +2711,21 @@ void launch_superbee(int ndof, const DevMesh& m0, double* U, hipStream_t s, int 
   const int nb = count < 0 ? (int)nblk(m.nie, 256) - first : count;
   if (nb <= 0) return;
   QDG_DISPATCH_NDOF(ndof, (k_superbee<N><<<nb, 256, 0, s>>>(m, U)));
+}
+
+void launch_upd_superbee(const DevMesh& m, const double* dt, const double* U0, const double* R,
+                         double* Uout, hipStream_t s)
+{
+  if (m.nie == 0) return;
+  k_upd_superbee<4><<<nblk(m.nie, 256), 256, 0, s>>>(m, dt, U0, R, Uout);
+}
+
+void launch_halo_pack_upd(const double* U0, const double* R, const double* dt, const double* vol,
+                          const int* send_elem, int nsend, double* slab, hipStream_t s)
+{
+  if (nsend == 0) return;
+  const size_t n = (size_t)nsend * NCOMP * 4;
+  k_halo_pack_upd<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(U0, R, dt, vol, send_elem, nsend, slab);
 }
 
 void launch_weno(int ndof, const DevMesh& m, double cweight, const double* Uin, double* Uout,

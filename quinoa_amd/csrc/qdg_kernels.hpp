@@ -28,6 +28,11 @@ void launch_rhs_p1t_rk(const DevMesh& m, const Phys& ph, double t, const double*
                        int first = 0, int count = -1);
 void launch_superbee(int ndof, const DevMesh& m, double* U, hipStream_t s, int first = 0,
                      int count = -1);
+// stage-0 RK update fused with the Superbee limiter of stage 1 (DG-P1), and its halo pack
+void launch_upd_superbee(const DevMesh& m, const double* dt, const double* U0, const double* R,
+                         double* Uout, hipStream_t s);
+void launch_halo_pack_upd(const double* U0, const double* R, const double* dt, const double* vol,
+                          const int* send_elem, int nsend, double* slab, hipStream_t s);
 void launch_weno(int ndof, const DevMesh& m, double cweight, const double* Uin, double* Uout,
                  hipStream_t s);
 void launch_copy_planes(const double* src, double* dst, int nprop, int n, int stride,

@@ -159,6 +159,9 @@ class DGDriver:
         if self.rccl:                            # the same sequence, inside libqdg
             m.step_comm(self.comm.comm, t, tleft)
             return
+        if isinstance(self.comm, SerialComm) and not self.nbr_rank:
+            m.step(t, tleft, want_dt=False)      # single chunk: qdg_step, one call per time step
+            return
         for stage in range(3):
             if self.pref and stage == 0:
                 m.stage_pdg_eval()               # DG::next: eval_ndof
