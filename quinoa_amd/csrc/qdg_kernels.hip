@@ -1564,7 +1564,9 @@ __global__ __launch_bounds__(256) void k_superbee(DevMesh m, double* __restrict_
       const int nb = m.nbr[(size_t)lf * stride + e];
       if (nb < 0) continue;
       const int r = nb - tile_e0;
-      if ((unsigned)r < 256u) {            // in-tile neighbour: means from LDS
+      // in-tile neighbour: means from LDS (a ghost id may fall into the id range of a
+      // ragged last tile: ghosts always come from global memory)
+      if (nb < m.nie && (unsigned)r < 256u) {
 #pragma unroll
         for (int c = 0; c < NCOMP; ++c) {
           const double v = lds[(size_t)r * NPROP + c * NDOF];
@@ -1652,7 +1654,7 @@ __global__ __launch_bounds__(256) void k_upd_superbee(DevMesh m, const double* _
     const int nb = m.nbr[(size_t)lf * stride + e];
     if (nb < 0) continue;
     const int rr = nb - tile_e0;
-    if ((unsigned)rr < 256u) {
+    if (nb < m.nie && (unsigned)rr < 256u) {     // (a ghost id may alias the ragged last tile)
 #pragma unroll
       for (int c = 0; c < NCOMP; ++c) {
         const double v = lds[(size_t)rr * NPROP + c * NDOF];

@@ -12,7 +12,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-NX, NY, NZ = 12, 8, 8
+NX, NY, NZ = 12, 8, 7      # chunk sizes that are no multiples of 256 or 248 (ragged last tiles)
 KW = dict(flux="hllc", limiter="superbeep1", problem="sod_shocktube", gamma=1.4)
 BC = dict(bc_sym=[3, 4, 5, 6], bc_extrapolate=[1, 2])
 NSTEP = 4
@@ -54,15 +54,16 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("pref", [False, True])
-def test_two_ranks_on_one_gpu_equal_single_chunk(tmp_path, pref):
+@pytest.mark.parametrize("pref,parts", [(False, (2, 1, 1)), (True, (2, 1, 1)), (False, (2, 2, 1))])
+def test_two_ranks_on_one_gpu_equal_single_chunk(tmp_path, pref, parts):
     """pref: p-adaptive DG -- the tets' ndof travels with the halo rows and
     propagate_ndof crosses the chunk boundary; the ndof field must be identical."""
     import torch.multiprocessing as mp
     out1 = str(tmp_path / "single%d.npz")
     out2 = str(tmp_path / "rank%d.npz")
     mp.spawn(_run, args=(1, 0, (1, 1, 1), out1, pref), nprocs=1, join=True)
-    mp.spawn(_run, args=(2, _free_port(), (2, 1, 1), out2, pref), nprocs=2, join=True)
+    world = parts[0] * parts[1] * parts[2]       # <= 4 processes on the one GPU of the test box
+    mp.spawn(_run, args=(world, _free_port(), parts, out2, pref), nprocs=world, join=True)
     s = np.load(out1 % 0)
     ref = np.zeros((NX * NY * NZ * 6, 20))
     ref[s["gid"]] = s["U"]
@@ -71,7 +72,7 @@ def test_two_ranks_on_one_gpu_equal_single_chunk(tmp_path, pref):
     if pref:
         assert 0 < (nref == 1).sum() < nref.size      # both orders present
     n = 0
-    for r in range(2):
+    for r in range(world):
         d = np.load(out2 % r)
         assert np.array_equal(d["ndof"], nref[d["gid"]]), r
         assert abs(float(d["t"]) - float(s["t"])) <= 1e-12 * float(s["t"])

@@ -98,8 +98,10 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("parts", [(2, 1, 1)])
+@pytest.mark.parametrize("parts", [(2, 1, 1), (2, 2, 1), (2, 2, 2)])
 def test_two_rank_halo_run_equals_serial(tmp_path, parts):
+    """2, 4 and 8 ranks: (2,2,2) is the decomposition of the 8-GPU bench run -- three
+    face neighbours per rank, every pair's send list / receive range must match"""
     world = parts[0] * parts[1] * parts[2]
     out = str(tmp_path / "rank%d.npz")
     mp.spawn(_rank_main, args=(world, _free_port(), parts, out), nprocs=world, join=True)
