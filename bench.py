@@ -152,6 +152,22 @@ def main():
     drv = dg.DGDriver(ctx, mesh, ch["nbr_rank"], ch["send_lists"], ch["recv_counts"], comm)
     mesh.state_initialize(0.0)
 
+    # outside the timed region: total mass and energy before / after the run.  Between
+    # symmetry walls and (still undisturbed) extrapolation faces they are conserved, and a
+    # flux that does not match across a chunk boundary would show up here.
+    vol = chunk.geoElem[0:4 * chunk.nielem:4]
+
+    def totals():
+        Uh = mesh.state_download().reshape(-1, 20)[:chunk.nielem]
+        v = np.array([(Uh[:, 0] * vol).sum(), (Uh[:, 16] * vol).sum()])
+        if world > 1:
+            tv = torch.tensor(v, dtype=torch.float64, device="cuda")
+            torch.distributed.all_reduce(tv, op=torch.distributed.ReduceOp.SUM)
+            v = tv.cpu().numpy()
+        return v
+
+    tot0 = totals()
+
     def sync():
         ctx.synchronize()
         torch.cuda.synchronize()
@@ -172,6 +188,9 @@ def main():
     dt_last = drv.dt_taken()
     if not (dt_last > 0.0 and np.isfinite(dt_last)):
         raise SystemExit("invalid run: dt = %r" % dt_last)
+    drift = np.abs(totals() - tot0) / np.abs(tot0)
+    if not args.self_halo and not (drift.max() <= 1e-9):
+        raise SystemExit("invalid run: mass / energy drift %r (halo or flux mismatch)" % (drift,))
 
     ntet = chunk.nielem
     if world > 1:
@@ -211,6 +230,9 @@ def main():
                          "traffic": traffic, "avg_launch_ms": avg_ms, "launches": nl,
                          "algorithmic_bytes_per_launch": alg},
             "dt_last": dt_last,
+            "check": {"mass_drift": float(drift[0]), "energy_drift": float(drift[1]),
+                      "note": "relative change of total mass / total energy over the whole run "
+                              "(conserved in this set-up; run aborts above 1e-9)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
