@@ -82,10 +82,11 @@ def test_two_ranks_on_one_gpu_equal_single_chunk(tmp_path, pref, parts):
     assert n == ref.shape[0]
 
 
-def _self_halo_run(kind, out, pref=False):
-    """chunk 0 of a 2x1x1 cut whose neighbour is this rank itself"""
+def _self_halo_run(kind, out, pref=False, parts=(2, 1, 1)):
+    """chunk 0 of a cut whose neighbours are all this rank itself"""
     from quinoa_amd import capi, dg, dgmesh, meshgen
-    ch = meshgen.kuhn_box_chunk(NX, NY, NZ, parts=(2, 1, 1), rank=0)
+    ch = meshgen.kuhn_box_chunk(NX, NY, NZ, parts=parts, rank=0)
+    assert [len(s) for s in ch["send_lists"]] == list(ch["recv_counts"])   # segments line up
     ck = dgmesh.build_chunk(ch["coord"], ch["inpoel"], ch["nielem"], ch["sidesets"])
     ctx = capi.Context(4, cfl=0.3, device=0, pref=pref, tolref=0.1, **KW, **BC)
     mesh = dgmesh.upload(ctx, ck)
@@ -93,7 +94,7 @@ def _self_halo_run(kind, out, pref=False):
         os.environ["QDG_OVERLAP"] = "1"          # read once per process by libqdg
     comm = dg.SelfComm() if kind == "copy" else \
         dg.RcclComm(ctx, rank=0, size=1, unique_id=capi.Comm.unique_id())
-    drv = dg.DGDriver(ctx, mesh, [0], ch["send_lists"], ch["recv_counts"], comm)
+    drv = dg.DGDriver(ctx, mesh, [0] * len(ch["nbr_rank"]), ch["send_lists"], ch["recv_counts"], comm)
     mesh.state_initialize(0.0)
     t = 0.0
     for _ in range(NSTEP):
@@ -107,7 +108,8 @@ def _self_halo_run(kind, out, pref=False):
     ctx.close()
 
 
-def test_rccl_transport_self_halo(tmp_path):
+@pytest.mark.parametrize("parts", [(2, 1, 1), (2, 2, 1)])
+def test_rccl_transport_self_halo(tmp_path, parts):
     """libqdg's RCCL path (qdg_comm_*, qdg_step_comm: pack, grouped ncclSend/ncclRecv,
     unpack, ncclAllReduce(min) of dt) on the one GPU of the test box: the rank's
     neighbour is the rank itself, and the result must equal the same plan moved
@@ -118,7 +120,7 @@ def test_rccl_transport_self_halo(tmp_path):
     outs = {}
     for kind in ("copy", "rccl", "rccl_overlap"):
         outs[kind] = str(tmp_path / (kind + ".npz"))
-        mp.spawn(_self_halo_run_spawn, args=(kind, outs[kind]), nprocs=1, join=True)
+        mp.spawn(_self_halo_run_spawn, args=(kind, outs[kind], False, parts), nprocs=1, join=True)
     a = np.load(outs["copy"])
     assert int(a["nie"]) < a["U"].shape[0]                 # there are ghost rows
     assert np.isfinite(a["U"]).all()
@@ -130,8 +132,8 @@ def test_rccl_transport_self_halo(tmp_path):
         assert err <= 1e-12, (kind, err)
 
 
-def _self_halo_run_spawn(_, kind, out, pref=False):
-    _self_halo_run(kind, out, pref)
+def _self_halo_run_spawn(_, kind, out, pref=False, parts=(2, 1, 1)):
+    _self_halo_run(kind, out, pref, parts)
 
 
 def test_rccl_transport_self_halo_pdg(tmp_path):
