@@ -13,6 +13,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 NX, NY, NZ = 12, 8, 7      # chunk sizes that are no multiples of 256 or 248 (ragged last tiles)
+if os.environ.get("QDG_TEST_BOX"):          # larger boxes for manual runs
+    NX, NY, NZ = (int(v) for v in os.environ["QDG_TEST_BOX"].split(","))
 KW = dict(flux="hllc", limiter="superbeep1", problem="sod_shocktube", gamma=1.4)
 BC = dict(bc_sym=[3, 4, 5, 6], bc_extrapolate=[1, 2])
 NSTEP = 4
