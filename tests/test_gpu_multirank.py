@@ -95,7 +95,8 @@ def test_two_ranks_on_one_gpu_equal_single_chunk(tmp_path, pref, parts):
 def _self_halo_run(kind, out, pref=False, parts=(2, 1, 1)):
     """chunk 0 of a cut whose neighbours are all this rank itself"""
     from quinoa_amd import capi, dg, dgmesh, meshgen
-    ch = meshgen.kuhn_box_chunk(NX, NY, NZ, parts=parts, rank=0)
+    nz = NZ if parts[2] == 1 else 2 * 5             # an even count for a cut along z
+    ch = meshgen.kuhn_box_chunk(NX, NY, nz, parts=parts, rank=0)
     assert [len(s) for s in ch["send_lists"]] == list(ch["recv_counts"])   # segments line up
     ck = dgmesh.build_chunk(ch["coord"], ch["inpoel"], ch["nielem"], ch["sidesets"])
     ctx = capi.Context(4, cfl=0.3, device=0, pref=pref, tolref=0.1, **KW, **BC)
@@ -118,7 +119,7 @@ def _self_halo_run(kind, out, pref=False, parts=(2, 1, 1)):
     ctx.close()
 
 
-@pytest.mark.parametrize("parts", [(2, 1, 1), (2, 2, 1)])
+@pytest.mark.parametrize("parts", [(2, 1, 1), (2, 2, 1), (2, 2, 2)])
 def test_rccl_transport_self_halo(tmp_path, parts):
     """libqdg's RCCL path (qdg_comm_*, qdg_step_comm: pack, grouped ncclSend/ncclRecv,
     unpack, ncclAllReduce(min) of dt) on the one GPU of the test box: the rank's
