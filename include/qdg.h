@@ -194,13 +194,47 @@ int qdg_ndofel_set(qdg_mesh* mesh, const size_t* ndofel);
 int qdg_step(qdg_mesh* mesh, double t, double tleft, double* dt_taken);
 /* sum_e sum_g wt*u^2, wt*(u-s)^2, max|u-s| per component (15 doubles) */
 int qdg_diag(qdg_mesh* mesh, double t_new, double* out15);
-/* Problem::fieldOutput on the device, numerical fields from the cell means of the
- * resident state (CompFlow: density, x/y/z-velocity, specific_total_energy,
- * pressure -- SodShocktube.cpp:139-237 and siblings; Transport: the scalar):
- * out[f*nielem + e], e in the caller's element numbering, f < qdg_field_count */
+/* Problem::fieldOutput on the device (as dg::CompFlow::fieldOutput / dg::Transport::fieldOutput
+ * call it, DGCompFlow.hpp:447-462, DGTransport.hpp:248-279): EVERY field of the Problem's
+ * own list -- numerical, analytical and err(.) fields -- from the cell means of the
+ * resident state at time t (SodShocktube.cpp:139-258, VorticalFlow.cpp:131-254,
+ * TaylorGreen.cpp:108-240, NLEnergyGrowth.cpp:208-318, RayleighTaylor.cpp:194-314,
+ * UserDefined.cpp:87-169; the err(.) fields are x/V with V = 0 exactly as the reference
+ * writes them); with p-adaptive DG the per-element ndof follows as the last field
+ * (DG::writeFields, DG.cpp:1201-1204).  out[f*nielem + e], e in the caller's element
+ * numbering, f < qdg_field_count; names from qdg_field_name (= Problem::fieldNames). */
 int qdg_field_count(qdg_mesh* mesh, size_t* nfield);
 const char* qdg_field_name(qdg_mesh* mesh, size_t f);
-int qdg_field_output(qdg_mesh* mesh, double* out);
+int qdg_field_output(qdg_mesh* mesh, double t, double* out);
+/* the same without a mesh handle -- the stateless DGPDE members:
+ *   qdg_ctx_field_count/name   DGPDE::fieldNames   (src/PDE/DGPDE.hpp:120-121)
+ *   qdg_field_output_from      DGPDE::fieldOutput  (DGPDE.hpp:126-131): nunk rows of U and
+ *                              geoElem in the caller's numbering, out[f*nunk + e] (no ndof field)
+ *   qdg_avg_elem_to_node       DGPDE::avgElemToNode (DGPDE.hpp:134-139 ->
+ *                              dg::CompFlow::avgElemToNode, DGCompFlow.hpp:465-552):
+ *                              out[f*nnode + n], f = density, x/y/z velocity, specific total
+ *                              energy, pressure averaged over the elements around node n
+ *   qdg_initialize_from        DGPDE::initialize (DGPDE.hpp:80-86) before the chare's mesh is
+ *                              uploaded -- DG::setup calls it first (DG.cpp:995-999) and its
+ *                              arguments carry no FaceData: needs inpoel, coord and L only
+ *                              (L may be NULL: volumes are then computed from coord);
+ *                              writes rows [0,nielem) of U_aos */
+int qdg_ctx_field_count(qdg_ctx* ctx, size_t* nfield);
+const char* qdg_ctx_field_name(qdg_ctx* ctx, size_t f);
+int qdg_field_output_from(qdg_ctx* ctx, double t, size_t nunk, const double* geoElem,
+                          const double* U_aos, double* out);
+int qdg_avg_elem_to_node(qdg_ctx* ctx, size_t nelem, size_t nnode, const size_t* inpoel,
+                         const double* U_aos, double* out);
+int qdg_initialize_from(qdg_ctx* ctx, size_t nielem, size_t nnode, const size_t* inpoel,
+                        const double* x, const double* y, const double* z,
+                        const double* L_aos, double t, double* U_aos);
+/* WENO_P1 / Superbee_P1 with the reference's free-function inputs (Limiter.cpp:29-44,
+ * 155-175: esuel, per-element ndofel, the solution) -- DG::lim runs before the first rhs/dt
+ * of a run (DG.cpp:1251-1260), i.e. possibly before the chare's mesh is uploaded.
+ * esuel has 4*nielem entries, U_aos nunk rows (in place); ndofel (nunk entries) may be NULL
+ * unless the context is p-adaptive */
+int qdg_limit_from(qdg_ctx* ctx, size_t nielem, size_t nunk, const int* esuel,
+                   const size_t* ndofel, double* U_aos);
 /* device pointer/stride of the resident SoA state, for zero-copy plumbing */
 int qdg_state_device_ptr(qdg_mesh* mesh, void** dptr, size_t* stride);
 

@@ -234,20 +234,21 @@ class DeviceDG {
   }
 
  public:
-  //! DGPDE::initialize (src/PDE/DGPDE.hpp:80-86)
+  //! DGPDE::initialize (src/PDE/DGPDE.hpp:80-86).  DG::setup calls it before any rhs/dt
+  //! (src/Inciter/DG.cpp:995-999) and its arguments carry no FaceData, so it does not need
+  //! the chare's mesh handle: the L2 projection of the initial condition is evaluated on
+  //! the device from inpoel, coord and L alone (Initialize.cpp:29-112 divides by L).
   void initialize(const Fields& L, const std::vector<std::size_t>& inpoel, const Coords& coord,
                   Fields& unk, real t, const std::size_t nielem) const
   {
-    (void)L; (void)coord; (void)nielem;
-    check(qdg_initialize(handle(inpoel), t, unk.data().data()));
+    check(qdg_initialize_from(m_state->ctx, nielem, coord[0].size(), inpoel.data(), coord[0].data(),
+                              coord[1].data(), coord[2].data(), L.data().data(), t, unk.data().data()));
   }
 
   //! DGPDE::lhs (src/PDE/DGPDE.hpp:89-90).  The mass matrix depends on geoElem
   //! only; before the chare's mesh is registered it is evaluated on the host.
   void lhs(const Fields& geoElem, Fields& l) const
   {
-    static const real f[10] = { 1.0, 1.0 / 10.0, 3.0 / 10.0, 3.0 / 5.0, 1.0 / 35.0, 1.0 / 21.0,
-                                1.0 / 14.0, 1.0 / 7.0, 3.0 / 14.0, 3.0 / 7.0 };
     const std::size_t nd = m_deck.ndof, ncomp = PDE == QDG_PDE_TRANSPORT ? 1 : 5;
     for (std::size_t e = 0; e < geoElem.nunk(); ++e)
       for (std::size_t c = 0; c < ncomp; ++c) {
@@ -259,7 +260,6 @@ class DeviceDG {
           l(e, c*nd+7, 0) = vol / 7.0;  l(e, c*nd+8, 0) = vol * 3.0 / 14.0; l(e, c*nd+9, 0) = vol * 3.0 / 7.0;
         }
       }
-    (void)f;
   }
 
   //! Register (upload) the mesh of one DG chare; also done lazily by rhs()/dt().
@@ -267,7 +267,17 @@ class DeviceDG {
               const std::vector<std::size_t>& inpoel, const Coords& coord) const
   {
     std::lock_guard<std::mutex> lock(m_state->mtx);
-    if (m_state->meshes.count(inpoel.data())) return;
+    {
+      // same storage, same sizes: the chare's mesh is already on the device.  A vector that was
+      // re-allocated at the same address with other sizes (AMR, migration) is re-uploaded.
+      auto it = m_state->meshes.find(inpoel.data());
+      if (it != m_state->meshes.end()) {
+        if (it->second.nunk == inpoel.size() / 4 && it->second.nnode == coord[0].size() &&
+            it->second.nfac == fd.Esuf().size() / 2) return;
+        qdg_mesh_destroy(it->second.h);
+        m_state->meshes.erase(it);
+      }
+    }
     std::vector<int32_t> ids; std::vector<std::size_t> off{0}, faces;
     for (const auto& s : fd.Bface()) {
       ids.push_back(s.first);
@@ -283,7 +293,7 @@ class DeviceDG {
                           coord[1].data(), coord[2].data(), fd.Nbfac(), fd.Esuf().size() / 2,
                           fd.Esuf().data(), fd.Esuel().data(), fd.Inpofa().data(),
                           geoFace.data().data(), geoElem.data().data(), &bf, &m));
-    m_state->meshes[inpoel.data()] = m;
+    m_state->meshes[inpoel.data()] = Cached{ m, nunk, coord[0].size(), fd.Esuf().size() / 2 };
   }
 
   //! Forget a chare's mesh (DG dtor, before resizePostAMR / migration)
@@ -291,7 +301,7 @@ class DeviceDG {
   {
     std::lock_guard<std::mutex> lock(m_state->mtx);
     auto it = m_state->meshes.find(inpoel.data());
-    if (it != m_state->meshes.end()) { qdg_mesh_destroy(it->second); m_state->meshes.erase(it); }
+    if (it != m_state->meshes.end()) { qdg_mesh_destroy(it->second.h); m_state->meshes.erase(it); }
   }
 
   //! DGPDE::rhs (src/PDE/DGPDE.hpp:93-104, dg::CompFlow::rhs DGCompFlow.hpp:130-195)
@@ -316,7 +326,16 @@ class DeviceDG {
     return v;
   }
 
-  //! WENO_P1 / Superbee_P1 as DG::lim calls them (src/Inciter/DG.cpp:1251-1260)
+  //! WENO_P1 / Superbee_P1 with the inputs DG::lim hands the reference's free functions
+  //! (src/Inciter/DG.cpp:1251-1260; Limiter.cpp:29-44, 155-175): works before the chare's
+  //! mesh is on the device (the first DG::lim of a run precedes the first rhs/dt)
+  void limit(const std::vector<int>& esuel, const std::vector<std::size_t>& /*inpoel*/,
+             const std::vector<std::size_t>& ndofel, const Coords& /*coord*/, Fields& U) const
+  {
+    check(qdg_limit_from(m_state->ctx, esuel.size() / 4, U.nunk(), esuel.data(),
+                         ndofel.empty() ? nullptr : ndofel.data(), U.data().data()));
+  }
+  //! the same through an attached mesh handle
   void limit(const std::vector<std::size_t>& inpoel, Fields& U) const
   { check(qdg_limit(handle(inpoel), U.data().data())); }
   //! Superbee_P1 with the per-element ndof of p-adaptive DG (Limiter.cpp:155-180)
@@ -334,12 +353,16 @@ class DeviceDG {
     return s;
   }
 
-  //! DGPDE::fieldNames (numerical fields; SodShocktube.cpp:139-158 and siblings)
+  //! DGPDE::fieldNames (src/PDE/DGPDE.hpp:120-121): the Problem's own list
+  //! (Problem::fieldNames, e.g. TaylorGreen.cpp:108-133: numerical, analytical and err fields)
   std::vector<std::string> fieldNames() const
   {
-    if (PDE == QDG_PDE_TRANSPORT) return { "c0_numerical" };
-    return { "density_numerical", "x-velocity_numerical", "y-velocity_numerical", "z-velocity_numerical",
-             "specific_total_energy_numerical", "pressure_numerical" };
+    std::size_t n = 0;
+    check(qdg_ctx_field_count(m_state->ctx, &n));
+    if (m_deck.pref && PDE == QDG_PDE_COMPFLOW) --n;   // "ndof" is named by dg::Transport only (DGTransport.hpp:225-226)
+    std::vector<std::string> names;
+    for (std::size_t f = 0; f < n; ++f) names.emplace_back(qdg_ctx_field_name(m_state->ctx, f));
+    return names;
   }
 
   //! DGPDE::names: labels of the integral variables in the diagnostics file
@@ -349,23 +372,34 @@ class DeviceDG {
     return { "r", "ru", "rv", "rw", "re" };
   }
 
-  //! DGPDE::fieldOutput (src/PDE/DGPDE.hpp:126-131): numerical fields from the cell means of U
-  //! (host-side like the reference's, SodShocktube.cpp:160-237; no device data involved)
-  std::vector<std::vector<real>> fieldOutput(real /*t*/, const Fields& /*geoElem*/, const Fields& U) const
+  //! DGPDE::fieldOutput (src/PDE/DGPDE.hpp:126-131): Problem::fieldOutput evaluated on the
+  //! device from the cell means of U and the centroids/volumes of geoElem, every field of
+  //! fieldNames() (DGCompFlow.hpp:447-462, DGTransport.hpp:248-279)
+  std::vector<std::vector<real>> fieldOutput(real t, const Fields& geoElem, Fields& U) const
   {
-    const std::size_t n = U.nunk(), nd = m_deck.ndof;
-    if (PDE == QDG_PDE_TRANSPORT) {
-      std::vector<std::vector<real>> out(1, std::vector<real>(n));
-      for (std::size_t e = 0; e < n; ++e) out[0][e] = U(e, 0, 0);
-      return out;
-    }
-    std::vector<std::vector<real>> out(6, std::vector<real>(n));
-    for (std::size_t e = 0; e < n; ++e) {
-      const real r = U(e, 0, 0), u = U(e, nd, 0) / r, v = U(e, 2 * nd, 0) / r, w = U(e, 3 * nd, 0) / r,
-                 re = U(e, 4 * nd, 0);
-      out[0][e] = r; out[1][e] = u; out[2][e] = v; out[3][e] = w; out[4][e] = re / r;
-      out[5][e] = (re - 0.5 * r * (u * u + v * v + w * w) - m_deck.pstiff) * (m_deck.gamma - 1.0) - m_deck.pstiff;
-    }
+    const std::size_t n = U.nunk();
+    std::size_t nf = 0;
+    check(qdg_ctx_field_count(m_state->ctx, &nf));
+    if (m_deck.pref) --nf;                      // the ndof column is added by DG::writeFields
+    std::vector<real> flat(nf * n);
+    check(qdg_field_output_from(m_state->ctx, t, n, geoElem.data().data(), U.data().data(), flat.data()));
+    std::vector<std::vector<real>> out(nf);
+    for (std::size_t f = 0; f < nf; ++f) out[f].assign(flat.begin() + f * n, flat.begin() + (f + 1) * n);
+    return out;
+  }
+
+  //! DGPDE::avgElemToNode (src/PDE/DGPDE.hpp:134-139; dg::CompFlow::avgElemToNode,
+  //! DGCompFlow.hpp:465-552; dg::Transport returns no nodal fields, DGTransport.hpp:231-239)
+  std::vector<std::vector<real>> avgElemToNode(const std::vector<std::size_t>& inpoel, const Coords& coord,
+                                               const Fields& /*geoElem*/, const Fields& U) const
+  {
+    std::vector<std::vector<real>> out;
+    if (PDE == QDG_PDE_TRANSPORT) return out;
+    const std::size_t nn = coord[0].size();
+    std::vector<real> flat(6 * nn);
+    check(qdg_avg_elem_to_node(m_state->ctx, inpoel.size() / 4, nn, inpoel.data(), U.data().data(), flat.data()));
+    out.resize(6);
+    for (std::size_t f = 0; f < 6; ++f) out[f].assign(flat.begin() + f * nn, flat.begin() + (f + 1) * nn);
     return out;
   }
 
@@ -378,17 +412,18 @@ class DeviceDG {
     std::lock_guard<std::mutex> lock(m_state->mtx);
     auto it = m_state->meshes.find(inpoel.data());
     if (it == m_state->meshes.end()) throw Exception("qdg: mesh not attached");
-    return it->second;
+    return it->second.h;
   }
 
  private:
+  struct Cached { qdg_mesh* h; std::size_t nunk, nnode, nfac; };
   struct State {
     qdg_ctx* ctx = nullptr;
     std::mutex mtx;
-    std::unordered_map<const std::size_t*, qdg_mesh*> meshes;
+    std::unordered_map<const std::size_t*, Cached> meshes;
     ~State()
     {
-      for (auto& m : meshes) qdg_mesh_destroy(m.second);
+      for (auto& m : meshes) qdg_mesh_destroy(m.second.h);
       if (ctx) qdg_ctx_destroy(ctx);
     }
   };

@@ -1857,3 +1857,154 @@ double orc_tr_diag_l2sum(int64_t ndof, const double* geoElem, const double* U, i
     }
   return sum;
 }
+
+/* =====================================================================
+ * Output side of the DGPDE interface: Problem::fieldOutput as DG::writeFields
+ * calls it, and dg::CompFlow::avgElemToNode.
+ * ===================================================================== */
+
+/* Number of element fields Problem::fieldNames returns:
+ * SodShocktube.cpp:139-158, SedovBlastwave.cpp:133-157 (6); VorticalFlow.cpp:131-154 (12);
+ * TaylorGreen.cpp:108-133 (15); NLEnergyGrowth.cpp:208-231 (14); RayleighTaylor.cpp:194-221 (18);
+ * UserDefined.cpp:87-103 (7) */
+int64_t orc_field_count(const orc_cfg* k)
+{
+  switch (k->problem) {
+    case ORC_PROB_VORTICAL: return 12;
+    case ORC_PROB_TAYLOR_GREEN: return 15;
+    case ORC_PROB_NLEG: return 14;
+    case ORC_PROB_RAYLEIGH_TAYLOR: return 18;
+    case ORC_PROB_USER: return 7;
+    default: return 6;
+  }
+}
+
+/* Problem::fieldOutput(system, ncomp, offset, t, V, vol, coord, U) with the arguments
+ * dg::CompFlow::fieldOutput passes (DGCompFlow.hpp:447-462): V = 0.0, vol = geoElem(:,0),
+ * coord = the element centroids geoElem(:,1..3); U holds nunk rows, cell means are U(e, c*rdof).
+ * out[f*nunk + e].  With V = 0 every err(.) field is x/0 = +inf (NaN where the error is
+ * exactly zero), which is what the reference's golden files hold.
+ * VorticalFlow.cpp:156-254, TaylorGreen.cpp:135-240, NLEnergyGrowth.cpp:233-318,
+ * RayleighTaylor.cpp:223-314 (reads U.extract(c, offset): component c, not c*rdof -- kept),
+ * UserDefined.cpp:105-169, SodShocktube.cpp:160-258 (Sedov, RotatedSod alike) */
+void orc_field_output(const orc_cfg* k, double t, int64_t nunk, const double* geoElem,
+                      const double* U, double* out)
+{
+  const int64_t rd = k->rdof, np = NCOMP * rd;
+  const double V = 0.0;
+  int64_t i;
+#define OUT(f) out[(int64_t)(f) * nunk + i]
+  for (i = 0; i < nunk; ++i) {
+    const double* Ue = U + i * np;
+    const double vol = geoElem[4 * i], x = geoElem[4 * i + 1], y = geoElem[4 * i + 2],
+                 z = geoElem[4 * i + 3];
+    const double r = Ue[0], ru = Ue[rd], rv = Ue[2 * rd], rw = Ue[3 * rd], re = Ue[4 * rd];
+    if (k->problem == ORC_PROB_VORTICAL) {
+      const double a = k->alpha, b = k->beta, p0 = k->p0, g = k->gamma;
+      double u, v, w, E;
+      OUT(0) = r; OUT(1) = 1.0;
+      OUT(2) = ru / r; u = a * x - b * y; OUT(3) = u;
+      OUT(4) = rv / r; v = b * x + a * y; OUT(5) = v;
+      OUT(6) = rw / r; w = -2.0 * a * z; OUT(7) = w;
+      OUT(8) = re / r;
+      E = 0.5 * (u * u + v * v + w * w) + (p0 - 2.0 * a * a * z * z) / (g - 1.0);
+      OUT(9) = E;
+      /* the velocity vectors were overwritten by the analytic ones before this call */
+      OUT(10) = eos_pressure(k, r, u, v, w, re);
+      OUT(11) = p0 - 2.0 * a * a * z * z;
+    } else if (k->problem == ORC_PROB_TAYLOR_GREEN) {
+      const double u = ru / r, v = rv / r, w = rw / r, E = re / r;
+      const double ua = sin(M_PI * x) * cos(M_PI * y), va = -cos(M_PI * x) * sin(M_PI * y), wa = 0.0;
+      const double Pa = 10.0 + r / 4.0 * (cos(2.0 * M_PI * x) + cos(2.0 * M_PI * y));
+      const double Ea = eos_totalenergy(k, r, ua / r, va / r, wa / r, Pa / r);
+      OUT(0) = r; OUT(1) = 1.0;
+      OUT(2) = u; OUT(3) = ua; OUT(4) = pow(ua - u, 2.0) * vol / V;
+      OUT(5) = v; OUT(6) = va; OUT(7) = pow(va - v, 2.0) * vol / V;
+      OUT(8) = w; OUT(9) = wa;
+      OUT(10) = E; OUT(11) = Ea; OUT(12) = pow(Ea - E, 2.0) * vol / V;
+      OUT(13) = eos_pressure(k, r, u, v, w, r * E);
+      OUT(14) = Pa;
+    } else if (k->problem == ORC_PROB_NLEG || k->problem == ORC_PROB_RAYLEIGH_TAYLOR) {
+      const int rt = k->problem == ORC_PROB_RAYLEIGH_TAYLOR;
+      /* RayleighTaylor extracts components 0..4 of the row, not c*rdof */
+      const double r_ = rt ? Ue[0] : r, u = (rt ? Ue[1] : ru) / r_, v = (rt ? Ue[2] : rv) / r_,
+                   w = (rt ? Ue[3] : rw) / r_, E = (rt ? Ue[4] : re) / r_;
+      const double p = eos_pressure(k, r_, u, v, w, r_ * E);
+      double s[NCOMP], ar, au, av, aw, aE, ap;
+      prob_solution(k, x, y, z, t, s);
+      ar = s[0]; au = s[1] / s[0]; av = s[2] / s[0]; aw = s[3] / s[0]; aE = s[4] / s[0];
+      ap = eos_pressure(k, ar, au, av, aw, ar * aE);
+      OUT(0) = r_; OUT(1) = u; OUT(2) = v; OUT(3) = w; OUT(4) = E; OUT(5) = p;
+      OUT(6) = ar; OUT(7) = au; OUT(8) = av; OUT(9) = aw; OUT(10) = aE; OUT(11) = ap;
+      OUT(12) = pow(r_ - s[0], 2.0) * vol / V;
+      OUT(13) = pow(E - s[4] / s[0], 2.0) * vol / V;
+      if (rt) {
+        const double ap0 = eos_pressure(k, s[0], s[1] / s[0], s[2] / s[0], s[3] / s[0], s[4]);
+        OUT(14) = pow(ap0 - ap, 2.0) * vol / V;
+        OUT(15) = pow(u - s[1] / s[0], 2.0) * vol / V;
+        OUT(16) = pow(v - s[2] / s[0], 2.0) * vol / V;
+        OUT(17) = pow(w - s[3] / s[0], 2.0) * vol / V;
+      }
+    } else {
+      const double u = ru / r, v = rv / r, w = rw / r, E = re / r;
+      OUT(0) = r; OUT(1) = u; OUT(2) = v; OUT(3) = w; OUT(4) = E;
+      OUT(5) = eos_pressure(k, r, u, v, w, r * E);
+      if (k->problem == ORC_PROB_USER)
+        OUT(6) = k->cv * (E - (u * u + v * v + w * w) / 2.0);
+    }
+  }
+#undef OUT
+}
+
+/* dg::CompFlow::avgElemToNode, src/PDE/CompFlow/DGCompFlow.hpp:465-552: the state of every
+ * element (ghosts included: the loop runs over inpoel.size()/4) evaluated at its four nodes
+ * with the P1 part of the basis (also for rdof = 10, :517-526), primitive quantities summed
+ * per node and divided by the number of elements around the node.  out[f*npoin + n],
+ * f = density, u, v, w, specific total energy, pressure. */
+void orc_avg_elem_to_node(const orc_cfg* k, const int64_t* inpoel, int64_t nelem, int64_t npoin,
+                          const double* x, const double* y, const double* z, const double* U,
+                          double* out)
+{
+  const int64_t rd = k->rdof, np = NCOMP * rd;
+  double* count = (double*)calloc((size_t)npoin, sizeof(double));
+  int64_t e, n; int i, c;
+  memset(out, 0, (size_t)(6 * npoin) * sizeof(double));
+  for (e = 0; e < nelem; ++e) {
+    double p[4][3], detT;
+    elem_coords(inpoel, e, x, y, z, p);
+    detT = jacobian(p[0], p[1], p[2], p[3]);
+    for (i = 0; i < 4; ++i) {
+      const double xi = jacobian(p[0], p[i], p[2], p[3]) / detT;
+      const double eta = jacobian(p[0], p[1], p[i], p[3]) / detT;
+      const double zeta = jacobian(p[0], p[1], p[2], p[i]) / detT;
+      const double B2 = 2.0 * xi + eta + zeta - 1.0, B3 = 3.0 * eta + zeta - 1.0, B4 = 4.0 * zeta - 1.0;
+      double ugp[NCOMP], u, v, w, pr;
+      for (c = 0; c < NCOMP; ++c) {
+        const double* Uc = U + e * np + c * rd;
+        ugp[c] = (rd == 1) ? Uc[0] : Uc[0] + Uc[1] * B2 + Uc[2] * B3 + Uc[3] * B4;
+      }
+      u = ugp[1] / ugp[0]; v = ugp[2] / ugp[0]; w = ugp[3] / ugp[0];
+      pr = eos_pressure(k, ugp[0], u, v, w, ugp[4]);
+      n = inpoel[4 * e + i];
+      out[n] += ugp[0]; out[npoin + n] += u; out[2 * npoin + n] += v; out[3 * npoin + n] += w;
+      out[4 * npoin + n] += ugp[4] / ugp[0]; out[5 * npoin + n] += pr;
+      count[n] += 1.0;
+    }
+  }
+  for (n = 0; n < npoin; ++n)
+    for (c = 0; c < 6; ++c) out[c * npoin + n] /= count[n];
+  free(count);
+}
+
+/* dg::Transport::fieldOutput, src/PDE/Transport/DGTransport.hpp:248-279 (one scalar):
+ * numerical mean, Problem::solution at the centroid, (analytic - numerical)^2 * vol */
+void orc_tr_field_output(int problem, int64_t ndof, double t, int64_t nunk, const double* geoElem,
+                         const double* U, double* out)
+{
+  int64_t e;
+  for (e = 0; e < nunk; ++e) {
+    const double u = U[e * ndof];
+    const double s = tr_solution(problem, geoElem[4 * e + 1], geoElem[4 * e + 2], geoElem[4 * e + 3], t);
+    out[e] = u; out[nunk + e] = s; out[2 * nunk + e] = pow(s - u, 2.0) * geoElem[4 * e];
+  }
+}

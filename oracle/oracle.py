@@ -69,6 +69,7 @@ def lib():
         _LIB.orc_step_pdg.restype = C.c_double
         _LIB.orc_jacobian.restype = C.c_double
         _LIB.orc_gen_nipfac.restype = C.c_int64
+        _LIB.orc_field_count.restype = C.c_int64
     return _LIB
 
 
@@ -360,6 +361,51 @@ class Oracle:
         p = (re - 0.5 * r * (u * u + v * v + w * w) - pc) * (g - 1.0) - pc
         return np.stack([r, u, v, w, re / r, p])
 
+    FIELD_NAMES = {
+        3: ["density_numerical", "density_analytical", "x-velocity_numerical", "x-velocity_analytical",
+            "y-velocity_numerical", "y-velocity_analytical", "z-velocity_numerical",
+            "z-velocity_analytical", "specific_total_energy_numerical",
+            "specific_total_energy_analytical", "pressure_numerical", "pressure_analytical"],
+        4: ["density_numerical", "density_analytical", "x-velocity_numerical", "x-velocity_analytical",
+            "err(u)", "y-velocity_numerical", "y-velocity_analytical", "err(v)", "z-velocity_numerical",
+            "z-velocity_analytical", "specific_total_energy_numerical",
+            "specific_total_energy_analytical", "err(E)", "pressure_numerical", "pressure_analytical"],
+        7: ["density_numerical", "x-velocity_numerical", "y-velocity_numerical", "z-velocity_numerical",
+            "specific_total_energy_numerical", "pressure_numerical", "density_analytical",
+            "x-velocity_analytical", "y-velocity_analytical", "z-velocity_analytical",
+            "specific_total_energy_analytical", "pressure_analytical", "err(rho)", "err(e)"],
+        0: ["density", "x-velocity", "y-velocity", "z-velocity", "specific total energy", "pressure",
+            "temperature"],
+    }
+    FIELD_NAMES[10] = FIELD_NAMES[7] + ["err(p)", "err(u)", "err(v)", "err(w)"]
+
+    def field_names(self):
+        """Problem::fieldNames (src/PDE/CompFlow/Problem/*.cpp)"""
+        six = ["density_numerical", "x-velocity_numerical", "y-velocity_numerical",
+               "z-velocity_numerical", "specific_total_energy_numerical", "pressure_numerical"]
+        return list(self.FIELD_NAMES.get(int(self.cfg.problem), six))
+
+    def field_output_all(self, U, t):
+        """Problem::fieldOutput as dg::CompFlow::fieldOutput calls it (V = 0): every field of
+        the Problem's list, [nfield, nelem]"""
+        nf = int(self.L_.orc_field_count(C.byref(self.cfg)))
+        out = np.zeros((nf, self.m.nelem))
+        Uc = np.ascontiguousarray(U, dtype=np.float64)
+        with np.errstate(all="ignore"):
+            self.L_.orc_field_output(C.byref(self.cfg), C.c_double(t), C.c_int64(self.m.nelem),
+                                     _p(self.m.geoElem, c_f64p), _p(Uc, c_f64p), _p(out, c_f64p))
+        return out
+
+    def avg_elem_to_node(self, U):
+        """dg::CompFlow::avgElemToNode (DGCompFlow.hpp:465-552): [6, npoin]"""
+        out = np.zeros((6, self.m.npoin))
+        Uc = np.ascontiguousarray(U, dtype=np.float64)
+        inp = np.ascontiguousarray(self.m.inpoel.reshape(-1))
+        self.L_.orc_avg_elem_to_node(C.byref(self.cfg), _p(inp, c_i64p), C.c_int64(self.m.nelem),
+                                     C.c_int64(self.m.npoin), _p(self.m.x, c_f64p), _p(self.m.y, c_f64p),
+                                     _p(self.m.z, c_f64p), _p(Uc, c_f64p), _p(out, c_f64p))
+        return out
+
 
 def run_case(case, fix, nstep=None, on_step=None):
     """Run one tests/golden case with the oracle.  Returns dict with the diag
@@ -377,6 +423,7 @@ def run_case(case, fix, nstep=None, on_step=None):
     t, it = 0.0, 0
     nstep = nstep or case["nstep"]
     diag_rows, fields, times = [], [orc.field_output(U)], [0.0]
+    fields_all = [orc.field_output_all(U, 0.0)]
     ndofs = [orc.ndofel.copy()] if orc.pref else []
     work = (np.zeros_like(U), np.zeros(mesh.nelem * orc.npropr))
     while it < nstep:
@@ -388,13 +435,14 @@ def run_case(case, fix, nstep=None, on_step=None):
         it += 1
         if it % case["plot_interval"] == 0 or it == nstep:
             fields.append(orc.field_output(U))
+            fields_all.append(orc.field_output_all(U, t))
             times.append(t)
             if orc.pref:
                 ndofs.append(orc.ndofel.copy())
         if on_step:
             on_step(it, t, dt, U)
     return {"mesh": mesh, "oracle": orc, "U": U, "L": Lm, "t": t,
-            "diag": np.array(diag_rows), "fields": np.array(fields),
+            "diag": np.array(diag_rows), "fields": np.array(fields), "fields_all": np.array(fields_all),
             "times": np.array(times), "ndof": np.array(ndofs)}
 
 

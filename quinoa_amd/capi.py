@@ -199,6 +199,50 @@ class Context:
                                 z.ctypes.data_as(c_f64p), C.c_double(t), out.ctypes.data_as(c_f64p)))
         return out
 
+    def field_names(self):
+        """DGPDE::fieldNames (+ 'ndof' with p-adaptive DG)"""
+        n = C.c_size_t()
+        _chk(lib().qdg_ctx_field_count(self.h, C.byref(n)))
+        lib().qdg_ctx_field_name.restype = C.c_char_p
+        lib().qdg_ctx_field_name.argtypes = [C.c_void_p, C.c_size_t]
+        return [lib().qdg_ctx_field_name(self.h, i).decode() for i in range(n.value)]
+
+    def field_output_from(self, t, geoElem, U):
+        """stateless DGPDE::fieldOutput: [nfield, nunk]"""
+        ge, pge = _f64(geoElem)
+        U, pU = _f64(U)
+        nunk = len(ge) // 4
+        nf = len(self.field_names()) - (1 if self.cfg.pref else 0)
+        out = np.zeros((nf, nunk))
+        _chk(lib().qdg_field_output_from(self.h, C.c_double(t), C.c_size_t(nunk), pge, pU,
+                                         out.ctypes.data_as(c_f64p)))
+        return out
+
+    def avg_elem_to_node(self, inpoel, nnode, U):
+        """stateless DGPDE::avgElemToNode: [6, nnode]"""
+        inp, pinp = _sz(np.asarray(inpoel).reshape(-1))
+        U, pU = _f64(U)
+        out = np.zeros((6, int(nnode)))
+        _chk(lib().qdg_avg_elem_to_node(self.h, C.c_size_t(len(inp) // 4), C.c_size_t(int(nnode)), pinp, pU,
+                                        out.ctypes.data_as(c_f64p)))
+        return out
+
+    def initialize_from(self, inpoel, coord, t=0.0, L=None, nielem=None):
+        """DGPDE::initialize without an uploaded mesh (inpoel, coord, L only)"""
+        inp = np.asarray(inpoel).reshape(-1, 4)
+        nie = inp.shape[0] if nielem is None else int(nielem)
+        inp, pinp = _sz(inp.reshape(-1))
+        coord = np.asarray(coord, dtype=np.float64)
+        x, px = _f64(coord[:, 0]); y, py = _f64(coord[:, 1]); z, pz = _f64(coord[:, 2])
+        U = np.zeros((len(inp) // 4) * self.nprop)
+        if L is not None:
+            L, pL = _f64(L)
+        else:
+            pL = None
+        _chk(lib().qdg_initialize_from(self.h, C.c_size_t(nie), C.c_size_t(coord.shape[0]), pinp, px, py, pz,
+                                       pL, C.c_double(t), U.ctypes.data_as(c_f64p)))
+        return U
+
     def set_stream(self, stream_ptr):
         _chk(lib().qdg_ctx_set_stream(self.h, C.c_void_p(stream_ptr)))
 
@@ -289,12 +333,13 @@ class Mesh:
     def state_initialize(self, t=0.0):
         _chk(lib().qdg_state_initialize(self.h, C.c_double(t)))
 
-    def field_output(self):
-        """numerical output fields [nfield, nielem] and their names"""
+    def field_output(self, t=0.0):
+        """Problem::fieldOutput of the resident state at time t: every field of the
+        Problem's list [nfield, nielem] (+ ndof with p-adaptive DG) and the names"""
         n = C.c_size_t()
         _chk(lib().qdg_field_count(self.h, C.byref(n)))
         out = np.zeros((n.value, self.nielem))
-        _chk(lib().qdg_field_output(self.h, out.ctypes.data_as(c_f64p)))
+        _chk(lib().qdg_field_output(self.h, C.c_double(t), out.ctypes.data_as(c_f64p)))
         lib().qdg_field_name.restype = C.c_char_p
         lib().qdg_field_name.argtypes = [C.c_void_p, C.c_size_t]
         return out, [lib().qdg_field_name(self.h, i).decode() for i in range(n.value)]

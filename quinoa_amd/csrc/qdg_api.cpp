@@ -236,6 +236,7 @@ extern "C" int qdg_ctx_create(const qdg_config* cfg, qdg_ctx** out)
   c->cfg.bc_type = c->bc_type.data();
   c->device = cfg->device;
   c->ph.gamma = cfg->gamma; c->ph.pstiff = cfg->pstiff; c->ph.cweight = cfg->cweight;
+  c->ph.cv = cfg->cv;
   c->ph.alpha = cfg->alpha; c->ph.beta = cfg->beta; c->ph.p0 = cfg->p0;
   c->ph.betax = cfg->betax; c->ph.betay = cfg->betay; c->ph.betaz = cfg->betaz;
   c->ph.r0 = cfg->r0; c->ph.ce = cfg->ce; c->ph.kappa = cfg->kappa;
@@ -852,6 +853,58 @@ extern "C" int qdg_limit(qdg_mesh* mesh, double* U_aos)
   QDG_CATCH
 }
 
+// WENO_P1 / Superbee_P1 as free functions of (esuel, U) -- what DG::lim calls before the
+// first rhs/dt of a run (src/Inciter/DG.cpp:1251-1260; Limiter.cpp:29-316 read only esuel,
+// ndofel and the solution): no mesh handle needed
+extern "C" int qdg_limit_from(qdg_ctx* ctx, size_t nielem, size_t nunk, const int* esuel,
+                              const size_t* ndofel, double* U_aos)
+{
+  QDG_TRY
+  if (!ctx || !esuel || !U_aos) return fail("qdg_limit_from: null argument");
+  if (nielem == 0 || nunk < nielem) return fail("qdg_limit_from: need 0 < nielem <= nunk");
+  if (nunk > (size_t)(INT32_MAX - 64) / 64) return fail("qdg_limit_from: chunk too large for one call");
+  if (ctx->cfg.ndof == 1 || ctx->cfg.limiter == QDG_LIMITER_NONE) return 0;    // DG.cpp:1251: rdof > 1 only
+  if (ctx->cfg.pref && !ndofel) return fail("qdg_limit_from: p-adaptive DG needs ndofel");
+  const size_t stride = (nunk + 63) / 64 * 64;
+  std::vector<int> h(4 * stride, -1);
+  for (size_t e = 0; e < nielem; ++e)
+    for (int lf = 0; lf < 4; ++lf) {
+      const int nb = esuel[4 * e + lf];
+      if (nb < -1 || (nb >= 0 && (size_t)nb >= nunk)) return fail("qdg_limit_from: esuel entry out of range");
+      h[lf * stride + e] = nb;
+    }
+  HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const int ncomp = ctx->cfg.pde == QDG_PDE_TRANSPORT ? 1 : NCOMP;
+  const size_t np = (size_t)ncomp * ctx->cfg.ndof, fsz = np * stride;
+  DevBuf<int> dn, dnd;
+  DevBuf<double> d;
+  HIPCHK(dn.upload(h, s));
+  HIPCHK(d.alloc(2 * fsz));
+  HIPCHK(hipMemsetAsync(d.p, 0, 2 * fsz * 8, s));
+  HIPCHK(hipMemcpyAsync(d.p, U_aos, np * nunk * 8, hipMemcpyHostToDevice, s));
+  DevMesh dm{};
+  dm.nie = (int)nielem; dm.ne = (int)nunk; dm.stride = (int)stride; dm.ncomp = ncomp; dm.nbr = dn.p;
+  if (ctx->cfg.pref) {
+    std::vector<int> nd(nunk);
+    for (size_t e = 0; e < nunk; ++e) nd[e] = (int)ndofel[e];
+    HIPCHK(dnd.upload(nd, s));
+    dm.ndofel = dnd.p;
+  }
+  double* cur = d.p;
+  if (ctx->cfg.limiter == QDG_LIMITER_SUPERBEEP1) {
+    launch_superbee(ctx->cfg.ndof, dm, cur, s);
+  } else {
+    launch_weno(ctx->cfg.ndof, dm, ctx->ph.cweight, cur, d.p + fsz, s);
+    cur = d.p + fsz;
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(U_aos, cur, np * nunk * 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return 0;
+  QDG_CATCH
+}
+
 // ---------------------------------------------------------------- resident
 
 extern "C" int qdg_state_upload(qdg_mesh* mesh, const double* U_aos)
@@ -885,35 +938,196 @@ extern "C" int qdg_state_initialize(qdg_mesh* mesh, double t)
   QDG_CATCH
 }
 
+// Problem::fieldNames (src/PDE/CompFlow/Problem/*.cpp; dg::Transport::fieldNames,
+// DGTransport.hpp:211-229 with depvar 'c')
+static const char* problem_field_name(const qdg_ctx* ctx, size_t f)
+{
+  static const char* six[] = { "density_numerical", "x-velocity_numerical", "y-velocity_numerical",
+                               "z-velocity_numerical", "specific_total_energy_numerical",
+                               "pressure_numerical" };
+  static const char* vort[] = { "density_numerical", "density_analytical", "x-velocity_numerical",
+                                "x-velocity_analytical", "y-velocity_numerical", "y-velocity_analytical",
+                                "z-velocity_numerical", "z-velocity_analytical",
+                                "specific_total_energy_numerical", "specific_total_energy_analytical",
+                                "pressure_numerical", "pressure_analytical" };
+  static const char* tg[] = { "density_numerical", "density_analytical", "x-velocity_numerical",
+                              "x-velocity_analytical", "err(u)", "y-velocity_numerical",
+                              "y-velocity_analytical", "err(v)", "z-velocity_numerical",
+                              "z-velocity_analytical", "specific_total_energy_numerical",
+                              "specific_total_energy_analytical", "err(E)", "pressure_numerical",
+                              "pressure_analytical" };
+  static const char* ms[] = { "density_numerical", "x-velocity_numerical", "y-velocity_numerical",
+                              "z-velocity_numerical", "specific_total_energy_numerical",
+                              "pressure_numerical", "density_analytical", "x-velocity_analytical",
+                              "y-velocity_analytical", "z-velocity_analytical",
+                              "specific_total_energy_analytical", "pressure_analytical", "err(rho)",
+                              "err(e)", "err(p)", "err(u)", "err(v)", "err(w)" };
+  static const char* ud[] = { "density", "x-velocity", "y-velocity", "z-velocity",
+                              "specific total energy", "pressure", "temperature" };
+  static const char* trn[] = { "c0_numerical", "c0_analytic", "c0_error" };
+  const int ncomp = ctx->cfg.pde == QDG_PDE_TRANSPORT ? 1 : NCOMP;
+  const size_t n = (size_t)field_count(ncomp, ctx->cfg.problem);
+  if (f >= n) return (f == n && ctx->cfg.pref) ? "ndof" : "";
+  if (ncomp == 1) return trn[f];
+  switch (ctx->cfg.problem) {
+    case QDG_PROBLEM_VORTICAL_FLOW: return vort[f];
+    case QDG_PROBLEM_TAYLOR_GREEN: return tg[f];
+    case QDG_PROBLEM_NL_ENERGY_GROWTH: case QDG_PROBLEM_RAYLEIGH_TAYLOR: return ms[f];
+    case QDG_PROBLEM_USER_DEFINED: return ud[f];
+    default: return six[f];
+  }
+}
+
+extern "C" int qdg_ctx_field_count(qdg_ctx* ctx, size_t* nfield)
+{
+  QDG_TRY
+  if (!ctx || !nfield) return fail("qdg_ctx_field_count: null argument");
+  *nfield = (size_t)field_count(ctx->cfg.pde == QDG_PDE_TRANSPORT ? 1 : NCOMP, ctx->cfg.problem) +
+            (ctx->cfg.pref ? 1 : 0);
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" const char* qdg_ctx_field_name(qdg_ctx* ctx, size_t f)
+{
+  return ctx ? problem_field_name(ctx, f) : "";
+}
+
 extern "C" int qdg_field_count(qdg_mesh* mesh, size_t* nfield)
 {
   QDG_TRY
   if (!mesh || !nfield) return fail("qdg_field_count: null argument");
-  *nfield = mesh->dm.ncomp == 1 ? 1 : 6;
-  return 0;
+  return qdg_ctx_field_count(mesh->ctx, nfield);
   QDG_CATCH
 }
 
 extern "C" const char* qdg_field_name(qdg_mesh* mesh, size_t f)
 {
-  static const char* cf[6] = { "density_numerical", "x-velocity_numerical", "y-velocity_numerical",
-                               "z-velocity_numerical", "specific_total_energy_numerical",
-                               "pressure_numerical" };
-  if (!mesh) return "";
-  if (mesh->dm.ncomp == 1) return f == 0 ? "c0_numerical" : "";
-  return f < 6 ? cf[f] : "";
+  return mesh ? problem_field_name(mesh->ctx, f) : "";
 }
 
-extern "C" int qdg_field_output(qdg_mesh* mesh, double* out)
+extern "C" int qdg_field_output(qdg_mesh* mesh, double t, double* out)
 {
   QDG_TRY
   MESH_ENTER("qdg_field_output");
   if (!out) return fail("qdg_field_output: null out");
-  const size_t nf = mesh->dm.ncomp == 1 ? 1 : 6, n = nf * mesh->nie;
+  size_t nf = 0;
+  if (int rc = qdg_ctx_field_count(ctx, &nf)) return rc;
+  const size_t n = nf * mesh->nie;
   if (mesh->fout.n < n) HIPCHK(mesh->fout.alloc(n));
-  launch_field_output(mesh->ndof, mesh->dm, ctx->ph, mesh->Ucur, mesh->fout.p, s);
+  launch_field_output(mesh->ndof, mesh->dm, ctx->ph, t, mesh->Ucur, nullptr, (int)mesh->nie, mesh->fout.p, s);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(out, mesh->fout.p, n * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return 0;
+  QDG_CATCH
+}
+
+// ---- stateless output-side members of the DGPDE interface (no mesh handle) -------------
+
+extern "C" int qdg_field_output_from(qdg_ctx* ctx, double t, size_t nunk, const double* geoElem,
+                                     const double* U_aos, double* out)
+{
+  QDG_TRY
+  if (!ctx || (nunk && (!geoElem || !U_aos || !out))) return fail("qdg_field_output_from: null argument");
+  if (nunk > (size_t)INT32_MAX / 64) return fail("qdg_field_output_from: too many elements for one call");
+  if (nunk == 0) return 0;
+  HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const int ncomp = ctx->cfg.pde == QDG_PDE_TRANSPORT ? 1 : NCOMP;
+  const size_t np = (size_t)ncomp * ctx->cfg.rdof, nf = (size_t)field_count(ncomp, ctx->cfg.problem);
+  DevBuf<double> d;
+  HIPCHK(d.alloc((np + 4 + nf) * nunk));
+  double* dU = d.p; double* dG = d.p + np * nunk; double* dO = dG + 4 * nunk;
+  HIPCHK(hipMemcpyAsync(dU, U_aos, np * nunk * 8, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(dG, geoElem, 4 * nunk * 8, hipMemcpyHostToDevice, s));
+  DevMesh dm{};
+  dm.ncomp = ncomp;
+  launch_field_output(ctx->cfg.rdof, dm, ctx->ph, t, dU, dG, (int)nunk, dO, s);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out, dO, nf * nunk * 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_avg_elem_to_node(qdg_ctx* ctx, size_t nelem, size_t nnode, const size_t* inpoel,
+                                    const double* U_aos, double* out)
+{
+  QDG_TRY
+  if (!ctx || !inpoel || !U_aos || !out) return fail("qdg_avg_elem_to_node: null argument");
+  if (ctx->cfg.pde != QDG_PDE_COMPFLOW)
+    return fail("qdg_avg_elem_to_node: dg::Transport returns no nodal fields (DGTransport.hpp:231-239)");
+  if (nelem > (size_t)INT32_MAX / 64 || nnode > (size_t)INT32_MAX / 8)
+    return fail("qdg_avg_elem_to_node: mesh too large for one call");
+  std::vector<int> h(4 * nelem);
+  for (size_t i = 0; i < 4 * nelem; ++i) {
+    if (inpoel[i] >= nnode) return fail("qdg_avg_elem_to_node: inpoel entry out of range");
+    h[i] = (int)inpoel[i];
+  }
+  if (nnode == 0) return 0;
+  HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const size_t np = (size_t)NCOMP * ctx->cfg.rdof;
+  DevBuf<int> di;
+  DevBuf<double> d;
+  HIPCHK(di.upload(h, s));
+  HIPCHK(d.alloc(np * nelem + 7 * nnode));
+  double* dU = d.p; double* dO = d.p + np * nelem; double* dC = dO + 6 * nnode;
+  HIPCHK(hipMemcpyAsync(dU, U_aos, np * nelem * 8, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemsetAsync(dO, 0, 7 * nnode * 8, s));
+  launch_avg_elem_to_node(ctx->ph, ctx->cfg.rdof, (int)nelem, (int)nnode, di.p, dU, dO, dC, s);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out, dO, 6 * nnode * 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_initialize_from(qdg_ctx* ctx, size_t nielem, size_t nnode, const size_t* inpoel,
+                                   const double* x, const double* y, const double* z,
+                                   const double* L_aos, double t, double* U_aos)
+{
+  QDG_TRY
+  if (!ctx || !inpoel || !x || !y || !z || !U_aos) return fail("qdg_initialize_from: null argument");
+  if (nielem > (size_t)(INT32_MAX - 64) / 64 || nnode > (size_t)INT32_MAX)
+    return fail("qdg_initialize_from: mesh too large for one call");
+  if (nielem == 0) return 0;
+  const size_t stride = (nielem + 63) / 64 * 64;
+  std::vector<int> h(4 * stride, 0);
+  for (size_t e = 0; e < nielem; ++e)
+    for (int i = 0; i < 4; ++i) {
+      if (inpoel[4 * e + i] >= nnode) return fail("qdg_initialize_from: inpoel entry out of range");
+      h[i * stride + e] = (int)inpoel[4 * e + i];
+    }
+  HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const int ncomp = ctx->cfg.pde == QDG_PDE_TRANSPORT ? 1 : NCOMP;
+  const size_t np = (size_t)ncomp * ctx->cfg.ndof;
+  DevBuf<int> di;
+  DevBuf<double> d;
+  HIPCHK(di.upload(h, s));
+  HIPCHK(d.alloc(3 * nnode + stride + np * nielem));
+  double* dx = d.p; double* dy = dx + nnode; double* dz = dy + nnode; double* dv = dz + nnode;
+  double* dU = dv + stride;
+  HIPCHK(hipMemcpyAsync(dx, x, nnode * 8, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(dy, y, nnode * 8, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(dz, z, nnode * 8, hipMemcpyHostToDevice, s));
+  if (L_aos) {
+    // the caller's mass matrix: L(e, 0) = vol_e (Mass.cpp:25-73), as tk::initialize divides by it
+    std::vector<double> hv(stride, 1.0);
+    for (size_t e = 0; e < nielem; ++e) hv[e] = L_aos[e * np];
+    HIPCHK(hipMemcpyAsync(dv, hv.data(), stride * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+  } else {
+    launch_tet_volumes((int)nielem, (int)stride, di.p, dx, dy, dz, dv, s);
+  }
+  DevMesh dm{};
+  dm.nie = dm.ne = (int)nielem; dm.stride = (int)stride; dm.nnode = (int)nnode; dm.ncomp = ncomp;
+  dm.inpoel = di.p; dm.x = dx; dm.y = dy; dm.z = dz; dm.vol = dv;
+  launch_init(ctx->cfg.ndof, dm, ctx->ph, t, dU, s);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(U_aos, dU, np * nielem * 8, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   return 0;
   QDG_CATCH

@@ -91,7 +91,7 @@ static_assert(TILE <= TILE_BS && TILE <= 256, "one lane per tet; local ids are 8
 enum { TASK_INT = 0, TASK_EXT = 1, TASK_BND = 2 };
 
 struct Phys {
-  double gamma, pstiff, cweight;
+  double gamma, pstiff, cweight, cv;
   double alpha, beta, p0;
   double betax, betay, betaz, r0, ce, kappa;   // nl_energy_growth
   int flux, problem, limiter;

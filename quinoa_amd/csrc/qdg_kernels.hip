@@ -2023,23 +2023,173 @@ __global__ __launch_bounds__(256) void k_solution(Phys ph, int n, const double* 
 }
 
 // ================================================================ field output
-// Problem::fieldOutput, numerical fields from the cell means
-// (src/PDE/CompFlow/Problem/SodShocktube.cpp:160-237: density, x/y/z velocity,
-// specific total energy, pressure; Transport: the scalar's mean).  out is
-// [nfield][nie] in the CALLER's element numbering.
-__global__ __launch_bounds__(256) void k_field_output(DevMesh m, Phys ph, int ndof,
+// Problem::fieldOutput as dg::CompFlow::fieldOutput calls it (DGCompFlow.hpp:447-462:
+// V = 0, vol = geoElem(:,0), coord = element centroids geoElem(:,1..3)) -- every field
+// of the Problem's own list, from the cell means:
+//   SodShocktube.cpp:160-258 (Sedov, RotatedSod alike; 6 numerical fields),
+//   VorticalFlow.cpp:156-254 (12: numerical/analytical interleaved; pressure_numerical is
+//     evaluated with the ANALYTIC velocities -- the reference overwrites u,v,w first),
+//   TaylorGreen.cpp:135-240 (15, three err(.) fields), NLEnergyGrowth.cpp:233-318 (14),
+//   RayleighTaylor.cpp:223-314 (18; reads row entries 0..4, not c*rdof), UserDefined.cpp:105-169 (7).
+// With V = 0 an err(.) field is x/0 (+inf, NaN where x == 0), as in the reference's goldens.
+// Two callers: the resident state (device rows, centroid = mean of the 4 nodes with the
+// association of tk::genGeoElemTet, output in the caller's numbering through d2h) and the
+// stateless DGPDE::fieldOutput (caller's rows + the caller's geoElem).
+template <int PROB> constexpr int prob_nfield()
+{
+  return PROB == 3 ? 12 : PROB == 4 ? 15 : PROB == 7 ? 14 : PROB == 10 ? 18 : PROB == 0 ? 7 : 6;
+}
+
+template <int PROB>
+__global__ __launch_bounds__(256) void k_field_output(DevMesh m, Phys ph, int ndof, double t,
                                                       const double* __restrict__ U,
+                                                      const double* __restrict__ geoElem, int nrows,
                                                       double* __restrict__ out)
 {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= m.nie) return;
-  const size_t h = (size_t)m.d2h[e], n = (size_t)m.nie;
-  const double* u = U + (size_t)e * m.ncomp * ndof;
-  if (m.ncomp == 1) { out[h] = u[0]; return; }
-  const double r = u[0], vx = u[ndof] / r, vy = u[2 * ndof] / r, vz = u[3 * ndof] / r, re = u[4 * ndof];
-  out[h] = r; out[n + h] = vx; out[2 * n + h] = vy; out[3 * n + h] = vz;
-  out[4 * n + h] = re / r;
-  out[5 * n + h] = eos_pressure(ph, r, vx, vy, vz, re);
+  if (e >= nrows) return;
+  size_t h;
+  double vol, x, y, z;
+  if (geoElem) {
+    h = (size_t)e;
+    vol = geoElem[4 * h]; x = geoElem[4 * h + 1]; y = geoElem[4 * h + 2]; z = geoElem[4 * h + 3];
+  } else {
+    h = (size_t)m.d2h[e];
+    vol = m.vol[e];
+    double p[4][3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int n = m.inpoel[(size_t)i * m.stride + e];
+      p[i][0] = m.x[n]; p[i][1] = m.y[n]; p[i][2] = m.z[n];
+    }
+    x = (p[0][0] + p[1][0] + p[2][0] + p[3][0]) / 4.0;
+    y = (p[0][1] + p[1][1] + p[2][1] + p[3][1]) / 4.0;
+    z = (p[0][2] + p[1][2] + p[2][2] + p[3][2]) / 4.0;
+  }
+  const size_t n = (size_t)nrows;
+  const double* ue = U + (size_t)e * NCOMP * ndof;
+  const double r = ue[0], ru = ue[ndof], rv = ue[2 * ndof], rw = ue[3 * ndof], re = ue[4 * ndof];
+  const double V = 0.0;
+#define OUT(f) out[(size_t)(f) * n + h]
+  if constexpr (PROB == 3) {
+    const double a = ph.alpha, b = ph.beta, p0 = ph.p0, g = ph.gamma;
+    const double u = a * x - b * y, v = b * x + a * y, w = -2.0 * a * z;
+    OUT(0) = r; OUT(1) = 1.0;
+    OUT(2) = ru / r; OUT(3) = u;
+    OUT(4) = rv / r; OUT(5) = v;
+    OUT(6) = rw / r; OUT(7) = w;
+    OUT(8) = re / r;
+    OUT(9) = 0.5 * (u * u + v * v + w * w) + (p0 - 2.0 * a * a * z * z) / (g - 1.0);
+    OUT(10) = eos_pressure(ph, r, u, v, w, re);
+    OUT(11) = p0 - 2.0 * a * a * z * z;
+  } else if constexpr (PROB == 4) {
+    const double pi = 3.14159265358979323846;
+    const double u = ru / r, v = rv / r, w = rw / r, E = re / r;
+    const double ua = sin(pi * x) * cos(pi * y), va = -cos(pi * x) * sin(pi * y), wa = 0.0;
+    const double Pa = 10.0 + r / 4.0 * (cos(2.0 * pi * x) + cos(2.0 * pi * y));
+    const double Ea = eos_totalenergy(ph, r, ua / r, va / r, wa / r, Pa / r);
+    OUT(0) = r; OUT(1) = 1.0;
+    OUT(2) = u; OUT(3) = ua; OUT(4) = (ua - u) * (ua - u) * vol / V;
+    OUT(5) = v; OUT(6) = va; OUT(7) = (va - v) * (va - v) * vol / V;
+    OUT(8) = w; OUT(9) = wa;
+    OUT(10) = E; OUT(11) = Ea; OUT(12) = (Ea - E) * (Ea - E) * vol / V;
+    OUT(13) = eos_pressure(ph, r, u, v, w, r * E);
+    OUT(14) = Pa;
+  } else if constexpr (PROB == 7 || PROB == 10) {
+    constexpr bool rt = PROB == 10;
+    const double r_ = rt ? ue[0] : r;
+    const double u = (rt ? ue[1] : ru) / r_, v = (rt ? ue[2] : rv) / r_, w = (rt ? ue[3] : rw) / r_,
+                 E = (rt ? ue[4] : re) / r_;
+    double s[NCOMP];
+    prob_solution<PROB>(ph, x, y, z, t, s);
+    const double ar = s[0], au = s[1] / s[0], av = s[2] / s[0], aw = s[3] / s[0], aE = s[4] / s[0];
+    const double ap = eos_pressure(ph, ar, au, av, aw, ar * aE);
+    OUT(0) = r_; OUT(1) = u; OUT(2) = v; OUT(3) = w; OUT(4) = E;
+    OUT(5) = eos_pressure(ph, r_, u, v, w, r_ * E);
+    OUT(6) = ar; OUT(7) = au; OUT(8) = av; OUT(9) = aw; OUT(10) = aE; OUT(11) = ap;
+    OUT(12) = (r_ - s[0]) * (r_ - s[0]) * vol / V;
+    OUT(13) = (E - aE) * (E - aE) * vol / V;
+    if constexpr (rt) {
+      const double ap0 = eos_pressure(ph, s[0], au, av, aw, s[4]);
+      OUT(14) = (ap0 - ap) * (ap0 - ap) * vol / V;
+      OUT(15) = (u - au) * (u - au) * vol / V;
+      OUT(16) = (v - av) * (v - av) * vol / V;
+      OUT(17) = (w - aw) * (w - aw) * vol / V;
+    }
+  } else {
+    const double u = ru / r, v = rv / r, w = rw / r, E = re / r;
+    OUT(0) = r; OUT(1) = u; OUT(2) = v; OUT(3) = w; OUT(4) = E;
+    OUT(5) = eos_pressure(ph, r, u, v, w, r * E);
+    if constexpr (PROB == 0) OUT(6) = ph.cv * (E - (u * u + v * v + w * w) / 2.0);
+  }
+#undef OUT
+}
+
+// per-element ndof of p-adaptive DG appended as one more element field
+// (DG::writeFields, src/Inciter/DG.cpp:1201-1204)
+__global__ __launch_bounds__(256) void k_field_ndof(DevMesh m, int nrows, double* __restrict__ out)
+{
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < nrows) out[m.d2h[e]] = (double)m.ndofel[e];
+}
+
+// dg::CompFlow::avgElemToNode, src/PDE/CompFlow/DGCompFlow.hpp:465-552: every element's
+// state at its four nodes (the P1 part of the basis, also for rdof = 10, :517-526; the
+// reference coordinates of a node are 0/1, its Jacobian ratios :497-505), primitive
+// quantities summed per node.  Caller's numbering (stateless call).  The sums are
+// double atomics: the order of the ~20 contributions per node is not fixed (last-bit
+// differences from run to run).
+__global__ __launch_bounds__(256) void k_avg_elem_to_node(Phys ph, int rdof, int nelem, int nnode,
+                                                          const int* __restrict__ inpoel,
+                                                          const double* __restrict__ U,
+                                                          double* __restrict__ out,
+                                                          double* __restrict__ count)
+{
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nelem) return;
+  const double* ue = U + (size_t)e * NCOMP * rdof;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    double b1, b2, b3, s[NCOMP];
+    vertex_basis(i, b1, b2, b3);
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c) {
+      const double* uc = ue + c * rdof;
+      s[c] = (rdof == 1) ? uc[0] : uc[0] + uc[1] * b1 + uc[2] * b2 + uc[3] * b3;
+    }
+    const double u = s[1] / s[0], v = s[2] / s[0], w = s[3] / s[0];
+    const double pr = eos_pressure(ph, s[0], u, v, w, s[4]);
+    const size_t n = (size_t)inpoel[4 * (size_t)e + i], N = (size_t)nnode;
+    atomicAdd(out + n, s[0]); atomicAdd(out + N + n, u); atomicAdd(out + 2 * N + n, v);
+    atomicAdd(out + 3 * N + n, w); atomicAdd(out + 4 * N + n, s[4] / s[0]);
+    atomicAdd(out + 5 * N + n, pr); atomicAdd(count + n, 1.0);
+  }
+}
+__global__ __launch_bounds__(256) void k_avg_finish(int nnode, double* __restrict__ out,
+                                                    const double* __restrict__ count)
+{
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= nnode) return;
+#pragma unroll
+  for (int c = 0; c < 6; ++c) out[(size_t)c * nnode + n] /= count[n];
+}
+
+// tet volumes of a mesh that has no device layout yet (mesh-less DGPDE::initialize):
+// tk::genGeoElemTet's triple product / 6 (src/Mesh/DerivedData.cpp:1457-1491)
+__global__ __launch_bounds__(256) void k_tet_volumes(int nelem, int stride, const int* __restrict__ inpoel,
+                                                     const double* __restrict__ x, const double* __restrict__ y,
+                                                     const double* __restrict__ z, double* __restrict__ vol)
+{
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nelem) return;
+  const int A = inpoel[e], B = inpoel[(size_t)stride + e], C = inpoel[(size_t)2 * stride + e],
+            D = inpoel[(size_t)3 * stride + e];
+  const double ba[3] = { x[B] - x[A], y[B] - y[A], z[B] - z[A] };
+  const double ca[3] = { x[C] - x[A], y[C] - y[A], z[C] - z[A] };
+  const double da[3] = { x[D] - x[A], y[D] - y[A], z[D] - z[A] };
+  const double cx = ca[1] * da[2] - ca[2] * da[1], cy = ca[2] * da[0] - ca[0] * da[2],
+               cz = ca[0] * da[1] - ca[1] * da[0];
+  vol[e] = (ba[0] * cx + ba[1] * cy + ba[2] * cz) / 6.0;
 }
 
 // ================================================================ p-adaptive DG
@@ -2857,11 +3007,69 @@ void launch_solution(int ncomp, const Phys& ph, int n, const double* x, const do
   QDG_DISPATCH_PROB(ph.problem, (k_solution<P><<<nblk(n, 256), 256, 0, s>>>(ph, n, x, y, z, t, out)));
 }
 
-void launch_field_output(int ndof, const DevMesh& m, const Phys& ph, const double* U, double* out,
-                         hipStream_t s)
+// dg::Transport::fieldOutput, src/PDE/Transport/DGTransport.hpp:248-279 (one scalar):
+// mean, Problem::solution at the centroid, (analytic - numerical)^2 * vol
+__global__ __launch_bounds__(256) void k_tr_field_output(DevMesh m, int problem, int ndof, double t,
+                                                         const double* __restrict__ U,
+                                                         const double* __restrict__ geoElem, int nrows,
+                                                         double* __restrict__ out)
 {
-  if (m.nie == 0) return;
-  k_field_output<<<nblk(m.nie, 256), 256, 0, s>>>(m, ph, ndof, U, out);
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nrows) return;
+  size_t h;
+  double vol, x, y, z;
+  if (geoElem) {
+    h = (size_t)e;
+    vol = geoElem[4 * h]; x = geoElem[4 * h + 1]; y = geoElem[4 * h + 2]; z = geoElem[4 * h + 3];
+  } else {
+    h = (size_t)m.d2h[e];
+    vol = m.vol[e];
+    double q[4][3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int n = m.inpoel[(size_t)i * m.stride + e];
+      q[i][0] = m.x[n]; q[i][1] = m.y[n]; q[i][2] = m.z[n];
+    }
+    x = (q[0][0] + q[1][0] + q[2][0] + q[3][0]) / 4.0;
+    y = (q[0][1] + q[1][1] + q[2][1] + q[3][1]) / 4.0;
+    z = (q[0][2] + q[1][2] + q[2][2] + q[3][2]) / 4.0;
+  }
+  const double u = U[(size_t)e * ndof], sa = tr::solution(problem, x, y, z, t);
+  out[h] = u; out[(size_t)nrows + h] = sa; out[2 * (size_t)nrows + h] = (sa - u) * (sa - u) * vol;
+}
+
+int field_count(int ncomp, int problem)
+{
+  if (ncomp == 1) return 3;
+  return problem == 3 ? 12 : problem == 4 ? 15 : problem == 7 ? 14 : problem == 10 ? 18 : problem == 0 ? 7 : 6;
+}
+
+// geoElem == nullptr: resident state in device rows, output permuted to the caller's
+// numbering; else U and geoElem are in the caller's numbering (nrows rows)
+void launch_field_output(int ndof, const DevMesh& m, const Phys& ph, double t, const double* U,
+                         const double* geoElem, int nrows, double* out, hipStream_t s)
+{
+  if (nrows == 0) return;
+  if (m.ncomp == 1) {
+    k_tr_field_output<<<nblk(nrows, 256), 256, 0, s>>>(m, ph.problem, ndof, t, U, geoElem, nrows, out);
+  } else {
+    QDG_DISPATCH_PROB(ph.problem, (k_field_output<P><<<nblk(nrows, 256), 256, 0, s>>>(m, ph, ndof, t, U, geoElem, nrows, out)));
+  }
+  if (!geoElem && m.ndofel)
+    k_field_ndof<<<nblk(nrows, 256), 256, 0, s>>>(m, nrows, out + (size_t)field_count(m.ncomp, ph.problem) * nrows);
+}
+
+void launch_avg_elem_to_node(const Phys& ph, int rdof, int nelem, int nnode, const int* inpoel,
+                             const double* U, double* out, double* count, hipStream_t s)
+{
+  if (nelem > 0) k_avg_elem_to_node<<<nblk(nelem, 256), 256, 0, s>>>(ph, rdof, nelem, nnode, inpoel, U, out, count);
+  if (nnode > 0) k_avg_finish<<<nblk(nnode, 256), 256, 0, s>>>(nnode, out, count);
+}
+
+void launch_tet_volumes(int nelem, int stride, const int* inpoel, const double* x, const double* y,
+                        const double* z, double* vol, hipStream_t s)
+{
+  if (nelem > 0) k_tet_volumes<<<nblk(nelem, 256), 256, 0, s>>>(nelem, stride, inpoel, x, y, z, vol);
 }
 
 // p-adaptive DG: eval_ndof + propagate_ndof + zeroing (stage 0); ndofel/tmp are [ne] ints

@@ -60,8 +60,14 @@ void launch_halo_unpack(const double* slab, int nprop, int stride, int nie, int 
 
 void launch_solution(int ncomp, const Phys& ph, int n, const double* x, const double* y, const double* z,
                      double t, double* out, hipStream_t s);
-void launch_field_output(int ndof, const DevMesh& m, const Phys& ph, const double* U, double* out,
-                         hipStream_t s);
+// number of element fields of Problem::fieldNames (without the ndof column of p-adaptive runs)
+int field_count(int ncomp, int problem);
+void launch_field_output(int ndof, const DevMesh& m, const Phys& ph, double t, const double* U,
+                         const double* geoElem, int nrows, double* out, hipStream_t s);
+void launch_avg_elem_to_node(const Phys& ph, int rdof, int nelem, int nnode, const int* inpoel,
+                             const double* U, double* out, double* count, hipStream_t s);
+void launch_tet_volumes(int nelem, int stride, const int* inpoel, const double* x, const double* y,
+                        const double* z, double* vol, hipStream_t s);
 // p-adaptive DG (DG::eval_ndof, propagate_ndof, zeroing of P0 high-order DOFs)
 void launch_pdg_eval(const DevMesh& m, const double* U, double tolref, int* ndofel, hipStream_t s);
 void launch_pdg_propagate(const DevMesh& m, const int* in, int* out, hipStream_t s);

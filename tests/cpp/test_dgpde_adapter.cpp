@@ -69,8 +69,7 @@ int main(int argc, char** argv)
     qdg::Fields L(nelem, nprop), U(nelem, nprop), R(nelem, nprop);
     std::vector<std::size_t> ndofel(nelem, 4);
     eq.lhs(geoElem, L);
-    eq.attach(geoFace, geoElem, fd, inpoel, coord);
-    eq.initialize(L, inpoel, coord, U, 0.0, nelem);
+    eq.initialize(L, inpoel, coord, U, 0.0, nelem);      // before the mesh is on the device (DG::setup)
     eq.rhs(0.0, geoFace, geoElem, fd, inpoel, coord, U, ndofel, R);
     const double dt = eq.dt(coord, inpoel, fd, geoFace, geoElem, ndofel, U);
     qdg::Fields Ulim = U;
@@ -109,7 +108,6 @@ int main(int argc, char** argv)
     qdg::Fields Lt(nelem, 1), Ut(nelem, 1), Rt(nelem, 1), Ut2(nelem, 1);
     std::vector<std::size_t> ndofel1(nelem, 1);
     tq.lhs(geoElem, Lt);
-    tq.attach(geoFace, geoElem, fd, inpoel, coord);
     tq.initialize(Lt, inpoel, coord, Ut, 0.0, nelem);
     tq.rhs(0.0, geoFace, geoElem, fd, inpoel, coord, Ut, ndofel1, Rt);
     const double tdt = tq.dt(coord, inpoel, fd, geoFace, geoElem, ndofel1, Ut);

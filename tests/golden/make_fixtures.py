@@ -119,6 +119,10 @@ def main():
             out["exo_times"] = t
             out["exo_names"] = np.array([names[i] for i in keep])
             out["exo_vals"] = vals[:, keep, :]
+            # every element field of the golden file, in the file's order (analytic and
+            # err(.) fields of the manufactured-solution problems included)
+            out["exo_names_all"] = np.array(names)
+            out["exo_vals_all"] = vals
         if c.get("golden_exo_chunks"):
             # per-chare golden chunks of a partitioned run (partition-local order):
             # keep, per tet, its centroid and the numerical solution at the last

@@ -43,8 +43,10 @@ def test_slot_cyl_config1_matches_reference_golden_and_oracle(cases):
             t += dt
             rows.append([it + 1, t, np.sqrt(mesh.diag(t)[0] / chunk.meshvol)])
         U = mesh.state_download()
-        fo, names = mesh.field_output()
-        assert names == ["c0_numerical"] and np.array_equal(fo[0], U)
+        fo, names = mesh.field_output(t)
+        # dg::Transport::fieldNames / fieldOutput (DGTransport.hpp:211-229, 248-279)
+        assert names == ["c0_numerical", "c0_analytic", "c0_error"] and np.array_equal(fo[0], U)
+        assert np.array_equal(fo[2], (fo[1] - fo[0]) ** 2 * chunk.geoElem[0::4])
     finally:
         mesh.close(); ctx.close()
     # reference diag table (iteration, time, dt, L2(c0)): 6 printed digits
@@ -107,7 +109,8 @@ def test_transport_regression_cases_match_reference_golden(name, cases):
     try:
         mesh.state_initialize(0.0)
         t, rows = 0.0, []
-        fields, times, ndofs = [mesh.field_output()[0][0]], [0.0], [mesh.ndofel_get()]
+        f0, names = mesh.field_output(0.0)
+        fields, times, ndofs, allf = [f0[0]], [0.0], [mesh.ndofel_get()], [f0]
         for it in range(case["nstep"]):
             t += mesh.step(t)
             if (it + 1) % case["diag_interval"] == 0:
@@ -115,7 +118,8 @@ def test_transport_regression_cases_match_reference_golden(name, cases):
                 rows.append([it + 1, t, case["dt"], np.sqrt(d[0] / chunk.meshvol),
                              np.sqrt(d[5] / chunk.meshvol), d[10]])
             if (it + 1) % case["plot_interval"] == 0 or it + 1 == case["nstep"]:
-                fields.append(mesh.field_output()[0][0]); times.append(t); ndofs.append(mesh.ndofel_get())
+                allf.append(mesh.field_output(t)[0])
+                fields.append(allf[-1][0]); times.append(t); ndofs.append(mesh.ndofel_get())
         U = mesh.state_download()
     finally:
         mesh.close(); ctx.close()
@@ -124,6 +128,10 @@ def test_transport_regression_cases_match_reference_golden(name, cases):
         assert np.abs(np.array(fields) - fix["exo_vals"][:, 0]).max() <= 1e-10     # north_star bar
         if case.get("pref"):
             assert np.array_equal(np.array(ndofs), fix["exo_vals"][:, 1].astype(np.int64))
+        # every element field of the golden file: c0_numerical, c0_analytic, c0_error (+ ndof)
+        assert names == [str(n) for n in fix["exo_names_all"]]
+        got, gold = np.array(allf), fix["exo_vals_all"]
+        assert np.abs(got - gold).max() <= 1e-10
     for row, g in zip(rows, fix["diag"]):
         assert int(row[0]) == int(g[0])
         for a, b in zip(row[1:len(g)], g[1:]):

@@ -36,6 +36,15 @@ def test_oracle_reproduces_reference_golden(name, cases):
         nvar = 5
     err = np.abs(r["fields"][:, :nvar] - fix["exo_vals"][:, :nvar]).max()
     assert err <= FIELD_ATOL[name], (name, err)
+    # --- every field of the Problem's list (numerical, analytic, err(.) = x/0 = inf: the
+    # reference's dg::CompFlow::fieldOutput passes V = 0, DGCompFlow.hpp:459-460) ---
+    names = [str(n) for n in fix["exo_names_all"]]
+    nprob = len(r["oracle"].field_names())
+    assert names[:nprob] == r["oracle"].field_names()
+    got, gold = r["fields_all"], fix["exo_vals_all"][:, :nprob]
+    fin = np.isfinite(gold)
+    assert np.array_equal(np.isinf(got), np.isinf(gold)) and np.array_equal(np.isnan(got), np.isnan(gold))
+    assert np.abs(got[fin] - gold[fin]).max() <= FIELD_ATOL[name], name
     if case.get("pref"):
         # p-adaptive run: the per-element number of DOFs the reference wrote out
         assert np.array_equal(r["ndof"], fix["exo_vals"][:, 6].astype(np.int64))
@@ -127,3 +136,35 @@ def test_oracle_reproduces_transport_goldens(name, cases):
         assert int(row[0]) == int(g[0])
         for a, b in zip(row[1:len(g)], g[1:]):
             assert abs(a - b) <= DIAG_RTOL * abs(b) + 1e-13, (name, int(row[0]), a, b)
+
+
+def test_oracle_avg_elem_to_node_reproduces_linear_fields():
+    """dg::CompFlow::avgElemToNode has no reference-held golden (DG::writeFields has the call
+    commented out, DG.cpp:1206-1211): known answers instead -- a state that is linear in x,y,z
+    projected onto P1 is reproduced exactly at every node, whatever the number of tets around it."""
+    from quinoa_amd import meshgen      # host-side mesh generator only (no device call)
+    ch = meshgen.kuhn_box(4, 3, 3)
+    coord, inpoel = ch["coord"], ch["inpoel"]
+    om = O.OracleMesh(coord, inpoel, ch["sidesets"])
+    orc = O.Oracle(om, O.make_cfg(4, problem="vortical_flow", gamma=5.0 / 3.0, alpha=0.1, beta=1.0, p0=10.0),
+                   [1, 2, 3, 4, 5, 6], [], [])
+    # P1 modal DOFs of the linear function f = a + b.x on each tet: nodal values -> modes
+    def modal(vals):          # vals [ne,4] at the tet's 4 nodes
+        m = np.zeros_like(vals)
+        mean = vals.mean(axis=1)
+        m[:, 0] = mean
+        m[:, 3] = (vals[:, 3] - mean) / 3.0
+        m[:, 2] = (vals[:, 2] - mean + m[:, 3]) / 2.0
+        m[:, 1] = vals[:, 1] - mean + m[:, 2] + m[:, 3]
+        return m
+    x, y, z = coord[:, 0], coord[:, 1], coord[:, 2]
+    nod = {0: 1.0 + 0.3 * x, 1: 0.2 * x - 0.1 * y, 2: 0.05 * z + 0.1, 3: 0.3 * y, 4: 9.0 + x + y + z}
+    U = np.zeros((inpoel.shape[0], 5, 4))
+    for c, f in nod.items():
+        U[:, c, :] = modal(f[inpoel])
+    out = orc.avg_elem_to_node(U.reshape(-1))
+    r, ru, rv, rw, re = (nod[c] for c in range(5))
+    u, v, w = ru / r, rv / r, rw / r
+    p = (re - 0.5 * r * (u * u + v * v + w * w)) * (5.0 / 3.0 - 1.0)
+    for got, want in zip(out, (r, u, v, w, re / r, p)):
+        assert np.abs(got - want).max() <= 1e-13
