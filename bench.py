@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- DG-P1 CompFlow element-updates/s on MI355X (BASELINE.json metric).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--nx NX]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--nx NX] [--no-north-star]
 
 Workload (config.workload): BASELINE.json configs[1] -- CompFlow Euler Sod
 shock tube, DG-P1 (dgp1), HLLC, Superbee limiter, CFL 0.3, on a synthetic
@@ -13,6 +13,13 @@ element-update = one tet through one RK stage's RHS evaluation, so
 value = tets * 3 * K / t.  N > 1: one process per GPU (torch.distributed,
 backend nccl = RCCL), block decomposition with one-layer ghost halo exchanged
 point-to-point, weak scaling (fixed tets per GPU).
+
+The same run then times the NORTH-STAR POINT (BASELINE.json north_star: DG-P1 RHS at
+~10 M tets; >= 6x strong scaling 1 -> 8): the same physics on a fixed-size 119^3 x 6 =
+10 110 954-tet box cut across the N ranks -- `north_star_point` in the JSON line, i.e.
+the roofline fraction of the RHS kernel at 10 M tets at N = 1 and a STRONG-scaling
+value for every N (`--no-north-star` skips it, `--strong-nx M` changes the box).
+BASELINE.md section 5: 5 warm-up + 50 timed steps (the defaults).
 
 Prints ONE JSON line on rank 0.
 """
@@ -86,67 +93,26 @@ def cpu_baseline(budget_s=10.0, budget_all_s=5.0):
     return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--nx", type=int, default=55, help="hexes per direction PER GPU")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--force-dist", action="store_true",
-                    help="initialise torch.distributed (nccl) even for one rank: exercises the "
-                         "device-tensor slabs, the shared stream and the dt all-reduce")
-    ap.add_argument("--comm", choices=["rccl", "torch"], default="rccl",
-                    help="multi-rank transport: libqdg's own RCCL calls (default) or "
-                         "torch.distributed point-to-point")
-    ap.add_argument("--self-halo", action="store_true",
-                    help="one rank, chunk 0 of a 2x1x1 cut whose neighbour is the rank itself: "
-                         "measures the halo machinery (pack, RCCL send/recv, unpack, all-reduce) "
-                         "on a single GPU; not a physical set-up, prints the same JSON line")
-    args = ap.parse_args()
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-    import __graft_entry__
-    __graft_entry__.ensure_built()          # no-op when libqdg.so is there
+def run_workload(args, rank, world, local_rank, dims, lengths, parts, steps, warmup, comm_kind, use_dist):
+    """One timed run of the Sod DG-P1 workload on the box `dims` (global hexes per axis) cut
+    into `parts`; returns the measurements of this rank's chunk (max/sum over ranks done)."""
     import numpy as np
     import torch
     from quinoa_amd import capi, dg, dgmesh, meshgen
-
-    comm = None
-    if world > 1 or args.force_dist or args.self_halo:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        comm = "pending"
-
-    # ---- synthetic mesh chunk of this rank (setup, untimed) ---------------
-    parts = meshgen.parts_for(world) if not args.self_halo else (2, 1, 1)
-    nx = args.nx
-    ch = meshgen.kuhn_box_chunk(nx * parts[0], nx * parts[1], nx * parts[2],
-                                lengths=(float(parts[0]), float(parts[1]), float(parts[2])),
-                                parts=parts, rank=rank)
-    if args.self_halo:
+    self_halo = args.self_halo
+    ch = meshgen.kuhn_box_chunk(dims[0], dims[1], dims[2], lengths=lengths, parts=parts, rank=rank)
+    if self_halo:
         ch["nbr_rank"] = [0 for _ in ch["nbr_rank"]]
     chunk = dgmesh.build_chunk(ch["coord"], ch["inpoel"], ch["nielem"], ch["sidesets"])
     ctx = capi.Context(4, flux="hllc", limiter="superbeep1", problem="sod_shocktube", gamma=1.4,
                        cfl=0.3, bc_extrapolate=[1, 2], bc_sym=[3, 4, 5, 6], device=local_rank)
     mesh = dgmesh.upload(ctx, chunk)
-    if comm is not None:
-        if args.comm == "rccl":
-            try:
-                comm = dg.RcclComm(ctx)
-            except capi.QdgError as ex:          # e.g. librccl not loadable: same on every rank
-                sys.stderr.write("rank %d: RCCL transport unavailable (%s); using torch.distributed\n" % (rank, ex))
-                comm = dg.TorchComm()
+    comm = None
+    if use_dist:
+        if comm_kind == "rccl":
+            # the product transport; a rank that cannot load RCCL ends the run (no silent
+            # degradation to another transport: ask for it with --comm torch)
+            comm = dg.RcclComm(ctx)
         else:
             comm = dg.TorchComm()
     drv = dg.DGDriver(ctx, mesh, ch["nbr_rank"], ch["send_lists"], ch["recv_counts"], comm)
@@ -171,15 +137,15 @@ def main():
     def sync():
         ctx.synchronize()
         torch.cuda.synchronize()
-        if comm is not None:
+        if use_dist:
             torch.distributed.barrier()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         drv.step(0.0)
     sync()
     mesh.profile_enable(True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         drv.step(0.0)
     sync()
     el = time.perf_counter() - t0
@@ -189,59 +155,143 @@ def main():
     if not (dt_last > 0.0 and np.isfinite(dt_last)):
         raise SystemExit("invalid run: dt = %r" % dt_last)
     drift = np.abs(totals() - tot0) / np.abs(tot0)
-    if not args.self_halo and not (drift.max() <= 1e-9):
+    if not self_halo and not (drift.max() <= 1e-9):
         raise SystemExit("invalid run: mass / energy drift %r (halo or flux mismatch)" % (drift,))
-
     ntet = chunk.nielem
     if world > 1:
         tt = torch.tensor([el, float(ntet)], dtype=torch.float64, device="cuda")
         mx = tt.clone(); torch.distributed.all_reduce(mx, op=torch.distributed.ReduceOp.MAX)
         sm = tt.clone(); torch.distributed.all_reduce(sm, op=torch.distributed.ReduceOp.SUM)
         el, ntet = float(mx[0]), int(round(float(sm[1])))
+    res = {"el": el, "ntet": ntet, "ntet_local": chunk.nielem, "avg_ms": ms / max(nl, 1), "launches": nl,
+           "alg": mesh.rhs_algorithmic_bytes(), "dt_last": dt_last, "drift": drift,
+           "backend": None if comm is None else comm.backend}
+    mesh.close()
+    if isinstance(comm, dg.RcclComm):
+        comm.close()
+    ctx.close()
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--nx", type=int, default=55, help="hexes per direction PER GPU (weak scaling)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-north-star", action="store_true",
+                    help="skip the fixed-size 10.1 M-tet north-star / strong-scaling point")
+    ap.add_argument("--strong-nx", type=int, default=119,
+                    help="hexes per direction of the fixed-size box of the strong-scaling point "
+                         "(119 -> 10 110 954 tets, 220 -> 63 888 000 tets = config 4)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (nccl) even for one rank: exercises the "
+                         "device-tensor slabs, the shared stream and the dt all-reduce")
+    ap.add_argument("--comm", choices=["rccl", "torch"], default="rccl",
+                    help="multi-rank transport: libqdg's own RCCL calls (default; the run FAILS if "
+                         "RCCL cannot be loaded) or torch.distributed point-to-point")
+    ap.add_argument("--self-halo", action="store_true",
+                    help="one rank, chunk 0 of a 2x1x1 cut whose neighbour is the rank itself: "
+                         "measures the halo machinery (pack, RCCL send/recv, unpack, all-reduce) "
+                         "on a single GPU; not a physical set-up, prints the same JSON line")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    import __graft_entry__
+    __graft_entry__.ensure_built()          # no-op when libqdg.so is there
+    import torch
+    from quinoa_amd import meshgen
+
+    use_dist = world > 1 or args.force_dist or args.self_halo
+    if use_dist:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    # ---- headline: weak scaling, NX^3 hexes per GPU ------------------------------------------
+    parts = meshgen.parts_for(world) if not args.self_halo else (2, 1, 1)
+    nx = args.nx
+    w = run_workload(args, rank, world, local_rank, (nx * parts[0], nx * parts[1], nx * parts[2]),
+                     (float(parts[0]), float(parts[1]), float(parts[2])), parts,
+                     args.steps, args.warmup, args.comm, use_dist)
+    # ---- north-star / strong-scaling point: fixed-size box cut across the ranks ---------------
+    ns = None
+    if not args.no_north_star and not args.self_halo:
+        sx = args.strong_nx
+        ns_steps, ns_warm = max(3, args.steps // 5), max(1, args.warmup // 2)
+        ns = run_workload(args, rank, world, local_rank, (sx, sx, sx), (1.0, 1.0, 1.0), parts, ns_steps, ns_warm,
+                          args.comm, use_dist)
+        ns["steps"], ns["warmup"] = ns_steps, ns_warm
 
     if rank == 0:
-        avg_ms = ms / max(nl, 1)
-        alg = mesh.rhs_algorithmic_bytes()
-        achieved = alg / (avg_ms * 1e-3) / 1e9
-        traffic = None
+        def roof(r):
+            ach = r["alg"] / (r["avg_ms"] * 1e-3) / 1e9
+            return ach, ach / HBM_PEAK_GBS
+        achieved, frac = roof(w)
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as fh:
                 tj = json.load(fh)
             if tj.get("nx") == nx and tj.get("n_gpus") == world:
                 traffic = tj.get("hbm_bytes_per_launch")
+                traffic_source = ("profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                  "round %s on this workload; not re-measured in this run)" % tj.get("round"))
         out = {
             "metric": "M element-updates/sec, DG-P1 CompFlow on unstructured tets",
-            "value": ntet * 3 * args.steps / el / 1e6,
+            "value": w["ntet"] * 3 * args.steps / w["el"] / 1e6,
             "unit": "M element-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": el / args.steps * 1e3,
+            "ms_per_step": w["el"] / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "CompFlow Euler Sod shock-tube DG-P1 (dgp1, HLLC, superbeep1, "
                                    "cfl 0.3), Kuhn-tet box %d^3 hexes per GPU" % nx,
-                       "tets_total": ntet, "tets_per_gpu": chunk.nielem,
+                       "tets_total": w["ntet"], "tets_per_gpu": w["ntet_local"],
                        "parallelism": "block decomposition %dx%dx%d, ghost-face halo" % parts
-                                      + ("" if comm is None else ", transport " + comm.backend)
+                                      + ("" if w["backend"] is None else ", transport " + w["backend"])
                                       + (" (SELF-HALO TEST: the neighbour is this rank)" if args.self_halo else ""),
                        "step": "SSP-RK3 time step = 3 x (halo, limiter, halo, [dt], rhs, update)"},
             "roofline": {"bound": "hbm", "kernel": "qdg::k_rhs_p1t (tile/face-task RHS; stage 0: + CFL dt; stages 1,2: + fused RK update; 357 B/tet counted for every launch)", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "avg_launch_ms": avg_ms, "launches": nl,
-                         "algorithmic_bytes_per_launch": alg},
-            "dt_last": dt_last,
-            "check": {"mass_drift": float(drift[0]), "energy_drift": float(drift[1]),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac,
+                         "traffic": traffic, "traffic_source": traffic_source,
+                         "avg_launch_ms": w["avg_ms"], "launches": w["launches"],
+                         "algorithmic_bytes_per_launch": w["alg"]},
+            "dt_last": w["dt_last"],
+            "check": {"mass_drift": float(w["drift"][0]), "energy_drift": float(w["drift"][1]),
                       "note": "relative change of total mass / total energy over the whole run "
                               "(conserved in this set-up; run aborts above 1e-9)"},
         }
+        if ns is not None:
+            a2, f2 = roof(ns)
+            out["north_star_point"] = {
+                "workload": "same physics, FIXED-SIZE Kuhn-tet box %d^3 hexes = %d tets cut %dx%dx%d across "
+                            "the %d rank(s): BASELINE.json north_star (P1 RHS at ~10 M tets; strong scaling 1->8)"
+                            % ((args.strong_nx, ns["ntet"]) + parts + (world,)),
+                "scaling": "strong", "tets_total": ns["ntet"], "tets_rank0": ns["ntet_local"],
+                "steps": ns["steps"], "warmup": ns["warmup"],
+                "value": ns["ntet"] * 3 * ns["steps"] / ns["el"] / 1e6, "unit": "M element-updates/s",
+                "ms_per_step": ns["el"] / ns["steps"] * 1e3,
+                "roofline": {"bound": "hbm", "kernel": "qdg::k_rhs_p1t on rank 0's chunk", "achieved": a2,
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": f2, "avg_launch_ms": ns["avg_ms"],
+                             "launches": ns["launches"], "algorithmic_bytes_per_launch": ns["alg"],
+                             "traffic": None},
+                "check": {"mass_drift": float(ns["drift"][0]), "energy_drift": float(ns["drift"][1])},
+            }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
-    mesh.close()
-    if isinstance(comm, dg.RcclComm):
-        comm.close()
-    ctx.close()
-    if comm is not None:
+    if use_dist:
         torch.distributed.destroy_process_group()
 
 

@@ -1335,6 +1335,12 @@ extern "C" int qdg_stage_update(qdg_mesh* mesh, int stage)
   if (stage < 0 || stage > 2) return fail("qdg_stage_update: stage must be 0,1,2");
   if (!mesh->Unp) return fail("qdg_stage_update: no stage in flight");
   if (mesh->Upending) {                       // the fused kernel already wrote the new state
+    // ghost rows are not written by the update: carry them over, as the unfused path does
+    if (mesh->ne > mesh->nie)
+      HIPCHK(hipMemcpyAsync(mesh->Upending + mesh->nie * (size_t)mesh->nprop,
+                            mesh->Ucur + mesh->nie * (size_t)mesh->nprop,
+                            (mesh->ne - mesh->nie) * (size_t)mesh->nprop * sizeof(double),
+                            hipMemcpyDeviceToDevice, s));
     mesh->Ucur = mesh->Upending;
     mesh->Upending = nullptr;
   } else {
@@ -1498,17 +1504,28 @@ extern "C" int qdg_halo_setup(qdg_mesh* mesh, size_t nnbr, const int32_t* nbr_ra
 {
   QDG_TRY
   MESH_ENTER("qdg_halo_setup");
-  if (nnbr > 0 && (!nbr_rank || !send_off || !send_elem || !recv_off))
-    return fail("qdg_halo_setup: null argument");
+  if (nnbr == 0) {
+    // no neighbours: clear the halo state, touch none of the (possibly null) arrays
+    if (mesh->ne != mesh->nie)
+      return fail("qdg_halo_setup: the chunk has ghost rows but no neighbour was given");
+    mesh->nnbr = mesh->nsend = mesh->nrecv = 0;
+    mesh->nbr_rank.clear(); mesh->send_off.assign(1, 0); mesh->recv_off.assign(1, 0);
+    return 0;
+  }
+  if (!nbr_rank || !send_off || !send_elem || !recv_off) return fail("qdg_halo_setup: null argument");
+  if (send_off[0] != 0 || recv_off[0] != 0) return fail("qdg_halo_setup: offsets must start at 0");
+  for (size_t i = 0; i < nnbr; ++i)
+    if (send_off[i + 1] < send_off[i] || recv_off[i + 1] < recv_off[i])
+      return fail("qdg_halo_setup: offsets must be non-decreasing");
+  if (recv_off[nnbr] != mesh->ne - mesh->nie)
+    return fail("qdg_halo_setup: receive counts must add up to the number of ghost rows");
+  if (send_off[nnbr] > (size_t)INT32_MAX / 64) return fail("qdg_halo_setup: send list too long");
   mesh->nnbr = nnbr;
   mesh->nbr_rank.assign(nbr_rank, nbr_rank + nnbr);
   mesh->send_off.assign(send_off, send_off + nnbr + 1);
   mesh->recv_off.assign(recv_off, recv_off + nnbr + 1);
-  mesh->nsend = nnbr ? send_off[nnbr] : 0;
-  mesh->nrecv = nnbr ? recv_off[nnbr] : 0;
-  if (nnbr && (send_off[0] != 0 || recv_off[0] != 0)) return fail("qdg_halo_setup: offsets must start at 0");
-  if (mesh->nrecv != mesh->ne - mesh->nie)
-    return fail("qdg_halo_setup: receive counts must add up to the number of ghost rows");
+  mesh->nsend = send_off[nnbr];
+  mesh->nrecv = recv_off[nnbr];
   // host tet id -> device row of the send list
   std::vector<int> d2h(mesh->ne), h2d(mesh->ne);
   HIPCHK(hipMemcpy(d2h.data(), mesh->d2h.p, mesh->ne * sizeof(int), hipMemcpyDeviceToHost));
@@ -1646,6 +1663,17 @@ struct qdg_comm {
   // communication stream and events of the overlapped step (qdg_step_comm)
   hipStream_t cs = nullptr;
   hipEvent_t ev_ready = nullptr, ev_x1 = nullptr, ev_x2 = nullptr;
+  qdg_comm() = default;
+  qdg_comm(const qdg_comm&) = delete;
+  qdg_comm& operator=(const qdg_comm&) = delete;
+  // releases whatever was created, on every path (a failed qdg_comm_create included)
+  ~qdg_comm()
+  {
+    (void)hipSetDevice(device);
+    if (cs) { (void)hipStreamSynchronize(cs); (void)hipStreamDestroy(cs); }
+    for (hipEvent_t e : { ev_ready, ev_x1, ev_x2 }) if (e) (void)hipEventDestroy(e);
+    if (comm) (void)rccl_api()->CommDestroy(comm);
+  }
 };
 
 extern "C" int qdg_comm_unique_id(void* id128)
@@ -1688,13 +1716,14 @@ extern "C" int qdg_comm_destroy(qdg_comm* comm)
 {
   QDG_TRY
   if (!comm) return 0;
+  ncclResult_t r = ncclSuccess;
   if (comm->comm) {
     (void)hipSetDevice(comm->device);
-    RCCLCHK(rccl_api()->CommDestroy(comm->comm));
+    r = rccl_api()->CommDestroy(comm->comm);
+    comm->comm = nullptr;
   }
-  if (comm->cs) { (void)hipStreamSynchronize(comm->cs); (void)hipStreamDestroy(comm->cs); }
-  for (hipEvent_t e : { comm->ev_ready, comm->ev_x1, comm->ev_x2 }) if (e) (void)hipEventDestroy(e);
-  delete comm;
+  delete comm;                       // stream and events go with it, whatever CommDestroy said
+  if (r != ncclSuccess) return fail(std::string("qdg_comm_destroy: ") + rccl_api()->GetErrorString(r));
   return 0;
   QDG_CATCH
 }
@@ -1714,15 +1743,20 @@ static int exchange_on(qdg_mesh* mesh, qdg_comm* comm, hipStream_t s)
                    mesh->send_ptr, s, mesh->dm.ndofel);
   HIPCHK(hipGetLastError());
   RCCLCHK(a->GroupStart());
-  for (size_t i = 0; i < mesh->nnbr; ++i) {
+  // an error inside the group must not leave it open: remember the first one, always
+  // close the group, then report
+  ncclResult_t first = ncclSuccess;
+  for (size_t i = 0; i < mesh->nnbr && first == ncclSuccess; ++i) {
     const size_t ns = (mesh->send_off[i + 1] - mesh->send_off[i]) * w;
     const size_t nr = (mesh->recv_off[i + 1] - mesh->recv_off[i]) * w;
     double* dst = direct ? mesh->Ucur + (mesh->nie + mesh->recv_off[i]) * np
                          : mesh->recv_ptr + mesh->recv_off[i] * w;
-    if (ns) RCCLCHK(a->Send(mesh->send_ptr + mesh->send_off[i] * w, ns, ncclDouble, mesh->nbr_rank[i], comm->comm, s));
-    if (nr) RCCLCHK(a->Recv(dst, nr, ncclDouble, mesh->nbr_rank[i], comm->comm, s));
+    if (ns) first = a->Send(mesh->send_ptr + mesh->send_off[i] * w, ns, ncclDouble, mesh->nbr_rank[i], comm->comm, s);
+    if (nr && first == ncclSuccess) first = a->Recv(dst, nr, ncclDouble, mesh->nbr_rank[i], comm->comm, s);
   }
-  RCCLCHK(a->GroupEnd());
+  const ncclResult_t endr = a->GroupEnd();
+  if (first != ncclSuccess) return fail(std::string("qdg_halo_exchange: ncclSend/ncclRecv: ") + a->GetErrorString(first));
+  if (endr != ncclSuccess) return fail(std::string("qdg_halo_exchange: ncclGroupEnd: ") + a->GetErrorString(endr));
   if (!direct) {                     // p-adaptive DG: rows carry the ndof column
     launch_halo_unpack(mesh->recv_ptr, mesh->nprop, (int)mesh->stride, (int)mesh->nie,
                        (int)mesh->nrecv, mesh->Ucur, s, mesh->ndofel.p);
@@ -1744,13 +1778,17 @@ static int exchange_upd(qdg_mesh* mesh, qdg_comm* comm, hipStream_t s, double* o
                        (int)mesh->nsend, mesh->send_ptr, s);
   HIPCHK(hipGetLastError());
   RCCLCHK(a->GroupStart());
-  for (size_t i = 0; i < mesh->nnbr; ++i) {
+  ncclResult_t first = ncclSuccess;
+  for (size_t i = 0; i < mesh->nnbr && first == ncclSuccess; ++i) {
     const size_t ns = (mesh->send_off[i + 1] - mesh->send_off[i]) * np;
     const size_t nr = (mesh->recv_off[i + 1] - mesh->recv_off[i]) * np;
-    if (ns) RCCLCHK(a->Send(mesh->send_ptr + mesh->send_off[i] * np, ns, ncclDouble, mesh->nbr_rank[i], comm->comm, s));
-    if (nr) RCCLCHK(a->Recv(out + (mesh->nie + mesh->recv_off[i]) * np, nr, ncclDouble, mesh->nbr_rank[i], comm->comm, s));
+    if (ns) first = a->Send(mesh->send_ptr + mesh->send_off[i] * np, ns, ncclDouble, mesh->nbr_rank[i], comm->comm, s);
+    if (nr && first == ncclSuccess)
+      first = a->Recv(out + (mesh->nie + mesh->recv_off[i]) * np, nr, ncclDouble, mesh->nbr_rank[i], comm->comm, s);
   }
-  RCCLCHK(a->GroupEnd());
+  const ncclResult_t endr = a->GroupEnd();
+  if (first != ncclSuccess) return fail(std::string("qdg_step_comm: ncclSend/ncclRecv: ") + a->GetErrorString(first));
+  if (endr != ncclSuccess) return fail(std::string("qdg_step_comm: ncclGroupEnd: ") + a->GetErrorString(endr));
   return 0;
 }
 

@@ -14,9 +14,16 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    # a fresh checkout has no built artefacts: build them once (no-op otherwise)
+    # a fresh checkout has no built artefacts: build them once (no-op otherwise).  Without
+    # hipcc (a CPU-only checkout) only the oracle is built: the `not gpu` tests that need
+    # libqdg.so (ABI symbols, host mesh mirrors) then fail loudly, the oracle tests still run
+    import shutil
     import __graft_entry__
-    __graft_entry__.ensure_built()
+    if shutil.which("hipcc") or os.path.exists(os.path.join(ROOT, "quinoa_amd", "lib", "libqdg.so")):
+        __graft_entry__.ensure_built()
+    else:
+        from oracle import oracle as O
+        O.build()
 
 
 @pytest.fixture(scope="session")
