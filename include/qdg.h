@@ -312,6 +312,33 @@ int qdg_bnd_faces(size_t nelem, const size_t* inpoel, size_t ntri,
                   const size_t* tri, const int32_t* tri_set, size_t* nbfac,
                   size_t* triinpoel, int32_t* face_set);
 
+/* -- decomposition of an arbitrary tet mesh over the ranks of a run ----------
+ * qdg_partition: geometric cut on the element centroids -- what Partitioner::partition
+ * asks Zoltan2 for (src/Inciter/Partitioner.cpp:137-170: RCB, RIB, HSFC, MJ).  part[e] in
+ * [0, nparts).  Both methods depend on the mesh alone (ties broken by element id).
+ * qdg_chunk_build: one rank's chunk as the DG chare holds it after its ghost set-up
+ * (src/Inciter/DG.cpp:134-949): the owned tets in input order, then one layer of ghost tets --
+ * the tets of other ranks that share a face with an owned tet (DG.cpp:468-712) -- grouped by
+ * owner rank (ascending) and ordered by global id inside a group; local node ids by first
+ * touch; per neighbour the list of owned tets it needs, in the order in which it stores them
+ * as ghosts.  esuel (4*nelem, FaceData::Esuel of the WHOLE mesh) may be NULL: it is then
+ * generated (qdg_gen_esuel).  Feed the result to qdg_mesh_upload (after the FaceData / geometry
+ * of the chunk) and qdg_halo_setup. */
+enum { QDG_PART_RCB = 0, QDG_PART_MORTON = 1 };
+typedef struct qdg_chunk qdg_chunk;
+int qdg_partition(size_t nelem, const size_t* inpoel, size_t nnode, const double* x, const double* y,
+                  const double* z, int nparts, int method, int32_t* part);
+int qdg_chunk_build(size_t nelem, size_t nnode, const size_t* inpoel, const int* esuel,
+                    const int32_t* part, int nparts, int rank, qdg_chunk** out);
+int qdg_chunk_sizes(const qdg_chunk* c, size_t* nielem, size_t* nunk, size_t* nnode, size_t* nnbr,
+                    size_t* nsend);
+/* copy-out (any pointer may be NULL): inpoel[4*nunk] local node ids, elem_gid[nunk],
+ * node_gid[nnode], nbr_rank[nnbr], send_off[nnbr+1], send_elem[nsend] (local owned ids),
+ * recv_off[nnbr+1] (ghost rows nielem + recv_off[i] ...) */
+int qdg_chunk_get(const qdg_chunk* c, size_t* inpoel, size_t* elem_gid, size_t* node_gid,
+                  int32_t* nbr_rank, size_t* send_off, size_t* send_elem, size_t* recv_off);
+int qdg_chunk_destroy(qdg_chunk* c);
+
 /* -- mesh-derived data generated on the device (first step) -----
  * The same arrays as qdg_gen_esuel / nipfac / inpofa / belem / esuf / geoface /
  * geoelem above (src/Inciter/FaceData.cpp:19-41, src/Mesh/DerivedData.cpp:937-1491),

@@ -349,6 +349,24 @@ class Oracle:
                               _p(Lm, c_f64p), _p(U, c_f64p), _p(Un, c_f64p), _p(R, c_f64p))
         return float(dt)
 
+    # --- p-adaptive DG pieces, for runs that exchange ghosts between them ---
+    def eval_ndof(self, U, tolref=None):
+        """DG::eval_ndof over the owned tets (DG.cpp:1088-1163)"""
+        m = self.m
+        self.L_.orc_eval_ndof(C.byref(self.cfg), C.c_int64(self.nie), _p(m.inpoel.reshape(-1), c_i64p),
+                              _p(m.x, c_f64p), _p(m.y, c_f64p), _p(m.z, c_f64p), _p(U, c_f64p),
+                              C.c_double(self.tolref if tolref is None else tolref), _p(self.ndofel, c_i64p))
+
+    def propagate_ndof(self):
+        """DG::propagate_ndof across interior and chare-boundary faces (DG.cpp:1284-1313)"""
+        m = self.m
+        self.L_.orc_propagate_ndof(C.c_int64(m.nelem), C.c_int64(m.nbfac), C.c_int64(m.nfac),
+                                   _p(m.esuf, c_i32p), _p(self.ndofel, c_i64p))
+
+    def pdg_zero(self, U):
+        """DG::solve, stage 0: zero the high-order DOFs of P0 tets (DG.cpp:1451-1469)"""
+        self.L_.orc_pdg_zero(C.byref(self.cfg), C.c_int64(self.m.nelem), _p(self.ndofel, c_i64p), _p(U, c_f64p))
+
     # --- field output (cell means), Problem::fieldOutput ------------------
     def field_output(self, U):
         """density, x/y/z velocity, specific total energy, pressure from cell

@@ -110,7 +110,7 @@ struct qdg_mesh {
   // mesh
   DevBuf<int> inpoel, nbr, finfo, fid, d2h;
   DevBuf<double> x, y, z, farea, fnx, fny, fnz, vol, fgeo, xyz4;
-  DevBuf<int> tile_off, task_a, task_nb, task_f;
+  DevBuf<int> tile_row, tile_off, task_a, task_nb, task_f;
   // fields (SoA planes [nprop][stride])
   DevBuf<double> U, Un, R, W;     // W: scratch state (stateless ops, WENO ping-pong)
   DevBuf<double> aos;             // [ne*nprop] staging in the caller's layout
@@ -534,14 +534,43 @@ extern "C" int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t 
 
   lap("device arrays (host side)");
   // ---- face tasks per tile (k_rhs_p1t) -----------------------------------------
-  const int ntile = (int)((nie + TILE - 1) / TILE);
+  // Tiles are runs of consecutive device rows: TILE rows each, or (QDG_TILE_TASKS=n) cut when
+  // the face tasks of a run would exceed n.  Measured (round 2, 1 M tets): runs cut at 512 tasks
+  // -- two full rounds of the workgroup's 256 lanes instead of 2.4 -- are no faster than plain
+  // 248-row tiles (0.204 vs 0.201 ms; 576: 0.198), so fixed tiles stay the default.
+  std::vector<int> h_tile_row(1, 0);
+  {
+    const char* lim = std::getenv("QDG_TILE_TASKS");
+    const int limit = lim ? std::atoi(lim) : 0;
+    if (limit <= 0) {
+      for (size_t r = TILE; r < nie; r += TILE) h_tile_row.push_back((int)r);
+    } else {
+      int start = 0, ntask = 0;
+      for (size_t d = 0; d < nie; ++d) {
+        int k = 0;
+        for (int lf = 0; lf < 4; ++lf) {
+          const int nb = h_nbr[lf * stride + d];
+          if (nb >= start && nb < (int)d) ++k;
+        }
+        if ((int)d - start >= TILE || (d > (size_t)start && ntask + 4 - k > limit)) {
+          h_tile_row.push_back((int)d);
+          start = (int)d; ntask = 0; k = 0;
+        }
+        ntask += 4 - k;
+      }
+    }
+    h_tile_row.push_back((int)nie);
+  }
+  const int ntile = (int)h_tile_row.size() - 1;
+  int ntile_inner = 0;
+  while (ntile_inner < ntile && (size_t)h_tile_row[ntile_inner + 1] <= ninner) ++ntile_inner;
   std::vector<int> h_tile_off(ntile + 1, 0), h_task_a, h_task_nb, h_task_f;
   {
     struct Task { int key, a, nb, f; };
     // tasks of tile t in its (kind, local face) order; two passes over the tiles on all
     // cores: count, then fill at the tile's offset
     auto tile_tasks = [&](int t, std::vector<Task>& tt) {
-      const size_t e0 = (size_t)t * TILE, e1 = std::min(nie, e0 + TILE);
+      const size_t e0 = (size_t)h_tile_row[t], e1 = (size_t)h_tile_row[t + 1];
       tt.clear();
       for (size_t d = e0; d < e1; ++d)
         for (int lf = 0; lf < 4; ++lf) {
@@ -580,8 +609,9 @@ extern "C" int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t 
       size_t cnt[3] = { 0, 0, 0 };
       for (int a : h_task_a) ++cnt[(a >> 17) & 3];
       std::fprintf(stderr, "qdg upload: %zu tets, %d tiles, tasks per tet: interior-in-tile %.3f, "
-                   "to other tiles/ghosts %.3f, boundary %.3f\n", nie, ntile, (double)cnt[TASK_INT] / nie,
-                   (double)cnt[TASK_EXT] / nie, (double)cnt[TASK_BND] / nie);
+                   "to other tiles/ghosts %.3f, boundary %.3f; tasks per tile %.1f, rows per tile %.1f\n", nie, ntile,
+                   (double)cnt[TASK_INT] / nie, (double)cnt[TASK_EXT] / nie, (double)cnt[TASK_BND] / nie,
+                   (double)h_task_a.size() / ntile, (double)nie / ntile);
     }
   }
 
@@ -629,9 +659,11 @@ extern "C" int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t 
   dm.farea = m->farea.p; dm.fnx = m->fnx.p; dm.fny = m->fny.p; dm.fnz = m->fnz.p;
   dm.vol = m->vol.p; dm.d2h = m->d2h.p;
   dm.fgeo = m->fgeo.p; dm.xyz4 = m->xyz4.p;
+  HIPCHK(m->tile_row.upload(h_tile_row, s));
   HIPCHK(m->tile_off.upload(h_tile_off, s)); HIPCHK(m->task_a.upload(h_task_a, s));
   HIPCHK(m->task_nb.upload(h_task_nb, s)); HIPCHK(m->task_f.upload(h_task_f, s));
-  dm.ntile = ntile; dm.tile_off = m->tile_off.p; dm.task_a = m->task_a.p;
+  dm.ntile = ntile; dm.ntile_inner = ntile_inner; dm.tile_row = m->tile_row.p;
+  dm.tile_off = m->tile_off.p; dm.task_a = m->task_a.p;
   dm.task_nb = m->task_nb.p; dm.task_f = m->task_f.p;
   dm.blk0 = 0; dm.ninner = (int)ninner; dm.ncomp = ncomp;
   dm.ndofel = nullptr;
@@ -759,7 +791,7 @@ static void run_rhs(qdg_mesh* mesh, double t, const double* U, double* R)
 {
   qdg_ctx* ctx = mesh->ctx;
   if (use_p1_fast(mesh) && use_tile(mesh) && mesh->split_rhs) {
-    const int inner = mesh->dm.ninner / TILE;
+    const int inner = mesh->dm.ntile_inner;
     launch_rhs_p1t(mesh->dm, ctx->ph, t, U, R, false, mesh->blockmin.p, 1.0, DBL_MAX,
                    mesh->dtraw.p, mesh->dt_ptr, ctx->stream, 0, inner);
     (void)hipStreamWaitEvent(ctx->stream, mesh->split_rhs, 0);
@@ -1265,7 +1297,7 @@ extern "C" int qdg_stage_rhs_dt(qdg_mesh* mesh, int stage, double t, double tlef
     double* out = free_buf(mesh, mesh->Ucur, mesh->Unp);
     if (int rc = prof_begin(mesh, &ev)) return rc;
     if (use_tile(mesh) && mesh->split_rhs) {
-      const int inner = mesh->dm.ninner / TILE;
+      const int inner = mesh->dm.ntile_inner;
       launch_rhs_p1t_rk(mesh->dm, ctx->ph, t, mesh->Ucur, out, RK[0][stage], RK[1][stage],
                         mesh->dt_ptr, mesh->Unp, s, 0, inner);
       if (ev) HIPCHK(hipEventRecord(ev->second, s));
@@ -1294,7 +1326,7 @@ extern "C" int qdg_stage_rhs_dt(qdg_mesh* mesh, int stage, double t, double tlef
     if (int rc = prof_begin(mesh, &ev)) return rc;
     // here the event pair also covers the 1-block dt reduction (~5 us)
     if (use_tile(mesh) && mesh->split_rhs) {
-      const int inner = mesh->dm.ninner / TILE;
+      const int inner = mesh->dm.ntile_inner;
       launch_rhs_p1t(mesh->dm, ctx->ph, t, mesh->Ucur, mesh->R.p, true, mesh->blockmin.p, scale,
                      tleft, mesh->dtraw.p, mesh->dt_ptr, s, 0, inner);
       if (ev) HIPCHK(hipEventRecord(ev->second, s));
@@ -1823,7 +1855,7 @@ static bool can_overlap(const qdg_mesh* mesh)
 {
   static const bool on = std::getenv("QDG_OVERLAP") != nullptr;
   return on && mesh->nnbr > 0 && !mesh->dm.ndofel && use_p1_fast(mesh) && use_tile(mesh) &&
-         mesh->ctx->cfg.limiter != QDG_LIMITER_WENOP1 && mesh->dm.ninner / TILE > 0 &&
+         mesh->ctx->cfg.limiter != QDG_LIMITER_WENOP1 && mesh->dm.ntile_inner > 0 &&
          mesh->dm.ninner / 256 > 0;
 }
 

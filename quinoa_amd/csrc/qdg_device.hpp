@@ -64,6 +64,8 @@ struct DevMesh {
   // are cut into tiles of TILE consecutive device rows; every face of a tile is
   // listed ONCE (by its left tet when both tets are in the tile)
   int ntile;
+  int ntile_inner;     // tiles that end at or before row ninner (see blk0 below)
+  const int* tile_row; // [ntile+1] first device row of each tile (<= TILE rows per tile)
   const int* tile_off; // [ntile+1] first task of each tile
   const int* task_a;   // packed: e_local(8) lf(2) own_left(1) code(6) kind(2) bc(2) partner_local(8)
   const int* task_nb;  // neighbour device row (kind EXT), else 0

@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include "qdg_device.hpp"
 #include "qdg_kernels.hpp"
 
@@ -33,6 +34,12 @@
 #endif
 #ifndef QDG_TILE_GP_UNROLL
 #define QDG_TILE_GP_UNROLL 1
+#endif
+#ifndef QDG_TILE_GP_SERIAL
+#define QDG_TILE_GP_SERIAL 1
+#endif
+#ifndef QDG_TILE_EARLY_GEOM
+#define QDG_TILE_EARLY_GEOM 0
 #endif
 #ifndef QDG_P1_WAVES
 #define QDG_P1_WAVES 2   // waves per SIMD the DG-P1 RHS kernel is register-budgeted for
@@ -1151,8 +1158,8 @@ __global__ __launch_bounds__(TILE_BS, QDG_TILE_WAVES) void k_rhs_p1t(DevMesh m, 
   __shared__ double sdelt[WITH_DT ? TILE : 1];
   const int tid = threadIdx.x;
   const int tile = m.blk0 + xcd_tile(blockIdx.x, gridDim.x);
-  const int tile_e0 = tile * TILE;
-  const int nloc = (m.nie - tile_e0 < TILE) ? m.nie - tile_e0 : TILE;
+  const int tile_e0 = m.tile_row[tile];
+  const int nloc = m.tile_row[tile + 1] - tile_e0;
 
   // this lane's task descriptors (up to MAXT rounds) and the first task's face
   // geometry / external row are requested before anything waits on LDS
@@ -1454,6 +1461,460 @@ __global__ __launch_bounds__(TILE_BS, QDG_TILE_WAVES) void k_rhs_p1t(DevMesh m, 
 #pragma unroll 1
       for (int ig = 0; ig < ngs; ++ig) {
         const bool one = PDG && p0;
+        const double xi = one ? 0.25 : T.vc[ig][0], eta = one ? 0.25 : T.vc[ig][1],
+                     zeta = one ? 0.25 : T.vc[ig][2];
+        const double w0 = 1.0 - xi - eta - zeta;
+        double P[3], s[NCOMP];
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+          P[d] = g.p[0][d] * w0 + g.p[1][d] * xi + g.p[2][d] * eta + g.p[3][d] * zeta;
+        prob_src<PROB>(ph, P[0], P[1], P[2], t, s);
+        const double wt = (one ? 1.0 : T.vw[ig]) * vol;
+#pragma unroll
+        for (int c = 0; c < NCOMP; ++c) {
+          const double ws = wt * s[c];
+          acc[c][0] += ws;
+          if (!one) {
+#pragma unroll
+            for (int k = 1; k < NDOF; ++k) acc[c][k] += ws * T.vB[ig][k];
+          }
+        }
+      }
+    }
+    if (FUSE_RK) {
+      constexpr double imf[4] = { 1.0, 10.0, 10.0 / 3.0, 5.0 / 3.0 };
+      const double dtv = dtp[0] / vol;
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c)
+#pragma unroll
+        for (int k = 0; k < NDOF; ++k)
+          acc[c][k] = rk_a * un[c][k] + rk_b * (u[c][k] + dtv * imf[k] * acc[c][k]);
+    }
+    store_row<NPROP>(R, e, &acc[0][0]);
+    if (WITH_DT) dte = vol / sdelt[tid];
+  }
+
+  if (WITH_DT) {
+    for (int off = 32; off > 0; off >>= 1) dte = fmin(dte, __shfl_down(dte, off, 64));
+    __shared__ double wmin[TILE_BS / 64];
+    const int lane = tid & 63, wv = tid >> 6;
+    if (lane == 0) wmin[wv] = dte;
+    __syncthreads();
+    if (tid == 0) {
+      double mn = wmin[0];
+      for (int w = 1; w < TILE_BS / 64; ++w) mn = fmin(mn, wmin[w]);
+      blockmin[tile] = mn;
+    }
+  }
+}
+
+// ------------------------------------------- DG-P1 RHS, tile / face-task form, version 2
+// Same tiles, task lists, LDS layout and phases as k_rhs_p1t; the face task is leaner:
+//  * own-frame evaluation with the mirrored HLLC ladder instead of swapping the two states
+//    into stored (left, right) order at every Gauss point (20 selects per point);
+//  * the 3-point rule's structure (one heavy vertex per point, equal weights): one FMA per
+//    state component per point, and the vertex-weighted flux sums formed once after the
+//    point loop from the three raw fluxes;
+//  * uniform order only (p-adaptive runs use k_rhs_p1t).
+template <bool WITH_DT, bool FUSE_RK, int PROB>
+__global__ __launch_bounds__(TILE_BS, QDG_TILE_WAVES) void k_rhs_p1v(DevMesh m, Phys ph, double t,
+                                                     const double* __restrict__ U,
+                                                     double* __restrict__ R,
+                                                     double* __restrict__ blockmin,
+                                                     double rk_a, double rk_b,
+                                                     const double* __restrict__ dtp,
+                                                     const double* __restrict__ Un)
+{
+  constexpr int NDOF = 4, NGF = 3, NGV = 5, NPROP = NCOMP * NDOF;
+  const Tables<4>& T = c_tab4;
+  // LDS: the tile's states in NODAL form, nod[e][vertex][c] (a P1 state is
+  // affine: its value at a face point is the barycentric mix of its vertex
+  // values), and per-vertex flux accumulators accN[e][vertex][c]
+  __shared__ double nod[TILE * NPROP];
+  __shared__ double accN[TILE * NPROP];
+  __shared__ double sdelt[WITH_DT ? TILE : 1];
+  const int tid = threadIdx.x;
+  const int tile = m.blk0 + xcd_tile(blockIdx.x, gridDim.x);
+  const int tile_e0 = m.tile_row[tile];
+  const int nloc = m.tile_row[tile + 1] - tile_e0;
+
+  // this lane's task descriptors (up to MAXT rounds) and the first task's face
+  // geometry / external row are requested before anything waits on LDS
+  constexpr int MAXT = 4;
+  const int t0 = m.tile_off[tile], t1 = m.tile_off[tile + 1];
+  int ta[MAXT], tf[MAXT], tn[MAXT];
+#pragma unroll
+  for (int q = 0; q < MAXT; ++q) {
+    const int it = t0 + tid + TILE_BS * q;
+    const bool ok = it < t1;
+    ta[q] = ok ? m.task_a[it] : -1;
+    tf[q] = ok ? m.task_f[it] : 0;
+    tn[q] = ok ? m.task_nb[it] : 0;
+  }
+
+  // ---- phase 0: modal row -> the 4 vertex states, accumulators = 0 ------------
+  if (tid < TILE) {
+    double r[NCOMP][NDOF];
+    if (tid < nloc) load_row<NPROP>(U, tile_e0 + tid, &r[0][0]);
+    else {
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) { r[c][0] = 1.0; r[c][1] = r[c][2] = r[c][3] = 0.0; }
+    }
+    double v[4][NCOMP];
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c) {
+      // B at the vertices: v0 (-1,-1,-1), v1 (1,-1,-1), v2 (0,2,-1), v3 (0,0,3)
+      const double a = r[c][0] - r[c][3];
+      v[0][c] = a - r[c][1] - r[c][2];
+      v[1][c] = a + r[c][1] - r[c][2];
+      v[2][c] = a + 2.0 * r[c][2];
+      v[3][c] = r[c][0] + 3.0 * r[c][3];
+    }
+    // LDS planes [vertex][component][tet]: lanes of a wave work on different tets at the
+    // same (vertex, component), so tet-fastest storage is free of bank conflicts
+#pragma unroll
+    for (int vx = 0; vx < 4; ++vx)
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) { nod[LIDX(tid, vx, c)] = v[vx][c]; accN[LIDX(tid, vx, c)] = 0.0; }
+    if (WITH_DT) sdelt[tid] = 0.0;
+  }
+#if QDG_TILE_EARLY_GEOM
+  // node ids of this lane's tet: requested now, the coordinates right after the first barrier,
+  // so that the two dependent gathers of the volume term are long back before phase 2
+  int nid[4] = { 0, 0, 0, 0 };
+  if (tid < nloc) {
+    const int e = tile_e0 + tid;
+    nid[0] = m.inpoel[e]; nid[1] = m.inpoel[(size_t)m.stride + e];
+    nid[2] = m.inpoel[(size_t)2 * m.stride + e]; nid[3] = m.inpoel[(size_t)3 * m.stride + e];
+  }
+#endif
+  double gnx[4], rnx[NCOMP][NDOF];
+  if (ta[0] >= 0) {
+    load_row<4>(m.fgeo, tf[0], gnx);
+    if (((ta[0] >> 17) & 3) == TASK_EXT) load_row<NPROP>(U, tn[0], &rnx[0][0]);
+  }
+  __syncthreads();
+#if QDG_TILE_EARLY_GEOM
+  ElemGeom g;
+  if (tid < nloc) {
+    double q[4];
+    load_row<4>(m.xyz4, nid[0], q); g.p[0][0] = q[0]; g.p[0][1] = q[1]; g.p[0][2] = q[2];
+    load_row<4>(m.xyz4, nid[1], q); g.p[1][0] = q[0]; g.p[1][1] = q[1]; g.p[1][2] = q[2];
+    load_row<4>(m.xyz4, nid[2], q); g.p[2][0] = q[0]; g.p[2][1] = q[1]; g.p[2][2] = q[2];
+    load_row<4>(m.xyz4, nid[3], q); g.p[3][0] = q[0]; g.p[3][1] = q[1]; g.p[3][2] = q[2];
+  }
+#endif
+
+  // ---- phase 1: one lane per face task ------------------------------------------
+  constexpr bool HAS_DIRICHLET = (PROB == 3 || PROB == 4 || PROB == 0 || PROB == 7 || PROB == 10);
+  if ((t1 - t0) > TILE_BS * MAXT) __builtin_trap();   // cannot happen: <= 4*TILE tasks per tile
+#ifdef QDG_KO_ATOM
+  double ko_sum = 0.0;
+#endif
+#pragma unroll 1
+  for (int q = 0; q < MAXT; ++q) {
+#ifdef QDG_KO_TASKS
+    break;
+#endif
+    const int a = (q == 0) ? ta[0] : (q == 1) ? ta[1] : (q == 2) ? ta[2] : ta[3];
+    if (a < 0) break;
+    const int el = a & 255, lf = (a >> 8) & 3, code = (a >> 11) & 63, kind = (a >> 17) & 3,
+              bc = (a >> 19) & 3, pl = (a >> 21) & 255;
+    const bool own_left = (a >> 10) & 1;
+    // everything below works in the OWN tet's frame: left' = own, right' = neighbour,
+    // n' = the own tet's outward normal (the stored normal or its negative).  For a face
+    // whose stored left tet is the neighbour this is the mirror image of the reference's
+    // evaluation: wave speeds change sign (Sl' = -Sr, Sm' = -Sm, Sr' = -Sl), so the
+    // reference's ladder (HLLC.hpp:93-124) is applied in its mirrored form -- same four
+    // fluxes, same fall-through of a NaN wave speed to the STORED right state -- and the
+    // own tet always loses what the neighbour gains.
+    const double area = gnx[0];
+    const double osg = own_left ? 1.0 : -1.0;
+    const double fn[3] = { osg * gnx[1], osg * gnx[2], osg * gnx[3] };
+    double rex[NCOMP][NDOF];
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c)
+#pragma unroll
+      for (int k = 0; k < NDOF; ++k) rex[c][k] = rnx[c][k];
+    {
+      // prefetch the next task of this lane
+      const int an = (q == 0) ? ta[1] : (q == 1) ? ta[2] : (q == 2) ? ta[3] : -1;
+      const int fq = (q == 0) ? tf[1] : (q == 1) ? tf[2] : tf[3];
+      const int nq = (q == 0) ? tn[1] : (q == 1) ? tn[2] : tn[3];
+      if (an >= 0) {
+        load_row<4>(m.fgeo, fq, gnx);
+#ifndef QDG_KO_EXT
+        if (((an >> 17) & 3) == TASK_EXT) load_row<NPROP>(U, nq, &rnx[0][0]);
+#endif
+      }
+    }
+    const bool bnd = kind == TASK_BND;
+
+    // vertex states of both tets at the three face vertices
+    double Vo[3][NCOMP], Vn[3][NCOMP];
+    int no[3], nn[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { no[j] = lpofa(lf, j); nn[j] = (code >> (2 * j)) & 3; }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+#pragma unroll
+#ifdef QDG_KO_LDSRD
+      for (int c = 0; c < NCOMP; ++c) Vo[j][c] = 1.0 + 0.01 * (c + j) + area;
+#else
+      for (int c = 0; c < NCOMP; ++c) Vo[j][c] = nod[LIDX(el, no[j], c)];
+#endif
+    }
+    if (kind == TASK_INT) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+#pragma unroll
+#ifdef QDG_KO_LDSRD
+        for (int c = 0; c < NCOMP; ++c) Vn[j][c] = 1.1 + 0.01 * (c + j) + area;
+#else
+        for (int c = 0; c < NCOMP; ++c) Vn[j][c] = nod[LIDX(pl, nn[j], c)];
+#endif
+      }
+    } else if (kind == TASK_EXT) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        double b1, b2, b3;
+        vertex_basis(nn[j], b1, b2, b3);
+#pragma unroll
+        for (int c = 0; c < NCOMP; ++c)
+          Vn[j][c] = rex[c][0] + rex[c][1] * b1 + rex[c][2] * b2 + rex[c][3] * b3;
+      }
+    } else {
+      // Extrapolate: u_r = u_l; Symmetry: mirrored momentum (DGCompFlow.hpp:672-690),
+      // a linear map, applied to the vertex states
+      const double refl = (bc == 2) ? 2.0 : 0.0;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const double vn2 = refl * (Vo[j][1] * fn[0] + Vo[j][2] * fn[1] + Vo[j][3] * fn[2]);
+        Vn[j][0] = Vo[j][0];
+        Vn[j][1] = Vo[j][1] - vn2 * fn[0];
+        Vn[j][2] = Vo[j][2] - vn2 * fn[1];
+        Vn[j][3] = Vo[j][3] - vn2 * fn[2];
+        Vn[j][4] = Vo[j][4];
+      }
+    }
+    const double wsel = (bnd && bc == 0) ? 0.0 : 1.0;   // boundary face without a BC: no flux
+
+    // The 3-point rule (Quadrature.cpp:261-339) puts weight 2/3 on one face vertex and 1/6
+    // on the other two, all three points weigh 1/3: with B = (V0+V1+V2)/6 the state at point g
+    // is B + V_h(g)/2, h(g) = (g+1)%3, and the vertex-weighted flux sums are
+    //   W_j = A/18 (F_0+F_1+F_2) + A/6 F_g(j),  g(j) = (j+2)%3
+    // -- one FMA per state component and no arithmetic on the fluxes inside the point loop.
+    double Bo[NCOMP], Bn[NCOMP], Fg[3][NCOMP], dsum = 0.0;
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c) {
+      Bo[c] = (Vo[0][c] + Vo[1][c] + Vo[2][c]) * (1.0 / 6.0);
+      Bn[c] = (Vn[0][c] + Vn[1][c] + Vn[2][c]) * (1.0 / 6.0);
+    }
+    [[maybe_unused]] ElemGeom gdir;
+    if constexpr (HAS_DIRICHLET) {
+      if (bnd && bc == 1) load_geom(m, tile_e0 + el, gdir);
+    }
+#pragma unroll
+    for (int ig = 0; ig < NGF; ++ig) {
+      constexpr int H[3] = { 1, 2, 0 };
+      const int h = H[ig];
+      double so[NCOMP], sn[NCOMP];
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) {
+        so[c] = fma(0.5, Vo[h][c], Bo[c]);
+        sn[c] = fma(0.5, Vn[h][c], Bn[c]);
+      }
+      if constexpr (HAS_DIRICHLET) {
+        if (bnd && bc == 1) {
+          double P[3];
+          face_point(gdir, lf, T.fs[ig][0], T.fs[ig][1], T.fs[ig][2], P);
+          prob_solution<PROB>(ph, P[0], P[1], P[2], t, sn);
+        }
+      }
+#ifdef QDG_KO_GP
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) Fg[ig][c] = so[c] + sn[c] * fn[c % 3];
+      continue;
+#endif
+      Prim qo, qn;
+      primitives(ph, fn, so, qo);
+      primitives(ph, fn, sn, qn);
+      if (WITH_DT) {
+        // delt += std::max(dSV_l, dSV_r) = (a < b) ? b : a in STORED (left, right) order;
+        // boundary faces: dSV_r = 0
+        const double d_o = fabs(qo.vn) + qo.a;
+        const double d_n = bnd ? 0.0 : fabs(qn.vn) + qn.a;
+        const bool take_n = own_left ? (d_o < d_n) : !(d_n < d_o);
+        dsum += take_n ? d_n : d_o;
+      }
+      if (ph.flux == 1) {
+        // Lax-Friedrichs is symmetric under the mirror image (LaxFriedrichs.hpp:34-88)
+        flux_lf_q(fn, so, sn, qo, qn, Fg[ig]);
+      } else {
+        const double rlr = fast_sqrt(sn[0] * qo.ir);
+        const double irlr1 = fast_rcp(1.0 + rlr);
+        const double vnroe = (qn.vn * rlr + qo.vn) * irlr1;
+        const double aroe = (qn.a * rlr + qo.a) * irlr1;
+        const double Sl = fmin(qo.vn - qo.a, vnroe - aroe);
+        const double Sr = fmax(qn.vn + qn.a, vnroe + aroe);
+        const double ml = so[0] * (Sl - qo.vn), mr = sn[0] * (Sr - qn.vn);
+        const double Sm = (mr * qn.vn - ml * qo.vn + qo.p - qn.p) * fast_rcp(mr - ml);
+        const double pStar = so[0] * (qo.vn - Sl) * (qo.vn - Sm) + qo.p;
+        // stored orientation = own frame:  Sl>0: own | Sl<=0,Sm>0: own* | Sm<=0,Sr>=0: nbr* | else nbr
+        // mirrored:                        Sr<0: nbr | Sr>=0,Sm<0: nbr* | Sm>=0,Sl<=0: own* | else own
+        const bool c1 = Sl > 0.0;
+        const bool c2 = !c1 && (Sl <= 0.0) && (Sm > 0.0);
+        const bool c3 = !c1 && !c2 && (Sm <= 0.0) && (Sr >= 0.0);
+        const bool m1 = Sr < 0.0;
+        const bool m2 = !m1 && (Sr >= 0.0) && (Sm < 0.0);
+        const bool m3 = !m1 && !m2 && (Sm >= 0.0) && (Sl <= 0.0);
+        const bool left = own_left ? (c1 || c2) : !(m1 || m2);
+        const bool star = own_left ? (c2 || c3) : (m2 || m3);
+        const double S = left ? Sl : Sr;
+        const double vn = left ? qo.vn : qn.vn;
+        const double p = left ? qo.p : qn.p;
+        const double u0 = left ? so[0] : sn[0], u1 = left ? so[1] : sn[1], u2 = left ? so[2] : sn[2],
+                     u3 = left ? so[3] : sn[3], u4 = left ? so[4] : sn[4];
+        const double id = star ? fast_rcp(S - Sm) : 1.0;
+        const double sv = star ? (S - vn) * id * Sm : vn;
+        const double dp = star ? (pStar - p) * id * Sm + pStar : p;
+        const double e4 = star ? ((pStar * Sm - p * vn) * id + pStar) * Sm : p * vn;
+        Fg[ig][0] = sv * u0;
+        Fg[ig][1] = sv * u1 + dp * fn[0];
+        Fg[ig][2] = sv * u2 + dp * fn[1];
+        Fg[ig][3] = sv * u3 + dp * fn[2];
+        Fg[ig][4] = sv * u4 + e4;
+      }
+#if QDG_TILE_GP_SERIAL
+      __builtin_amdgcn_sched_barrier(0);     // keep the three points in sequence (register pressure)
+#endif
+    }
+
+    // ---- scatter the vertex-weighted flux sums: the own tet loses, the neighbour gains ---
+    {
+      const double k1 = area * wsel * (1.0 / 18.0), k2 = area * wsel * (1.0 / 6.0);
+      double W[3][NCOMP];
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) {
+        const double Ssum = k1 * ((Fg[0][c] + Fg[1][c]) + Fg[2][c]);
+        W[0][c] = fma(k2, Fg[2][c], Ssum);
+        W[1][c] = fma(k2, Fg[0][c], Ssum);
+        W[2][c] = fma(k2, Fg[1][c], Ssum);
+      }
+#ifdef QDG_KO_ATOM
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int c = 0; c < NCOMP; ++c) ko_sum += W[j][c];
+      continue;
+#endif
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+#pragma unroll
+        for (int c = 0; c < NCOMP; ++c)
+          __hip_atomic_fetch_add(accN + LIDX(el, no[j], c), -W[j][c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      if (WITH_DT) {
+        dsum *= area * (1.0 / 3.0);
+        __hip_atomic_fetch_add(sdelt + el, dsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      if (kind == TASK_INT) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+#pragma unroll
+          for (int c = 0; c < NCOMP; ++c)
+            __hip_atomic_fetch_add(accN + LIDX(pl, nn[j], c), W[j][c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (WITH_DT) __hip_atomic_fetch_add(sdelt + pl, dsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+  }
+#ifdef QDG_KO_ATOM
+  if (ko_sum == 1234.56789) accN[tid] = ko_sum;
+#endif
+  // phase-2 inputs are requested before the barrier (their latency overlaps the
+  // other waves' last tasks)
+  double u[NCOMP][NDOF], un[NCOMP][NDOF];
+  double vol = 1.0;
+#if !QDG_TILE_EARLY_GEOM
+  ElemGeom g;
+#endif
+  if (tid < nloc) {
+    const int e = tile_e0 + tid;
+    load_row<NPROP>(U, e, &u[0][0]);          // modal row again (L1/L2 hit)
+    if (FUSE_RK) load_row<NPROP>(Un, e, &un[0][0]);
+    vol = m.vol[e];
+#if !QDG_TILE_EARLY_GEOM
+    const int stride = m.stride;
+    const int n0 = m.inpoel[e], n1 = m.inpoel[(size_t)stride + e], n2 = m.inpoel[(size_t)2 * stride + e],
+              n3 = m.inpoel[(size_t)3 * stride + e];
+    double q[4];
+    load_row<4>(m.xyz4, n0, q); g.p[0][0] = q[0]; g.p[0][1] = q[1]; g.p[0][2] = q[2];
+    load_row<4>(m.xyz4, n1, q); g.p[1][0] = q[0]; g.p[1][1] = q[1]; g.p[1][2] = q[2];
+    load_row<4>(m.xyz4, n2, q); g.p[2][0] = q[0]; g.p[2][1] = q[1]; g.p[2][2] = q[2];
+    load_row<4>(m.xyz4, n3, q); g.p[3][0] = q[0]; g.p[3][1] = q[1]; g.p[3][2] = q[2];
+#endif
+  }
+  __syncthreads();
+
+  // ---- phase 2: one lane per tet: volume (+source) term, epilogue, store --------
+  double dte = DBL_MAX;
+  if (tid < nloc) {
+    const int e = tile_e0 + tid;
+    double acc[NCOMP][NDOF];
+    {
+      // R[c][k] = sum_v accN[v][c] * B_k(vertex v)
+      double nv[4][NCOMP];
+#pragma unroll
+      for (int vx = 0; vx < 4; ++vx)
+#pragma unroll
+        for (int c = 0; c < NCOMP; ++c) nv[vx][c] = accN[LIDX(tid, vx, c)];
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) {
+        acc[c][0] = (nv[0][c] + nv[1][c]) + (nv[2][c] + nv[3][c]);
+        acc[c][1] = nv[1][c] - nv[0][c];
+        acc[c][2] = 2.0 * nv[2][c] - nv[0][c] - nv[1][c];
+        acc[c][3] = 3.0 * nv[3][c] - nv[0][c] - nv[1][c] - nv[2][c];
+      }
+    }
+#ifndef QDG_KO_P2VOL
+    {
+      double ji[3][3];
+      inverse_jacobian(g, ji);
+      double Fs[NCOMP][3];
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) Fs[c][0] = Fs[c][1] = Fs[c][2] = 0.0;
+#pragma unroll
+      for (int ig = 0; ig < NGV; ++ig) {
+        double s[NCOMP];
+        state_from<NDOF>(u, T.vB[ig], s);
+        const double ir = fast_rcp(s[0]);
+        const double uu = s[1] * ir, vv = s[2] * ir, ww = s[3] * ir;
+        const double p = eos_pressure(ph, s[0], uu, vv, ww, s[4]);
+        const double wg = T.vw[ig];
+        const double h = s[4] + p;
+        Fs[0][0] += wg * s[1];            Fs[0][1] += wg * s[2];            Fs[0][2] += wg * s[3];
+        Fs[1][0] += wg * (s[1] * uu + p); Fs[1][1] += wg * (s[2] * uu);     Fs[1][2] += wg * (s[3] * uu);
+        Fs[2][0] += wg * (s[1] * vv);     Fs[2][1] += wg * (s[2] * vv + p); Fs[2][2] += wg * (s[3] * vv);
+        Fs[3][0] += wg * (s[1] * ww);     Fs[3][1] += wg * (s[2] * ww);     Fs[3][2] += wg * (s[3] * ww + p);
+        Fs[4][0] += wg * (uu * h);        Fs[4][1] += wg * (vv * h);        Fs[4][2] += wg * (ww * h);
+      }
+#pragma unroll
+      for (int k = 1; k < NDOF; ++k) {
+        const double g0 = T.vdB[0][0][k], g1 = T.vdB[0][1][k], g2 = T.vdB[0][2][k];
+        const double dx = vol * (g0 * ji[0][0] + g1 * ji[1][0] + g2 * ji[2][0]);
+        const double dy = vol * (g0 * ji[0][1] + g1 * ji[1][1] + g2 * ji[2][1]);
+        const double dz = vol * (g0 * ji[0][2] + g1 * ji[1][2] + g2 * ji[2][2]);
+#pragma unroll
+        for (int c = 0; c < NCOMP; ++c) acc[c][k] += Fs[c][0] * dx + Fs[c][1] * dy + Fs[c][2] * dz;
+      }
+    }
+#endif
+    if constexpr (prob_has_source<PROB>()) {
+      const int ngs = NGV;
+#pragma unroll 1
+      for (int ig = 0; ig < ngs; ++ig) {
+        constexpr bool one = false;
         const double xi = one ? 0.25 : T.vc[ig][0], eta = one ? 0.25 : T.vc[ig][1],
                      zeta = one ? 0.25 : T.vc[ig][2];
         const double w0 = 1.0 - xi - eta - zeta;
@@ -2807,6 +3268,13 @@ void launch_rhs_p1(const DevMesh& m, const Phys& ph, double t, const double* U, 
   }
 }
 
+// version 2 of the tile kernel unless the run is p-adaptive (QDG_TILE_V1=1 keeps version 1
+// for A/B runs)
+static bool tile_v2(const DevMesh& m)
+{
+  return !m.ndofel && std::getenv("QDG_TILE_V1") == nullptr;
+}
+
 // tile / face-task form of the P1 RHS; tiles [first, first+count) (count < 0: all).
 // With with_dt the launch that ends at the last tile also reduces the per-tile
 // minima to the time step.
@@ -2818,7 +3286,13 @@ void launch_rhs_p1t(const DevMesh& m0, const Phys& ph, double t, const double* U
   DevMesh m = m0;
   m.blk0 = first;
   const int nb = count < 0 ? m.ntile - first : count;
-  if (nb > 0) {
+  if (nb > 0 && tile_v2(m)) {
+    if (with_dt) {
+      QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1v<true, false, P><<<nb, TILE_BS, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr)));
+    } else {
+      QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1v<false, false, P><<<nb, TILE_BS, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr)));
+    }
+  } else if (nb > 0) {
     if (with_dt) {
       QDG_DISPATCH_PDG(m, QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1t<true, false, P, G><<<nb, TILE_BS, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr))));
     } else {
@@ -2838,6 +3312,10 @@ void launch_rhs_p1t_rk(const DevMesh& m0, const Phys& ph, double t, const double
   m.blk0 = first;
   const int nb = count < 0 ? m.ntile - first : count;
   if (nb <= 0) return;
+  if (tile_v2(m)) {
+    QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1v<false, true, P><<<nb, TILE_BS, 0, s>>>(m, ph, t, U, Uout, nullptr, a, b, dt, Un)));
+    return;
+  }
   QDG_DISPATCH_PDG(m, QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1t<false, true, P, G><<<nb, TILE_BS, 0, s>>>(m, ph, t, U, Uout, nullptr, a, b, dt, Un))));
 }
 

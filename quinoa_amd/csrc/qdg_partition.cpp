@@ -1,0 +1,236 @@
+// qdg_partition.cpp -- host side of the mesh decomposition for one-process-per-GPU
+// runs: a geometric partitioner for an arbitrary tetrahedron connectivity and the
+// builder of one rank's chunk (owned tets, one-layer face-neighbour ghosts, halo
+// plan) in the data model the DG chare holds after its ghost set-up.
+//
+//   reference                                            here
+//   ---------------------------------------------------  -------------------------
+//   Partitioner::partition -> tk::geomPartMesh (Zoltan2   qdg_partition: the same kind
+//   RCB / RIB / HSFC / MJ on the element centroids,      of cut (coordinate bisection or a
+//   src/Inciter/Partitioner.cpp:137-170,                  space-filling-curve order of the
+//   src/LoadBalance/ZoltanInterOp.cpp)                    centroids), own implementation
+//   DG::DG ... DG::adj: chare-boundary faces, ghost       qdg_chunk_build: ghosts = tets of
+//   tets and their numbering, m_ghostData / m_ghost       other ranks that share a FACE with
+//   (src/Inciter/DG.cpp:134-949, 468-712)                 an owned tet, grouped by owner
+//
+// Zoltan2 itself is a third-party library that is absent here; WHICH tet lands in
+// which part therefore differs from a reference run (as it does between the
+// reference's own partitioners) -- the physics does not depend on it.
+#include <algorithm>
+#include <cfloat>
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/qdg.h"
+#include "qdg_host.hpp"
+
+using namespace qdg;
+
+namespace {
+
+inline uint64_t spread21(uint64_t v)
+{
+  v &= 0x1fffff;
+  v = (v | v << 32) & 0x1f00000000ffffULL;
+  v = (v | v << 16) & 0x1f0000ff0000ffULL;
+  v = (v | v << 8) & 0x100f00f00f00f00fULL;
+  v = (v | v << 4) & 0x10c30c30c30c30c3ULL;
+  v = (v | v << 2) & 0x1249249249249249ULL;
+  return v;
+}
+
+// recursive coordinate bisection of idx[b,e) into parts [p0, p0+np): split the longest
+// extent at the weighted median (np/2 : np - np/2), so any number of parts works
+void rcb(std::vector<int>& idx, size_t b, size_t e, int p0, int np, const std::vector<double>& cx,
+         const std::vector<double>& cy, const std::vector<double>& cz, int32_t* part)
+{
+  if (np <= 1 || e - b <= 1) {
+    for (size_t i = b; i < e; ++i) part[idx[i]] = p0;
+    return;
+  }
+  double lo[3] = { DBL_MAX, DBL_MAX, DBL_MAX }, hi[3] = { -DBL_MAX, -DBL_MAX, -DBL_MAX };
+  for (size_t i = b; i < e; ++i) {
+    const double c[3] = { cx[idx[i]], cy[idx[i]], cz[idx[i]] };
+    for (int d = 0; d < 3; ++d) { lo[d] = std::min(lo[d], c[d]); hi[d] = std::max(hi[d], c[d]); }
+  }
+  int ax = 0;
+  for (int d = 1; d < 3; ++d) if (hi[d] - lo[d] > hi[ax] - lo[ax]) ax = d;
+  const std::vector<double>& c = ax == 0 ? cx : ax == 1 ? cy : cz;
+  const int npl = np / 2;
+  const size_t mid = b + (size_t)((double)(e - b) * npl / np + 0.5);
+  // ties broken by element id: the cut is a function of the mesh alone
+  std::nth_element(idx.begin() + b, idx.begin() + mid, idx.begin() + e,
+                   [&](int p, int q) { return c[p] < c[q] || (c[p] == c[q] && p < q); });
+  rcb(idx, b, mid, p0, npl, cx, cy, cz, part);
+  rcb(idx, mid, e, p0 + npl, np - npl, cx, cy, cz, part);
+}
+
+}  // namespace
+
+extern "C" int qdg_partition(size_t nelem, const size_t* inpoel, size_t nnode, const double* x,
+                             const double* y, const double* z, int nparts, int method, int32_t* part)
+{
+  QDG_TRY
+  if (!inpoel || !x || !y || !z || !part) return fail("qdg_partition: null argument");
+  if (nparts < 1) return fail("qdg_partition: nparts must be >= 1");
+  if (nelem > (size_t)INT32_MAX) return fail("qdg_partition: too many elements");
+  if (method != QDG_PART_RCB && method != QDG_PART_MORTON) return fail("qdg_partition: unknown method");
+  std::vector<double> cx(nelem), cy(nelem), cz(nelem);
+  for (size_t e = 0; e < nelem; ++e) {
+    double s[3] = { 0.0, 0.0, 0.0 };
+    for (int i = 0; i < 4; ++i) {
+      const size_t n = inpoel[4 * e + i];
+      if (n >= nnode) return fail("qdg_partition: inpoel entry out of range");
+      s[0] += x[n]; s[1] += y[n]; s[2] += z[n];
+    }
+    cx[e] = 0.25 * s[0]; cy[e] = 0.25 * s[1]; cz[e] = 0.25 * s[2];
+  }
+  std::vector<int> idx(nelem);
+  std::iota(idx.begin(), idx.end(), 0);
+  if (method == QDG_PART_RCB) {
+    rcb(idx, 0, nelem, 0, nparts, cx, cy, cz, part);
+    return 0;
+  }
+  // space-filling curve: Morton order of the centroids, cut into nparts equal runs
+  double lo[3] = { DBL_MAX, DBL_MAX, DBL_MAX }, hi[3] = { -DBL_MAX, -DBL_MAX, -DBL_MAX };
+  for (size_t e = 0; e < nelem; ++e) {
+    lo[0] = std::min(lo[0], cx[e]); hi[0] = std::max(hi[0], cx[e]);
+    lo[1] = std::min(lo[1], cy[e]); hi[1] = std::max(hi[1], cy[e]);
+    lo[2] = std::min(lo[2], cz[e]); hi[2] = std::max(hi[2], cz[e]);
+  }
+  const double ext = std::max({ hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2], 1e-300 });
+  std::vector<uint64_t> key(nelem);
+  for (size_t e = 0; e < nelem; ++e) {
+    const double c[3] = { cx[e], cy[e], cz[e] };
+    uint64_t k = 0;
+    for (int d = 0; d < 3; ++d) {
+      const double t = (c[d] - lo[d]) / ext;
+      k |= spread21((uint64_t)std::min(2097151.0, std::max(0.0, t * 2097152.0))) << d;
+    }
+    key[e] = k;
+  }
+  std::sort(idx.begin(), idx.end(), [&](int p, int q) { return key[p] < key[q] || (key[p] == key[q] && p < q); });
+  for (size_t i = 0; i < nelem; ++i) part[idx[i]] = (int32_t)((i * (size_t)nparts) / nelem);
+  return 0;
+  QDG_CATCH
+}
+
+struct qdg_chunk {
+  size_t nielem = 0, nunk = 0, nnode = 0;
+  std::vector<size_t> inpoel;     // [4*nunk] local node ids
+  std::vector<size_t> elem_gid;   // [nunk]
+  std::vector<size_t> node_gid;   // [nnode]
+  std::vector<int32_t> nbr_rank;  // ascending
+  std::vector<size_t> send_off, send_elem, recv_off;
+};
+
+extern "C" int qdg_chunk_build(size_t nelem, size_t nnode, const size_t* inpoel, const int* esuel,
+                               const int32_t* part, int nparts, int rank, qdg_chunk** out)
+{
+  QDG_TRY
+  if (!inpoel || !part || !out) return fail("qdg_chunk_build: null argument");
+  *out = nullptr;
+  if (rank < 0 || rank >= nparts) return fail("qdg_chunk_build: rank outside [0, nparts)");
+  std::vector<int> own_esuel;
+  if (!esuel) {                       // face adjacency of the whole mesh (FaceData.cpp:19-41 -> genEsuelTet)
+    own_esuel.resize(4 * nelem);
+    if (int rc = qdg_gen_esuel(nelem, inpoel, own_esuel.data())) return rc;
+    esuel = own_esuel.data();
+  }
+  std::unique_ptr<qdg_chunk> c(new qdg_chunk);
+  // owned tets keep the input order (a serial run keeps the file's numbering too)
+  std::vector<size_t> owned;
+  for (size_t e = 0; e < nelem; ++e) {
+    if (part[e] < 0 || part[e] >= nparts) return fail("qdg_chunk_build: part entry outside [0, nparts)");
+    if (part[e] == rank) owned.push_back(e);
+  }
+  if (owned.empty()) return fail("qdg_chunk_build: this rank owns no element");
+  // (neighbour rank, global tet id) pairs: what we receive (their tets) and what we send (ours)
+  std::vector<std::pair<int32_t, size_t>> recv, send;
+  for (size_t e : owned)
+    for (int lf = 0; lf < 4; ++lf) {
+      const int nb = esuel[4 * e + lf];
+      if (nb < -1 || (nb >= 0 && (size_t)nb >= nelem)) return fail("qdg_chunk_build: esuel entry out of range");
+      if (nb >= 0 && part[nb] != rank) {
+        recv.emplace_back(part[nb], (size_t)nb);
+        send.emplace_back(part[nb], e);
+      }
+    }
+  auto uniq = [](std::vector<std::pair<int32_t, size_t>>& v) {
+    std::sort(v.begin(), v.end());
+    v.erase(std::unique(v.begin(), v.end()), v.end());
+  };
+  // both sides order a pair's tets by global id: the sender's list for q IS the order in which q
+  // stores the ghosts it gets from us (DG.cpp:1023-1031 sends m_ghostData[q] in the order q's
+  // m_ghost map expects)
+  uniq(recv); uniq(send);
+  for (const auto& r : recv) if (c->nbr_rank.empty() || c->nbr_rank.back() != r.first) c->nbr_rank.push_back(r.first);
+  const size_t nnbr = c->nbr_rank.size();
+  c->nielem = owned.size();
+  c->nunk = owned.size() + recv.size();
+  c->elem_gid = owned;
+  c->recv_off.assign(nnbr + 1, 0); c->send_off.assign(nnbr + 1, 0);
+  {
+    size_t i = 0, j = 0;
+    for (size_t k = 0; k < nnbr; ++k) {
+      while (i < recv.size() && recv[i].first == c->nbr_rank[k]) { c->elem_gid.push_back(recv[i].second); ++i; }
+      c->recv_off[k + 1] = i;
+      while (j < send.size() && send[j].first == c->nbr_rank[k]) ++j;
+      c->send_off[k + 1] = j;
+    }
+    if (j != send.size()) return fail("qdg_chunk_build: a rank receives from us but sends nothing (asymmetric esuel)");
+  }
+  // global -> local ids
+  std::vector<int> e_g2l(nelem, -1);
+  for (size_t l = 0; l < c->nielem; ++l) e_g2l[owned[l]] = (int)l;
+  c->send_elem.resize(send.size());
+  for (size_t j = 0; j < send.size(); ++j) c->send_elem[j] = (size_t)e_g2l[send[j].second];
+  std::vector<int> n_g2l(nnode, -1);
+  c->inpoel.resize(4 * c->nunk);
+  for (size_t l = 0; l < c->nunk; ++l)
+    for (int i = 0; i < 4; ++i) {
+      const size_t g = inpoel[4 * c->elem_gid[l] + i];
+      if (g >= nnode) return fail("qdg_chunk_build: inpoel entry out of range");
+      if (n_g2l[g] < 0) { n_g2l[g] = (int)c->node_gid.size(); c->node_gid.push_back(g); }
+      c->inpoel[4 * l + i] = (size_t)n_g2l[g];
+    }
+  c->nnode = c->node_gid.size();
+  *out = c.release();
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_chunk_sizes(const qdg_chunk* c, size_t* nielem, size_t* nunk, size_t* nnode, size_t* nnbr,
+                               size_t* nsend)
+{
+  QDG_TRY
+  if (!c || !nielem || !nunk || !nnode || !nnbr || !nsend) return fail("qdg_chunk_sizes: null argument");
+  *nielem = c->nielem; *nunk = c->nunk; *nnode = c->nnode; *nnbr = c->nbr_rank.size();
+  *nsend = c->send_elem.size();
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_chunk_get(const qdg_chunk* c, size_t* inpoel, size_t* elem_gid, size_t* node_gid,
+                             int32_t* nbr_rank, size_t* send_off, size_t* send_elem, size_t* recv_off)
+{
+  QDG_TRY
+  if (!c) return fail("qdg_chunk_get: null chunk");
+  auto cp = [](auto* dst, const auto& v) { if (dst && !v.empty()) std::memcpy(dst, v.data(), v.size() * sizeof(v[0])); };
+  cp(inpoel, c->inpoel); cp(elem_gid, c->elem_gid); cp(node_gid, c->node_gid); cp(nbr_rank, c->nbr_rank);
+  cp(send_off, c->send_off); cp(send_elem, c->send_elem); cp(recv_off, c->recv_off);
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_chunk_destroy(qdg_chunk* c)
+{
+  QDG_TRY
+  delete c;
+  return 0;
+  QDG_CATCH
+}

@@ -1,0 +1,76 @@
+"""Decomposition of an arbitrary tetrahedral mesh into the chunks of a one-process-per-GPU
+run: ctypes front-end of qdg_partition / qdg_chunk_build (quinoa_amd/csrc/qdg_partition.cpp).
+
+Stand-in for what Inciter's Partitioner (Zoltan2 geometric cut, src/Inciter/Partitioner.cpp:
+137-170) and the DG chare's ghost set-up (src/Inciter/DG.cpp:134-949) produce; the result has
+the same shape as meshgen.kuhn_box_chunk and feeds dgmesh.build_chunk + Mesh.halo_setup.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+METHOD = {"rcb": 0, "morton": 1}
+
+
+def partition(coord, inpoel, nparts, method="rcb"):
+    """part[e] in [0, nparts) for every tet"""
+    L = capi.lib()
+    coord = np.asarray(coord, dtype=np.float64)
+    inp, pinp = capi._sz(np.asarray(inpoel).reshape(-1))
+    x, px = capi._f64(coord[:, 0]); y, py = capi._f64(coord[:, 1]); z, pz = capi._f64(coord[:, 2])
+    part = np.zeros(len(inp) // 4, dtype=np.int32)
+    capi._chk(L.qdg_partition(C.c_size_t(len(inp) // 4), pinp, C.c_size_t(coord.shape[0]), px, py, pz,
+                              C.c_int(int(nparts)), C.c_int(METHOD[method]), part.ctypes.data_as(capi.c_i32p)))
+    return part
+
+
+def build_chunk(coord, inpoel, sidesets, part, nparts, rank, esuel=None):
+    """One rank's chunk: dict(coord, inpoel, nielem, sidesets, gid, node_gid, nbr_rank,
+    send_lists, recv_counts) in local numbering (owned tets first, ghosts grouped by owner)."""
+    L = capi.lib()
+    coord = np.asarray(coord, dtype=np.float64)
+    inp, pinp = capi._sz(np.asarray(inpoel).reshape(-1))
+    part = np.ascontiguousarray(part, dtype=np.int32)
+    pes = None
+    if esuel is not None:
+        esuel = np.ascontiguousarray(esuel, dtype=np.int32)
+        pes = esuel.ctypes.data_as(capi.c_i32p)
+    h = C.c_void_p()
+    capi._chk(L.qdg_chunk_build(C.c_size_t(len(inp) // 4), C.c_size_t(coord.shape[0]), pinp, pes,
+                                part.ctypes.data_as(capi.c_i32p), C.c_int(int(nparts)), C.c_int(int(rank)),
+                                C.byref(h)))
+    try:
+        n = [C.c_size_t() for _ in range(5)]
+        capi._chk(L.qdg_chunk_sizes(h, *[C.byref(v) for v in n]))
+        nielem, nunk, nnode, nnbr, nsend = (int(v.value) for v in n)
+        linp = np.zeros(4 * nunk, dtype=np.uint64)
+        egid = np.zeros(nunk, dtype=np.uint64)
+        ngid = np.zeros(nnode, dtype=np.uint64)
+        nbr = np.zeros(max(nnbr, 1), dtype=np.int32)
+        soff = np.zeros(nnbr + 1, dtype=np.uint64)
+        roff = np.zeros(nnbr + 1, dtype=np.uint64)
+        selem = np.zeros(max(nsend, 1), dtype=np.uint64)
+        capi._chk(L.qdg_chunk_get(h, linp.ctypes.data_as(capi.c_szp), egid.ctypes.data_as(capi.c_szp),
+                                  ngid.ctypes.data_as(capi.c_szp), nbr.ctypes.data_as(capi.c_i32p),
+                                  soff.ctypes.data_as(capi.c_szp), selem.ctypes.data_as(capi.c_szp),
+                                  roff.ctypes.data_as(capi.c_szp)))
+    finally:
+        L.qdg_chunk_destroy(h)
+    ngid = ngid.astype(np.int64)
+    g2l = np.full(coord.shape[0], -1, dtype=np.int64)
+    g2l[ngid] = np.arange(nnode)
+    ss = {}
+    for sid, tri in (sidesets or {}).items():
+        tri = np.asarray(tri, dtype=np.int64).reshape(-1, 3)
+        loc = g2l[tri]
+        keep = (loc >= 0).all(axis=1)
+        if keep.any():
+            ss[int(sid)] = loc[keep]
+    soff = soff.astype(np.int64); roff = roff.astype(np.int64)
+    return {"coord": coord[ngid], "inpoel": linp.astype(np.int64).reshape(-1, 4), "nielem": nielem,
+            "sidesets": ss, "gid": egid.astype(np.int64), "node_gid": ngid,
+            "nbr_rank": [int(r) for r in nbr[:nnbr]],
+            "send_lists": [selem[soff[i]:soff[i + 1]].astype(np.int64) for i in range(nnbr)],
+            "recv_counts": [int(roff[i + 1] - roff[i]) for i in range(nnbr)]}

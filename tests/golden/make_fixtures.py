@@ -123,12 +123,14 @@ def main():
             # err(.) fields of the manufactured-solution problems included)
             out["exo_names_all"] = np.array(names)
             out["exo_vals_all"] = vals
-        if c.get("golden_exo_chunks"):
-            # per-chare golden chunks of a partitioned run (partition-local order):
-            # keep, per tet, its centroid and the numerical solution at the last
-            # output time; tests match tets to the input mesh by centroid
-            cents, vals, tlast = [], [], None
-            for fn in c["golden_exo_chunks"]:
+        for key, tag in (("golden_exo_chunks", "chunk"), ("golden_exo_chunks_overdecomposed", "ochunk")):
+            if not c.get(key):
+                continue
+            # per-chare golden chunks of a partitioned run (partition-local order): keep, per tet,
+            # its centroid and EVERY element field at the last output time; tests match tets to
+            # the input mesh by centroid (Zoltan's assignment of tets to chares is not reproduced)
+            cents, vals, tlast, names0 = [], [], None, None
+            for fn in c[key]:
                 f = netcdf_file(os.path.join(d, fn), "r", mmap=False)
                 v = f.variables
                 xyz = np.stack([v["coordx"][:], v["coordy"][:], v["coordz"][:]], axis=1).astype(np.float64)
@@ -136,14 +138,20 @@ def main():
                        if v["connect%d" % b].elem_type.decode().upper().startswith("TET")][0]
                 conn = np.array(v["connect%d" % blk][:], dtype=np.int64) - 1
                 names = [_str(r) for r in v["name_elem_var"][:]]
-                iv = names.index("c0_numerical") + 1
+                names0 = names0 or names
+                assert names == names0
                 cents.append(xyz[conn].mean(axis=1))
-                vals.append(np.array(v["vals_elem_var%deb%d" % (iv, blk)][:], dtype=np.float64)[-1])
+                vals.append(np.stack([np.array(v["vals_elem_var%deb%d" % (i + 1, blk)][:], dtype=np.float64)[-1]
+                                      for i in range(len(names))]))
                 tlast = float(v["time_whole"][:][-1])
                 f.close()
-            out["chunk_centroid"] = np.concatenate(cents)
-            out["chunk_c0_last"] = np.concatenate(vals)
-            out["chunk_time_last"] = np.array([tlast])
+            out[tag + "_centroid"] = np.concatenate(cents)
+            out[tag + "_names"] = np.array(names0)
+            out[tag + "_vals_last"] = np.concatenate(vals, axis=1)            # [nfield, ntet]
+            out[tag + "_sizes"] = np.array([len(x) for x in cents])
+            out[tag + "_time_last"] = np.array([tlast])
+            if "c0_numerical" in names0:                                       # (kept for the transport test)
+                out[tag + "_c0_last"] = out[tag + "_vals_last"][names0.index("c0_numerical")]
         if c.get("golden_diag"):
             out["diag"] = read_diag(os.path.join(d, c["golden_diag"]))
         path = os.path.join(HERE, name + ".npz")

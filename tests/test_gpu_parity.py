@@ -109,7 +109,9 @@ def test_time_stepping_matches_reference_golden(name, cases):
         got, gold = np.array(fields), fix["exo_vals_all"]
         assert got.shape == gold.shape
         fin = np.isfinite(gold)
-        assert np.array_equal(np.isinf(got), np.isinf(gold)) and np.array_equal(np.isnan(got), np.isnan(gold))
+        # an err(.) field is x*vol/0: inf, or NaN where x is EXACTLY zero -- which of the two
+        # hinges on the last bit of x, so only "not finite" is compared
+        assert np.array_equal(np.isfinite(got), fin)
         scale = np.maximum(1.0, np.abs(np.where(fin, gold, 0.0)).max(axis=(0, 2)))[None, :, None]
         err = (np.abs(np.where(fin, got - gold, 0.0)) / scale).max()
         assert err <= TOL, (name, err)

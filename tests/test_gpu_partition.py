@@ -1,0 +1,74 @@
+"""A general decomposition (qdg_partition + qdg_chunk_build) of the reference's own Sedov
+fixture run on the GPU: 4 chunks with ghost halos against the reference's committed 4-PE
+baselines (sedov_blastwave_dgp1_pe4.std.exo.{0-3}, sedov_blastwave_pdg_pe4_u0.0.std.exo.{0-3}),
+tets matched by centroid, and against the single-chunk GPU run.  All chunks live on the one GPU
+of the test box (quinoa_amd.dg.LocalChunks: halo slabs moved by device copies)."""
+import numpy as np
+import pytest
+
+from conftest import load_fixture
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10          # north_star bar (the reference's harness: relative 1e-7, exodiff_dg.cfg)
+
+
+def _centroid_order(c):
+    q = np.round(np.asarray(c) * 1e9).astype(np.int64)
+    return np.lexsort((q[:, 2], q[:, 1], q[:, 0]))
+
+
+def _run(case, fix, nparts, method):
+    from quinoa_amd import capi, dg, dgmesh, partition
+    ss = {int(s): fix["ss_tri_%d" % s] for s in fix["ss_ids"]}
+    coord, inpoel = fix["coord"], fix["inpoel"]
+    part = partition.partition(coord, inpoel, nparts, method)
+    ctxs, meshes, chunks, cks = [], [], [], []
+    for r in range(nparts):
+        ch = partition.build_chunk(coord, inpoel, ss, part, nparts, r)
+        ck = dgmesh.build_chunk(ch["coord"], ch["inpoel"], ch["nielem"], ch["sidesets"])
+        ctx = capi.Context(case["ndof"], flux=case["flux"], limiter=case["limiter"], problem=case["problem"],
+                           gamma=case["gamma"], cfl=case["cfl"], dt=case["dt"], bc_dirichlet=case["bc_dirichlet"],
+                           bc_sym=case["bc_sym"], bc_extrapolate=case["bc_extrapolate"],
+                           pref=case.get("pref", False), tolref=case.get("tolref", 0.1))
+        ctxs.append(ctx); meshes.append(dgmesh.upload(ctx, ck)); chunks.append(ch); cks.append(ck)
+    try:
+        drv = dg.LocalChunks(ctxs, meshes, chunks) if nparts > 1 else None
+        for m in meshes:
+            m.state_initialize(0.0)
+        t = 0.0
+        for _ in range(case["nstep"]):
+            t += drv.step(t) if drv else meshes[0].step(t)
+        ne = inpoel.shape[0]
+        nf = len(ctxs[0].field_names())
+        F = np.zeros((nf, ne))
+        for m, ch in zip(meshes, chunks):
+            f, names = m.field_output(t)
+            F[:, ch["gid"][:ch["nielem"]]] = f
+        return F, names, t
+    finally:
+        for m in meshes:
+            m.close()
+        for c in ctxs:
+            c.close()
+
+
+@pytest.mark.parametrize("name,method", [("sedov_dgp1", "rcb"), ("sedov_dgp1", "morton"), ("sedov_pdg", "rcb")])
+def test_partitioned_gpu_run_matches_reference_pe4_goldens(name, method, cases):
+    case, fix = cases[name], load_fixture(name)
+    F4, names, t4 = _run(case, fix, 4, method)
+    F1, _, t1 = _run(case, fix, 1, method)
+    assert names == [str(n) for n in fix["chunk_names"]]
+    scale = np.maximum(1.0, np.abs(F1).max(axis=1))[:, None]
+    assert abs(t4 - t1) <= 1e-11 * t1
+    assert (np.abs(F4 - F1) / scale).max() <= TOL                       # 4 chunks == 1 chunk
+    om = O.OracleMesh(fix["coord"], fix["inpoel"], {})
+    cent = om.geoElem.reshape(-1, 4)[:, 1:]
+    for tag in (("chunk", "ochunk") if name == "sedov_pdg" else ("chunk",)):
+        oa, ob = _centroid_order(cent), _centroid_order(fix[tag + "_centroid"])
+        assert np.abs(cent[oa] - fix[tag + "_centroid"][ob]).max() < 1e-12
+        gold = fix[tag + "_vals_last"][:, ob]
+        assert abs(t4 - float(fix[tag + "_time_last"][0])) <= 1e-10 * t4
+        assert (np.abs(F4[:, oa] - gold) / scale).max() <= TOL          # == the reference's 4-PE / 40-chare run
+        if name == "sedov_pdg":
+            assert np.array_equal(F4[6, oa], gold[6])                   # the per-element ndof field

@@ -56,12 +56,26 @@ def _exchange(comm, drv, U, nielem):
     Um[nielem:nielem + n] = drv.recv_slab[:n * drv.nprop].numpy().reshape(n, drv.nprop)   # halo_unpack
 
 
+def _general_chunk(rank, world, method):
+    """this rank's chunk of the global box mesh through the GENERAL decomposition
+    (qdg_partition + qdg_chunk_build), as for a mesh read from a file"""
+    from quinoa_amd import partition
+    g = meshgen.kuhn_box(NX, NY, NZ)
+    part = partition.partition(g["coord"], g["inpoel"], world, method)
+    ch = partition.build_chunk(g["coord"], g["inpoel"], g["sidesets"], part, world, rank)
+    ch["gid"] = g["gid"][ch["gid"]]          # ids of the undivided generator mesh
+    return ch
+
+
 def _rank_main(rank, world, port, parts, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        ch = meshgen.kuhn_box_chunk(NX, NY, NZ, parts=parts, rank=rank)
+        if isinstance(parts, str):
+            ch = _general_chunk(rank, world, parts)
+        else:
+            ch = meshgen.kuhn_box_chunk(NX, NY, NZ, parts=parts, rank=rank)
         ck = dgmesh.build_chunk(ch["coord"], ch["inpoel"], ch["nielem"], ch["sidesets"])
         cm = O.ChunkMesh(ck.coord, ck.inpoel, ck.nielem, ck.esuel, ck.esuf, ck.inpofa, ck.geoFace,
                          ck.geoElem, ck.bface, ck.nbfac)
@@ -98,11 +112,16 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("parts", [(2, 1, 1), (2, 2, 1), (2, 2, 2)])
+@pytest.mark.parametrize("parts", [(2, 1, 1), (2, 2, 1), (2, 2, 2), "rcb:2", "morton:3"])
 def test_two_rank_halo_run_equals_serial(tmp_path, parts):
     """2, 4 and 8 ranks: (2,2,2) is the decomposition of the 8-GPU bench run -- three
-    face neighbours per rank, every pair's send list / receive range must match"""
-    world = parts[0] * parts[1] * parts[2]
+    face neighbours per rank, every pair's send list / receive range must match.  "rcb:2" /
+    "morton:3": the same run on chunks cut by the general partitioner (qdg_partition +
+    qdg_chunk_build) instead of the box generator's own block cut."""
+    if isinstance(parts, str):
+        parts, world = parts.split(":")[0], int(parts.split(":")[1])
+    else:
+        world = parts[0] * parts[1] * parts[2]
     out = str(tmp_path / "rank%d.npz")
     mp.spawn(_rank_main, args=(world, _free_port(), parts, out), nprocs=world, join=True)
     # serial oracle on the undivided mesh
