@@ -339,6 +339,27 @@ int qdg_chunk_get(const qdg_chunk* c, size_t* inpoel, size_t* elem_gid, size_t* 
                   int32_t* nbr_rank, size_t* send_off, size_t* send_elem, size_t* recv_off);
 int qdg_chunk_destroy(qdg_chunk* c);
 
+/* -- mesh refinement during time stepping (BASELINE config 5) ----------------------------
+ * qdg_refine_uniform: uniform 1:8 refinement, the one refinement the reference's DG scheme
+ * performs at t > 0 (Refiner::dtref with amr::dtref_uniform, src/Inciter/Refiner.cpp:403-408);
+ * children as AMR::refinement_t::refine_one_to_eight builds them
+ * (src/Inciter/AMR/refinement.hpp:425-536).  Result: 8*nelem tets (child 8*e+k of parent e),
+ * the old nodes followed by the edge midpoints, parent[child], 4*ntri side-set triangles
+ * (child 4*t+k of triangle t, same side set).  qdg_refined_get copies out (any pointer may be
+ * NULL): inpoel[32*nelem], parent[8*nelem], x/y/z[nnode_new], tri[12*ntri].
+ * qdg_state_transfer: the solution on the new mesh as DG::resizePostAMR sets it
+ * (src/Inciter/DG.cpp:1597-1605): every child takes its parent's row (all DOFs), device to
+ * device between two mesh handles of one context; parent_of_child in the caller's numbering
+ * of both meshes (nunk(to) entries). */
+typedef struct qdg_refined qdg_refined;
+int qdg_refine_uniform(size_t nelem, size_t nnode, const size_t* inpoel, const double* x,
+                       const double* y, const double* z, size_t ntri, const size_t* tri,
+                       qdg_refined** out);
+int qdg_refined_get(const qdg_refined* r, size_t* nnode, size_t* inpoel, size_t* parent,
+                    double* x, double* y, double* z, size_t* tri);
+int qdg_refined_destroy(qdg_refined* r);
+int qdg_state_transfer(qdg_mesh* from, qdg_mesh* to, const size_t* parent_of_child);
+
 /* -- mesh-derived data generated on the device (first step) -----
  * The same arrays as qdg_gen_esuel / nipfac / inpofa / belem / esuf / geoface /
  * geoelem above (src/Inciter/FaceData.cpp:19-41, src/Mesh/DerivedData.cpp:937-1491),

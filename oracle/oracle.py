@@ -468,12 +468,13 @@ def run_case(case, fix, nstep=None, on_step=None):
 TR_PROBLEM = {"slot_cyl": 1, "cyl_advect": 2, "gauss_hump": 3}
 
 
-def run_transport_case(case, fix, nstep=None):
+def run_transport_case(case, fix, nstep=None, U0=None, t0=0.0, it0=0):
     """dg::Transport with one scalar (src/PDE/Transport/DGTransport.hpp:129-186,
     Upwind flux) on one chunk, fixed dt, in the DG chare's stage order: limiter
     (WENO_P1 / Superbee_P1 with ncomp = 1), rhs, SSP-RK3; with scheme pdg also
     eval_ndof / propagate_ndof / zeroing at stage 0.  BASELINE config 1 is the
-    slot_cyl DG-P0 case."""
+    slot_cyl DG-P0 case.  U0 / t0 / it0: continue from a given state (after a mesh refinement:
+    the state DG::resizePostAMR hands over) instead of projecting the initial condition."""
     L = lib()
     m = OracleMesh(fix["coord"], fix["inpoel"],
                    {int(s): fix["ss_tri_%d" % s] for s in fix["ss_ids"]})
@@ -499,17 +500,19 @@ def run_transport_case(case, fix, nstep=None):
     U = np.zeros(ne * ndof)
     L.orc_tr_initialize(prob, C.c_int64(ndof), _p(Lm, c_f64p), _p(inp, c_i64p), _p(m.x, c_f64p),
                         _p(m.y, c_f64p), _p(m.z, c_f64p), _p(U, c_f64p), C.c_double(0.0), C.c_int64(ne))
+    if U0 is not None:
+        U[:] = np.asarray(U0, dtype=np.float64).reshape(-1)
     ndofel = np.full(ne, ndof, dtype=np.int64)
     Un, R = np.zeros_like(U), np.zeros_like(U)
-    t, dt, rows = 0.0, case["dt"], []
+    t, dt, rows = float(t0), case["dt"], []
     nstep = case["nstep"] if nstep is None else nstep
     plot = case.get("plot_interval", 1)
     means = lambda: U.reshape(ne, ndof)[:, 0].copy()
-    fields, times, ndofs = [means()], [0.0], [ndofel.copy()]
+    fields, times, ndofs = [means()], [t], [ndofel.copy()]
     if pref:
         L.orc_set_ndofel(_p(ndofel, c_i64p))
     try:
-        for it in range(nstep):
+        for it in range(it0, it0 + nstep):
             for stage in range(3):
                 if pref and stage == 0:
                     L.orc_tr_eval_ndof(C.c_int64(ndof), C.c_int64(ne), *mesh_args, _p(U, c_f64p),
@@ -538,7 +541,7 @@ def run_transport_case(case, fix, nstep=None):
                 L.orc_tr_diag(prob, C.c_int64(ndof), C.c_double(t), *mesh_args, _p(m.geoElem, c_f64p),
                               _p(U, c_f64p), C.c_int64(ne), _p(out, c_f64p))
                 rows.append([it + 1, t, dt, np.sqrt(out[0] / m.meshvol), np.sqrt(out[1] / m.meshvol), out[2]])
-            if (it + 1) % plot == 0 or it + 1 == nstep:
+            if (it + 1) % plot == 0 or it + 1 == it0 + nstep:
                 fields.append(means()); times.append(t); ndofs.append(ndofel.copy())
     finally:
         if pref:

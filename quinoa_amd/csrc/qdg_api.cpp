@@ -1525,6 +1525,38 @@ extern "C" int qdg_diag(qdg_mesh* mesh, double t_new, double* out15)
   QDG_CATCH
 }
 
+// ---------------------------------------------------------------- state transfer after AMR
+
+extern "C" int qdg_state_transfer(qdg_mesh* from, qdg_mesh* to, const size_t* parent_of_child)
+{
+  QDG_TRY
+  if (!from || !to || !parent_of_child) return fail("qdg_state_transfer: null argument");
+  if (from->ctx != to->ctx) return fail("qdg_state_transfer: the two meshes must belong to one context");
+  if (from->nprop != to->nprop) return fail("qdg_state_transfer: row length differs");
+  if (from->dm.ndofel || to->dm.ndofel)
+    return fail("qdg_state_transfer: p-adaptive runs are not combined with mesh refinement "
+                "(DG::resizePostAMR does not carry m_ndof over either)");
+  qdg_ctx* ctx = to->ctx;
+  HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  std::vector<int> par(to->ne), d2h(from->ne), h2d(from->ne);
+  for (size_t c = 0; c < to->ne; ++c) {
+    if (parent_of_child[c] >= from->ne) return fail("qdg_state_transfer: parent id out of range");
+    par[c] = (int)parent_of_child[c];
+  }
+  HIPCHK(hipMemcpy(d2h.data(), from->d2h.p, from->ne * sizeof(int), hipMemcpyDeviceToHost));
+  for (size_t d = 0; d < from->ne; ++d) h2d[d2h[d]] = (int)d;
+  DevBuf<int> dpar, dh2d;
+  HIPCHK(dpar.upload(par, s));
+  HIPCHK(dh2d.upload(h2d, s));
+  launch_state_transfer((int)to->ne, to->nprop, to->d2h.p, dpar.p, dh2d.p, from->Ucur, to->Ucur, s);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(s));
+  to->Unp = nullptr; to->Upending = nullptr;
+  return 0;
+  QDG_CATCH
+}
+
 // ---------------------------------------------------------------- halo
 
 // doubles per slab row: the row of U, plus the tet's ndof with p-adaptive DG

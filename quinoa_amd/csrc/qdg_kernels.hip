@@ -3126,6 +3126,31 @@ __global__ void k_copy_rows(const double* __restrict__ src, double* __restrict__
   if (i < n) dst[i] = src[i];
 }
 
+// DG::resizePostAMR (src/Inciter/DG.cpp:1597-1605): a child takes its parent's row.
+// to-row d (device order of the new mesh) <- from-row h2d_from[parent[d2h_to[d]]]
+__global__ __launch_bounds__(256) void k_state_transfer(int nrow, int nchunk, const int* __restrict__ d2h_to,
+                                                        const int* __restrict__ parent,
+                                                        const int* __restrict__ h2d_from,
+                                                        const double2* __restrict__ Ufrom,
+                                                        double2* __restrict__ Uto)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)nrow * nchunk) return;
+  const int d = (int)(i / nchunk), p = (int)(i - (size_t)d * nchunk);
+  Uto[i] = Ufrom[(size_t)h2d_from[parent[d2h_to[d]]] * nchunk + p];
+}
+__global__ __launch_bounds__(256) void k_state_transfer1(int nrow, int nprop, const int* __restrict__ d2h_to,
+                                                         const int* __restrict__ parent,
+                                                         const int* __restrict__ h2d_from,
+                                                         const double* __restrict__ Ufrom,
+                                                         double* __restrict__ Uto)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)nrow * nprop) return;
+  const int d = (int)(i / nprop), p = (int)(i - (size_t)d * nprop);
+  Uto[i] = Ufrom[(size_t)h2d_from[parent[d2h_to[d]]] * nprop + p];
+}
+
 // ------------------------------------------------------------- halo
 // DG::next / DG::lim send side (src/Inciter/DG.cpp:1023-1036, 1266-1279):
 // slab row j = U[send_elem[j]] (element-major rows of nprop doubles)
@@ -3443,6 +3468,21 @@ void launch_soa2aos(const double* soa, int nprop, const int* d2h, int n0, int n1
   if (n1 <= n0) return;
   const size_t n = (size_t)(n1 - n0) * nprop;
   k_rows_out<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(soa, nprop, d2h, n0, n1, aos);
+}
+
+void launch_state_transfer(int nrow, int nprop, const int* d2h_to, const int* parent, const int* h2d_from,
+                           const double* Ufrom, double* Uto, hipStream_t s)
+{
+  if (nrow == 0) return;
+  if (nprop % 2 == 0) {
+    const size_t n = (size_t)nrow * (nprop / 2);
+    k_state_transfer<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(nrow, nprop / 2, d2h_to, parent, h2d_from,
+                                                                 reinterpret_cast<const double2*>(Ufrom),
+                                                                 reinterpret_cast<double2*>(Uto));
+  } else {
+    const size_t n = (size_t)nrow * nprop;
+    k_state_transfer1<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(nrow, nprop, d2h_to, parent, h2d_from, Ufrom, Uto);
+  }
 }
 
 void launch_halo_pack(const double* U, int nprop, int /*stride*/, const int* send_elem, int nsend,

@@ -58,6 +58,8 @@ void launch_halo_pack(const double* U, int nprop, int stride, const int* send_el
 void launch_halo_unpack(const double* slab, int nprop, int stride, int nie, int nrecv, double* U,
                         hipStream_t s, int* ndofel = nullptr);
 
+void launch_state_transfer(int nrow, int nprop, const int* d2h_to, const int* parent, const int* h2d_from,
+                           const double* Ufrom, double* Uto, hipStream_t s);
 void launch_solution(int ncomp, const Phys& ph, int n, const double* x, const double* y, const double* z,
                      double t, double* out, hipStream_t s);
 // number of element fields of Problem::fieldNames (without the ndof column of p-adaptive runs)

@@ -234,3 +234,118 @@ extern "C" int qdg_chunk_destroy(qdg_chunk* c)
   return 0;
   QDG_CATCH
 }
+
+// ---------------------------------------------------------------------------------------
+// Uniform 1:8 refinement of a tetrahedron mesh -- the only kind of mesh refinement the
+// reference's DG scheme runs during time stepping (Refiner::dtref with amr::dtref_uniform,
+// src/Inciter/Refiner.cpp:403-408; error-based refinement does nothing for element-centred
+// schemes, :946-950).  Children and their local node order follow AMR::refinement_t::
+// refine_one_to_eight (src/Inciter/AMR/refinement.hpp:425-536): for the tet (A,B,C,D) with
+// edge midpoints AB..CD, four corner tets and four tets of the inner octahedron cut along its
+// AC-BD diagonal, in an order that keeps the Jacobian positive.  A boundary triangle (a,b,c)
+// becomes (a,ab,ac), (b,bc,ab), (c,ac,bc), (ab,bc,ac) on the same side set (Refiner::boundary
+// regenerates the side sets of the children).  New nodes are the edge midpoints, numbered after
+// the old ones in the order the tets meet their edges.
+struct qdg_refined {
+  size_t nnode = 0;
+  std::vector<size_t> inpoel, parent, tri;
+  std::vector<double> x, y, z;
+};
+
+extern "C" int qdg_refine_uniform(size_t nelem, size_t nnode, const size_t* inpoel, const double* x,
+                                  const double* y, const double* z, size_t ntri, const size_t* tri,
+                                  qdg_refined** out)
+{
+  QDG_TRY
+  if (!inpoel || !x || !y || !z || !out || (ntri && !tri)) return fail("qdg_refine_uniform: null argument");
+  *out = nullptr;
+  if (nnode > (size_t)UINT32_MAX) return fail("qdg_refine_uniform: too many nodes");
+  std::unique_ptr<qdg_refined> r(new qdg_refined);
+  r->x.assign(x, x + nnode); r->y.assign(y, y + nnode); r->z.assign(z, z + nnode);
+  // edge (min,max) -> midpoint node: sort-based (no hashing: deterministic and cache friendly)
+  static const int EDG[6][2] = { {0, 1}, {0, 2}, {0, 3}, {1, 2}, {1, 3}, {2, 3} };   // AB AC AD BC BD CD
+  struct E { uint64_t key; size_t slot; };
+  std::vector<E> ed(6 * nelem);
+  for (size_t e = 0; e < nelem; ++e)
+    for (int k = 0; k < 6; ++k) {
+      const size_t a = inpoel[4 * e + EDG[k][0]], b = inpoel[4 * e + EDG[k][1]];
+      if (a >= nnode || b >= nnode) return fail("qdg_refine_uniform: inpoel entry out of range");
+      if (a == b) return fail("qdg_refine_uniform: degenerate tet");
+      ed[6 * e + k] = { ((uint64_t)std::min(a, b) << 32) | (uint64_t)std::max(a, b), 6 * e + k };
+    }
+  std::vector<E> sorted = ed;
+  std::sort(sorted.begin(), sorted.end(), [](const E& p, const E& q) { return p.key < q.key || (p.key == q.key && p.slot < q.slot); });
+  // the first slot (in tet order) that meets an edge numbers its midpoint
+  std::vector<size_t> mid(6 * nelem), first(6 * nelem);
+  for (size_t i = 0; i < sorted.size();) {
+    size_t j = i;
+    while (j < sorted.size() && sorted[j].key == sorted[i].key) { first[sorted[j].slot] = sorted[i].slot; ++j; }
+    i = j;
+  }
+  size_t nn = nnode;
+  for (size_t s = 0; s < 6 * nelem; ++s)
+    if (first[s] == s) {
+      const size_t a = (size_t)(ed[s].key >> 32), b = (size_t)(ed[s].key & 0xffffffffu);
+      mid[s] = nn++;
+      r->x.push_back(0.5 * (x[a] + x[b])); r->y.push_back(0.5 * (y[a] + y[b])); r->z.push_back(0.5 * (z[a] + z[b]));
+    }
+  for (size_t s = 0; s < 6 * nelem; ++s) mid[s] = mid[first[s]];
+  r->nnode = nn;
+  r->inpoel.resize(32 * nelem); r->parent.resize(8 * nelem);
+  for (size_t e = 0; e < nelem; ++e) {
+    const size_t A = inpoel[4 * e], B = inpoel[4 * e + 1], C = inpoel[4 * e + 2], D = inpoel[4 * e + 3];
+    const size_t AB = mid[6 * e], AC = mid[6 * e + 1], AD = mid[6 * e + 2], BC = mid[6 * e + 3],
+                 BD = mid[6 * e + 4], CD = mid[6 * e + 5];
+    const size_t ch[8][4] = { { A, AB, AC, AD }, { B, BC, AB, BD }, { C, AC, BC, CD }, { D, AD, CD, BD },
+                              { BC, CD, AC, BD }, { AB, BD, AC, AD }, { AB, BC, AC, BD }, { AC, BD, CD, AD } };
+    for (int k = 0; k < 8; ++k) {
+      for (int i = 0; i < 4; ++i) r->inpoel[4 * (8 * e + k) + i] = ch[k][i];
+      r->parent[8 * e + k] = e;
+    }
+  }
+  // boundary triangles: midpoints looked up among the tets' edges
+  if (ntri) {
+    std::vector<std::pair<uint64_t, size_t>> keymid(sorted.size());
+    for (size_t i = 0; i < sorted.size(); ++i) keymid[i] = { sorted[i].key, mid[sorted[i].slot] };
+    auto find = [&](size_t a, size_t b, size_t& m) {
+      const uint64_t key = ((uint64_t)std::min(a, b) << 32) | (uint64_t)std::max(a, b);
+      auto it = std::lower_bound(keymid.begin(), keymid.end(), std::make_pair(key, (size_t)0));
+      if (it == keymid.end() || it->first != key) return false;
+      m = it->second;
+      return true;
+    };
+    r->tri.resize(12 * ntri);
+    for (size_t t = 0; t < ntri; ++t) {
+      const size_t a = tri[3 * t], b = tri[3 * t + 1], c = tri[3 * t + 2];
+      size_t ab, bc, ac;
+      if (a >= nnode || b >= nnode || c >= nnode || !find(a, b, ab) || !find(b, c, bc) || !find(a, c, ac))
+        return fail("qdg_refine_uniform: a side-set triangle is not a face of the mesh");
+      const size_t ct[4][3] = { { a, ab, ac }, { b, bc, ab }, { c, ac, bc }, { ab, bc, ac } };
+      for (int k = 0; k < 4; ++k)
+        for (int i = 0; i < 3; ++i) r->tri[3 * (4 * t + k) + i] = ct[k][i];
+    }
+  }
+  *out = r.release();
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_refined_get(const qdg_refined* r, size_t* nnode, size_t* inpoel, size_t* parent,
+                               double* x, double* y, double* z, size_t* tri)
+{
+  QDG_TRY
+  if (!r) return fail("qdg_refined_get: null handle");
+  if (nnode) *nnode = r->nnode;
+  auto cp = [](auto* dst, const auto& v) { if (dst && !v.empty()) std::memcpy(dst, v.data(), v.size() * sizeof(v[0])); };
+  cp(inpoel, r->inpoel); cp(parent, r->parent); cp(x, r->x); cp(y, r->y); cp(z, r->z); cp(tri, r->tri);
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_refined_destroy(qdg_refined* r)
+{
+  QDG_TRY
+  delete r;
+  return 0;
+  QDG_CATCH
+}

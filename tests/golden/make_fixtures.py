@@ -58,6 +58,13 @@ def read_mesh(path):
         ids = np.array(v["ss_prop1"][:], dtype=np.int64)
         for k, sid in enumerate(ids, start=1):
             el = np.array(v["elem_ss%d" % k][:], dtype=np.int64)
+            if tri is None:
+                # side sets given as (tet, ExodusII side number): side 1..4 of a TETRA are its
+                # nodes (1,2,4), (2,3,4), (1,4,3), (1,3,2)
+                side = np.array(v["side_ss%d" % k][:], dtype=np.int64)
+                tab = np.array([[0, 1, 3], [1, 2, 3], [0, 3, 2], [0, 2, 1]])
+                ss[int(sid)] = tet[el - 1][np.arange(len(el))[:, None], tab[side - 1]]
+                continue
             # every side set of the CompFlow fixtures references TRI-block
             # elements (file ids tri_first_id .. tri_first_id+ntri-1)
             loc = el - tri_first_id
@@ -152,6 +159,23 @@ def main():
             out[tag + "_time_last"] = np.array([tlast])
             if "c0_numerical" in names0:                                       # (kept for the transport test)
                 out[tag + "_c0_last"] = out[tag + "_vals_last"][names0.index("c0_numerical")]
+        if c.get("golden_exo_series"):
+            # a run with mesh refinement during time stepping writes one file per mesh: keep, per
+            # series, the refined mesh itself (coordinates + tets: this is what pins the 1:8 child
+            # pattern), the output times and every element field
+            for k, fn in enumerate(c["golden_exo_series"]):
+                f = netcdf_file(os.path.join(d, fn), "r", mmap=False)
+                v = f.variables
+                blk = [b for b in range(1, f.dimensions["num_el_blk"] + 1)
+                       if v["connect%d" % b].elem_type.decode().upper().startswith("TET")][0]
+                names = [_str(r) for r in v["name_elem_var"][:]]
+                out["s%d_coord" % k] = np.stack([v["coordx"][:], v["coordy"][:], v["coordz"][:]], axis=1).astype(np.float64)
+                out["s%d_inpoel" % k] = np.array(v["connect%d" % blk][:], dtype=np.int64) - 1
+                out["s%d_times" % k] = np.array(v["time_whole"][:], dtype=np.float64)
+                out["s%d_vals" % k] = np.stack([np.array(v["vals_elem_var%deb%d" % (i + 1, blk)][:], dtype=np.float64)
+                                               for i in range(len(names))], axis=1)      # [time, var, elem]
+                out["series_names"] = np.array(names)
+                f.close()
         if c.get("golden_diag"):
             out["diag"] = read_diag(os.path.join(d, c["golden_diag"]))
         path = os.path.join(HERE, name + ".npz")

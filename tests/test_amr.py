@@ -1,0 +1,79 @@
+"""Mesh refinement during time stepping (BASELINE config 5's loop): uniform 1:8 refinement
+(qdg_refine_uniform) + the state hand-over of DG::resizePostAMR, pinned on the reference's own
+DG regression case with t>0 refinement: tests/regression/inciter/mesh_refinement/dtref/
+gauss_hump.q (dg::Transport, DG-P0, uniform refinement every 5 of 10 steps, 112 -> 896 -> 7 168
+tets) and its committed goldens gauss_hump_u_trans_pe1_u0.0.std.e-s.{0,1,2}.1.0 + gauss_hump_dg.std.
+Host code + CPU oracle only."""
+import numpy as np
+
+from conftest import load_fixture
+from oracle import oracle as O
+from quinoa_amd import amr
+
+
+def _ss(fix):
+    return {int(s): fix["ss_tri_%d" % s] for s in fix["ss_ids"]}
+
+
+def test_uniform_refinement_reproduces_the_reference_refined_meshes():
+    """the children of refine_one_to_eight (AMR/refinement.hpp:425-536): same tets in the same
+    order and the same coordinates as the meshes inside the reference's golden files, twice"""
+    fix = load_fixture("gauss_hump_dtref")
+    c, i, s = fix["coord"], fix["inpoel"], _ss(fix)
+    assert np.array_equal(fix["s0_inpoel"], i)
+    for k in (1, 2):
+        ne = i.shape[0]
+        c, i, s, par = amr.refine_uniform(c, i, s)
+        gc, gi = fix["s%d_coord" % k], fix["s%d_inpoel" % k]
+        assert i.shape == gi.shape and c.shape == gc.shape
+        assert np.array_equal(par, np.repeat(np.arange(ne), 8))
+        # element by element: the same four points (node numbering of the new nodes may differ)
+        assert np.abs(c[i].mean(axis=1) - gc[gi].mean(axis=1)).max() <= 1e-15
+        # children tile the parent: positive volumes that add up
+        v = np.einsum("ij,ij->i", c[i[:, 1]] - c[i[:, 0]], np.cross(c[i[:, 2]] - c[i[:, 0]], c[i[:, 3]] - c[i[:, 0]])) / 6.0
+        assert v.min() > 0.0 and abs(v.sum() - 1.0) <= 1e-13
+        # side sets: 4 children per boundary triangle, all still on the boundary of the new mesh
+        om = O.OracleMesh(c, i, s)
+        assert om.nbfac == sum(len(t) for t in s.values()) == int((om.esuel == -1).sum())
+
+
+def test_refined_run_matches_reference_dtref_goldens(cases):
+    """10 steps with uniform refinement after steps 5 and 10 (DG::refine, DG.cpp:1511-1534:
+    It % dtfreq == 0), child <- parent (DG.cpp:1597-1605): every output time of the three golden
+    files (c0_numerical, c0_analytic, c0_error) and the diagnostics table."""
+    case, fix = cases["gauss_hump_dtref"], load_fixture("gauss_hump_dtref")
+    c, i, s = fix["coord"], fix["inpoel"], _ss(fix)
+    U, t, it, rows = None, 0.0, 0, []
+    for k in range(3):
+        f = {"coord": c, "inpoel": i, "ss_ids": np.array(sorted(s))}
+        for sid in s:
+            f["ss_tri_%d" % sid] = s[sid]
+        nstep = case["dtfreq"] if k < 2 else 0
+        r = O.run_transport_case(case, f, nstep=nstep, U0=U, t0=t, it0=it)
+        gt, gv = fix["s%d_times" % k], fix["s%d_vals" % k]
+        nout = len(gt)
+        # the step that triggers the refinement is written on the NEW mesh: the old mesh's file
+        # ends one output earlier
+        assert np.allclose(r["times"][:nout], gt, rtol=0, atol=1e-15)
+        assert np.abs(r["fields"][:nout] - gv[:, 0]).max() <= 1e-13          # c0_numerical
+        m = r["mesh"]
+        ge = m.geoElem.reshape(-1, 4)
+        for j in range(nout):
+            out = np.zeros((3, m.nelem))
+            O.lib().orc_tr_field_output(O.TR_PROBLEM["gauss_hump"], O.C.c_int64(1), O.C.c_double(gt[j]),
+                                        O.C.c_int64(m.nelem), O._p(m.geoElem, O.c_f64p),
+                                        O._p(np.ascontiguousarray(r["fields"][j]), O.c_f64p), O._p(out, O.c_f64p))
+            assert np.abs(out[1] - gv[j, 1]).max() <= 1e-14                   # c0_analytic
+            assert np.abs(out[2] - gv[j, 2]).max() <= 1e-15                   # c0_error
+        rows += [row for row in r["diag"]]
+        U, t, it = r["U"], r["t"], it + nstep
+        if k < 2:
+            c, i, s, par = amr.refine_uniform(c, i, s)
+            U = U.reshape(-1, 1)[par].reshape(-1)        # DG::resizePostAMR: child <- parent
+    gold = {int(g[0]): g for g in fix["diag"]}
+    assert sorted(int(r[0]) for r in rows) == sorted(gold)
+    for r in rows:
+        g = gold[int(r[0])]
+        # L2(c0) and L2(c0 - analytic): the latter jumps by two orders after the first refinement
+        # in the reference's table too (1.27e-3 -> 1.01e-1)
+        assert abs(r[1] - g[1]) <= 1e-12 and abs(r[3] - g[3]) <= 6e-7 * g[3] and abs(r[4] - g[4]) <= 6e-7 * g[4], (r, g)

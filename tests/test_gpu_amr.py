@@ -1,0 +1,95 @@
+"""BASELINE config 5's loop on the GPU: uniform 1:8 refinement while time stepping -- host
+refinement (qdg_refine_uniform), mesh-derived data of the new mesh generated on the device
+(qdg_mesh_from_connectivity), state handed over on the device (qdg_state_transfer) -- against
+the reference's own t>0-refinement golden (mesh_refinement/dtref/gauss_hump.q) and, for the
+config's CompFlow DG-P1 physics, against the oracle on the refined mesh."""
+import numpy as np
+import pytest
+
+from conftest import load_fixture
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _ss(fix):
+    return {int(s): fix["ss_tri_%d" % s] for s in fix["ss_ids"]}
+
+
+def test_gpu_refined_run_matches_reference_dtref_goldens(cases):
+    from quinoa_amd import amr, capi
+    case, fix = cases["gauss_hump_dtref"], load_fixture("gauss_hump_dtref")
+    ctx = capi.Context(1, flux="upwind", problem="gauss_hump", dt=case["dt"], pde="transport",
+                       bc_extrapolate=case["bc_extrapolate"], bc_inlet=case["bc_inlet"], bc_outlet=case["bc_outlet"])
+    run = amr.RefinedRun(ctx, fix["coord"], fix["inpoel"], _ss(fix))
+    try:
+        run.mesh.state_initialize(0.0)
+        t, it, rows = 0.0, 0, []
+        for k in range(3):
+            gt, gv = fix["s%d_times" % k], fix["s%d_vals" % k]
+            out = [run.mesh.field_output(t)[0]]
+            vol = None
+            for _ in range(case["dtfreq"] if k < 2 else 0):
+                t += run.mesh.step(t)
+                it += 1
+                if it % case["diag_interval"] == 0:
+                    if vol is None:
+                        vol = O.OracleMesh(run.coord, run.inpoel, {}).meshvol
+                    d = run.mesh.diag(t)
+                    rows.append([it, t, np.sqrt(d[0] / vol), np.sqrt(d[5] / vol)])
+                out.append(run.mesh.field_output(t)[0])
+            got = np.array(out[:len(gt)])            # [time, var, elem]
+            assert got.shape == gv.shape
+            assert np.abs(got - gv).max() <= 1e-10, k
+            if k < 2:
+                run.refine()
+                assert run.mesh.nielem == 8 * gv.shape[2]
+        gold = {int(g[0]): g for g in fix["diag"]}
+        assert len(rows) == len(gold)
+        for r in rows:
+            g = gold[int(r[0])]
+            assert abs(r[1] - g[1]) <= 1e-12 and abs(r[2] - g[3]) <= 6e-7 * g[3] and abs(r[3] - g[4]) <= 6e-7 * g[4]
+    finally:
+        run.mesh.close(); ctx.close()
+
+
+@pytest.mark.parametrize("ndof,limiter", [(4, "superbeep1"), (1, "nolimiter")])
+def test_config5_physics_refine_once_matches_oracle(ndof, limiter):
+    """config 5: CompFlow (Sod) with a uniform refinement in the middle of the run.  GPU: 4 steps,
+    refine + rebuild on the device + transfer, 4 more steps.  Oracle: the same steps on the two
+    meshes with the state copied child <- parent (all DOFs of the row, DG.cpp:1597-1605)."""
+    from quinoa_amd import amr, capi, meshgen
+    ch = meshgen.kuhn_box(6, 4, 3, lengths=(1.0, 0.4, 0.3))
+    kw = dict(flux="hllc", limiter=limiter, problem="sod_shocktube", gamma=1.4)
+    bc = dict(bc_sym=[3, 4, 5, 6], bc_extrapolate=[1, 2])
+    ctx = capi.Context(ndof, cfl=0.3, **kw, **bc)
+    run = amr.RefinedRun(ctx, ch["coord"], ch["inpoel"], ch["sidesets"])
+    try:
+        run.mesh.state_initialize(0.0)
+        om = O.OracleMesh(ch["coord"], ch["inpoel"], ch["sidesets"])
+        orc = O.Oracle(om, O.make_cfg(ndof, **kw), **bc)
+        Lm = orc.lhs(); U = orc.initialize(Lm, 0.0)
+        t = 0.0
+        for _ in range(4):
+            dtg = run.mesh.step(t)
+            dto = orc.step(t, U, Lm, cfl=0.3)
+            assert abs(dtg - dto) <= 1e-11 * dto
+            t += dto
+        assert np.abs(run.mesh.state_download() - U).max() <= 1e-10
+        tim = run.refine()
+        assert len(tim) == 3 and run.mesh.nielem == 8 * om.nelem
+        c2, i2, s2, par = amr.refine_uniform(ch["coord"], ch["inpoel"], ch["sidesets"])
+        assert np.array_equal(i2, run.inpoel)
+        U = U.reshape(om.nelem, -1)[par].reshape(-1)
+        assert np.array_equal(run.mesh.state_download(), U)          # the hand-over is a pure copy
+        om2 = O.OracleMesh(c2, i2, s2)
+        orc2 = O.Oracle(om2, O.make_cfg(ndof, **kw), **bc)
+        L2 = orc2.lhs()
+        for _ in range(4):
+            dtg = run.mesh.step(t)
+            dto = orc2.step(t, U, L2, cfl=0.3)
+            assert abs(dtg - dto) <= 1e-11 * dto
+            t += dto
+        assert np.abs(run.mesh.state_download() - U).max() <= 1e-10 * max(1.0, np.abs(U).max())
+    finally:
+        run.mesh.close(); ctx.close()
