@@ -256,6 +256,9 @@ int qdg_halo_buffers(qdg_mesh* mesh, void** send_dev, void** recv_dev,
 int qdg_halo_use_buffers(qdg_mesh* mesh, void* send_dev, void* recv_dev);
 int qdg_halo_sizes(qdg_mesh* mesh, size_t* nsend_rows, size_t* nrecv_rows);
 int qdg_stage_dt_use_buffer(qdg_mesh* mesh, void* dt_dev);
+/* local transport between chunks of ONE context (same device, same stream): send-slab rows of
+ * src -> receive-slab rows of dst */
+int qdg_halo_copy(qdg_mesh* dst, size_t dst_row0, qdg_mesh* src, size_t src_row0, size_t nrows);
 int qdg_halo_pack(qdg_mesh* mesh);     /* U[send list] -> send slab */
 int qdg_halo_unpack(qdg_mesh* mesh);   /* recv slab -> ghost rows of U */
 

@@ -452,6 +452,11 @@ class Mesh:
         _chk(lib().qdg_rhs_algorithmic_bytes(self.h, C.byref(b)))
         return b.value
 
+    def halo_copy_from(self, dst_row0, src, src_row0, nrows):
+        """send-slab rows of `src` -> receive-slab rows of this chunk (same context)"""
+        _chk(lib().qdg_halo_copy(self.h, C.c_size_t(int(dst_row0)), src.h, C.c_size_t(int(src_row0)),
+                                 C.c_size_t(int(nrows))))
+
     def halo_pack(self):
         _chk(lib().qdg_halo_pack(self.h))
 

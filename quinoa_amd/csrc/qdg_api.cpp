@@ -562,9 +562,11 @@ extern "C" int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t 
     h_tile_row.push_back((int)nie);
   }
   const int ntile = (int)h_tile_row.size() - 1;
+  const bool fixed_tiles = [&] { const char* l = std::getenv("QDG_TILE_TASKS"); return !(l && std::atoi(l) > 0); }();
   int ntile_inner = 0;
   while (ntile_inner < ntile && (size_t)h_tile_row[ntile_inner + 1] <= ninner) ++ntile_inner;
   std::vector<int> h_tile_off(ntile + 1, 0), h_task_a, h_task_nb, h_task_f;
+  int task_stride = 0;
   {
     struct Task { int key, a, nb, f; };
     // tasks of tile t in its (kind, local face) order; two passes over the tiles on all
@@ -595,23 +597,27 @@ extern "C" int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t 
     }, 256);
     for (int t = 0; t < ntile; ++t) h_tile_off[t + 1] += h_tile_off[t];
     const size_t ntask = (size_t)h_tile_off[ntile];
-    h_task_a.resize(ntask); h_task_nb.resize(ntask); h_task_f.resize(ntask);
+    // QDG_TASK_PAD=1: fixed-stride task lists (4 rounds of the workgroup per tile, unused slots
+    // -1) for the v2 tile kernel: no offset load in front of the descriptors
+    task_stride = (std::getenv("QDG_TASK_PAD") && !ctx->cfg.pref) ? 4 * TILE_BS : 0;
+    const size_t nslot = task_stride ? (size_t)ntile * task_stride : ntask;
+    h_task_a.assign(nslot, -1); h_task_nb.assign(nslot, 0); h_task_f.assign(nslot, 0);
     parallel_for((size_t)ntile, [&](size_t t0, size_t t1) {
       std::vector<Task> tt;
       for (size_t t = t0; t < t1; ++t) {
         tile_tasks((int)t, tt);
-        size_t o = (size_t)h_tile_off[t];
+        size_t o = task_stride ? t * (size_t)task_stride : (size_t)h_tile_off[t];
         for (const Task& k : tt) { h_task_a[o] = k.a; h_task_nb[o] = k.nb; h_task_f[o] = k.f; ++o; }
       }
     }, 256);
     lap("face tasks per tile");
     if (stats) {
       size_t cnt[3] = { 0, 0, 0 };
-      for (int a : h_task_a) ++cnt[(a >> 17) & 3];
+      for (int a : h_task_a) if (a >= 0) ++cnt[(a >> 17) & 3];
       std::fprintf(stderr, "qdg upload: %zu tets, %d tiles, tasks per tet: interior-in-tile %.3f, "
                    "to other tiles/ghosts %.3f, boundary %.3f; tasks per tile %.1f, rows per tile %.1f\n", nie, ntile,
                    (double)cnt[TASK_INT] / nie, (double)cnt[TASK_EXT] / nie, (double)cnt[TASK_BND] / nie,
-                   (double)h_task_a.size() / ntile, (double)nie / ntile);
+                   (double)ntask / ntile, (double)nie / ntile);
     }
   }
 
@@ -662,7 +668,8 @@ extern "C" int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t 
   HIPCHK(m->tile_row.upload(h_tile_row, s));
   HIPCHK(m->tile_off.upload(h_tile_off, s)); HIPCHK(m->task_a.upload(h_task_a, s));
   HIPCHK(m->task_nb.upload(h_task_nb, s)); HIPCHK(m->task_f.upload(h_task_f, s));
-  dm.ntile = ntile; dm.ntile_inner = ntile_inner; dm.tile_row = m->tile_row.p;
+  dm.ntile = ntile; dm.ntile_inner = ntile_inner; dm.tile_row = m->tile_row.p; dm.task_stride = task_stride;
+  dm.tile_rows = fixed_tiles ? TILE : 0;
   dm.tile_off = m->tile_off.p; dm.task_a = m->task_a.p;
   dm.task_nb = m->task_nb.p; dm.task_f = m->task_f.p;
   dm.blk0 = 0; dm.ninner = (int)ninner; dm.ncomp = ncomp;
@@ -1636,6 +1643,25 @@ extern "C" int qdg_halo_unpack(qdg_mesh* mesh)
   launch_halo_unpack(mesh->recv_ptr, mesh->nprop, (int)mesh->stride, (int)mesh->nie,
                      (int)mesh->nrecv, mesh->Ucur, s, mesh->ndofel.p);
   HIPCHK(hipGetLastError());
+  return 0;
+  QDG_CATCH
+}
+
+// chunks that live on the same device under one context (several chares of one PE in the
+// reference exchange through memory too): rows [src_row0, src_row0+nrows) of src's send slab ->
+// rows [dst_row0, ...) of dst's receive slab, on the context's stream
+extern "C" int qdg_halo_copy(qdg_mesh* dst, size_t dst_row0, qdg_mesh* src, size_t src_row0, size_t nrows)
+{
+  QDG_TRY
+  if (!dst || !src) return fail("qdg_halo_copy: null mesh");
+  if (dst->ctx != src->ctx) return fail("qdg_halo_copy: both chunks must belong to one context");
+  if (slab_w(dst) != slab_w(src)) return fail("qdg_halo_copy: row length differs");
+  if (src_row0 + nrows > src->nsend || dst_row0 + nrows > dst->nrecv) return fail("qdg_halo_copy: row range outside the slabs");
+  if (nrows == 0) return 0;
+  HIPCHK(hipSetDevice(dst->ctx->device));
+  const size_t w = slab_w(dst);
+  HIPCHK(hipMemcpyAsync(dst->recv_ptr + dst_row0 * w, src->send_ptr + src_row0 * w, nrows * w * sizeof(double),
+                        hipMemcpyDeviceToDevice, dst->ctx->stream));
   return 0;
   QDG_CATCH
 }

@@ -66,7 +66,9 @@ struct DevMesh {
   int ntile;
   int ntile_inner;     // tiles that end at or before row ninner (see blk0 below)
   const int* tile_row; // [ntile+1] first device row of each tile (<= TILE rows per tile)
-  const int* tile_off; // [ntile+1] first task of each tile
+  int tile_rows;       // > 0: every tile has this many rows (tile t starts at t*tile_rows), no table look-up
+  const int* tile_off; // [ntile+1] first task of each tile (task_stride == 0)
+  int task_stride;     // > 0: padded task lists, tile t owns slots [t*stride, (t+1)*stride), unused = -1
   const int* task_a;   // packed: e_local(8) lf(2) own_left(1) code(6) kind(2) bc(2) partner_local(8)
   const int* task_nb;  // neighbour device row (kind EXT), else 0
   const int* task_f;   // device face id

@@ -38,6 +38,15 @@
 #ifndef QDG_TILE_GP_SERIAL
 #define QDG_TILE_GP_SERIAL 1
 #endif
+#ifndef QDG_STAGGER
+#define QDG_STAGGER 0
+#endif
+#ifndef QDG_TILE_PER_WG
+#define QDG_TILE_PER_WG 1
+#endif
+#ifndef QDG_TILE_EARLY_UN
+#define QDG_TILE_EARLY_UN 0
+#endif
 #ifndef QDG_TILE_EARLY_GEOM
 #define QDG_TILE_EARLY_GEOM 0
 #endif
@@ -1158,8 +1167,10 @@ __global__ __launch_bounds__(TILE_BS, QDG_TILE_WAVES) void k_rhs_p1t(DevMesh m, 
   __shared__ double sdelt[WITH_DT ? TILE : 1];
   const int tid = threadIdx.x;
   const int tile = m.blk0 + xcd_tile(blockIdx.x, gridDim.x);
-  const int tile_e0 = m.tile_row[tile];
-  const int nloc = m.tile_row[tile + 1] - tile_e0;
+  // fixed TILE-row tiles (the default): no load in front of the tile's own rows
+  const int tile_e0 = m.tile_rows ? tile * m.tile_rows : m.tile_row[tile];
+  const int nloc = m.tile_rows ? ((m.nie - tile_e0 < m.tile_rows) ? m.nie - tile_e0 : m.tile_rows)
+                               : m.tile_row[tile + 1] - tile_e0;
 
   // this lane's task descriptors (up to MAXT rounds) and the first task's face
   // geometry / external row are requested before anything waits on LDS
@@ -1523,7 +1534,7 @@ __global__ __launch_bounds__(TILE_BS, QDG_TILE_WAVES) void k_rhs_p1v(DevMesh m, 
                                                      double* __restrict__ blockmin,
                                                      double rk_a, double rk_b,
                                                      const double* __restrict__ dtp,
-                                                     const double* __restrict__ Un)
+                                                     const double* __restrict__ Un, int tile_end)
 {
   constexpr int NDOF = 4, NGF = 3, NGV = 5, NPROP = NCOMP * NDOF;
   const Tables<4>& T = c_tab4;
@@ -1534,22 +1545,58 @@ __global__ __launch_bounds__(TILE_BS, QDG_TILE_WAVES) void k_rhs_p1v(DevMesh m, 
   __shared__ double accN[TILE * NPROP];
   __shared__ double sdelt[WITH_DT ? TILE : 1];
   const int tid = threadIdx.x;
+#if QDG_STAGGER > 0
+  // The two workgroups of a CU start together and take equally long: left alone they stay in
+  // step -- both waiting on memory, then both computing.  Delaying the second resident set of
+  // the launch (workgroups 256..511: the second one on every CU) by about half a tile's time
+  // puts one workgroup's memory phases under the other's face loop.
+  if (blockIdx.x >= 256 && blockIdx.x < 512) {
+#pragma unroll 1
+    for (int i = 0; i < QDG_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+#endif
+#if QDG_TILE_PER_WG > 1
+  // several consecutive tiles per workgroup: fewer dispatches and kernel-argument loads, and the
+  // compiler may hoist the next tile's first loads above the tail of the current one
+#pragma unroll 1
+  for (int rep = 0; rep < QDG_TILE_PER_WG; ++rep) {
+  const int tile = m.blk0 + xcd_tile(blockIdx.x, gridDim.x) * QDG_TILE_PER_WG + rep;
+  if (tile >= tile_end) break;
+  if (rep > 0) __syncthreads();          // the previous tile's LDS reads are over
+#else
   const int tile = m.blk0 + xcd_tile(blockIdx.x, gridDim.x);
-  const int tile_e0 = m.tile_row[tile];
-  const int nloc = m.tile_row[tile + 1] - tile_e0;
+#endif
+  const int tile_e0 = m.tile_rows ? tile * m.tile_rows : m.tile_row[tile];
+  const int nloc = m.tile_rows ? ((m.nie - tile_e0 < m.tile_rows) ? m.nie - tile_e0 : m.tile_rows)
+                               : m.tile_row[tile + 1] - tile_e0;
 
   // this lane's task descriptors (up to MAXT rounds) and the first task's face
   // geometry / external row are requested before anything waits on LDS
   constexpr int MAXT = 4;
-  const int t0 = m.tile_off[tile], t1 = m.tile_off[tile + 1];
   int ta[MAXT], tf[MAXT], tn[MAXT];
+  int t0 = 0, t1 = 0;
+  if (m.task_stride > 0) {
+    // padded task lists (unused slots hold -1): a tile's slots start at tile * stride, so the
+    // descriptors need no offset load in front of them (one dependent memory latency less on
+    // the way to the first neighbour row)
+    const size_t base = (size_t)tile * m.task_stride;
 #pragma unroll
-  for (int q = 0; q < MAXT; ++q) {
-    const int it = t0 + tid + TILE_BS * q;
-    const bool ok = it < t1;
-    ta[q] = ok ? m.task_a[it] : -1;
-    tf[q] = ok ? m.task_f[it] : 0;
-    tn[q] = ok ? m.task_nb[it] : 0;
+    for (int q = 0; q < MAXT; ++q) {
+      const size_t it = base + tid + TILE_BS * q;
+      ta[q] = m.task_a[it];
+      tf[q] = m.task_f[it];
+      tn[q] = m.task_nb[it];
+    }
+  } else {
+    t0 = m.tile_off[tile]; t1 = m.tile_off[tile + 1];
+#pragma unroll
+    for (int q = 0; q < MAXT; ++q) {
+      const int it = t0 + tid + TILE_BS * q;
+      const bool ok = it < t1;
+      ta[q] = ok ? m.task_a[it] : -1;
+      tf[q] = ok ? m.task_f[it] : 0;
+      tn[q] = ok ? m.task_nb[it] : 0;
+    }
   }
 
   // ---- phase 0: modal row -> the 4 vertex states, accumulators = 0 ------------
@@ -1594,6 +1641,12 @@ __global__ __launch_bounds__(TILE_BS, QDG_TILE_WAVES) void k_rhs_p1v(DevMesh m, 
     if (((ta[0] >> 17) & 3) == TASK_EXT) load_row<NPROP>(U, tn[0], &rnx[0][0]);
   }
   __syncthreads();
+#if QDG_TILE_EARLY_UN
+  // the stage-0 state of the fused RK update comes from HBM: request it now, a whole phase
+  // ahead of its use
+  double un[NCOMP][NDOF];
+  if (FUSE_RK && tid < nloc) load_row<NPROP>(Un, tile_e0 + tid, &un[0][0]);
+#endif
 #if QDG_TILE_EARLY_GEOM
   ElemGeom g;
   if (tid < nloc) {
@@ -1834,7 +1887,11 @@ __global__ __launch_bounds__(TILE_BS, QDG_TILE_WAVES) void k_rhs_p1v(DevMesh m, 
 #endif
   // phase-2 inputs are requested before the barrier (their latency overlaps the
   // other waves' last tasks)
+#if QDG_TILE_EARLY_UN
+  double u[NCOMP][NDOF];
+#else
   double u[NCOMP][NDOF], un[NCOMP][NDOF];
+#endif
   double vol = 1.0;
 #if !QDG_TILE_EARLY_GEOM
   ElemGeom g;
@@ -1842,7 +1899,9 @@ __global__ __launch_bounds__(TILE_BS, QDG_TILE_WAVES) void k_rhs_p1v(DevMesh m, 
   if (tid < nloc) {
     const int e = tile_e0 + tid;
     load_row<NPROP>(U, e, &u[0][0]);          // modal row again (L1/L2 hit)
+#if !QDG_TILE_EARLY_UN
     if (FUSE_RK) load_row<NPROP>(Un, e, &un[0][0]);
+#endif
     vol = m.vol[e];
 #if !QDG_TILE_EARLY_GEOM
     const int stride = m.stride;
@@ -1960,6 +2019,9 @@ __global__ __launch_bounds__(TILE_BS, QDG_TILE_WAVES) void k_rhs_p1v(DevMesh m, 
       blockmin[tile] = mn;
     }
   }
+#if QDG_TILE_PER_WG > 1
+  }
+#endif
 }
 
 // ------------------------------------------------------------- limiters
@@ -3311,11 +3373,12 @@ void launch_rhs_p1t(const DevMesh& m0, const Phys& ph, double t, const double* U
   DevMesh m = m0;
   m.blk0 = first;
   const int nb = count < 0 ? m.ntile - first : count;
+  const int nbv = (nb + QDG_TILE_PER_WG - 1) / QDG_TILE_PER_WG;     // workgroups of the v2 kernel
   if (nb > 0 && tile_v2(m)) {
     if (with_dt) {
-      QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1v<true, false, P><<<nb, TILE_BS, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr)));
+      QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1v<true, false, P><<<nbv, TILE_BS, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr, first + nb)));
     } else {
-      QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1v<false, false, P><<<nb, TILE_BS, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr)));
+      QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1v<false, false, P><<<nbv, TILE_BS, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr, first + nb)));
     }
   } else if (nb > 0) {
     if (with_dt) {
@@ -3338,7 +3401,8 @@ void launch_rhs_p1t_rk(const DevMesh& m0, const Phys& ph, double t, const double
   const int nb = count < 0 ? m.ntile - first : count;
   if (nb <= 0) return;
   if (tile_v2(m)) {
-    QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1v<false, true, P><<<nb, TILE_BS, 0, s>>>(m, ph, t, U, Uout, nullptr, a, b, dt, Un)));
+    const int nbv = (nb + QDG_TILE_PER_WG - 1) / QDG_TILE_PER_WG;
+    QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1v<false, true, P><<<nbv, TILE_BS, 0, s>>>(m, ph, t, U, Uout, nullptr, a, b, dt, Un, first + nb)));
     return;
   }
   QDG_DISPATCH_PDG(m, QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1t<false, true, P, G><<<nb, TILE_BS, 0, s>>>(m, ph, t, U, Uout, nullptr, a, b, dt, Un))));

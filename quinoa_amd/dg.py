@@ -184,48 +184,37 @@ class DGDriver:
 
 
 class LocalChunks:
-    """All chunks of a decomposition driven by ONE process on ONE GPU: every chunk has its own
-    context and mesh handle, ghost rows move between them as device copies of the halo slabs, the
-    time step is the minimum over the chunks.  Same per-stage sequence as DGDriver.step.  For
-    tests of a decomposition (qdg_partition / qdg_chunk_build) on a one-GPU box; a production run
-    has one process per GPU (DGDriver + RcclComm)."""
+    """All chunks of a decomposition driven by ONE process on ONE GPU under ONE context (one
+    stream): ghost rows move between the chunks' halo slabs as device copies (qdg_halo_copy),
+    the time step is the minimum over the chunks (read back, like DG::dt's contribute(min)).
+    Same per-stage sequence as DGDriver.step.  For tests of a decomposition (qdg_partition /
+    qdg_chunk_build) on a one-GPU box; a production run has one process per GPU (DGDriver +
+    RcclComm).  No torch here: a process that initialised HIP through libqdg must not bring up
+    PyTorch's own HIP runtime afterwards."""
 
-    def __init__(self, ctxs, meshes, chunks):
-        import torch
-        self.torch = torch
-        self.ctxs, self.meshes, self.chunks = ctxs, meshes, chunks
-        self.pref = bool(ctxs[0].cfg.pref)
-        self.limiter_active = ctxs[0].cfg.limiter != 0 and ctxs[0].ndof > 1
-        dev = torch.device("cuda", torch.cuda.current_device())
-        stream = torch.cuda.current_stream().cuda_stream
-        self.send, self.recv, self.dt, self.soff, self.roff = [], [], [], [], []
-        for ctx, mesh, ch in zip(ctxs, meshes, chunks):
+    def __init__(self, ctx, meshes, chunks):
+        self.ctx, self.meshes, self.chunks = ctx, meshes, chunks
+        self.pref = bool(ctx.cfg.pref)
+        self.limiter_active = ctx.cfg.limiter != 0 and ctx.ndof > 1
+        self.soff, self.roff = [], []
+        for mesh, ch in zip(meshes, chunks):
             mesh.halo_setup(ch["nbr_rank"], ch["send_lists"], ch["recv_counts"])
-            ns, nr = mesh.halo_sizes()
-            self.roww = mesh.halo_buffers()[2] // 8
-            self.send.append(torch.zeros(max(1, ns * self.roww), dtype=torch.float64, device=dev))
-            self.recv.append(torch.zeros(max(1, nr * self.roww), dtype=torch.float64, device=dev))
-            self.dt.append(torch.zeros(1, dtype=torch.float64, device=dev))
-            mesh.halo_use_buffers(self.send[-1].data_ptr(), self.recv[-1].data_ptr())
-            mesh.stage_dt_use_buffer(self.dt[-1].data_ptr())
-            ctx.set_stream(stream)
             self.soff.append(np.concatenate([[0], np.cumsum([len(s) for s in ch["send_lists"]])]).astype(np.int64))
             self.roff.append(np.concatenate([[0], np.cumsum(ch["recv_counts"])]).astype(np.int64))
 
     def exchange(self):
         for m in self.meshes:
             m.halo_pack()
-        w = self.roww
         for r, ch in enumerate(self.chunks):
             for i, q in enumerate(ch["nbr_rank"]):
                 j = self.chunks[q]["nbr_rank"].index(r)
-                self.recv[r][self.roff[r][i] * w:self.roff[r][i + 1] * w].copy_(
-                    self.send[q][self.soff[q][j] * w:self.soff[q][j + 1] * w])
+                n = self.roff[r][i + 1] - self.roff[r][i]
+                assert n == self.soff[q][j + 1] - self.soff[q][j]
+                self.meshes[r].halo_copy_from(self.roff[r][i], self.meshes[q], self.soff[q][j], n)
         for m in self.meshes:
             m.halo_unpack()
 
     def step(self, t, tleft=1e300):
-        torch = self.torch
         for stage in range(3):
             if self.pref and stage == 0:
                 for m in self.meshes:
@@ -241,9 +230,9 @@ class LocalChunks:
             for m in self.meshes:
                 m.stage_rhs_dt(stage, t, tleft)
             if stage == 0:
-                mn = torch.stack(self.dt).min()
-                for d in self.dt:
-                    d.fill_(mn)
+                dt = min(m.stage_dt_get() for m in self.meshes)
+                for m in self.meshes:
+                    m.stage_dt_set(dt)
             for m in self.meshes:
                 m.stage_update(stage)
-        return float(self.dt[0].item())
+        return dt

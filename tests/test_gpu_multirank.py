@@ -175,3 +175,56 @@ def test_other_orders_and_weno_across_the_halo(tmp_path, ndof, limiter):
         d = np.load(out2 % r)
         assert abs(float(d["t"]) - float(s["t"])) <= 1e-12 * float(s["t"])
         assert np.abs(d["U"] - ref[d["gid"]]).max() / np.abs(ref).max() <= 1e-10, r
+
+
+def _run_rccl(rank, world, port, parts, out):
+    """one rank per GPU, the PRODUCT transport: libqdg's own RCCL calls (qdg_step_comm) between
+    different devices; torch.distributed (nccl) only carries the RCCL id"""
+    import torch
+    import torch.distributed as dist
+    from quinoa_amd import capi, dg, dgmesh, meshgen
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    try:
+        ch = meshgen.kuhn_box_chunk(NX, NY, NZ, parts=parts, rank=rank)
+        ck = dgmesh.build_chunk(ch["coord"], ch["inpoel"], ch["nielem"], ch["sidesets"])
+        ctx = capi.Context(4, cfl=0.3, device=rank, **KW, **BC)
+        mesh = dgmesh.upload(ctx, ck)
+        comm = dg.RcclComm(ctx)
+        drv = dg.DGDriver(ctx, mesh, ch["nbr_rank"], ch["send_lists"], ch["recv_counts"], comm)
+        mesh.state_initialize(0.0)
+        t = 0.0
+        for _ in range(NSTEP):
+            drv.step(t)
+            t += drv.dt_taken()
+        U = mesh.state_download().reshape(-1, 20)[:ck.nielem]
+        np.savez(out % rank, gid=ch["gid"][:ck.nielem], U=U, t=t)
+        mesh.close(); comm.close(); ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("parts", [(2, 1, 1)])
+def test_rccl_between_two_gpus_equals_single_chunk(tmp_path, parts):
+    """RcclComm / qdg_step_comm -- what `bench.py --gpus N` runs -- across two DIFFERENT devices
+    vs the single-chunk run.  Needs a lease with >= 2 GPUs: skipped on the one-GPU test box
+    (torch.cuda.device_count() does not initialise the GPU)."""
+    import torch
+    import torch.multiprocessing as mp
+    world = parts[0] * parts[1] * parts[2]
+    if torch.cuda.device_count() < world:
+        pytest.skip("needs %d GPUs, this box exposes %d" % (world, torch.cuda.device_count()))
+    out1 = str(tmp_path / "single%d.npz")
+    out2 = str(tmp_path / "rank%d.npz")
+    mp.spawn(_run, args=(1, 0, (1, 1, 1), out1, False), nprocs=1, join=True)
+    mp.spawn(_run_rccl, args=(world, _free_port(), parts, out2), nprocs=world, join=True)
+    s = np.load(out1 % 0)
+    ref = np.zeros((NX * NY * NZ * 6, 20))
+    ref[s["gid"]] = s["U"]
+    for r in range(world):
+        d = np.load(out2 % r)
+        assert abs(float(d["t"]) - float(s["t"])) <= 1e-12 * float(s["t"])
+        assert np.abs(d["U"] - ref[d["gid"]]).max() / np.abs(ref).max() <= 1e-10, r

@@ -23,24 +23,24 @@ def _run(case, fix, nparts, method):
     ss = {int(s): fix["ss_tri_%d" % s] for s in fix["ss_ids"]}
     coord, inpoel = fix["coord"], fix["inpoel"]
     part = partition.partition(coord, inpoel, nparts, method)
-    ctxs, meshes, chunks, cks = [], [], [], []
+    ctx = capi.Context(case["ndof"], flux=case["flux"], limiter=case["limiter"], problem=case["problem"],
+                       gamma=case["gamma"], cfl=case["cfl"], dt=case["dt"], bc_dirichlet=case["bc_dirichlet"],
+                       bc_sym=case["bc_sym"], bc_extrapolate=case["bc_extrapolate"],
+                       pref=case.get("pref", False), tolref=case.get("tolref", 0.1))
+    meshes, chunks = [], []
     for r in range(nparts):
         ch = partition.build_chunk(coord, inpoel, ss, part, nparts, r)
         ck = dgmesh.build_chunk(ch["coord"], ch["inpoel"], ch["nielem"], ch["sidesets"])
-        ctx = capi.Context(case["ndof"], flux=case["flux"], limiter=case["limiter"], problem=case["problem"],
-                           gamma=case["gamma"], cfl=case["cfl"], dt=case["dt"], bc_dirichlet=case["bc_dirichlet"],
-                           bc_sym=case["bc_sym"], bc_extrapolate=case["bc_extrapolate"],
-                           pref=case.get("pref", False), tolref=case.get("tolref", 0.1))
-        ctxs.append(ctx); meshes.append(dgmesh.upload(ctx, ck)); chunks.append(ch); cks.append(ck)
+        meshes.append(dgmesh.upload(ctx, ck)); chunks.append(ch)
     try:
-        drv = dg.LocalChunks(ctxs, meshes, chunks) if nparts > 1 else None
+        drv = dg.LocalChunks(ctx, meshes, chunks) if nparts > 1 else None
         for m in meshes:
             m.state_initialize(0.0)
         t = 0.0
         for _ in range(case["nstep"]):
             t += drv.step(t) if drv else meshes[0].step(t)
         ne = inpoel.shape[0]
-        nf = len(ctxs[0].field_names())
+        nf = len(ctx.field_names())
         F = np.zeros((nf, ne))
         for m, ch in zip(meshes, chunks):
             f, names = m.field_output(t)
@@ -49,8 +49,7 @@ def _run(case, fix, nparts, method):
     finally:
         for m in meshes:
             m.close()
-        for c in ctxs:
-            c.close()
+        ctx.close()
 
 
 @pytest.mark.parametrize("name,method", [("sedov_dgp1", "rcb"), ("sedov_dgp1", "morton"), ("sedov_pdg", "rcb")])
