@@ -173,6 +173,45 @@ def run_workload(args, rank, world, local_rank, dims, lengths, parts, steps, war
     return res
 
 
+def amr_point(local_rank, nx=32, steps=20):
+    """BASELINE config 5's loop once, on one GPU: Sod DG-P1 on an nx^3 Kuhn box, `steps` time
+    steps, uniform 1:8 refinement (the refinement the reference's DG scheme performs during
+    time stepping), mesh-derived data of the new mesh on the device, state handed over on the
+    device, `steps` more steps.  Reports what the re-partition / re-upload step costs."""
+    import numpy as np
+    from quinoa_amd import amr, capi, meshgen
+    ch = meshgen.kuhn_box(nx, nx, nx)
+    ctx = capi.Context(4, flux="hllc", limiter="superbeep1", problem="sod_shocktube", gamma=1.4,
+                       cfl=0.3, bc_extrapolate=[1, 2], bc_sym=[3, 4, 5, 6], device=local_rank)
+    run = amr.RefinedRun(ctx, ch["coord"], ch["inpoel"], ch["sidesets"])
+    run.mesh.state_initialize(0.0)
+    ne0 = run.mesh.nielem
+
+    def advance(n):
+        run.mesh.step(0.0, want_dt=False)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            run.mesh.step(0.0, want_dt=False)
+        ctx.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    ms0 = advance(steps) * 1e3
+    th, tr, tt = run.refine()
+    ms1 = advance(steps) * 1e3
+    U = run.mesh.state_download()
+    ne1 = run.mesh.nielem
+    ok = bool(np.isfinite(U).all())
+    run.mesh.close(); ctx.close()
+    return {"workload": "Sod DG-P1 + Superbee, %d^3 box: %d steps, uniform 1:8 refinement, %d steps" % (nx, steps, steps),
+            "tets_before": ne0, "tets_after": ne1, "ms_per_step_before": ms0, "ms_per_step_after": ms1,
+            "refine_host_ms": th * 1e3, "rebuild_upload_ms": tr * 1e3, "state_transfer_ms": tt * 1e3,
+            "rebuild_upload_ms_per_Mtet": tr * 1e3 / (ne1 / 1e6),
+            "steps_of_new_mesh_per_rebuild": tr * 1e3 / ms1, "finite": ok,
+            "note": "rebuild = qdg_mesh_from_connectivity on the refined mesh: boundary faces (host), "
+                    "FaceData + geometry (device), device layout + face tasks (host, all cores), upload"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -182,6 +221,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-north-star", action="store_true",
                     help="skip the fixed-size 10.1 M-tet north-star / strong-scaling point")
+    ap.add_argument("--no-amr", action="store_true", help="skip the config-5 refinement point (N = 1 only)")
     ap.add_argument("--strong-nx", type=int, default=119,
                     help="hexes per direction of the fixed-size box of the strong-scaling point "
                          "(119 -> 10 110 954 tets, 220 -> 63 888 000 tets = config 4)")
@@ -288,6 +328,8 @@ def main():
                              "traffic": None},
                 "check": {"mass_drift": float(ns["drift"][0]), "energy_drift": float(ns["drift"][1])},
             }
+        if world == 1 and not args.no_amr and not args.self_halo:
+            out["amr_point"] = amr_point(local_rank)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

@@ -38,18 +38,6 @@
 #ifndef QDG_TILE_GP_SERIAL
 #define QDG_TILE_GP_SERIAL 1
 #endif
-#ifndef QDG_STAGGER
-#define QDG_STAGGER 0
-#endif
-#ifndef QDG_TILE_PER_WG
-#define QDG_TILE_PER_WG 1
-#endif
-#ifndef QDG_TILE_EARLY_UN
-#define QDG_TILE_EARLY_UN 0
-#endif
-#ifndef QDG_TILE_EARLY_GEOM
-#define QDG_TILE_EARLY_GEOM 0
-#endif
 #ifndef QDG_P1_WAVES
 #define QDG_P1_WAVES 2   // waves per SIMD the DG-P1 RHS kernel is register-budgeted for
 #endif
@@ -1534,7 +1522,7 @@ __global__ __launch_bounds__(TILE_BS, QDG_TILE_WAVES) void k_rhs_p1v(DevMesh m, 
                                                      double* __restrict__ blockmin,
                                                      double rk_a, double rk_b,
                                                      const double* __restrict__ dtp,
-                                                     const double* __restrict__ Un, int tile_end)
+                                                     const double* __restrict__ Un)
 {
   constexpr int NDOF = 4, NGF = 3, NGV = 5, NPROP = NCOMP * NDOF;
   const Tables<4>& T = c_tab4;
@@ -1545,27 +1533,7 @@ __global__ __launch_bounds__(TILE_BS, QDG_TILE_WAVES) void k_rhs_p1v(DevMesh m, 
   __shared__ double accN[TILE * NPROP];
   __shared__ double sdelt[WITH_DT ? TILE : 1];
   const int tid = threadIdx.x;
-#if QDG_STAGGER > 0
-  // The two workgroups of a CU start together and take equally long: left alone they stay in
-  // step -- both waiting on memory, then both computing.  Delaying the second resident set of
-  // the launch (workgroups 256..511: the second one on every CU) by about half a tile's time
-  // puts one workgroup's memory phases under the other's face loop.
-  if (blockIdx.x >= 256 && blockIdx.x < 512) {
-#pragma unroll 1
-    for (int i = 0; i < QDG_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-  }
-#endif
-#if QDG_TILE_PER_WG > 1
-  // several consecutive tiles per workgroup: fewer dispatches and kernel-argument loads, and the
-  // compiler may hoist the next tile's first loads above the tail of the current one
-#pragma unroll 1
-  for (int rep = 0; rep < QDG_TILE_PER_WG; ++rep) {
-  const int tile = m.blk0 + xcd_tile(blockIdx.x, gridDim.x) * QDG_TILE_PER_WG + rep;
-  if (tile >= tile_end) break;
-  if (rep > 0) __syncthreads();          // the previous tile's LDS reads are over
-#else
   const int tile = m.blk0 + xcd_tile(blockIdx.x, gridDim.x);
-#endif
   const int tile_e0 = m.tile_rows ? tile * m.tile_rows : m.tile_row[tile];
   const int nloc = m.tile_rows ? ((m.nie - tile_e0 < m.tile_rows) ? m.nie - tile_e0 : m.tile_rows)
                                : m.tile_row[tile + 1] - tile_e0;
@@ -1625,38 +1593,12 @@ __global__ __launch_bounds__(TILE_BS, QDG_TILE_WAVES) void k_rhs_p1v(DevMesh m, 
       for (int c = 0; c < NCOMP; ++c) { nod[LIDX(tid, vx, c)] = v[vx][c]; accN[LIDX(tid, vx, c)] = 0.0; }
     if (WITH_DT) sdelt[tid] = 0.0;
   }
-#if QDG_TILE_EARLY_GEOM
-  // node ids of this lane's tet: requested now, the coordinates right after the first barrier,
-  // so that the two dependent gathers of the volume term are long back before phase 2
-  int nid[4] = { 0, 0, 0, 0 };
-  if (tid < nloc) {
-    const int e = tile_e0 + tid;
-    nid[0] = m.inpoel[e]; nid[1] = m.inpoel[(size_t)m.stride + e];
-    nid[2] = m.inpoel[(size_t)2 * m.stride + e]; nid[3] = m.inpoel[(size_t)3 * m.stride + e];
-  }
-#endif
   double gnx[4], rnx[NCOMP][NDOF];
   if (ta[0] >= 0) {
     load_row<4>(m.fgeo, tf[0], gnx);
     if (((ta[0] >> 17) & 3) == TASK_EXT) load_row<NPROP>(U, tn[0], &rnx[0][0]);
   }
   __syncthreads();
-#if QDG_TILE_EARLY_UN
-  // the stage-0 state of the fused RK update comes from HBM: request it now, a whole phase
-  // ahead of its use
-  double un[NCOMP][NDOF];
-  if (FUSE_RK && tid < nloc) load_row<NPROP>(Un, tile_e0 + tid, &un[0][0]);
-#endif
-#if QDG_TILE_EARLY_GEOM
-  ElemGeom g;
-  if (tid < nloc) {
-    double q[4];
-    load_row<4>(m.xyz4, nid[0], q); g.p[0][0] = q[0]; g.p[0][1] = q[1]; g.p[0][2] = q[2];
-    load_row<4>(m.xyz4, nid[1], q); g.p[1][0] = q[0]; g.p[1][1] = q[1]; g.p[1][2] = q[2];
-    load_row<4>(m.xyz4, nid[2], q); g.p[2][0] = q[0]; g.p[2][1] = q[1]; g.p[2][2] = q[2];
-    load_row<4>(m.xyz4, nid[3], q); g.p[3][0] = q[0]; g.p[3][1] = q[1]; g.p[3][2] = q[2];
-  }
-#endif
 
   // ---- phase 1: one lane per face task ------------------------------------------
   constexpr bool HAS_DIRICHLET = (PROB == 3 || PROB == 4 || PROB == 0 || PROB == 7 || PROB == 10);
@@ -1887,23 +1829,14 @@ __global__ __launch_bounds__(TILE_BS, QDG_TILE_WAVES) void k_rhs_p1v(DevMesh m, 
 #endif
   // phase-2 inputs are requested before the barrier (their latency overlaps the
   // other waves' last tasks)
-#if QDG_TILE_EARLY_UN
-  double u[NCOMP][NDOF];
-#else
   double u[NCOMP][NDOF], un[NCOMP][NDOF];
-#endif
   double vol = 1.0;
-#if !QDG_TILE_EARLY_GEOM
   ElemGeom g;
-#endif
   if (tid < nloc) {
     const int e = tile_e0 + tid;
     load_row<NPROP>(U, e, &u[0][0]);          // modal row again (L1/L2 hit)
-#if !QDG_TILE_EARLY_UN
     if (FUSE_RK) load_row<NPROP>(Un, e, &un[0][0]);
-#endif
     vol = m.vol[e];
-#if !QDG_TILE_EARLY_GEOM
     const int stride = m.stride;
     const int n0 = m.inpoel[e], n1 = m.inpoel[(size_t)stride + e], n2 = m.inpoel[(size_t)2 * stride + e],
               n3 = m.inpoel[(size_t)3 * stride + e];
@@ -1912,7 +1845,6 @@ __global__ __launch_bounds__(TILE_BS, QDG_TILE_WAVES) void k_rhs_p1v(DevMesh m, 
     load_row<4>(m.xyz4, n1, q); g.p[1][0] = q[0]; g.p[1][1] = q[1]; g.p[1][2] = q[2];
     load_row<4>(m.xyz4, n2, q); g.p[2][0] = q[0]; g.p[2][1] = q[1]; g.p[2][2] = q[2];
     load_row<4>(m.xyz4, n3, q); g.p[3][0] = q[0]; g.p[3][1] = q[1]; g.p[3][2] = q[2];
-#endif
   }
   __syncthreads();
 
@@ -2019,9 +1951,6 @@ __global__ __launch_bounds__(TILE_BS, QDG_TILE_WAVES) void k_rhs_p1v(DevMesh m, 
       blockmin[tile] = mn;
     }
   }
-#if QDG_TILE_PER_WG > 1
-  }
-#endif
 }
 
 // ------------------------------------------------------------- limiters
@@ -3373,12 +3302,11 @@ void launch_rhs_p1t(const DevMesh& m0, const Phys& ph, double t, const double* U
   DevMesh m = m0;
   m.blk0 = first;
   const int nb = count < 0 ? m.ntile - first : count;
-  const int nbv = (nb + QDG_TILE_PER_WG - 1) / QDG_TILE_PER_WG;     // workgroups of the v2 kernel
   if (nb > 0 && tile_v2(m)) {
     if (with_dt) {
-      QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1v<true, false, P><<<nbv, TILE_BS, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr, first + nb)));
+      QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1v<true, false, P><<<nb, TILE_BS, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr)));
     } else {
-      QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1v<false, false, P><<<nbv, TILE_BS, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr, first + nb)));
+      QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1v<false, false, P><<<nb, TILE_BS, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr)));
     }
   } else if (nb > 0) {
     if (with_dt) {
@@ -3401,8 +3329,7 @@ void launch_rhs_p1t_rk(const DevMesh& m0, const Phys& ph, double t, const double
   const int nb = count < 0 ? m.ntile - first : count;
   if (nb <= 0) return;
   if (tile_v2(m)) {
-    const int nbv = (nb + QDG_TILE_PER_WG - 1) / QDG_TILE_PER_WG;
-    QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1v<false, true, P><<<nbv, TILE_BS, 0, s>>>(m, ph, t, U, Uout, nullptr, a, b, dt, Un, first + nb)));
+    QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1v<false, true, P><<<nb, TILE_BS, 0, s>>>(m, ph, t, U, Uout, nullptr, a, b, dt, Un)));
     return;
   }
   QDG_DISPATCH_PDG(m, QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1t<false, true, P, G><<<nb, TILE_BS, 0, s>>>(m, ph, t, U, Uout, nullptr, a, b, dt, Un))));
