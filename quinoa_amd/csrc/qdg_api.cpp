@@ -25,6 +25,7 @@
 #include "../../include/qdg.h"
 #include "qdg_device.hpp"
 #include "qdg_host.hpp"
+#include "qdg_handles.hpp"
 #include "qdg_kernels.hpp"
 #include "qdg_tables.hpp"
 
@@ -56,98 +57,9 @@ template <class F> static void parallel_for(size_t n, F&& fn, size_t serial_belo
   for (auto& t : th) t.join();
 }
 
-// owning device buffer
-template <class T> struct DevBuf {
-  T* p = nullptr;
-  size_t n = 0;
-  DevBuf() = default;
-  DevBuf(const DevBuf&) = delete;
-  DevBuf& operator=(const DevBuf&) = delete;
-  ~DevBuf() { if (p) (void)hipFree(p); }
-  hipError_t alloc(size_t count)
-  {
-    if (p) { (void)hipFree(p); p = nullptr; }
-    n = count;
-    if (count == 0) return hipSuccess;
-    return hipMalloc((void**)&p, count * sizeof(T));
-  }
-  hipError_t upload(const std::vector<T>& h, hipStream_t s)
-  {
-    hipError_t e = alloc(h.size());
-    if (e != hipSuccess || h.empty()) return e;
-    e = hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s);
-    if (e != hipSuccess) return e;
-    return hipStreamSynchronize(s);   // h may be a temporary of the caller
-  }
-};
-
 }  // namespace qdg
 
 using namespace qdg;
-
-struct qdg_ctx {
-  qdg_config cfg;
-  std::vector<int32_t> bc_sideset, bc_type;
-  Phys ph;
-  int device = 0;
-  hipStream_t stream = nullptr;
-  bool own_stream = false;
-  ~qdg_ctx()
-  {
-    if (own_stream && stream) {
-      (void)hipSetDevice(device);
-      (void)hipStreamSynchronize(stream);
-      (void)hipStreamDestroy(stream);
-    }
-  }
-};
-
-struct qdg_mesh {
-  qdg_ctx* ctx = nullptr;
-  DevMesh dm{};
-  int ndof = 1, nprop = 5;
-  size_t nie = 0, ne = 0, stride = 0;
-  // mesh
-  DevBuf<int> inpoel, nbr, finfo, fid, d2h;
-  DevBuf<double> x, y, z, farea, fnx, fny, fnz, vol, fgeo, xyz4;
-  DevBuf<int> tile_row, tile_off, task_a, task_nb, task_f;
-  // fields (SoA planes [nprop][stride])
-  DevBuf<double> U, Un, R, W;     // W: scratch state (stateless ops, WENO ping-pong)
-  DevBuf<double> aos;             // [ne*nprop] staging in the caller's layout
-  DevBuf<double> blockmin, dtraw, dtdev, diagpart, diagout;
-  // the three field buffers U, Un, W rotate: Ucur = current state, Unp = the
-  // stage-0 state of the running step (may alias Ucur until the first update),
-  // the remaining one is free (RK output / WENO ping-pong)
-  double* Ucur = nullptr;
-  double* Unp = nullptr;
-  double* Upending = nullptr;     // output of a fused RHS+RK launch, adopted by qdg_stage_update
-  DevBuf<double> S1, S2;          // scratch of the stateless operators (allocated on first use)
-  DevBuf<int> ndofel, ndofel2;    // p-adaptive DG: DG::m_ndof per device row (+ Jacobi copy)
-  DevBuf<double> fout;            // field output staging (allocated on first use)
-  // halo
-  size_t nnbr = 0, nsend = 0, nrecv = 0;
-  std::vector<int32_t> nbr_rank;
-  std::vector<size_t> send_off, recv_off;
-  DevBuf<int> send_elem;
-  DevBuf<double> send_slab, recv_slab;
-  double* send_ptr = nullptr;     // slabs in use (own or caller-provided)
-  double* recv_ptr = nullptr;
-  double* dt_ptr = nullptr;       // dt scalar in use
-  size_t nnode_used = 0;
-  // halo overlap (qdg_step_comm): when set, the limiter / the tile RHS run the
-  // rows without a ghost neighbour first, then wait for this event (end of the
-  // exchange on the communication stream) before the rows next to the halo
-  hipEvent_t split_lim = nullptr, split_rhs = nullptr;
-  // measurement: event pairs around the RHS kernel (cont: second part of a split launch)
-  bool prof = false;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
-  std::vector<char> ev_cont;
-  size_t ev_used = 0;
-  ~qdg_mesh()
-  {
-    for (auto& e : ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-  }
-};
 
 namespace qdg {
 // for the other translation units of the library (qdg_devmesh.hip)
@@ -316,6 +228,27 @@ extern "C" int qdg_solution(qdg_ctx* ctx, size_t n, const double* x, const doubl
   return 0;
   QDG_CATCH
 }
+
+namespace qdg {
+// fields and work buffers of a mesh handle whose sizes (nie, ne, stride, nprop) are set
+int mesh_alloc_state(qdg_mesh* m, int ntile)
+{
+  hipStream_t s = m->ctx->stream;
+  const size_t fsz = (size_t)m->nprop * m->stride;
+  HIPCHK(m->U.alloc(fsz)); HIPCHK(m->Un.alloc(fsz)); HIPCHK(m->R.alloc(fsz)); HIPCHK(m->W.alloc(fsz));
+  HIPCHK(m->aos.alloc(m->ne * (size_t)m->nprop));
+  HIPCHK(hipMemsetAsync(m->U.p, 0, fsz * sizeof(double), s));
+  HIPCHK(hipMemsetAsync(m->Un.p, 0, fsz * sizeof(double), s));
+  HIPCHK(hipMemsetAsync(m->R.p, 0, fsz * sizeof(double), s));
+  HIPCHK(hipMemsetAsync(m->W.p, 0, fsz * sizeof(double), s));
+  const size_t nblk = std::max((m->nie + 255) / 256, (size_t)ntile);
+  HIPCHK(m->blockmin.alloc(nblk)); HIPCHK(m->dtraw.alloc(1)); HIPCHK(m->dtdev.alloc(1));
+  HIPCHK(m->diagpart.alloc(nblk * 15)); HIPCHK(m->diagout.alloc(15));
+  m->Ucur = m->U.p;
+  m->dt_ptr = m->dtdev.p;
+  return 0;
+}
+}  // namespace qdg
 
 // ---------------------------------------------------------------- upload
 
@@ -645,18 +578,7 @@ extern "C" int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t 
     HIPCHK(m->fgeo.upload(h_fgeo, s));
     HIPCHK(m->xyz4.upload(h_xyz4, s));
   }
-  const size_t fsz = (size_t)m->nprop * stride;
-  HIPCHK(m->U.alloc(fsz)); HIPCHK(m->Un.alloc(fsz)); HIPCHK(m->R.alloc(fsz)); HIPCHK(m->W.alloc(fsz));
-  HIPCHK(m->aos.alloc(ne * (size_t)m->nprop));
-  HIPCHK(hipMemsetAsync(m->U.p, 0, fsz * sizeof(double), s));
-  HIPCHK(hipMemsetAsync(m->Un.p, 0, fsz * sizeof(double), s));
-  HIPCHK(hipMemsetAsync(m->R.p, 0, fsz * sizeof(double), s));
-  HIPCHK(hipMemsetAsync(m->W.p, 0, fsz * sizeof(double), s));
-  const size_t nblk = std::max((nie + 255) / 256, (size_t)ntile);
-  HIPCHK(m->blockmin.alloc(nblk)); HIPCHK(m->dtraw.alloc(1)); HIPCHK(m->dtdev.alloc(1));
-  HIPCHK(m->diagpart.alloc(nblk * 15)); HIPCHK(m->diagout.alloc(15));
-  m->Ucur = m->U.p;
-  m->dt_ptr = m->dtdev.p;
+  if (int rc = mesh_alloc_state(m.get(), ntile)) return rc;
   m->nnode_used = (size_t)ncount;
 
   DevMesh& dm = m->dm;

@@ -14,15 +14,20 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
+#include <rocprim/device/device_reduce.hpp>
+
 #include "../../include/qdg.h"
 #include "qdg_host.hpp"
+#include "qdg_handles.hpp"
 
 namespace qdg {
 // defined in qdg_api.cpp
@@ -40,6 +45,8 @@ namespace {
     if (e_ != hipSuccess)                                                         \
       return ::qdg::fail(std::string(#call) + ": " + hipGetErrorString(e_));      \
   } while (0)
+
+#define HIPCHK(call) DHIP(call)
 
 template <class T> struct Buf {
   T* p = nullptr;
@@ -185,16 +192,20 @@ inline unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
 
-extern "C" int qdg_dev_facedata(qdg_ctx* ctx, size_t nelem, size_t nnode, const size_t* inpoel,
-                                const double* x, const double* y, const double* z, size_t nbfac,
-                                const size_t* triinpoel, int* esuel, size_t* nipfac_out,
-                                size_t* inpofa, int* esuf, size_t* belem, double* geoFace,
-                                double* geoElem)
+// the FaceData arrays and the geometry of a chunk, resident on the device
+struct DevFD {
+  Buf<uint64_t> inpoel, tri, inpofa, belem;
+  Buf<double> x, y, z, geoFace, geoElem;
+  Buf<int> esuel, esuf;
+  size_t nelem = 0, nnode = 0, nbfac = 0, nipfac = 0;
+};
+
+static int dev_facedata_keep(qdg_ctx* ctx, size_t nelem, size_t nnode, const size_t* inpoel,
+                             const double* x, const double* y, const double* z, size_t nbfac,
+                             const size_t* triinpoel, DevFD& fd)
 {
-  QDG_TRY
-  if (!ctx || !inpoel || !x || !y || !z || !esuel || !nipfac_out || !inpofa || !esuf || !geoFace || !geoElem)
-    return fail("qdg_dev_facedata: null argument");
-  if (nbfac > 0 && (!triinpoel || !belem)) return fail("qdg_dev_facedata: null boundary arrays");
+  if (!ctx || !inpoel || !x || !y || !z) return fail("qdg_dev_facedata: null argument");
+  if (nbfac > 0 && !triinpoel) return fail("qdg_dev_facedata: null boundary arrays");
   if (nelem == 0) return fail("qdg_dev_facedata: empty mesh");
   if (nelem > (size_t)INT32_MAX / 4 || nnode > (size_t)INT32_MAX)
     return fail("qdg_dev_facedata: chunk too large for 32-bit ids");
@@ -205,26 +216,25 @@ extern "C" int qdg_dev_facedata(qdg_ctx* ctx, size_t nelem, size_t nnode, const 
   DHIP(hipSetDevice(ctx_device(ctx)));
   hipStream_t s = ctx_stream(ctx);
   const size_t n4 = 4 * nelem, nfmax = nbfac + 2 * nelem;
+  fd.nelem = nelem; fd.nnode = nnode; fd.nbfac = nbfac;
 
-  Buf<uint64_t> d_inpoel, d_tri, d_inpofa, d_belem;
-  Buf<double> d_x, d_y, d_z, d_geoFace, d_geoElem;
   Buf<uint32_t> ka, kb, kc, perm, perm2, key, key2;
-  Buf<int> d_esuel, d_flag, d_pos, d_esuf, d_err;
-  DHIP(d_inpoel.alloc(n4)); DHIP(d_tri.alloc(3 * nbfac));
-  DHIP(d_x.alloc(nnode)); DHIP(d_y.alloc(nnode)); DHIP(d_z.alloc(nnode));
+  Buf<int> d_flag, d_pos, d_err;
+  DHIP(fd.inpoel.alloc(n4)); DHIP(fd.tri.alloc(3 * nbfac));
+  DHIP(fd.x.alloc(nnode)); DHIP(fd.y.alloc(nnode)); DHIP(fd.z.alloc(nnode));
   DHIP(ka.alloc(n4)); DHIP(kb.alloc(n4)); DHIP(kc.alloc(n4));
   DHIP(perm.alloc(n4)); DHIP(perm2.alloc(n4)); DHIP(key.alloc(n4)); DHIP(key2.alloc(n4));
-  DHIP(d_esuel.alloc(n4)); DHIP(d_flag.alloc(n4 + 1)); DHIP(d_pos.alloc(n4 + 1)); DHIP(d_err.alloc(1));
+  DHIP(fd.esuel.alloc(n4)); DHIP(d_flag.alloc(n4 + 1)); DHIP(d_pos.alloc(n4 + 1)); DHIP(d_err.alloc(1));
   static_assert(sizeof(size_t) == sizeof(uint64_t), "size_t is 64 bits in this ABI");
-  DHIP(hipMemcpyAsync(d_inpoel.p, inpoel, n4 * 8, hipMemcpyHostToDevice, s));
-  if (nbfac) DHIP(hipMemcpyAsync(d_tri.p, triinpoel, 3 * nbfac * 8, hipMemcpyHostToDevice, s));
-  DHIP(hipMemcpyAsync(d_x.p, x, nnode * 8, hipMemcpyHostToDevice, s));
-  DHIP(hipMemcpyAsync(d_y.p, y, nnode * 8, hipMemcpyHostToDevice, s));
-  DHIP(hipMemcpyAsync(d_z.p, z, nnode * 8, hipMemcpyHostToDevice, s));
+  DHIP(hipMemcpyAsync(fd.inpoel.p, inpoel, n4 * 8, hipMemcpyHostToDevice, s));
+  if (nbfac) DHIP(hipMemcpyAsync(fd.tri.p, triinpoel, 3 * nbfac * 8, hipMemcpyHostToDevice, s));
+  DHIP(hipMemcpyAsync(fd.x.p, x, nnode * 8, hipMemcpyHostToDevice, s));
+  DHIP(hipMemcpyAsync(fd.y.p, y, nnode * 8, hipMemcpyHostToDevice, s));
+  DHIP(hipMemcpyAsync(fd.z.p, z, nnode * 8, hipMemcpyHostToDevice, s));
   DHIP(hipMemsetAsync(d_err.p, 0, sizeof(int), s));
 
   // ---- sort the 4*nelem faces by (a, b, c), ties in (element, local face) order ----
-  k_face_keys<<<nblk(n4), 256, 0, s>>>(d_inpoel.p, n4, ka.p, kb.p, kc.p, perm.p);
+  k_face_keys<<<nblk(n4), 256, 0, s>>>(fd.inpoel.p, n4, ka.p, kb.p, kc.p, perm.p);
   unsigned bits = 1;
   while (bits < 32 && ((size_t)1 << bits) < nnode) ++bits;
   size_t tmp_bytes = 0;
@@ -239,7 +249,6 @@ extern "C" int qdg_dev_facedata(qdg_ctx* ctx, size_t nelem, size_t nnode, const 
     std::swap(pin, pout);
   }
   const uint32_t* sperm = pin;                          // sorted position -> 4*e + f
-  // sorted keys (ka/kb/kc are reused as sa/sb/sc through key buffers)
   Buf<uint32_t> sa, sb, sc;
   DHIP(sa.alloc(n4)); DHIP(sb.alloc(n4)); DHIP(sc.alloc(n4));
   k_gather<<<nblk(n4), 256, 0, s>>>(ka.p, sperm, n4, sa.p);
@@ -247,10 +256,10 @@ extern "C" int qdg_dev_facedata(qdg_ctx* ctx, size_t nelem, size_t nnode, const 
   k_gather<<<nblk(n4), 256, 0, s>>>(kc.p, sperm, n4, sc.p);
 
   // ---- esuel ------------------------------------------------------------------------
-  k_match<<<nblk(n4), 256, 0, s>>>(sa.p, sb.p, sc.p, sperm, n4, d_esuel.p, d_err.p);
+  k_match<<<nblk(n4), 256, 0, s>>>(sa.p, sb.p, sc.p, sperm, n4, fd.esuel.p, d_err.p);
 
   // ---- interior faces in the reference's order ---------------------------------------
-  k_flag<<<nblk(n4), 256, 0, s>>>(d_esuel.p, n4, d_flag.p);
+  k_flag<<<nblk(n4), 256, 0, s>>>(fd.esuel.p, n4, d_flag.p);
   size_t scan_bytes = 0;
   DHIP(rocprim::exclusive_scan(nullptr, scan_bytes, d_flag.p, d_pos.p, 0, n4, rocprim::plus<int>(), s));
   Buf<char> tmp2;
@@ -264,30 +273,476 @@ extern "C" int qdg_dev_facedata(qdg_ctx* ctx, size_t nelem, size_t nnode, const 
   if (herr == 1) return fail("qdg_dev_facedata: face shared by more than two tets (non-manifold mesh)");
   const size_t nint = (size_t)last_pos + (size_t)last_flag, nipfac = nbfac + nint;
   if (nipfac > nfmax) return fail("qdg_dev_facedata: inconsistent face count");
-  DHIP(d_inpofa.alloc(3 * nipfac)); DHIP(d_esuf.alloc(2 * nipfac)); DHIP(d_belem.alloc(nbfac));
-  DHIP(d_geoFace.alloc(7 * nipfac)); DHIP(d_geoElem.alloc(4 * nelem));
-  k_interior_faces<<<nblk(n4), 256, 0, s>>>(d_inpoel.p, d_esuel.p, d_flag.p, d_pos.p, n4, nbfac,
-                                           d_inpofa.p, d_esuf.p);
+  fd.nipfac = nipfac;
+  DHIP(fd.inpofa.alloc(3 * nipfac)); DHIP(fd.esuf.alloc(2 * nipfac)); DHIP(fd.belem.alloc(nbfac));
+  DHIP(fd.geoFace.alloc(7 * nipfac)); DHIP(fd.geoElem.alloc(4 * nelem));
+  k_interior_faces<<<nblk(n4), 256, 0, s>>>(fd.inpoel.p, fd.esuel.p, d_flag.p, d_pos.p, n4, nbfac,
+                                           fd.inpofa.p, fd.esuf.p);
   if (nbfac)
-    k_boundary_faces<<<nblk(nbfac), 256, 0, s>>>(d_tri.p, nbfac, sa.p, sb.p, sc.p, sperm, n4, d_inpofa.p,
-                                                 d_esuf.p, d_belem.p, d_err.p);
+    k_boundary_faces<<<nblk(nbfac), 256, 0, s>>>(fd.tri.p, nbfac, sa.p, sb.p, sc.p, sperm, n4, fd.inpofa.p,
+                                                 fd.esuf.p, fd.belem.p, d_err.p);
   // ---- geometry ----------------------------------------------------------------------
-  k_geoface<<<nblk(nipfac), 256, 0, s>>>(d_inpofa.p, nipfac, d_x.p, d_y.p, d_z.p, d_geoFace.p);
-  k_geoelem<<<nblk(nelem), 256, 0, s>>>(d_inpoel.p, nelem, d_x.p, d_y.p, d_z.p, d_geoElem.p);
+  k_geoface<<<nblk(nipfac), 256, 0, s>>>(fd.inpofa.p, nipfac, fd.x.p, fd.y.p, fd.z.p, fd.geoFace.p);
+  k_geoelem<<<nblk(nelem), 256, 0, s>>>(fd.inpoel.p, nelem, fd.x.p, fd.y.p, fd.z.p, fd.geoElem.p);
   DHIP(hipGetLastError());
-
   DHIP(hipMemcpyAsync(&herr, d_err.p, sizeof(int), hipMemcpyDeviceToHost, s));
-  DHIP(hipMemcpyAsync(esuel, d_esuel.p, n4 * sizeof(int), hipMemcpyDeviceToHost, s));
-  DHIP(hipMemcpyAsync(inpofa, d_inpofa.p, 3 * nipfac * 8, hipMemcpyDeviceToHost, s));
-  DHIP(hipMemcpyAsync(esuf, d_esuf.p, 2 * nipfac * sizeof(int), hipMemcpyDeviceToHost, s));
-  if (nbfac) DHIP(hipMemcpyAsync(belem, d_belem.p, nbfac * 8, hipMemcpyDeviceToHost, s));
-  DHIP(hipMemcpyAsync(geoFace, d_geoFace.p, 7 * nipfac * 8, hipMemcpyDeviceToHost, s));
-  DHIP(hipMemcpyAsync(geoElem, d_geoElem.p, 4 * nelem * 8, hipMemcpyDeviceToHost, s));
   DHIP(hipStreamSynchronize(s));
   if (herr == 2) return fail("qdg_dev_facedata: a boundary face is not a face of any tet");
+  return 0;
+}
+
+extern "C" int qdg_dev_facedata(qdg_ctx* ctx, size_t nelem, size_t nnode, const size_t* inpoel,
+                                const double* x, const double* y, const double* z, size_t nbfac,
+                                const size_t* triinpoel, int* esuel, size_t* nipfac_out,
+                                size_t* inpofa, int* esuf, size_t* belem, double* geoFace,
+                                double* geoElem)
+{
+  QDG_TRY
+  if (!esuel || !nipfac_out || !inpofa || !esuf || !geoFace || !geoElem) return fail("qdg_dev_facedata: null argument");
+  if (nbfac > 0 && !belem) return fail("qdg_dev_facedata: null boundary arrays");
+  DevFD fd;
+  if (int rc = dev_facedata_keep(ctx, nelem, nnode, inpoel, x, y, z, nbfac, triinpoel, fd)) return rc;
+  hipStream_t s = ctx_stream(ctx);
+  const size_t n4 = 4 * nelem, nipfac = fd.nipfac;
+  DHIP(hipMemcpyAsync(esuel, fd.esuel.p, n4 * sizeof(int), hipMemcpyDeviceToHost, s));
+  DHIP(hipMemcpyAsync(inpofa, fd.inpofa.p, 3 * nipfac * 8, hipMemcpyDeviceToHost, s));
+  DHIP(hipMemcpyAsync(esuf, fd.esuf.p, 2 * nipfac * sizeof(int), hipMemcpyDeviceToHost, s));
+  if (nbfac) DHIP(hipMemcpyAsync(belem, fd.belem.p, nbfac * 8, hipMemcpyDeviceToHost, s));
+  DHIP(hipMemcpyAsync(geoFace, fd.geoFace.p, 7 * nipfac * 8, hipMemcpyDeviceToHost, s));
+  DHIP(hipMemcpyAsync(geoElem, fd.geoElem.p, 4 * nelem * 8, hipMemcpyDeviceToHost, s));
+  DHIP(hipStreamSynchronize(s));
   *nipfac_out = nipfac;
   return 0;
   QDG_CATCH
+}
+
+// ======================================================================================
+// Device layout of a chunk WITHOUT ghosts built on the device (second step):
+// everything qdg_mesh_upload derives on the host -- Morton order of the tets, node and face
+// numbering by first touch, neighbour / face-code / face-id planes, packed geometry records,
+// the face-task lists of the tile kernels -- from the resident FaceData (DevFD), with the SAME
+// ordering rules, so that a mesh built here is row for row the mesh qdg_mesh_upload builds.
+// This is what a re-mesh during time stepping pays (DG::resizePostAMR, DG.cpp:1536-1612).
+namespace {
+
+__device__ __forceinline__ unsigned long long dord(double v)     // order-preserving bits
+{
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__host__ inline double dord_inv(unsigned long long k)
+{
+  const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+  double v; std::memcpy(&v, &b, 8); return v;
+}
+
+__global__ void k_bbox(const double* __restrict__ geoElem, size_t ne, unsigned long long* __restrict__ mm)
+{
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= ne) return;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const unsigned long long k = dord(geoElem[4 * e + 1 + d]);
+    atomicMin(mm + d, k); atomicMax(mm + 3 + d, k);
+  }
+}
+
+__device__ __forceinline__ uint64_t spread21d(uint64_t v)
+{
+  v &= 0x1fffff;
+  v = (v | v << 32) & 0x1f00000000ffffULL;
+  v = (v | v << 16) & 0x1f0000ff0000ffULL;
+  v = (v | v << 8) & 0x100f00f00f00f00fULL;
+  v = (v | v << 4) & 0x10c30c30c30c30c3ULL;
+  v = (v | v << 2) & 0x1249249249249249ULL;
+  return v;
+}
+
+__global__ void k_morton(const double* __restrict__ geoElem, size_t ne, double lx, double ly, double lz,
+                         double ext, uint64_t* __restrict__ key, uint32_t* __restrict__ val)
+{
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= ne) return;
+  const double lo[3] = { lx, ly, lz };
+  uint64_t k = 0;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const double t = (geoElem[4 * e + 1 + d] - lo[d]) / ext;
+    const uint64_t q = (uint64_t)fmin(2097151.0, fmax(0.0, t * 2097152.0));
+    k |= spread21d(q) << d;
+  }
+  key[e] = k; val[e] = (uint32_t)e;
+}
+
+__global__ void k_invert(const uint32_t* __restrict__ d2h, size_t n, int* __restrict__ h2d, int* __restrict__ d2h_i)
+{
+  const size_t d = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= n) return;
+  h2d[d2h[d]] = (int)d; d2h_i[d] = (int)d2h[d];
+}
+
+__global__ void k_fill_u32(uint32_t* p, size_t n, uint32_t v)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+// (host tet, local face) -> reference face id, from esuf (one thread per face)
+__global__ void k_rface(size_t nf, const int* __restrict__ esuf, const int* __restrict__ esuel,
+                        const uint64_t* __restrict__ inpoel, const uint64_t* __restrict__ inpofa,
+                        int* __restrict__ rface, int* __restrict__ err)
+{
+  const size_t f = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= nf) return;
+  const int el = esuf[2 * f], er = esuf[2 * f + 1];
+  if (er == -1) {
+    int found = -1;
+    for (int lf = 0; lf < 4 && found < 0; ++lf) {
+      int cnt = 0;
+      for (int j = 0; j < 3; ++j)
+        for (int k = 0; k < 3; ++k)
+          if (inpoel[4 * (size_t)el + c_lpofa[lf][j]] == inpofa[3 * f + k]) ++cnt;
+      if (cnt == 3) found = lf;
+    }
+    if (found < 0) { *err = 3; return; }
+    rface[4 * (size_t)el + found] = (int)f;
+  } else {
+    int a = -1, b = -1;
+    for (int lf = 0; lf < 4; ++lf) if (esuel[4 * (size_t)el + lf] == er) a = lf;
+    for (int lf = 0; lf < 4; ++lf) if (esuel[4 * (size_t)er + lf] == el) b = lf;
+    if (a < 0 || b < 0) { *err = 4; return; }
+    rface[4 * (size_t)el + a] = (int)f;
+    rface[4 * (size_t)er + b] = (int)f;
+  }
+}
+
+// first touch of nodes and faces in device element order: slot = 4*d + i
+__global__ void k_first_touch(size_t ne, const int* __restrict__ d2h, const uint64_t* __restrict__ inpoel,
+                              const int* __restrict__ rface, uint32_t* __restrict__ first_node,
+                              uint32_t* __restrict__ first_face)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 4 * ne) return;
+  const size_t d = i >> 2; const int k = (int)(i & 3);
+  const size_t h = (size_t)d2h[d];
+  atomicMin(first_node + inpoel[4 * h + k], (uint32_t)i);
+  atomicMin(first_face + rface[4 * h + k], (uint32_t)i);
+}
+
+// rank in the order of first touch -> new id; untouched entries (key 0xffffffff) get none
+__global__ void k_rank(size_t n, const uint32_t* __restrict__ sorted_key, const uint32_t* __restrict__ sorted_val,
+                       int* __restrict__ newid, int* __restrict__ count)
+{
+  const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  if (sorted_key[r] != 0xffffffffu) { newid[sorted_val[r]] = (int)r; atomicAdd(count, 1); }
+  else newid[sorted_val[r]] = -1;
+}
+
+__global__ void k_layout_rows(size_t ne, int stride, const int* __restrict__ d2h, const int* __restrict__ h2d,
+                              const uint64_t* __restrict__ inpoel, const int* __restrict__ esuel,
+                              const int* __restrict__ esuf, const int* __restrict__ rface,
+                              const int* __restrict__ nnew, const int* __restrict__ fmap,
+                              const int* __restrict__ bcface, const double* __restrict__ geoElem,
+                              int* __restrict__ o_inpoel, int* __restrict__ o_nbr, int* __restrict__ o_finfo,
+                              int* __restrict__ o_fid, double* __restrict__ o_vol, int* __restrict__ err)
+{
+  const size_t d = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= ne) return;
+  const size_t h = (size_t)d2h[d];
+  for (int i = 0; i < 4; ++i) o_inpoel[(size_t)i * stride + d] = nnew[inpoel[4 * h + i]];
+  o_vol[d] = geoElem[4 * h];
+  for (int lf = 0; lf < 4; ++lf) {
+    const int f = rface[4 * h + lf];
+    o_fid[(size_t)lf * stride + d] = fmap[f];
+    const int nb = esuel[4 * h + lf];
+    int info = ((size_t)esuf[2 * f] == h) ? (1 << 6) : 0;
+    if (nb < 0) {
+      o_nbr[(size_t)lf * stride + d] = -(1 + bcface[f]);
+    } else {
+      o_nbr[(size_t)lf * stride + d] = h2d[nb];
+      for (int j = 0; j < 3; ++j) {
+        const uint64_t g = inpoel[4 * h + c_lpofa[lf][j]];
+        int m = -1;
+        for (int q = 0; q < 4; ++q) if (inpoel[4 * (size_t)nb + q] == g) m = q;
+        if (m < 0) { *err = 5; m = 0; }
+        info |= m << (2 * j);
+      }
+    }
+    o_finfo[(size_t)lf * stride + d] = info;
+  }
+}
+
+__global__ void k_layout_nodes(size_t nnode, const int* __restrict__ nnew, const double* __restrict__ x,
+                               const double* __restrict__ y, const double* __restrict__ z,
+                               double* __restrict__ ox, double* __restrict__ oy, double* __restrict__ oz,
+                               double* __restrict__ xyz4)
+{
+  const size_t n = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= nnode) return;
+  const int k = nnew[n];
+  if (k < 0) return;
+  ox[k] = x[n]; oy[k] = y[n]; oz[k] = z[n];
+  xyz4[4 * (size_t)k] = x[n]; xyz4[4 * (size_t)k + 1] = y[n]; xyz4[4 * (size_t)k + 2] = z[n]; xyz4[4 * (size_t)k + 3] = 0.0;
+}
+
+__global__ void k_layout_faces(size_t nf, const int* __restrict__ fmap, const double* __restrict__ geoFace,
+                               double* __restrict__ area, double* __restrict__ nx, double* __restrict__ ny,
+                               double* __restrict__ nz, double* __restrict__ fgeo)
+{
+  const size_t f = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= nf) return;
+  const int k = fmap[f];
+  if (k < 0) return;
+  const double a = geoFace[7 * f], b = geoFace[7 * f + 1], c = geoFace[7 * f + 2], d = geoFace[7 * f + 3];
+  area[k] = a; nx[k] = b; ny[k] = c; nz[k] = d;
+  fgeo[4 * (size_t)k] = a; fgeo[4 * (size_t)k + 1] = b; fgeo[4 * (size_t)k + 2] = c; fgeo[4 * (size_t)k + 3] = d;
+}
+
+// face tasks: sort key (tile, kind, local face) of every (device row, local face); in-tile faces
+// are listed by their left tet only (the other side gets the "dropped" key)
+__device__ __forceinline__ bool task_of(size_t d, int lf, int stride, int tile_rows, size_t ne, const int* nbr,
+                                        const int* finfo, const int* fid, int& a, int& nbid, int& f, uint32_t& key)
+{
+  const int nb = nbr[(size_t)lf * stride + d], info = finfo[(size_t)lf * stride + d];
+  const int own_left = (info >> 6) & 1, code = info & 63;
+  const size_t tile = d / tile_rows, e0 = tile * tile_rows, e1 = (e0 + tile_rows < ne) ? e0 + tile_rows : ne;
+  int kind, bc = 0, pl = 0;
+  nbid = 0;
+  if (nb < 0) { kind = TASK_BND; bc = -nb - 1; }
+  else if ((size_t)nb >= e0 && (size_t)nb < e1) {
+    if (!own_left) return false;
+    kind = TASK_INT; pl = nb - (int)e0;
+  } else { kind = TASK_EXT; nbid = nb; }
+  a = (int)(d - e0) | (lf << 8) | (own_left << 10) | (code << 11) | (kind << 17) | (bc << 19) | (pl << 21);
+  f = fid[(size_t)lf * stride + d];
+  key = (uint32_t)(tile << 4) | (uint32_t)((kind << 2) | lf);
+  return true;
+}
+
+__global__ void k_task_keys(size_t ne, int stride, int tile_rows, const int* __restrict__ nbr,
+                            const int* __restrict__ finfo, const int* __restrict__ fid,
+                            uint32_t* __restrict__ key, uint32_t* __restrict__ val, int* __restrict__ count)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 4 * ne) return;
+  int a, nbid, f; uint32_t k;
+  const bool ok = task_of(i >> 2, (int)(i & 3), stride, tile_rows, ne, nbr, finfo, fid, a, nbid, f, k);
+  key[i] = ok ? k : 0xffffffffu; val[i] = (uint32_t)i;
+  if (ok) atomicAdd(count, 1);
+}
+
+__global__ void k_tile_off(size_t ntask, int ntile, const uint32_t* __restrict__ skey, int* __restrict__ tile_off)
+{
+  const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > ntask) return;
+  if (r == ntask) { tile_off[ntile] = (int)ntask; return; }
+  const int t = (int)(skey[r] >> 4);
+  if (r == 0 || (int)(skey[r - 1] >> 4) != t) tile_off[t] = (int)r;
+}
+
+__global__ void k_task_fill(size_t ntask, size_t ne, int stride, int tile_rows, int task_stride,
+                            const int* __restrict__ nbr, const int* __restrict__ finfo, const int* __restrict__ fid,
+                            const uint32_t* __restrict__ sval, const int* __restrict__ tile_off,
+                            int* __restrict__ task_a, int* __restrict__ task_nb, int* __restrict__ task_f)
+{
+  const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= ntask) return;
+  const size_t i = sval[r];
+  int a, nbid, f; uint32_t k;
+  task_of(i >> 2, (int)(i & 3), stride, tile_rows, ne, nbr, finfo, fid, a, nbid, f, k);
+  const size_t tile = k >> 4;
+  const size_t pos = task_stride ? tile * (size_t)task_stride + (r - (size_t)tile_off[tile]) : r;
+  task_a[pos] = a; task_nb[pos] = nbid; task_f[pos] = f;
+}
+
+__global__ void k_fill_i32(int* p, size_t n, int v)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+// sort (key, value) pairs of 32-bit keys; results in ko / vo
+static int sort32(uint32_t* ki, uint32_t* ko, uint32_t* vi, uint32_t* vo, size_t n, hipStream_t s)
+{
+  size_t bytes = 0;
+  DHIP(rocprim::radix_sort_pairs(nullptr, bytes, ki, ko, vi, vo, n, 0, 32, s));
+  Buf<char> tmp;
+  DHIP(tmp.alloc(bytes));
+  DHIP(rocprim::radix_sort_pairs(tmp.p, bytes, ki, ko, vi, vo, n, 0, 32, s));
+  DHIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+}  // namespace
+
+// fd: resident FaceData of the chunk; bcface[nbfac]: BC type of every boundary face (0 = none)
+static int dev_build_layout(qdg_ctx* ctx, DevFD& fd, const std::vector<int>& bcface, qdg_mesh** out)
+{
+  DHIP(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const size_t ne = fd.nelem, nnode = fd.nnode, nf = fd.nipfac, n4 = 4 * ne;
+  const size_t stride = (ne + 63) / 64 * 64;
+  if (ne > (size_t)(INT32_MAX - 64) / 4 || nf > (size_t)INT32_MAX) return fail("qdg_mesh_from_connectivity: chunk too large");
+  std::unique_ptr<qdg_mesh> m(new qdg_mesh);
+  m->ctx = ctx;
+  m->ndof = ctx->cfg.ndof;
+  const int ncomp = ctx->cfg.pde == QDG_PDE_TRANSPORT ? 1 : NCOMP;
+  m->nprop = ncomp * m->ndof;
+  m->nie = ne; m->ne = ne; m->stride = stride;
+
+  Buf<int> d_err, d_count;
+  DHIP(d_err.alloc(1)); DHIP(d_count.alloc(2));
+  DHIP(hipMemsetAsync(d_err.p, 0, sizeof(int), s));
+  DHIP(hipMemsetAsync(d_count.p, 0, 2 * sizeof(int), s));
+
+  // ---- device order: Morton curve of the centroids (ties by tet id) --------------------
+  Buf<unsigned long long> d_mm;
+  DHIP(d_mm.alloc(6));
+  {
+    const unsigned long long init[6] = { ~0ull, ~0ull, ~0ull, 0ull, 0ull, 0ull };
+    DHIP(hipMemcpyAsync(d_mm.p, init, sizeof init, hipMemcpyHostToDevice, s));
+  }
+  k_bbox<<<nblk(ne), 256, 0, s>>>(fd.geoElem.p, ne, d_mm.p);
+  unsigned long long hmm[6];
+  DHIP(hipMemcpyAsync(hmm, d_mm.p, sizeof hmm, hipMemcpyDeviceToHost, s));
+  DHIP(hipStreamSynchronize(s));
+  double lo[3], hi[3];
+  for (int d = 0; d < 3; ++d) { lo[d] = dord_inv(hmm[d]); hi[d] = dord_inv(hmm[3 + d]); }
+  const double ext = std::max({ hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2], 1e-300 });
+  Buf<uint64_t> mkey, mkey2;
+  Buf<uint32_t> mval, mval2;
+  DHIP(mkey.alloc(ne)); DHIP(mkey2.alloc(ne)); DHIP(mval.alloc(ne)); DHIP(mval2.alloc(ne));
+  k_morton<<<nblk(ne), 256, 0, s>>>(fd.geoElem.p, ne, lo[0], lo[1], lo[2], ext, mkey.p, mval.p);
+  {
+    size_t bytes = 0;
+    DHIP(rocprim::radix_sort_pairs(nullptr, bytes, mkey.p, mkey2.p, mval.p, mval2.p, ne, 0, 63, s));
+    Buf<char> tmp;
+    DHIP(tmp.alloc(bytes));
+    DHIP(rocprim::radix_sort_pairs(tmp.p, bytes, mkey.p, mkey2.p, mval.p, mval2.p, ne, 0, 63, s));
+    DHIP(hipStreamSynchronize(s));
+  }
+  Buf<int> h2d;
+  DHIP(h2d.alloc(ne));
+  HIPCHK(m->d2h.alloc(ne));
+  k_invert<<<nblk(ne), 256, 0, s>>>(mval2.p, ne, h2d.p, m->d2h.p);
+
+  // ---- reference face id per (tet, local face); first touch of nodes and faces ---------
+  Buf<int> rface;
+  DHIP(rface.alloc(n4));
+  k_fill_i32<<<nblk(n4), 256, 0, s>>>(rface.p, n4, -1);
+  k_rface<<<nblk(nf), 256, 0, s>>>(nf, fd.esuf.p, fd.esuel.p, fd.inpoel.p, fd.inpofa.p, rface.p, d_err.p);
+  Buf<uint32_t> fkn, fkn2, vn, vn2, fkf, fkf2, vf, vf2;
+  DHIP(fkn.alloc(nnode)); DHIP(fkn2.alloc(nnode)); DHIP(vn.alloc(nnode)); DHIP(vn2.alloc(nnode));
+  DHIP(fkf.alloc(nf)); DHIP(fkf2.alloc(nf)); DHIP(vf.alloc(nf)); DHIP(vf2.alloc(nf));
+  k_fill_u32<<<nblk(nnode), 256, 0, s>>>(fkn.p, nnode, 0xffffffffu);
+  k_fill_u32<<<nblk(nf), 256, 0, s>>>(fkf.p, nf, 0xffffffffu);
+  {
+    int herr = 0;
+    DHIP(hipMemcpyAsync(&herr, d_err.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    DHIP(hipStreamSynchronize(s));
+    if (herr) return fail("qdg_mesh_from_connectivity: inconsistent FaceData (esuf / esuel / inpofa)");
+  }
+  k_first_touch<<<nblk(n4), 256, 0, s>>>(ne, m->d2h.p, fd.inpoel.p, rface.p, fkn.p, fkf.p);
+  // identity values
+  {
+    std::vector<uint32_t> iota(std::max(nnode, nf));
+    for (size_t i = 0; i < iota.size(); ++i) iota[i] = (uint32_t)i;
+    DHIP(hipMemcpyAsync(vn.p, iota.data(), nnode * 4, hipMemcpyHostToDevice, s));
+    DHIP(hipMemcpyAsync(vf.p, iota.data(), nf * 4, hipMemcpyHostToDevice, s));
+    DHIP(hipStreamSynchronize(s));
+  }
+  if (int rc = sort32(fkn.p, fkn2.p, vn.p, vn2.p, nnode, s)) return rc;
+  if (int rc = sort32(fkf.p, fkf2.p, vf.p, vf2.p, nf, s)) return rc;
+  Buf<int> nnew, fmap;
+  DHIP(nnew.alloc(nnode)); DHIP(fmap.alloc(nf));
+  k_rank<<<nblk(nnode), 256, 0, s>>>(nnode, fkn2.p, vn2.p, nnew.p, d_count.p);
+  k_rank<<<nblk(nf), 256, 0, s>>>(nf, fkf2.p, vf2.p, fmap.p, d_count.p + 1);
+  int hcount[2];
+  DHIP(hipMemcpyAsync(hcount, d_count.p, sizeof hcount, hipMemcpyDeviceToHost, s));
+  DHIP(hipStreamSynchronize(s));
+  const int ncount = hcount[0], nfd = hcount[1];
+
+  // ---- rows, nodes, faces in device numbering ---------------------------------------------
+  Buf<int> d_bc;
+  DHIP(d_bc.alloc(std::max<size_t>(bcface.size(), 1)));
+  if (!bcface.empty()) DHIP(hipMemcpyAsync(d_bc.p, bcface.data(), bcface.size() * sizeof(int), hipMemcpyHostToDevice, s));
+  HIPCHK(m->inpoel.alloc(4 * stride)); HIPCHK(m->nbr.alloc(4 * stride)); HIPCHK(m->finfo.alloc(4 * stride));
+  HIPCHK(m->fid.alloc(4 * stride)); HIPCHK(m->vol.alloc(stride));
+  k_fill_i32<<<nblk(4 * stride), 256, 0, s>>>(m->inpoel.p, 4 * stride, 0);
+  k_fill_i32<<<nblk(4 * stride), 256, 0, s>>>(m->nbr.p, 4 * stride, -1);
+  k_fill_i32<<<nblk(4 * stride), 256, 0, s>>>(m->finfo.p, 4 * stride, 0);
+  k_fill_i32<<<nblk(4 * stride), 256, 0, s>>>(m->fid.p, 4 * stride, 0);
+  {
+    std::vector<double> ones(stride, 1.0);
+    DHIP(hipMemcpyAsync(m->vol.p, ones.data(), stride * 8, hipMemcpyHostToDevice, s));
+    DHIP(hipStreamSynchronize(s));
+  }
+  k_layout_rows<<<nblk(ne), 256, 0, s>>>(ne, (int)stride, m->d2h.p, h2d.p, fd.inpoel.p, fd.esuel.p, fd.esuf.p,
+                                         rface.p, nnew.p, fmap.p, d_bc.p, fd.geoElem.p, m->inpoel.p, m->nbr.p,
+                                         m->finfo.p, m->fid.p, m->vol.p, d_err.p);
+  const size_t nn1 = (size_t)std::max(ncount, 1), nf1 = (size_t)std::max(nfd, 1);
+  HIPCHK(m->x.alloc(nn1)); HIPCHK(m->y.alloc(nn1)); HIPCHK(m->z.alloc(nn1)); HIPCHK(m->xyz4.alloc(4 * nn1));
+  HIPCHK(m->farea.alloc(nf1)); HIPCHK(m->fnx.alloc(nf1)); HIPCHK(m->fny.alloc(nf1)); HIPCHK(m->fnz.alloc(nf1));
+  HIPCHK(m->fgeo.alloc(4 * nf1));
+  k_layout_nodes<<<nblk(nnode), 256, 0, s>>>(nnode, nnew.p, fd.x.p, fd.y.p, fd.z.p, m->x.p, m->y.p, m->z.p, m->xyz4.p);
+  k_layout_faces<<<nblk(nf), 256, 0, s>>>(nf, fmap.p, fd.geoFace.p, m->farea.p, m->fnx.p, m->fny.p, m->fnz.p, m->fgeo.p);
+
+  // ---- face tasks of the tile kernels -------------------------------------------------------
+  const int tile_rows = TILE;
+  const int ntile = (int)((ne + TILE - 1) / TILE);
+  Buf<uint32_t> tk, tk2, tv, tv2;
+  DHIP(tk.alloc(n4)); DHIP(tk2.alloc(n4)); DHIP(tv.alloc(n4)); DHIP(tv2.alloc(n4));
+  Buf<int> d_nt;
+  DHIP(d_nt.alloc(1));
+  DHIP(hipMemsetAsync(d_nt.p, 0, sizeof(int), s));
+  k_task_keys<<<nblk(n4), 256, 0, s>>>(ne, (int)stride, tile_rows, m->nbr.p, m->finfo.p, m->fid.p, tk.p, tv.p, d_nt.p);
+  if (int rc = sort32(tk.p, tk2.p, tv.p, tv2.p, n4, s)) return rc;
+  int ntask = 0, herr = 0;
+  DHIP(hipMemcpyAsync(&ntask, d_nt.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  DHIP(hipMemcpyAsync(&herr, d_err.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  DHIP(hipStreamSynchronize(s));
+  if (herr) return fail("qdg_mesh_from_connectivity: neighbour does not share the face nodes (bad connectivity)");
+  const int task_stride = (!std::getenv("QDG_TASK_COMPACT") && !ctx->cfg.pref) ? 4 * TILE_BS : 0;
+  const size_t nslot = task_stride ? (size_t)ntile * task_stride : (size_t)ntask;
+  HIPCHK(m->tile_off.alloc(ntile + 1)); HIPCHK(m->tile_row.alloc(ntile + 1));
+  HIPCHK(m->task_a.alloc(std::max<size_t>(nslot, 1))); HIPCHK(m->task_nb.alloc(std::max<size_t>(nslot, 1)));
+  HIPCHK(m->task_f.alloc(std::max<size_t>(nslot, 1)));
+  k_fill_i32<<<nblk(nslot), 256, 0, s>>>(m->task_a.p, nslot, -1);
+  k_fill_i32<<<nblk(nslot), 256, 0, s>>>(m->task_nb.p, nslot, 0);
+  k_fill_i32<<<nblk(nslot), 256, 0, s>>>(m->task_f.p, nslot, 0);
+  k_tile_off<<<nblk((size_t)ntask + 1), 256, 0, s>>>((size_t)ntask, ntile, tk2.p, m->tile_off.p);
+  k_task_fill<<<nblk((size_t)ntask), 256, 0, s>>>((size_t)ntask, ne, (int)stride, tile_rows, task_stride, m->nbr.p,
+                                                  m->finfo.p, m->fid.p, tv2.p, m->tile_off.p, m->task_a.p,
+                                                  m->task_nb.p, m->task_f.p);
+  {
+    std::vector<int> rows(ntile + 1);
+    for (int t = 0; t <= ntile; ++t) rows[t] = (int)std::min((size_t)t * TILE, ne);
+    DHIP(hipMemcpyAsync(m->tile_row.p, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    DHIP(hipStreamSynchronize(s));
+  }
+  DHIP(hipGetLastError());
+
+  if (int rc = mesh_alloc_state(m.get(), ntile)) return rc;
+  m->nnode_used = (size_t)ncount;
+  DevMesh& dm = m->dm;
+  dm.nie = (int)ne; dm.ne = (int)ne; dm.stride = (int)stride; dm.nnode = ncount; dm.nfac = nfd;
+  dm.inpoel = m->inpoel.p; dm.nbr = m->nbr.p; dm.finfo = m->finfo.p; dm.fid = m->fid.p;
+  dm.x = m->x.p; dm.y = m->y.p; dm.z = m->z.p;
+  dm.farea = m->farea.p; dm.fnx = m->fnx.p; dm.fny = m->fny.p; dm.fnz = m->fnz.p;
+  dm.vol = m->vol.p; dm.d2h = m->d2h.p; dm.fgeo = m->fgeo.p; dm.xyz4 = m->xyz4.p;
+  dm.ntile = ntile; dm.ntile_inner = ntile; dm.tile_row = m->tile_row.p; dm.task_stride = task_stride;
+  dm.tile_rows = TILE;
+  dm.tile_off = m->tile_off.p; dm.task_a = m->task_a.p; dm.task_nb = m->task_nb.p; dm.task_f = m->task_f.p;
+  dm.blk0 = 0; dm.ninner = (int)ne; dm.ncomp = ncomp; dm.ndofel = nullptr;
+  if (ctx->cfg.pref) {
+    HIPCHK(m->ndofel.alloc(ne)); HIPCHK(m->ndofel2.alloc(ne));
+    k_fill_i32<<<nblk(ne), 256, 0, s>>>(m->ndofel.p, ne, 4);
+    dm.ndofel = m->ndofel.p;
+  }
+  DHIP(hipStreamSynchronize(s));
+  *out = m.release();
+  return 0;
 }
 
 extern "C" int qdg_mesh_from_connectivity(qdg_ctx* ctx, size_t nelem, size_t nnode, const size_t* inpoel,
@@ -306,6 +761,27 @@ extern "C" int qdg_mesh_from_connectivity(qdg_ctx* ctx, size_t nelem, size_t nno
   if (ntri)
     if (int rc = qdg_bnd_faces(nelem, inpoel, ntri, tri, tri_set, &nbfac, triinpoel.data(), fset.data()))
       return rc;
+  if (!std::getenv("QDG_HOST_LAYOUT")) {
+    // FaceData, geometry AND the device layout on the GPU: nothing but the connectivity, the
+    // coordinates and the boundary faces cross PCIe
+    DevFD fd;
+    if (int rc = dev_facedata_keep(ctx, nelem, nnode, inpoel, x, y, z, nbfac, triinpoel.data(), fd)) return rc;
+    // BC type per boundary face: bndSurfInt over the configured side sets of each type
+    // (src/PDE/Integrate/Boundary.cpp:84-90); faces of unconfigured sets get no flux
+    std::vector<int> bcface(nbfac, 0);
+    for (size_t f = 0; f < nbfac; ++f) {
+      int type = 0;
+      for (size_t i = 0; i < ctx->bc_sideset.size(); ++i)
+        if (ctx->bc_sideset[i] == fset[f]) {
+          if (type != 0 && type != ctx->bc_type[i])
+            return fail("qdg_mesh_from_connectivity: a side set is configured with two different BC types");
+          type = ctx->bc_type[i];
+        }
+      bcface[f] = type;
+    }
+    return dev_build_layout(ctx, fd, bcface, out);
+  }
+  // QDG_HOST_LAYOUT=1: FaceData on the device, copied back, layout by qdg_mesh_upload (A/B, tests)
   const size_t nfmax = nbfac + 2 * nelem;
   std::vector<int> esuel(4 * nelem), esuf(2 * nfmax);
   std::vector<size_t> inpofa(3 * nfmax), belem(std::max<size_t>(nbfac, 1));

@@ -1,0 +1,114 @@
+// qdg_handles.hpp -- the opaque handles of the C ABI (qdg_ctx, qdg_mesh) and the owning
+// device buffer they are made of; shared by the translation units of libqdg that create or
+// fill a mesh handle (qdg_api.cpp: upload from host arrays; qdg_devmesh.hip: layout built on
+// the device).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/qdg.h"
+#include "qdg_device.hpp"
+#include "qdg_host.hpp"
+
+namespace qdg {
+
+// owning device buffer
+template <class T> struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t count)
+  {
+    if (p) { (void)hipFree(p); p = nullptr; }
+    n = count;
+    if (count == 0) return hipSuccess;
+    return hipMalloc((void**)&p, count * sizeof(T));
+  }
+  hipError_t upload(const std::vector<T>& h, hipStream_t s)
+  {
+    hipError_t e = alloc(h.size());
+    if (e != hipSuccess || h.empty()) return e;
+    e = hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return e;
+    return hipStreamSynchronize(s);   // h may be a temporary of the caller
+  }
+};
+
+}  // namespace qdg
+
+
+struct qdg_ctx {
+  qdg_config cfg;
+  std::vector<int32_t> bc_sideset, bc_type;
+  qdg::Phys ph;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  ~qdg_ctx()
+  {
+    if (own_stream && stream) {
+      (void)hipSetDevice(device);
+      (void)hipStreamSynchronize(stream);
+      (void)hipStreamDestroy(stream);
+    }
+  }
+};
+
+struct qdg_mesh {
+  qdg_ctx* ctx = nullptr;
+  qdg::DevMesh dm{};
+  int ndof = 1, nprop = 5;
+  size_t nie = 0, ne = 0, stride = 0;
+  // mesh
+  qdg::DevBuf<int> inpoel, nbr, finfo, fid, d2h;
+  qdg::DevBuf<double> x, y, z, farea, fnx, fny, fnz, vol, fgeo, xyz4;
+  qdg::DevBuf<int> tile_row, tile_off, task_a, task_nb, task_f;
+  // fields (SoA planes [nprop][stride])
+  qdg::DevBuf<double> U, Un, R, W;     // W: scratch state (stateless ops, WENO ping-pong)
+  qdg::DevBuf<double> aos;             // [ne*nprop] staging in the caller's layout
+  qdg::DevBuf<double> blockmin, dtraw, dtdev, diagpart, diagout;
+  // the three field buffers U, Un, W rotate: Ucur = current state, Unp = the
+  // stage-0 state of the running step (may alias Ucur until the first update),
+  // the remaining one is free (RK output / WENO ping-pong)
+  double* Ucur = nullptr;
+  double* Unp = nullptr;
+  double* Upending = nullptr;     // output of a fused RHS+RK launch, adopted by qdg_stage_update
+  qdg::DevBuf<double> S1, S2;          // scratch of the stateless operators (allocated on first use)
+  qdg::DevBuf<int> ndofel, ndofel2;    // p-adaptive DG: DG::m_ndof per device row (+ Jacobi copy)
+  qdg::DevBuf<double> fout;            // field output staging (allocated on first use)
+  // halo
+  size_t nnbr = 0, nsend = 0, nrecv = 0;
+  std::vector<int32_t> nbr_rank;
+  std::vector<size_t> send_off, recv_off;
+  qdg::DevBuf<int> send_elem;
+  qdg::DevBuf<double> send_slab, recv_slab;
+  double* send_ptr = nullptr;     // slabs in use (own or caller-provided)
+  double* recv_ptr = nullptr;
+  double* dt_ptr = nullptr;       // dt scalar in use
+  size_t nnode_used = 0;
+  // halo overlap (qdg_step_comm): when set, the limiter / the tile RHS run the
+  // rows without a ghost neighbour first, then wait for this event (end of the
+  // exchange on the communication stream) before the rows next to the halo
+  hipEvent_t split_lim = nullptr, split_rhs = nullptr;
+  // measurement: event pairs around the RHS kernel (cont: second part of a split launch)
+  bool prof = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+  std::vector<char> ev_cont;
+  size_t ev_used = 0;
+  ~qdg_mesh()
+  {
+    for (auto& e : ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  }
+};
+
+
+namespace qdg {
+// qdg_api.cpp
+int mesh_alloc_state(qdg_mesh* m, int ntile);
+}  // namespace qdg
