@@ -363,6 +363,18 @@ int qdg_refined_get(const qdg_refined* r, size_t* nnode, size_t* inpoel, size_t*
 int qdg_refined_destroy(qdg_refined* r);
 int qdg_state_transfer(qdg_mesh* from, qdg_mesh* to, const size_t* parent_of_child);
 
+/* -- element-field output in ExodusII layout -----------------------------------
+ * What DG::writeFields hands tk::ExodusIIMeshWriter (src/Inciter/DG.cpp:1165-1215,
+ * src/IO/ExodusIIMeshWriter.cpp: writeMesh, writeElemVarNames, writeTimeStamp, writeElemScalar)
+ * written as a netCDF classic file with 64-bit offsets (CDF-2) in ExodusII conventions -- one
+ * TETRA block, side sets as (element, ExodusII side 1..4) pairs, element variables -- so that the
+ * reference's exodiff configuration (exodiff_dg.cfg) can compare it with a golden file.
+ * vals[(t*nvar + v)*nelem + e]; all time steps are written by the one call. */
+int qdg_exo_write(const char* path, const char* title, size_t nnode, const double* x, const double* y,
+                  const double* z, size_t nelem, const size_t* inpoel, size_t nss, const int32_t* ss_id,
+                  const size_t* ss_off, const size_t* ss_elem, const int32_t* ss_side, size_t nvar,
+                  const char* const* var_names, size_t ntime, const double* times, const double* vals);
+
 /* -- mesh-derived data generated on the device (first step) -----
  * The same arrays as qdg_gen_esuel / nipfac / inpofa / belem / esuf / geoface /
  * geoelem above (src/Inciter/FaceData.cpp:19-41, src/Mesh/DerivedData.cpp:937-1491),

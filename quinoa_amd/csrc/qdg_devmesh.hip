@@ -13,7 +13,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -200,37 +202,150 @@ struct DevFD {
   size_t nelem = 0, nnode = 0, nbfac = 0, nipfac = 0;
 };
 
-static int dev_facedata_keep(qdg_ctx* ctx, size_t nelem, size_t nnode, const size_t* inpoel,
-                             const double* x, const double* y, const double* z, size_t nbfac,
-                             const size_t* triinpoel, DevFD& fd)
+// connectivity and coordinates of a chunk to the device (validated on the host first)
+static int dev_upload_mesh(qdg_ctx* ctx, size_t nelem, size_t nnode, const size_t* inpoel, const double* x,
+                           const double* y, const double* z, DevFD& fd)
 {
   if (!ctx || !inpoel || !x || !y || !z) return fail("qdg_dev_facedata: null argument");
-  if (nbfac > 0 && !triinpoel) return fail("qdg_dev_facedata: null boundary arrays");
   if (nelem == 0) return fail("qdg_dev_facedata: empty mesh");
   if (nelem > (size_t)INT32_MAX / 4 || nnode > (size_t)INT32_MAX)
     return fail("qdg_dev_facedata: chunk too large for 32-bit ids");
   for (size_t i = 0; i < 4 * nelem; ++i)
     if (inpoel[i] >= nnode) return fail("qdg_dev_facedata: inpoel entry out of range");
-  for (size_t i = 0; i < 3 * nbfac; ++i)
-    if (triinpoel[i] >= nnode) return fail("qdg_dev_facedata: triinpoel entry out of range");
   DHIP(hipSetDevice(ctx_device(ctx)));
   hipStream_t s = ctx_stream(ctx);
-  const size_t n4 = 4 * nelem, nfmax = nbfac + 2 * nelem;
-  fd.nelem = nelem; fd.nnode = nnode; fd.nbfac = nbfac;
-
-  Buf<uint32_t> ka, kb, kc, perm, perm2, key, key2;
-  Buf<int> d_flag, d_pos, d_err;
-  DHIP(fd.inpoel.alloc(n4)); DHIP(fd.tri.alloc(3 * nbfac));
-  DHIP(fd.x.alloc(nnode)); DHIP(fd.y.alloc(nnode)); DHIP(fd.z.alloc(nnode));
-  DHIP(ka.alloc(n4)); DHIP(kb.alloc(n4)); DHIP(kc.alloc(n4));
-  DHIP(perm.alloc(n4)); DHIP(perm2.alloc(n4)); DHIP(key.alloc(n4)); DHIP(key2.alloc(n4));
-  DHIP(fd.esuel.alloc(n4)); DHIP(d_flag.alloc(n4 + 1)); DHIP(d_pos.alloc(n4 + 1)); DHIP(d_err.alloc(1));
+  fd.nelem = nelem; fd.nnode = nnode;
   static_assert(sizeof(size_t) == sizeof(uint64_t), "size_t is 64 bits in this ABI");
-  DHIP(hipMemcpyAsync(fd.inpoel.p, inpoel, n4 * 8, hipMemcpyHostToDevice, s));
-  if (nbfac) DHIP(hipMemcpyAsync(fd.tri.p, triinpoel, 3 * nbfac * 8, hipMemcpyHostToDevice, s));
+  DHIP(fd.inpoel.alloc(4 * nelem));
+  DHIP(fd.x.alloc(nnode)); DHIP(fd.y.alloc(nnode)); DHIP(fd.z.alloc(nnode));
+  DHIP(hipMemcpyAsync(fd.inpoel.p, inpoel, 4 * nelem * 8, hipMemcpyHostToDevice, s));
   DHIP(hipMemcpyAsync(fd.x.p, x, nnode * 8, hipMemcpyHostToDevice, s));
   DHIP(hipMemcpyAsync(fd.y.p, y, nnode * 8, hipMemcpyHostToDevice, s));
   DHIP(hipMemcpyAsync(fd.z.p, z, nnode * 8, hipMemcpyHostToDevice, s));
+  return 0;
+}
+
+// Boundary-face regeneration of the mesh loader (src/Inciter/Partitioner.cpp:357-393) on the
+// device: the side-set triangles are order-independent keys; every tet, in order, contributes
+// its faces {0,2,1},{0,1,3},{0,3,2},{1,2,3} that match a key, in that node order; faces come out
+// grouped by ascending side-set id, within a set in tet order (same as qdg_bnd_faces).
+__constant__ int c_bfa[4][3] = { { 0, 2, 1 }, { 0, 1, 3 }, { 0, 3, 2 }, { 1, 2, 3 } };
+
+__global__ void k_bnd_match(const uint64_t* __restrict__ inpoel, size_t n4, const uint32_t* __restrict__ ta,
+                            const uint32_t* __restrict__ tb, const uint32_t* __restrict__ tc,
+                            const uint32_t* __restrict__ trank, size_t ntri, uint64_t* __restrict__ okey,
+                            int* __restrict__ count)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const size_t e = i >> 2; const int f = (int)(i & 3);
+  uint32_t k0 = (uint32_t)inpoel[4 * e + c_bfa[f][0]], k1 = (uint32_t)inpoel[4 * e + c_bfa[f][1]],
+           k2 = (uint32_t)inpoel[4 * e + c_bfa[f][2]], t;
+  if (k0 > k1) { t = k0; k0 = k1; k1 = t; }
+  if (k1 > k2) { t = k1; k1 = k2; k2 = t; }
+  if (k0 > k1) { t = k0; k0 = k1; k1 = t; }
+  size_t lo = 0, hi = ntri;
+  while (lo < hi) {
+    const size_t mid = (lo + hi) >> 1;
+    const bool less = ta[mid] < k0 || (ta[mid] == k0 && (tb[mid] < k1 || (tb[mid] == k1 && tc[mid] < k2)));
+    if (less) lo = mid + 1; else hi = mid;
+  }
+  const bool hit = lo < ntri && ta[lo] == k0 && tb[lo] == k1 && tc[lo] == k2;
+  okey[i] = hit ? (((uint64_t)trank[lo] << 40) | (uint64_t)i) : ~0ull;
+  if (hit) atomicAdd(count, 1);
+}
+
+__global__ void k_bnd_emit(const uint64_t* __restrict__ skey, size_t nb, const uint64_t* __restrict__ inpoel,
+                           uint64_t* __restrict__ tri, int* __restrict__ rank_of_face)
+{
+  const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nb) return;
+  const uint64_t i = skey[b] & 0xffffffffffull;
+  const size_t e = i >> 2; const int f = (int)(i & 3);
+  tri[3 * b] = inpoel[4 * e + c_bfa[f][0]];
+  tri[3 * b + 1] = inpoel[4 * e + c_bfa[f][1]];
+  tri[3 * b + 2] = inpoel[4 * e + c_bfa[f][2]];
+  rank_of_face[b] = (int)(skey[b] >> 40);
+}
+
+// fd.inpoel resident; out: fd.tri (device), fd.nbfac, fset (host: side-set id of every boundary face)
+static int dev_bnd_faces(qdg_ctx* ctx, DevFD& fd, size_t ntri, const size_t* tri, const int32_t* tri_set,
+                         std::vector<int32_t>& fset)
+{
+  hipStream_t s = ctx_stream(ctx);
+  fd.nbfac = 0;
+  fset.clear();
+  if (ntri == 0) { DHIP(fd.tri.alloc(1)); return 0; }
+  // sorted keys of the side-set triangles (host: ntri is a surface quantity)
+  struct K { uint32_t a, b, c; int32_t set; };
+  std::vector<K> keys(ntri);
+  std::vector<int32_t> sets;
+  for (size_t i = 0; i < ntri; ++i) {
+    size_t a = tri[3 * i], b = tri[3 * i + 1], c = tri[3 * i + 2];
+    if (a >= fd.nnode || b >= fd.nnode || c >= fd.nnode) return fail("qdg_mesh_from_connectivity: side-set triangle node out of range");
+    if (a > b) std::swap(a, b);
+    if (b > c) std::swap(b, c);
+    if (a > b) std::swap(a, b);
+    keys[i] = { (uint32_t)a, (uint32_t)b, (uint32_t)c, tri_set[i] };
+    sets.push_back(tri_set[i]);
+  }
+  std::sort(keys.begin(), keys.end(), [](const K& p, const K& q) {
+    return p.a != q.a ? p.a < q.a : p.b != q.b ? p.b < q.b : p.c != q.c ? p.c < q.c : p.set < q.set; });
+  std::sort(sets.begin(), sets.end());
+  sets.erase(std::unique(sets.begin(), sets.end()), sets.end());
+  if (sets.size() >= (1u << 20)) return fail("qdg_mesh_from_connectivity: too many side sets");
+  std::vector<uint32_t> ha(ntri), hb(ntri), hc(ntri), hr(ntri);
+  for (size_t i = 0; i < ntri; ++i) {
+    ha[i] = keys[i].a; hb[i] = keys[i].b; hc[i] = keys[i].c;
+    hr[i] = (uint32_t)(std::lower_bound(sets.begin(), sets.end(), keys[i].set) - sets.begin());
+  }
+  Buf<uint32_t> ta, tb, tc, tr;
+  DHIP(ta.alloc(ntri)); DHIP(tb.alloc(ntri)); DHIP(tc.alloc(ntri)); DHIP(tr.alloc(ntri));
+  DHIP(hipMemcpyAsync(ta.p, ha.data(), ntri * 4, hipMemcpyHostToDevice, s));
+  DHIP(hipMemcpyAsync(tb.p, hb.data(), ntri * 4, hipMemcpyHostToDevice, s));
+  DHIP(hipMemcpyAsync(tc.p, hc.data(), ntri * 4, hipMemcpyHostToDevice, s));
+  DHIP(hipMemcpyAsync(tr.p, hr.data(), ntri * 4, hipMemcpyHostToDevice, s));
+  const size_t n4 = 4 * fd.nelem;
+  Buf<uint64_t> okey, skey;
+  Buf<int> cnt;
+  DHIP(okey.alloc(n4)); DHIP(skey.alloc(n4)); DHIP(cnt.alloc(1));
+  DHIP(hipMemsetAsync(cnt.p, 0, sizeof(int), s));
+  k_bnd_match<<<nblk(n4), 256, 0, s>>>(fd.inpoel.p, n4, ta.p, tb.p, tc.p, tr.p, ntri, okey.p, cnt.p);
+  size_t bytes = 0;
+  DHIP(rocprim::radix_sort_keys(nullptr, bytes, okey.p, skey.p, n4, 0, 64, s));
+  Buf<char> tmp;
+  DHIP(tmp.alloc(bytes));
+  DHIP(rocprim::radix_sort_keys(tmp.p, bytes, okey.p, skey.p, n4, 0, 64, s));
+  int nb = 0;
+  DHIP(hipMemcpyAsync(&nb, cnt.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  DHIP(hipStreamSynchronize(s));
+  fd.nbfac = (size_t)nb;
+  DHIP(fd.tri.alloc(3 * (size_t)nb));
+  Buf<int> rk;
+  DHIP(rk.alloc((size_t)nb));
+  if (nb) {
+    k_bnd_emit<<<nblk((size_t)nb), 256, 0, s>>>(skey.p, (size_t)nb, fd.inpoel.p, fd.tri.p, rk.p);
+    std::vector<int> hrk(nb);
+    DHIP(hipMemcpyAsync(hrk.data(), rk.p, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, s));
+    DHIP(hipStreamSynchronize(s));
+    fset.resize(nb);
+    for (int b = 0; b < nb; ++b) fset[b] = sets[hrk[b]];
+  }
+  return 0;
+}
+
+// FaceData + geometry from the resident connectivity, coordinates and boundary faces (fd.tri)
+static int dev_facedata_from(qdg_ctx* ctx, DevFD& fd)
+{
+  DHIP(hipSetDevice(ctx_device(ctx)));
+  hipStream_t s = ctx_stream(ctx);
+  const size_t nelem = fd.nelem, nnode = fd.nnode, nbfac = fd.nbfac;
+  const size_t n4 = 4 * nelem, nfmax = nbfac + 2 * nelem;
+  Buf<uint32_t> ka, kb, kc, perm, perm2, key, key2;
+  Buf<int> d_flag, d_pos, d_err;
+  DHIP(ka.alloc(n4)); DHIP(kb.alloc(n4)); DHIP(kc.alloc(n4));
+  DHIP(perm.alloc(n4)); DHIP(perm2.alloc(n4)); DHIP(key.alloc(n4)); DHIP(key2.alloc(n4));
+  DHIP(fd.esuel.alloc(n4)); DHIP(d_flag.alloc(n4 + 1)); DHIP(d_pos.alloc(n4 + 1)); DHIP(d_err.alloc(1));
   DHIP(hipMemsetAsync(d_err.p, 0, sizeof(int), s));
 
   // ---- sort the 4*nelem faces by (a, b, c), ties in (element, local face) order ----
@@ -289,6 +404,20 @@ static int dev_facedata_keep(qdg_ctx* ctx, size_t nelem, size_t nnode, const siz
   DHIP(hipStreamSynchronize(s));
   if (herr == 2) return fail("qdg_dev_facedata: a boundary face is not a face of any tet");
   return 0;
+}
+
+static int dev_facedata_keep(qdg_ctx* ctx, size_t nelem, size_t nnode, const size_t* inpoel,
+                             const double* x, const double* y, const double* z, size_t nbfac,
+                             const size_t* triinpoel, DevFD& fd)
+{
+  if (nbfac > 0 && !triinpoel) return fail("qdg_dev_facedata: null boundary arrays");
+  for (size_t i = 0; i < 3 * nbfac; ++i)
+    if (triinpoel[i] >= nnode) return fail("qdg_dev_facedata: triinpoel entry out of range");
+  if (int rc = dev_upload_mesh(ctx, nelem, nnode, inpoel, x, y, z, fd)) return rc;
+  fd.nbfac = nbfac;
+  DHIP(fd.tri.alloc(3 * nbfac));
+  if (nbfac) DHIP(hipMemcpyAsync(fd.tri.p, triinpoel, 3 * nbfac * 8, hipMemcpyHostToDevice, ctx_stream(ctx)));
+  return dev_facedata_from(ctx, fd);
 }
 
 extern "C" int qdg_dev_facedata(qdg_ctx* ctx, size_t nelem, size_t nnode, const size_t* inpoel,
@@ -576,11 +705,26 @@ static int sort32(uint32_t* ki, uint32_t* ko, uint32_t* vi, uint32_t* vo, size_t
 
 }  // namespace
 
+// QDG_UPLOAD_STATS=1: wall time of the sections of the device build, on stderr
+struct Lap {
+  bool on; hipStream_t s; std::chrono::steady_clock::time_point t;
+  explicit Lap(hipStream_t st) : on(std::getenv("QDG_UPLOAD_STATS") != nullptr), s(st), t(std::chrono::steady_clock::now()) {}
+  void operator()(const char* what)
+  {
+    if (!on) return;
+    (void)hipStreamSynchronize(s);
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "qdg device build: %-40s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+    t = now;
+  }
+};
+
 // fd: resident FaceData of the chunk; bcface[nbfac]: BC type of every boundary face (0 = none)
 static int dev_build_layout(qdg_ctx* ctx, DevFD& fd, const std::vector<int>& bcface, qdg_mesh** out)
 {
   DHIP(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
+  Lap lap(s);
   const size_t ne = fd.nelem, nnode = fd.nnode, nf = fd.nipfac, n4 = 4 * ne;
   const size_t stride = (ne + 63) / 64 * 64;
   if (ne > (size_t)(INT32_MAX - 64) / 4 || nf > (size_t)INT32_MAX) return fail("qdg_mesh_from_connectivity: chunk too large");
@@ -622,6 +766,7 @@ static int dev_build_layout(qdg_ctx* ctx, DevFD& fd, const std::vector<int>& bcf
     DHIP(rocprim::radix_sort_pairs(tmp.p, bytes, mkey.p, mkey2.p, mval.p, mval2.p, ne, 0, 63, s));
     DHIP(hipStreamSynchronize(s));
   }
+  lap("Morton order");
   Buf<int> h2d;
   DHIP(h2d.alloc(ne));
   HIPCHK(m->d2h.alloc(ne));
@@ -654,6 +799,7 @@ static int dev_build_layout(qdg_ctx* ctx, DevFD& fd, const std::vector<int>& bcf
   }
   if (int rc = sort32(fkn.p, fkn2.p, vn.p, vn2.p, nnode, s)) return rc;
   if (int rc = sort32(fkf.p, fkf2.p, vf.p, vf2.p, nf, s)) return rc;
+  lap("rface + first touch + sorts");
   Buf<int> nnew, fmap;
   DHIP(nnew.alloc(nnode)); DHIP(fmap.alloc(nf));
   k_rank<<<nblk(nnode), 256, 0, s>>>(nnode, fkn2.p, vn2.p, nnew.p, d_count.p);
@@ -663,6 +809,7 @@ static int dev_build_layout(qdg_ctx* ctx, DevFD& fd, const std::vector<int>& bcf
   DHIP(hipStreamSynchronize(s));
   const int ncount = hcount[0], nfd = hcount[1];
 
+  lap("numbering");
   // ---- rows, nodes, faces in device numbering ---------------------------------------------
   Buf<int> d_bc;
   DHIP(d_bc.alloc(std::max<size_t>(bcface.size(), 1)));
@@ -688,6 +835,7 @@ static int dev_build_layout(qdg_ctx* ctx, DevFD& fd, const std::vector<int>& bcf
   k_layout_nodes<<<nblk(nnode), 256, 0, s>>>(nnode, nnew.p, fd.x.p, fd.y.p, fd.z.p, m->x.p, m->y.p, m->z.p, m->xyz4.p);
   k_layout_faces<<<nblk(nf), 256, 0, s>>>(nf, fmap.p, fd.geoFace.p, m->farea.p, m->fnx.p, m->fny.p, m->fnz.p, m->fgeo.p);
 
+  lap("rows / nodes / faces");
   // ---- face tasks of the tile kernels -------------------------------------------------------
   const int tile_rows = TILE;
   const int ntile = (int)((ne + TILE - 1) / TILE);
@@ -723,6 +871,7 @@ static int dev_build_layout(qdg_ctx* ctx, DevFD& fd, const std::vector<int>& bcf
   }
   DHIP(hipGetLastError());
 
+  lap("face tasks");
   if (int rc = mesh_alloc_state(m.get(), ntile)) return rc;
   m->nnode_used = (size_t)ncount;
   DevMesh& dm = m->dm;
@@ -741,6 +890,7 @@ static int dev_build_layout(qdg_ctx* ctx, DevFD& fd, const std::vector<int>& bcf
     dm.ndofel = m->ndofel.p;
   }
   DHIP(hipStreamSynchronize(s));
+  lap("state allocation");
   *out = m.release();
   return 0;
 }
@@ -754,22 +904,23 @@ extern "C" int qdg_mesh_from_connectivity(qdg_ctx* ctx, size_t nelem, size_t nno
   if (!ctx || !out || !inpoel || !x || !y || !z) return fail("qdg_mesh_from_connectivity: null argument");
   if (ntri > 0 && (!tri || !tri_set)) return fail("qdg_mesh_from_connectivity: null side-set arrays");
   *out = nullptr;
-  // boundary faces in the reference's order (Partitioner.cpp:357-393), grouped by side set
-  std::vector<size_t> triinpoel(3 * std::max<size_t>(ntri, 1));
-  std::vector<int32_t> fset(std::max<size_t>(ntri, 1));
-  size_t nbfac = 0;
-  if (ntri)
-    if (int rc = qdg_bnd_faces(nelem, inpoel, ntri, tri, tri_set, &nbfac, triinpoel.data(), fset.data()))
-      return rc;
   if (!std::getenv("QDG_HOST_LAYOUT")) {
-    // FaceData, geometry AND the device layout on the GPU: nothing but the connectivity, the
-    // coordinates and the boundary faces cross PCIe
+    // Everything on the GPU: boundary faces regenerated from the side-set triangles, FaceData,
+    // geometry and the device layout.  Only the connectivity, the coordinates and the side-set
+    // triangles cross PCIe.
+    Lap lap(ctx->stream);
     DevFD fd;
-    if (int rc = dev_facedata_keep(ctx, nelem, nnode, inpoel, x, y, z, nbfac, triinpoel.data(), fd)) return rc;
+    if (int rc = dev_upload_mesh(ctx, nelem, nnode, inpoel, x, y, z, fd)) return rc;
+    lap("validation + upload of inpoel, coord");
+    std::vector<int32_t> fset;
+    if (int rc = dev_bnd_faces(ctx, fd, ntri, tri, tri_set, fset)) return rc;
+    lap("boundary faces (device)");
+    if (int rc = dev_facedata_from(ctx, fd)) return rc;
+    lap("FaceData + geometry (device)");
     // BC type per boundary face: bndSurfInt over the configured side sets of each type
     // (src/PDE/Integrate/Boundary.cpp:84-90); faces of unconfigured sets get no flux
-    std::vector<int> bcface(nbfac, 0);
-    for (size_t f = 0; f < nbfac; ++f) {
+    std::vector<int> bcface(fd.nbfac, 0);
+    for (size_t f = 0; f < fd.nbfac; ++f) {
       int type = 0;
       for (size_t i = 0; i < ctx->bc_sideset.size(); ++i)
         if (ctx->bc_sideset[i] == fset[f]) {
@@ -781,7 +932,14 @@ extern "C" int qdg_mesh_from_connectivity(qdg_ctx* ctx, size_t nelem, size_t nno
     }
     return dev_build_layout(ctx, fd, bcface, out);
   }
-  // QDG_HOST_LAYOUT=1: FaceData on the device, copied back, layout by qdg_mesh_upload (A/B, tests)
+  // QDG_HOST_LAYOUT=1: boundary faces on the host (qdg_bnd_faces), FaceData on the device, copied
+  // back, layout by qdg_mesh_upload (A/B runs, equivalence tests)
+  std::vector<size_t> triinpoel(3 * std::max<size_t>(ntri, 1));
+  std::vector<int32_t> fset(std::max<size_t>(ntri, 1));
+  size_t nbfac = 0;
+  if (ntri)
+    if (int rc = qdg_bnd_faces(nelem, inpoel, ntri, tri, tri_set, &nbfac, triinpoel.data(), fset.data()))
+      return rc;
   const size_t nfmax = nbfac + 2 * nelem;
   std::vector<int> esuel(4 * nelem), esuf(2 * nfmax);
   std::vector<size_t> inpofa(3 * nfmax), belem(std::max<size_t>(nbfac, 1));

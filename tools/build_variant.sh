@@ -11,5 +11,5 @@ hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $flags -c $root/quinoa_amd/csrc
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $flags -c $root/quinoa_amd/csrc/qdg_api.cpp -o $obj/qdg_api_$name.o &
 wait
 hipcc --offload-arch=gfx950 -fPIC -shared -o $root/quinoa_amd/lib/libqdg_$name.so $obj/qdg_kernels_$name.o \
-  $obj/qdg_devmesh.o $obj/qdg_api_$name.o $obj/qdg_meshdata.o $obj/qdg_partition.o -ldl
+  $obj/qdg_devmesh.o $obj/qdg_api_$name.o $obj/qdg_meshdata.o $obj/qdg_partition.o $obj/qdg_exo.o -ldl
 echo built libqdg_$name.so
