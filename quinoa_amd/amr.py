@@ -73,3 +73,93 @@ class RefinedRun:
         self.mesh, self.coord, self.inpoel, self.sidesets = new, c2, i2, s2
         self.timings.append((t1 - t0, t2 - t1, t3 - t2))
         return self.timings[-1]
+
+
+def _face_keys(inpoel):
+    """sorted node triples of the 4 faces of every tet: [ne*4, 3], row 4*e + lf"""
+    lp = np.array([[1, 2, 3], [2, 0, 3], [3, 0, 1], [0, 2, 1]])
+    return np.sort(np.asarray(inpoel)[:, lp].reshape(-1, 3), axis=1)
+
+
+def _rows(a):
+    a = np.ascontiguousarray(a, dtype=np.int64)
+    return a.view([("", a.dtype)] * a.shape[1]).reshape(-1)
+
+
+def refine_chunk(ch):
+    """Uniform 1:8 refinement of ONE RANK's chunk of a partitioned mesh (a dict as
+    partition.build_chunk / meshgen.kuhn_box_chunk return it), done by the rank alone:
+    owned and ghost tets are refined with the same pattern (edge midpoints coincide across the
+    chunk boundary, so the refined mesh stays conforming), the children of the owned tets are the
+    new owned tets, and the new ghost layer is the set of children of OLD ghosts that share a
+    face with a new owned tet.  The halo plan follows without communication: a child of my tet A
+    touches a child of rank q's tet B only if A and B touched, i.e. only where both ranks already
+    hold the other's tet -- so my send list to q (my children that touch a child of one of q's
+    tets) and q's new ghosts from me are the same set, and both sides order it by (global id of
+    the parent, child number).  Uniform refinement keeps the load balance of the cut, so this IS
+    the re-partition step of BASELINE config 5 (DG::resizePostAMR, DG.cpp:1536-1612 rebuilds
+    FaceData and ghosts from the refined chunk the same way).
+    Returns (new chunk dict, parent[8*nunk_old] local id of every child's parent)."""
+    coord, inpoel, nie = ch["coord"], np.asarray(ch["inpoel"]).reshape(-1, 4), int(ch["nielem"])
+    nunk = inpoel.shape[0]
+    # side-set triangles that are faces of a local tet (a triangle can have its three nodes in
+    # the chunk without being one)
+    allf = _rows(_face_keys(inpoel))
+    ss_in = {}
+    for sid, tri in (ch["sidesets"] or {}).items():
+        tri = np.asarray(tri).reshape(-1, 3)
+        ok = np.isin(_rows(np.sort(tri, axis=1)), allf)
+        if ok.any():
+            ss_in[int(sid)] = tri[ok]
+    c2, i2, s2, par = refine_uniform(coord, inpoel, ss_in)
+    gid = np.asarray(ch["gid"], dtype=np.int64)
+    cgid = 8 * gid[par] + np.tile(np.arange(8), nunk)             # global id of a child
+    owned = np.arange(8 * nie)                                     # children of owned tets come first
+    # faces of the owned children that have no owned partner and are not physical boundary
+    fk = _face_keys(i2)
+    vo = _rows(fk[:4 * 8 * nie])
+    uniq, cnt = np.unique(vo, return_counts=True)
+    free = np.isin(vo, uniq[cnt == 1])
+    if s2:
+        bkey = _rows(np.sort(np.concatenate([np.asarray(t).reshape(-1, 3) for t in s2.values()]), axis=1))
+        free &= ~np.isin(vo, bkey)
+    # ghost children that own one of those faces; and, the other way round, owned children that
+    # share a face with a child of a neighbour's tet
+    vg = _rows(fk[4 * 8 * nie:])
+    gface_used = np.isin(vg, vo[free])
+    ghost_child = np.unique(np.nonzero(gface_used)[0] // 4) + 8 * nie
+    oface_used = free & np.isin(vo, vg)
+    # owner rank of every old ghost
+    off = np.concatenate([[0], np.cumsum(ch["recv_counts"])]).astype(np.int64)
+    owner_of_ghost = np.zeros(nunk - nie, dtype=np.int64)
+    for i, q in enumerate(ch["nbr_rank"]):
+        owner_of_ghost[off[i]:off[i + 1]] = q
+    gowner = owner_of_ghost[par[ghost_child] - nie]
+    order = np.lexsort((cgid[ghost_child], gowner))                # by owner rank, then global child id
+    ghost_child, gowner = ghost_child[order], gowner[order]
+    # send lists: owned children by the rank whose tet's child they touch
+    send_lists = []
+    lookup = {}
+    gf = np.nonzero(gface_used)[0]
+    for key, g in zip(vg[gf], gf // 4 + 8 * nie):
+        lookup[key.tobytes()] = owner_of_ghost[par[g] - nie]
+    of = np.nonzero(oface_used)[0]
+    dest = np.array([lookup[k.tobytes()] for k in vo[of]], dtype=np.int64) if len(of) else np.zeros(0, np.int64)
+    for q in ch["nbr_rank"]:
+        mine = np.unique(of[dest == q] // 4)
+        send_lists.append(mine[np.argsort(cgid[mine], kind="stable")])
+    keep = np.concatenate([owned, ghost_child])
+    nodes, inv = np.unique(i2[keep].reshape(-1), return_inverse=True)
+    g2l = np.full(c2.shape[0], -1, dtype=np.int64)
+    g2l[nodes] = np.arange(len(nodes))
+    ss = {}
+    for sid, tri in s2.items():
+        loc = g2l[np.asarray(tri).reshape(-1, 3)]
+        ok = (loc >= 0).all(axis=1)
+        if ok.any():
+            ss[int(sid)] = loc[ok]
+    new = {"coord": c2[nodes], "inpoel": inv.reshape(-1, 4), "nielem": 8 * nie, "sidesets": ss,
+           "gid": cgid[keep], "nbr_rank": list(ch["nbr_rank"]),
+           "send_lists": send_lists,
+           "recv_counts": [int((gowner == q).sum()) for q in ch["nbr_rank"]]}
+    return new, par[keep]

@@ -77,3 +77,115 @@ def test_refined_run_matches_reference_dtref_goldens(cases):
         # L2(c0) and L2(c0 - analytic): the latter jumps by two orders after the first refinement
         # in the reference's table too (1.27e-3 -> 1.01e-1)
         assert abs(r[1] - g[1]) <= 1e-12 and abs(r[3] - g[3]) <= 6e-7 * g[3] and abs(r[4] - g[4]) <= 6e-7 * g[4], (r, g)
+
+
+def test_partitioned_chunks_refine_independently_and_stay_consistent():
+    """config 5 on several ranks: every rank refines ITS chunk (owned + ghost tets) alone
+    (amr.refine_chunk); the refined chunks must be what the general chunk builder makes of the
+    refined GLOBAL mesh with every child on its parent's rank -- same owned tets, same ghost layer,
+    send lists that match the neighbours' ghost order -- and a partitioned oracle run across the
+    refinement must equal the serial run on the refined mesh."""
+    from quinoa_amd import dgmesh, meshgen, partition
+    g = meshgen.kuhn_box(5, 4, 3)
+    coord, inpoel, ss = g["coord"], g["inpoel"], g["sidesets"]
+    nparts = 3
+    part = partition.partition(coord, inpoel, nparts, "rcb")
+    chunks = [partition.build_chunk(coord, inpoel, ss, part, nparts, r) for r in range(nparts)]
+    new = [amr.refine_chunk(ch) for ch in chunks]
+    # reference: refine the global mesh, children inherit the rank
+    c2, i2, s2, par = amr.refine_uniform(coord, inpoel, ss)
+    part2 = part[par]
+    for r in range(nparts):
+        ref = partition.build_chunk(c2, i2, s2, part2, nparts, r)
+        ch, _ = new[r]
+        nie = ch["nielem"]
+        assert nie == ref["nielem"] and ch["nbr_rank"] == ref["nbr_rank"]
+        assert np.array_equal(ch["gid"][:nie], ref["gid"][:nie])                     # owned children, same order
+        assert np.array_equal(np.sort(ch["gid"][nie:]), np.sort(ref["gid"][nie:]))   # the same ghost layer
+        assert ch["recv_counts"] == ref["recv_counts"]
+        # tets carry the same coordinates
+        a = ch["coord"][ch["inpoel"]].mean(axis=1); b = ref["coord"][ref["inpoel"]].mean(axis=1)
+        oa, ob = np.argsort(ch["gid"], kind="stable"), np.argsort(ref["gid"], kind="stable")
+        assert np.abs(a[oa] - b[ob]).max() <= 1e-15
+        off = np.concatenate([[0], np.cumsum(ch["recv_counts"])])
+        for i, q in enumerate(ch["nbr_rank"]):
+            j = new[q][0]["nbr_rank"].index(r)
+            sent = new[q][0]["gid"][new[q][0]["send_lists"][j]]
+            assert np.array_equal(sent, ch["gid"][nie + off[i]:nie + off[i + 1]])    # q's send order = my ghost order
+        ck = dgmesh.build_chunk(ch["coord"], ch["inpoel"], nie, ch["sidesets"])      # ghost faces all match
+        assert ck.nfac > ck.nipfac
+
+
+def test_partitioned_run_across_a_refinement_equals_serial_run():
+    """config 5 end to end on 3 chunks with the oracle as the per-chunk numerics: 3 steps, every
+    rank refines its own chunk and hands its state over (child <- parent), 3 more steps with the
+    halo plan refine_chunk derived -- equal to the serial run across the same refinement."""
+    import test_partition as TP
+    from quinoa_amd import dgmesh, meshgen, partition
+    g = meshgen.kuhn_box(5, 4, 3)
+    kw = dict(flux="hllc", limiter="superbeep1", problem="sod_shocktube", gamma=1.4)
+    bc = dict(bc_sym=[3, 4, 5, 6], bc_extrapolate=[1, 2])
+    nparts, cfl = 3, 0.3
+
+    def oracle_of(ch):
+        ck = dgmesh.build_chunk(ch["coord"], ch["inpoel"], ch["nielem"], ch["sidesets"])
+        cm = O.ChunkMesh(ck.coord, ck.inpoel, ck.nielem, ck.esuel, ck.esuf, ck.inpofa, ck.geoFace, ck.geoElem,
+                         ck.bface, ck.nbfac)
+        return O.Oracle(cm, O.make_cfg(4, **kw), **bc)
+
+    def steps(runs, t, n):
+        for _ in range(n):
+            for stage in range(3):
+                TP._exchange(runs, 20)
+                for r in runs:
+                    r["orc"].limit(r["U"])
+                TP._exchange(runs, 20)
+                if stage == 0:
+                    dt = min(r["orc"].dt(r["U"]) for r in runs) * cfl / 3.0
+                    for r in runs:
+                        r["Un"] = r["U"].copy()
+                for r in runs:
+                    R = r["orc"].rhs(t, r["U"])
+                    r["orc"].rk_update(stage, dt, r["Un"], R, r["L"], r["U"])
+            t += dt
+        return t
+
+    part = partition.partition(g["coord"], g["inpoel"], nparts, "morton")
+    runs = []
+    for r in range(nparts):
+        ch = partition.build_chunk(g["coord"], g["inpoel"], g["sidesets"], part, nparts, r)
+        orc = oracle_of(ch)
+        L = orc.lhs()
+        runs.append({"ch": ch, "orc": orc, "L": L, "U": orc.initialize(L, 0.0)})
+    t = steps(runs, 0.0, 3)
+    for r in runs:
+        ch2, par = amr.refine_chunk(r["ch"])
+        U2 = r["U"].reshape(-1, 20)[par].reshape(-1)          # DG::resizePostAMR: child <- parent
+        orc = oracle_of(ch2)
+        r.update(ch=ch2, orc=orc, L=orc.lhs(), U=U2)
+    t = steps(runs, t, 3)
+    # serial
+    om = O.OracleMesh(g["coord"], g["inpoel"], g["sidesets"])
+    so = O.Oracle(om, O.make_cfg(4, **kw), **bc)
+    L = so.lhs(); U = so.initialize(L, 0.0)
+    ts = 0.0
+    for _ in range(3):
+        ts += so.step(ts, U, L, cfl=cfl)
+    c2, i2, s2, par = amr.refine_uniform(g["coord"], g["inpoel"], g["sidesets"])
+    U = U.reshape(-1, 20)[par].reshape(-1)
+    so2 = O.Oracle(O.OracleMesh(c2, i2, s2), O.make_cfg(4, **kw), **bc)
+    L2 = so2.lhs()
+    for _ in range(3):
+        ts += so2.step(ts, U, L2, cfl=cfl)
+    assert abs(t - ts) <= 1e-12 * ts
+    ref = U.reshape(-1, 20)
+    # global id of a child = 8 * (global id of the parent) + k = its row in the serially refined mesh
+    gmap = g["gid"]                                             # generator ids of the undivided mesh
+    seen = 0
+    for r in runs:
+        nie = r["ch"]["nielem"]
+        rows = r["ch"]["gid"][:nie]
+        err = np.abs(r["U"].reshape(-1, 20)[:nie] - ref[rows]).max() / np.abs(ref).max()
+        assert err <= 1e-12, err
+        seen += nie
+    assert seen == ref.shape[0] and gmap is not None

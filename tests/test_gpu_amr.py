@@ -95,3 +95,57 @@ def test_config5_physics_refine_once_matches_oracle(ndof, limiter):
         assert np.abs(run.mesh.state_download() - U).max() <= 1e-10 * max(1.0, np.abs(U).max())
     finally:
         run.mesh.close(); ctx.close()
+
+
+def test_config5_partitioned_chunks_refine_on_the_gpu():
+    """config 5 with a decomposition: 3 chunks on the GPU (dg.LocalChunks), 3 steps, every chunk
+    refined by its own rank's logic (amr.refine_chunk) + re-uploaded + state handed over on the
+    device (qdg_state_transfer across the two numberings, ghost rows included), 3 more steps;
+    equal to the single-chunk run across the same refinement (amr.RefinedRun)."""
+    from quinoa_amd import amr, capi, dg, dgmesh, meshgen, partition
+    g = meshgen.kuhn_box(6, 5, 4)
+    kw = dict(flux="hllc", limiter="superbeep1", problem="sod_shocktube", gamma=1.4, cfl=0.3,
+              bc_sym=[3, 4, 5, 6], bc_extrapolate=[1, 2])
+    nparts = 3
+    part = partition.partition(g["coord"], g["inpoel"], nparts, "rcb")
+    ctx = capi.Context(4, **kw)
+    chunks = [partition.build_chunk(g["coord"], g["inpoel"], g["sidesets"], part, nparts, r) for r in range(nparts)]
+
+    def upload(ch):
+        return dgmesh.upload(ctx, dgmesh.build_chunk(ch["coord"], ch["inpoel"], ch["nielem"], ch["sidesets"]))
+
+    meshes = [upload(ch) for ch in chunks]
+    ctx1 = capi.Context(4, **kw)
+    one = amr.RefinedRun(ctx1, g["coord"], g["inpoel"], g["sidesets"])
+    try:
+        for m in meshes:
+            m.state_initialize(0.0)
+        one.mesh.state_initialize(0.0)
+        drv = dg.LocalChunks(ctx, meshes, chunks)
+        t = t1 = 0.0
+        for _ in range(3):
+            t += drv.step(t)
+            t1 += one.mesh.step(t1)
+        new_chunks, new_meshes = [], []
+        for ch, m in zip(chunks, meshes):
+            ch2, par = amr.refine_chunk(ch)
+            m2 = upload(ch2)
+            amr.state_transfer(m, m2, par)
+            m.close()
+            new_chunks.append(ch2); new_meshes.append(m2)
+        chunks, meshes = new_chunks, new_meshes
+        one.refine()
+        drv = dg.LocalChunks(ctx, meshes, chunks)
+        for _ in range(3):
+            t += drv.step(t)
+            t1 += one.mesh.step(t1)
+        assert abs(t - t1) <= 1e-12 * t1
+        ref = one.mesh.state_download().reshape(-1, 20)
+        for ch, m in zip(chunks, meshes):
+            nie = ch["nielem"]
+            U = m.state_download().reshape(-1, 20)[:nie]
+            assert np.abs(U - ref[ch["gid"][:nie]]).max() <= 1e-10 * np.abs(ref).max()
+    finally:
+        for m in meshes:
+            m.close()
+        one.mesh.close(); ctx.close(); ctx1.close()
