@@ -208,8 +208,10 @@ def amr_point(local_rank, nx=32, steps=20):
             "refine_host_ms": th * 1e3, "rebuild_upload_ms": tr * 1e3, "state_transfer_ms": tt * 1e3,
             "rebuild_upload_ms_per_Mtet": tr * 1e3 / (ne1 / 1e6),
             "steps_of_new_mesh_per_rebuild": tr * 1e3 / ms1, "finite": ok,
-            "note": "rebuild = qdg_mesh_from_connectivity on the refined mesh: boundary faces (host), "
-                    "FaceData + geometry (device), device layout + face tasks (host, all cores), upload"}
+            "note": "refine = qdg_refine_uniform on the host (AMR bookkeeping stays host-side); rebuild = "
+                    "qdg_mesh_from_connectivity on the refined mesh, all on the device: boundary faces, "
+                    "FaceData, geometry, Morton order, numbering, face tasks (only connectivity + "
+                    "coordinates cross PCIe); transfer = qdg_state_transfer (child <- parent, device)"}
 
 
 def main():
