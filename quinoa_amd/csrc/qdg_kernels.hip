@@ -38,6 +38,9 @@
 #ifndef QDG_TILE_GP_SERIAL
 #define QDG_TILE_GP_SERIAL 1
 #endif
+#ifndef QDG_NT
+#define QDG_NT 0
+#endif
 #ifndef QDG_P1_WAVES
 #define QDG_P1_WAVES 2   // waves per SIMD the DG-P1 RHS kernel is register-budgeted for
 #endif
@@ -99,6 +102,27 @@ __device__ __forceinline__ void load_row(const double* __restrict__ U, int e, do
     for (int i = 0; i < NPROP; ++i) r[i] = p[i];
   }
 }
+// streaming variants: data that one launch touches exactly once (the stage-0 state read by the
+// fused RK update, the new state it writes) is moved with the non-temporal hint so that it does
+// not displace the rows of U that neighbouring tiles come back for in the XCD's L2
+typedef double qdg_d2 __attribute__((ext_vector_type(2)));
+template <int NPROP>
+__device__ __forceinline__ void load_row_nt(const double* __restrict__ U, int e, double* r)
+{
+  static_assert(NPROP % 2 == 0, "16-byte rows");
+  const qdg_d2* q = reinterpret_cast<const qdg_d2*>(__builtin_assume_aligned(U + (size_t)e * NPROP, 16));
+#pragma unroll
+  for (int i = 0; i < NPROP / 2; ++i) { const qdg_d2 v = __builtin_nontemporal_load(q + i); r[2 * i] = v.x; r[2 * i + 1] = v.y; }
+}
+template <int NPROP>
+__device__ __forceinline__ void store_row_nt(double* __restrict__ U, int e, const double* r)
+{
+  static_assert(NPROP % 2 == 0, "16-byte rows");
+  qdg_d2* q = reinterpret_cast<qdg_d2*>(__builtin_assume_aligned(U + (size_t)e * NPROP, 16));
+#pragma unroll
+  for (int i = 0; i < NPROP / 2; ++i) { qdg_d2 v; v.x = r[2 * i]; v.y = r[2 * i + 1]; __builtin_nontemporal_store(v, q + i); }
+}
+
 template <int NPROP>
 __device__ __forceinline__ void store_row(double* __restrict__ U, int e, const double* r)
 {
@@ -1835,7 +1859,11 @@ __global__ __launch_bounds__(TILE_BS, QDG_TILE_WAVES) void k_rhs_p1v(DevMesh m, 
   if (tid < nloc) {
     const int e = tile_e0 + tid;
     load_row<NPROP>(U, e, &u[0][0]);          // modal row again (L1/L2 hit)
+#if QDG_NT
+    if (FUSE_RK) load_row_nt<NPROP>(Un, e, &un[0][0]);
+#else
     if (FUSE_RK) load_row<NPROP>(Un, e, &un[0][0]);
+#endif
     vol = m.vol[e];
     const int stride = m.stride;
     const int n0 = m.inpoel[e], n1 = m.inpoel[(size_t)stride + e], n2 = m.inpoel[(size_t)2 * stride + e],
@@ -1935,7 +1963,11 @@ __global__ __launch_bounds__(TILE_BS, QDG_TILE_WAVES) void k_rhs_p1v(DevMesh m, 
         for (int k = 0; k < NDOF; ++k)
           acc[c][k] = rk_a * un[c][k] + rk_b * (u[c][k] + dtv * imf[k] * acc[c][k]);
     }
+#if QDG_NT
+    store_row_nt<NPROP>(R, e, &acc[0][0]);
+#else
     store_row<NPROP>(R, e, &acc[0][0]);
+#endif
     if (WITH_DT) dte = vol / sdelt[tid];
   }
 
