@@ -304,7 +304,7 @@ def main():
                                       + ("" if w["backend"] is None else ", transport " + w["backend"])
                                       + (" (SELF-HALO TEST: the neighbour is this rank)" if args.self_halo else ""),
                        "step": "SSP-RK3 time step = 3 x (halo, limiter, halo, [dt], rhs, update)"},
-            "roofline": {"bound": "hbm", "kernel": "qdg::k_rhs_p1t (tile/face-task RHS; stage 0: + CFL dt; stages 1,2: + fused RK update; 357 B/tet counted for every launch)", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "qdg::k_rhs_p1v (tile/face-task RHS, version 2; stage 0: + CFL dt; stages 1,2: + fused RK update; 357 B/tet counted for every launch)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac,
                          "traffic": traffic, "traffic_source": traffic_source,
                          "avg_launch_ms": w["avg_ms"], "launches": w["launches"],
@@ -324,7 +324,7 @@ def main():
                 "steps": ns["steps"], "warmup": ns["warmup"],
                 "value": ns["ntet"] * 3 * ns["steps"] / ns["el"] / 1e6, "unit": "M element-updates/s",
                 "ms_per_step": ns["el"] / ns["steps"] * 1e3,
-                "roofline": {"bound": "hbm", "kernel": "qdg::k_rhs_p1t on rank 0's chunk", "achieved": a2,
+                "roofline": {"bound": "hbm", "kernel": "qdg::k_rhs_p1v on rank 0's chunk", "achieved": a2,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": f2, "avg_launch_ms": ns["avg_ms"],
                              "launches": ns["launches"], "algorithmic_bytes_per_launch": ns["alg"],
                              "traffic": None},

@@ -38,8 +38,8 @@
 #ifndef QDG_TILE_GP_SERIAL
 #define QDG_TILE_GP_SERIAL 1
 #endif
-#ifndef QDG_NT
-#define QDG_NT 0
+#ifndef QDG_U_FROM_LDS
+#define QDG_U_FROM_LDS 0
 #endif
 #ifndef QDG_P1_WAVES
 #define QDG_P1_WAVES 2   // waves per SIMD the DG-P1 RHS kernel is register-budgeted for
@@ -102,27 +102,6 @@ __device__ __forceinline__ void load_row(const double* __restrict__ U, int e, do
     for (int i = 0; i < NPROP; ++i) r[i] = p[i];
   }
 }
-// streaming variants: data that one launch touches exactly once (the stage-0 state read by the
-// fused RK update, the new state it writes) is moved with the non-temporal hint so that it does
-// not displace the rows of U that neighbouring tiles come back for in the XCD's L2
-typedef double qdg_d2 __attribute__((ext_vector_type(2)));
-template <int NPROP>
-__device__ __forceinline__ void load_row_nt(const double* __restrict__ U, int e, double* r)
-{
-  static_assert(NPROP % 2 == 0, "16-byte rows");
-  const qdg_d2* q = reinterpret_cast<const qdg_d2*>(__builtin_assume_aligned(U + (size_t)e * NPROP, 16));
-#pragma unroll
-  for (int i = 0; i < NPROP / 2; ++i) { const qdg_d2 v = __builtin_nontemporal_load(q + i); r[2 * i] = v.x; r[2 * i + 1] = v.y; }
-}
-template <int NPROP>
-__device__ __forceinline__ void store_row_nt(double* __restrict__ U, int e, const double* r)
-{
-  static_assert(NPROP % 2 == 0, "16-byte rows");
-  qdg_d2* q = reinterpret_cast<qdg_d2*>(__builtin_assume_aligned(U + (size_t)e * NPROP, 16));
-#pragma unroll
-  for (int i = 0; i < NPROP / 2; ++i) { qdg_d2 v; v.x = r[2 * i]; v.y = r[2 * i + 1]; __builtin_nontemporal_store(v, q + i); }
-}
-
 template <int NPROP>
 __device__ __forceinline__ void store_row(double* __restrict__ U, int e, const double* r)
 {
@@ -1858,12 +1837,10 @@ __global__ __launch_bounds__(TILE_BS, QDG_TILE_WAVES) void k_rhs_p1v(DevMesh m, 
   ElemGeom g;
   if (tid < nloc) {
     const int e = tile_e0 + tid;
-    load_row<NPROP>(U, e, &u[0][0]);          // modal row again (L1/L2 hit)
-#if QDG_NT
-    if (FUSE_RK) load_row_nt<NPROP>(Un, e, &un[0][0]);
-#else
-    if (FUSE_RK) load_row<NPROP>(Un, e, &un[0][0]);
+#if !QDG_U_FROM_LDS
+    load_row<NPROP>(U, e, &u[0][0]);          // modal row again
 #endif
+    if (FUSE_RK) load_row<NPROP>(Un, e, &un[0][0]);
     vol = m.vol[e];
     const int stride = m.stride;
     const int n0 = m.inpoel[e], n1 = m.inpoel[(size_t)stride + e], n2 = m.inpoel[(size_t)2 * stride + e],
@@ -1880,6 +1857,21 @@ __global__ __launch_bounds__(TILE_BS, QDG_TILE_WAVES) void k_rhs_p1v(DevMesh m, 
   double dte = DBL_MAX;
   if (tid < nloc) {
     const int e = tile_e0 + tid;
+#if QDG_U_FROM_LDS
+    // the tet's modal row back from its vertex states in LDS (the inverse of phase 0's map)
+    // instead of a second read of the row: with 64 tiles in flight per XCD the 4 MiB L2 no
+    // longer holds what phase 0 read a face loop ago
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c) {
+      const double v0 = nod[LIDX(tid, 0, c)], v1 = nod[LIDX(tid, 1, c)], v2 = nod[LIDX(tid, 2, c)],
+                   v3 = nod[LIDX(tid, 3, c)];
+      const double a = (v0 + v1 + v2) * (1.0 / 3.0);
+      u[c][0] = 0.25 * ((v0 + v1) + (v2 + v3));
+      u[c][1] = 0.5 * (v1 - v0);
+      u[c][2] = 0.5 * (v2 - a);
+      u[c][3] = (v3 - u[c][0]) * (1.0 / 3.0);
+    }
+#endif
     double acc[NCOMP][NDOF];
     {
       // R[c][k] = sum_v accN[v][c] * B_k(vertex v)
@@ -1963,11 +1955,7 @@ __global__ __launch_bounds__(TILE_BS, QDG_TILE_WAVES) void k_rhs_p1v(DevMesh m, 
         for (int k = 0; k < NDOF; ++k)
           acc[c][k] = rk_a * un[c][k] + rk_b * (u[c][k] + dtv * imf[k] * acc[c][k]);
     }
-#if QDG_NT
-    store_row_nt<NPROP>(R, e, &acc[0][0]);
-#else
     store_row<NPROP>(R, e, &acc[0][0]);
-#endif
     if (WITH_DT) dte = vol / sdelt[tid];
   }
 
