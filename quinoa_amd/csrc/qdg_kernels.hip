@@ -38,9 +38,6 @@
 #ifndef QDG_TILE_GP_SERIAL
 #define QDG_TILE_GP_SERIAL 1
 #endif
-#ifndef QDG_U_FROM_LDS
-#define QDG_U_FROM_LDS 0
-#endif
 #ifndef QDG_P1_WAVES
 #define QDG_P1_WAVES 2   // waves per SIMD the DG-P1 RHS kernel is register-budgeted for
 #endif
@@ -1532,7 +1529,7 @@ __global__ __launch_bounds__(TILE_BS, QDG_TILE_WAVES) void k_rhs_p1v(DevMesh m, 
   // LDS: the tile's states in NODAL form, nod[e][vertex][c] (a P1 state is
   // affine: its value at a face point is the barycentric mix of its vertex
   // values), and per-vertex flux accumulators accN[e][vertex][c]
-  __shared__ double nod[TILE * NPROP];
+  __shared__ __attribute__((aligned(16))) double nod[TILE * NPROP];
   __shared__ double accN[TILE * NPROP];
   __shared__ double sdelt[WITH_DT ? TILE : 1];
   const int tid = threadIdx.x;
@@ -1837,9 +1834,7 @@ __global__ __launch_bounds__(TILE_BS, QDG_TILE_WAVES) void k_rhs_p1v(DevMesh m, 
   ElemGeom g;
   if (tid < nloc) {
     const int e = tile_e0 + tid;
-#if !QDG_U_FROM_LDS
     load_row<NPROP>(U, e, &u[0][0]);          // modal row again
-#endif
     if (FUSE_RK) load_row<NPROP>(Un, e, &un[0][0]);
     vol = m.vol[e];
     const int stride = m.stride;
@@ -1855,24 +1850,8 @@ __global__ __launch_bounds__(TILE_BS, QDG_TILE_WAVES) void k_rhs_p1v(DevMesh m, 
 
   // ---- phase 2: one lane per tet: volume (+source) term, epilogue, store --------
   double dte = DBL_MAX;
+  double acc[NCOMP][NDOF];
   if (tid < nloc) {
-    const int e = tile_e0 + tid;
-#if QDG_U_FROM_LDS
-    // the tet's modal row back from its vertex states in LDS (the inverse of phase 0's map)
-    // instead of a second read of the row: with 64 tiles in flight per XCD the 4 MiB L2 no
-    // longer holds what phase 0 read a face loop ago
-#pragma unroll
-    for (int c = 0; c < NCOMP; ++c) {
-      const double v0 = nod[LIDX(tid, 0, c)], v1 = nod[LIDX(tid, 1, c)], v2 = nod[LIDX(tid, 2, c)],
-                   v3 = nod[LIDX(tid, 3, c)];
-      const double a = (v0 + v1 + v2) * (1.0 / 3.0);
-      u[c][0] = 0.25 * ((v0 + v1) + (v2 + v3));
-      u[c][1] = 0.5 * (v1 - v0);
-      u[c][2] = 0.5 * (v2 - a);
-      u[c][3] = (v3 - u[c][0]) * (1.0 / 3.0);
-    }
-#endif
-    double acc[NCOMP][NDOF];
     {
       // R[c][k] = sum_v accN[v][c] * B_k(vertex v)
       double nv[4][NCOMP];
@@ -1955,8 +1934,28 @@ __global__ __launch_bounds__(TILE_BS, QDG_TILE_WAVES) void k_rhs_p1v(DevMesh m, 
         for (int k = 0; k < NDOF; ++k)
           acc[c][k] = rk_a * un[c][k] + rk_b * (u[c][k] + dtv * imf[k] * acc[c][k]);
     }
-    store_row<NPROP>(R, e, &acc[0][0]);
     if (WITH_DT) dte = vol / sdelt[tid];
+  }
+  // rows out, coalesced: a lane storing its own 160-B row issues 64 separate 16-B write
+  // requests per wave instruction (3.4 TB/s measured, tools/ubench_rowstream.hip); the tile's
+  // rows are one contiguous span, so they go through LDS (row-major over the vertex states,
+  // which nobody reads any more) and leave as 1-KiB wave stores (6.1 TB/s)
+  __syncthreads();
+  if (tid < nloc) {
+    double2* row = reinterpret_cast<double2*>(nod + (size_t)tid * NPROP);
+#pragma unroll
+    for (int j = 0; j < NPROP / 2; ++j) row[j] = make_double2((&acc[0][0])[2 * j], (&acc[0][0])[2 * j + 1]);
+  }
+  __syncthreads();
+  {
+    const double2* src = reinterpret_cast<const double2*>(nod);
+    double2* dst = reinterpret_cast<double2*>(R + (size_t)tile_e0 * NPROP);
+    const int nvalid = nloc * (NPROP / 2);
+#pragma unroll
+    for (int j = 0; j < NPROP / 2; ++j) {
+      const int i = j * TILE_BS + tid;
+      if (i < nvalid) dst[i] = src[i];
+    }
   }
 
   if (WITH_DT) {
