@@ -241,7 +241,7 @@ int mesh_alloc_state(qdg_mesh* m, int ntile)
   HIPCHK(hipMemsetAsync(m->Un.p, 0, fsz * sizeof(double), s));
   HIPCHK(hipMemsetAsync(m->R.p, 0, fsz * sizeof(double), s));
   HIPCHK(hipMemsetAsync(m->W.p, 0, fsz * sizeof(double), s));
-  const size_t nblk = std::max((m->nie + 255) / 256, (size_t)ntile);
+  const size_t nblk = std::max((m->nie + 127) / 128, (size_t)ntile);   // k_rhs_p2s: 128 tets per workgroup
   HIPCHK(m->blockmin.alloc(nblk)); HIPCHK(m->dtraw.alloc(1)); HIPCHK(m->dtdev.alloc(1));
   HIPCHK(m->diagpart.alloc(nblk * 15)); HIPCHK(m->diagout.alloc(15));
   m->Ucur = m->U.p;

@@ -115,6 +115,21 @@ template <int NDOF> struct Tables {
   double vdB[NGV][3][NDOF];   // dB_k/dxi_j at the volume Gauss points
 };
 
+// Tables of the two-lanes-per-tet DG-P2 kernel (k_rhs_p2s): lane half h of a tet works on the
+// modes k in [5h, 5h+5), so every basis value it needs is indexed by (h, point) per lane and
+// comes from LDS instead of scalar constants.
+struct P2Split {
+  // basis at the six face points of a tet whose local nodes (m0, m1, m2) carry the face's three
+  // nodes: [rank of (m0, m1, m2)][point][h][k - 5h], 5 values padded to 6 (48-byte records)
+  double face[24][6][2][6];
+  double fq[6][4];           // face point: barycentric weights of the 3 face nodes, weight
+  // volume points: [point][h]{ B[5], dB/dxi[5], dB/deta[5], dB/dzeta[5] }; point 11 = point 0
+  // with weight 0 (the pair of lanes takes the 11 points two at a time)
+  double vol[12][2][20];
+  double vw[12];
+  double vc[12][4];
+};
+
 // generic tet rule (initialisation: 14 points; diagnostics: 1/4/14 points)
 struct QuadTet {
   int ng;

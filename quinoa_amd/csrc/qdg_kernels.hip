@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include "qdg_device.hpp"
 #include "qdg_kernels.hpp"
+#include "qdg_tables.hpp"
 
 #ifndef QDG_RCP_NR
 #define QDG_RCP_NR 1    // Newton steps after v_rcp_f64 (1 step: R agrees with the fp64-division CPU result to 1e-15)
@@ -38,6 +39,9 @@
 #ifndef QDG_TILE_GP_SERIAL
 #define QDG_TILE_GP_SERIAL 1
 #endif
+#ifndef QDG_P2_ILP
+#define QDG_P2_ILP 0
+#endif
 #ifndef QDG_P1_WAVES
 #define QDG_P1_WAVES 2   // waves per SIMD the DG-P1 RHS kernel is register-budgeted for
 #endif
@@ -49,6 +53,7 @@ __constant__ Tables<4> c_tab4;
 __constant__ Tables<10> c_tab10;
 __constant__ QuadTet c_qinit[3];   // NGinit rule per order index
 __constant__ QuadTet c_qdiag[3];   // NGdiag rule per order index
+__device__ P2Split g_p2s;          // copied to LDS by every workgroup of k_rhs_p2s
 
 #ifdef QDG_STAMPS
 // diagnostic build only: per-segment cycle sums of the P1 RHS kernel (lane 0 of
@@ -860,6 +865,605 @@ __global__ __launch_bounds__(256, (NDOF > 4 ? 1 : 2)) void k_rhs(DevMesh m, Phys
   }
 }
 
+
+// HLLC in the OWN tet's frame (left' = own, right' = neighbour, n' = the own tet's outward
+// normal).  For a face whose stored left tet is the neighbour this is the mirror image of the
+// reference's evaluation (Sl' = -Sr, Sm' = -Sm, Sr' = -Sl), so the reference's ladder
+// (HLLC.hpp:93-124) is applied in its mirrored form: the same four fluxes and the same
+// fall-through of a NaN wave speed to the STORED right state.
+__device__ __forceinline__ void flux_hllc_own(const double* fn, const double* so, const double* sn,
+                                              const Prim& qo, const Prim& qn, bool own_left, double* flx)
+{
+  const double rlr = fast_sqrt(sn[0] * qo.ir);
+  const double irlr1 = fast_rcp(1.0 + rlr);
+  const double vnroe = (qn.vn * rlr + qo.vn) * irlr1;
+  const double aroe = (qn.a * rlr + qo.a) * irlr1;
+  const double Sl = fmin(qo.vn - qo.a, vnroe - aroe);
+  const double Sr = fmax(qn.vn + qn.a, vnroe + aroe);
+  const double ml = so[0] * (Sl - qo.vn), mr = sn[0] * (Sr - qn.vn);
+  const double Sm = (mr * qn.vn - ml * qo.vn + qo.p - qn.p) * fast_rcp(mr - ml);
+  const double pStar = so[0] * (qo.vn - Sl) * (qo.vn - Sm) + qo.p;
+  const bool c1 = Sl > 0.0;
+  const bool c2 = !c1 && (Sl <= 0.0) && (Sm > 0.0);
+  const bool c3 = !c1 && !c2 && (Sm <= 0.0) && (Sr >= 0.0);
+  const bool m1 = Sr < 0.0;
+  const bool m2 = !m1 && (Sr >= 0.0) && (Sm < 0.0);
+  const bool m3 = !m1 && !m2 && (Sm >= 0.0) && (Sl <= 0.0);
+  const bool left = own_left ? (c1 || c2) : !(m1 || m2);
+  const bool star = own_left ? (c2 || c3) : (m2 || m3);
+  const double S = left ? Sl : Sr;
+  const double vn = left ? qo.vn : qn.vn;
+  const double p = left ? qo.p : qn.p;
+  const double u0 = left ? so[0] : sn[0], u1 = left ? so[1] : sn[1], u2 = left ? so[2] : sn[2],
+               u3 = left ? so[3] : sn[3], u4 = left ? so[4] : sn[4];
+  const double id = star ? fast_rcp(S - Sm) : 1.0;
+  const double sv = star ? (S - vn) * id * Sm : vn;
+  const double dp = star ? (pStar - p) * id * Sm + pStar : p;
+  const double e4 = star ? ((pStar * Sm - p * vn) * id + pStar) * Sm : p * vn;
+  flx[0] = sv * u0;
+  flx[1] = sv * u1 + dp * fn[0];
+  flx[2] = sv * u2 + dp * fn[1];
+  flx[3] = sv * u3 + dp * fn[2];
+  flx[4] = sv * u4 + e4;
+}
+
+// ------------------------------------------------- DG-P2 RHS, face-batched form
+// Same algorithm and MODEs as k_rhs<10>, one lane per tet, organised around what the issue
+// slots of the generic kernel were spent on (its rows sit in accumulation registers at one wave
+// per SIMD, and every Gauss point read all 150 doubles of u, the neighbour row and the
+// accumulators through v_accvgpr moves -- a third of its instructions):
+//  * a face's six Gauss points are handled together: the neighbour row is consumed into the six
+//    neighbour states while it arrives, the own states are formed mode by mode (each mode of u
+//    is read once per face, the basis values are scalar loads), the six fluxes are computed in
+//    the own tet's frame (no left/right swaps), and the accumulators are visited once per face
+//    with the six weighted fluxes of a component;
+//  * the volume term contracts the Euler flux with the inverse Jacobian first
+//    (G[c][j] = sum_d F[c][d] J^-1[j][d], 45 FMAs) and then with the reference gradients of the
+//    basis (3 FMAs per accumulator) instead of forming dB/dx per mode and point;
+//  * the new rows leave through LDS as coalesced wave stores.
+template <int PROB, int MODE>
+__global__ __launch_bounds__(256, 1) void k_rhs_p2(DevMesh m, Phys ph, double t,
+                                                   const double* __restrict__ U,
+                                                   double* __restrict__ R,
+                                                   double* __restrict__ blockmin,
+                                                   double rk_a, double rk_b,
+                                                   const double* __restrict__ dtp,
+                                                   const double* __restrict__ Un)
+{
+  constexpr int NDOF = 10, NGF = 6, NGV = 11, NPROP = NCOMP * NDOF;
+  constexpr bool WITH_DT = MODE == 1, FUSE_RK = MODE == 2;
+  __shared__ __attribute__((aligned(16))) double stage[256 * NPROP];
+  const Tables<10>& T = c_tab10;
+  const int blk = xcd_tile(blockIdx.x, gridDim.x);
+  const int e0 = blk * 256 + threadIdx.x;
+  const bool active = e0 < m.nie;
+  const int e = active ? e0 : m.nie - 1;       // every lane runs to the barriers
+  const int stride = m.stride;
+  double delt = 0.0;
+
+  double acc[NCOMP][NDOF], u[NCOMP][NDOF];
+#pragma unroll
+  for (int c = 0; c < NCOMP; ++c)
+#pragma unroll
+    for (int k = 0; k < NDOF; ++k) acc[c][k] = 0.0;
+  load_row<NPROP>(U, e, &u[0][0]);
+  ElemGeom g;
+  load_geom(m, e, g);
+
+  // ---- faces ------------------------------------------------------------
+#pragma unroll 1
+  for (int lf = 0; lf < 4; ++lf) {
+    const int nb = m.nbr[(size_t)lf * stride + e];
+    if (nb == -1 && !WITH_DT) continue;       // boundary face without a BC (dt still counts it)
+    const int info = m.finfo[(size_t)lf * stride + e];
+    const int f = m.fid[(size_t)lf * stride + e];
+    double gq[4];
+    load_row<4>(m.fgeo, f, gq);
+    const bool own_left = (info >> 6) & 1;
+    const double area = gq[0];
+    const double osg = own_left ? 1.0 : -1.0;
+    const double fn[3] = { osg * gq[1], osg * gq[2], osg * gq[3] };
+
+    double so[NGF][NCOMP], sn[NGF][NCOMP];
+    if (nb >= 0) {
+      double un[NCOMP][NDOF];
+      load_row<NPROP>(U, nb, &un[0][0]);
+#pragma unroll
+      for (int ig = 0; ig < NGF; ++ig) {
+        double xi, eta, zeta, Bn[NDOF];
+        nbr_ref_coords(info, T.fs[ig][0], T.fs[ig][1], T.fs[ig][2], xi, eta, zeta);
+        eval_basis<NDOF>(xi, eta, zeta, Bn);
+        state_from<NDOF>(un, Bn, sn[ig]);
+      }
+    }
+    // own states, mode by mode
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c)
+#pragma unroll
+      for (int ig = 0; ig < NGF; ++ig) so[ig][c] = u[c][0];
+#pragma unroll
+    for (int k = 1; k < NDOF; ++k)
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c)
+#pragma unroll
+        for (int ig = 0; ig < NGF; ++ig) so[ig][c] = fma(u[c][k], T.fB[lf][ig][k], so[ig][c]);
+    if (nb < 0) {
+#pragma unroll 1
+      for (int ig = 0; ig < NGF; ++ig) {
+        // (runtime index on so/sn would go to scratch: select the point's states)
+        double P[3], sl[NCOMP], sr[NCOMP];
+        face_point(g, lf, T.fs[ig][0], T.fs[ig][1], T.fs[ig][2], P);
+#pragma unroll
+        for (int c = 0; c < NCOMP; ++c) {
+          sl[c] = so[0][c];
+#pragma unroll
+          for (int j = 1; j < NGF; ++j) sl[c] = (ig == j) ? so[j][c] : sl[c];
+        }
+        bc_state<PROB>(ph, -nb - 1, sl, P[0], P[1], P[2], t, fn, sr);
+#pragma unroll
+        for (int c = 0; c < NCOMP; ++c) {
+#pragma unroll
+          for (int j = 0; j < NGF; ++j) sn[j][c] = (ig == j) ? sr[c] : sn[j][c];
+        }
+      }
+    }
+    // fluxes in the own frame, weighted: the own tet loses what leaves through the face.
+    // The six points are independent: one straight-line block for all of them lets the
+    // scheduler interleave their dependency chains (one wave per SIMD has nothing else to
+    // hide the fp64 latency with).
+    const double wsel = (nb == -1) ? 0.0 : 1.0;
+    const bool lf_flux = ph.flux == 1;
+    double wq[NGF];
+#pragma unroll
+    for (int ig = 0; ig < NGF; ++ig) wq[ig] = T.fw[ig] * area;
+    if (!lf_flux) {
+#pragma unroll
+      for (int ig = 0; ig < NGF; ++ig) {
+        Prim qo, qn;
+        primitives(ph, fn, so[ig], qo);
+        primitives(ph, fn, sn[ig], qn);
+        if (WITH_DT) {
+          // std::max(dSV_l, dSV_r) as (a < b) ? b : a in STORED (left, right) order
+          const double d_o = wq[ig] * (fabs(qo.vn) + qo.a);
+          const double d_n = (nb < 0) ? 0.0 : wq[ig] * (fabs(qn.vn) + qn.a);
+          const bool take_n = own_left ? (d_o < d_n) : !(d_n < d_o);
+          delt += take_n ? d_n : d_o;
+        }
+        double fl[NCOMP];
+        flux_hllc_own(fn, so[ig], sn[ig], qo, qn, own_left, fl);
+        const double wt = -wq[ig] * wsel;
+#pragma unroll
+        for (int c = 0; c < NCOMP; ++c) so[ig][c] = wt * fl[c];
+#if !QDG_P2_ILP
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+      }
+    } else {
+#pragma unroll
+      for (int ig = 0; ig < NGF; ++ig) {
+        Prim qo, qn;
+        primitives(ph, fn, so[ig], qo);
+        primitives(ph, fn, sn[ig], qn);
+        if (WITH_DT) {
+          const double d_o = wq[ig] * (fabs(qo.vn) + qo.a);
+          const double d_n = (nb < 0) ? 0.0 : wq[ig] * (fabs(qn.vn) + qn.a);
+          const bool take_n = own_left ? (d_o < d_n) : !(d_n < d_o);
+          delt += take_n ? d_n : d_o;
+        }
+        double fl[NCOMP];
+        flux_lf_q(fn, so[ig], sn[ig], qo, qn, fl);
+        const double wt = -wq[ig] * wsel;
+#pragma unroll
+        for (int c = 0; c < NCOMP; ++c) so[ig][c] = wt * fl[c];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c) {
+      acc[c][0] += ((so[0][c] + so[1][c]) + (so[2][c] + so[3][c])) + (so[4][c] + so[5][c]);
+#pragma unroll
+      for (int k = 1; k < NDOF; ++k) {
+        double a = acc[c][k];
+#pragma unroll
+        for (int ig = 0; ig < NGF; ++ig) a = fma(so[ig][c], T.fB[lf][ig][k], a);
+        acc[c][k] = a;
+      }
+    }
+  }
+
+  const double vol = m.vol[e];
+
+  // ---- volume integral, src/PDE/Integrate/Volume.cpp:20-168 -------------
+  {
+    double ji[3][3];
+    inverse_jacobian(g, ji);
+#if QDG_P2_ILP >= 2
+#pragma unroll 2
+#else
+#pragma unroll 1
+#endif
+    for (int ig = 0; ig < NGV; ++ig) {
+      double s[NCOMP];
+      state_from<NDOF>(u, T.vB[ig], s);
+      const double ir = fast_rcp(s[0]);
+      const double uu = s[1] * ir, vv = s[2] * ir, ww = s[3] * ir;
+      const double p = eos_pressure(ph, s[0], uu, vv, ww, s[4]);
+      const double wt = T.vw[ig] * vol;
+      const double h = s[4] + p;
+      // Euler flux F[c][d], src/PDE/CompFlow/DGCompFlow.hpp:599-635
+      const double F[NCOMP][3] = {
+        { s[1], s[2], s[3] },
+        { s[1] * uu + p, s[2] * uu, s[3] * uu },
+        { s[1] * vv, s[2] * vv + p, s[3] * vv },
+        { s[1] * ww, s[2] * ww, s[3] * ww + p },
+        { uu * h, vv * h, ww * h } };
+      // dB_k/dx_d = sum_j dB_k/dxi_j jacInv[j][d] (Basis.cpp:77-265): contract F with jacInv first
+      double G[NCOMP][3];
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          G[c][j] = wt * (F[c][0] * ji[j][0] + F[c][1] * ji[j][1] + F[c][2] * ji[j][2]);
+#pragma unroll
+      for (int k = 1; k < NDOF; ++k) {
+        const double g0 = T.vdB[ig][0][k], g1 = T.vdB[ig][1][k], g2 = T.vdB[ig][2][k];
+#pragma unroll
+        for (int c = 0; c < NCOMP; ++c)
+          acc[c][k] += G[c][0] * g0 + G[c][1] * g1 + G[c][2] * g2;
+      }
+    }
+  }
+
+  // ---- source integral, src/PDE/Integrate/Source.cpp:21-141 -------------
+  if constexpr (prob_has_source<PROB>()) {
+#pragma unroll 1
+    for (int ig = 0; ig < NGV; ++ig) {
+      const double xi = T.vc[ig][0], eta = T.vc[ig][1], zeta = T.vc[ig][2];
+      const double w0 = 1.0 - xi - eta - zeta;
+      double P[3], s[NCOMP];
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+        P[d] = g.p[0][d] * w0 + g.p[1][d] * xi + g.p[2][d] * eta + g.p[3][d] * zeta;
+      prob_src<PROB>(ph, P[0], P[1], P[2], t, s);
+      const double wt = T.vw[ig] * vol;
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) {
+        const double ws = wt * s[c];
+        acc[c][0] += ws;
+#pragma unroll
+        for (int k = 1; k < NDOF; ++k) acc[c][k] += ws * T.vB[ig][k];
+      }
+    }
+  }
+
+  if constexpr (FUSE_RK) {
+    constexpr double imf[10] = { 1.0, 10.0, 10.0 / 3.0, 5.0 / 3.0, 35.0, 21.0, 14.0, 7.0,
+                                 14.0 / 3.0, 7.0 / 3.0 };
+    const double dtv = dtp[0] / vol;
+    // Un row streamed component by component (the own row u is still in registers)
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c) {
+      double un[NDOF];
+#pragma unroll
+      for (int k = 0; k < NDOF; ++k) un[k] = Un[(size_t)e * NPROP + c * NDOF + k];
+#pragma unroll
+      for (int k = 0; k < NDOF; ++k)
+        acc[c][k] = rk_a * un[k] + rk_b * (u[c][k] + dtv * imf[k] * acc[c][k]);
+    }
+  }
+  // rows out, coalesced (see k_rhs_p1v): deposit in LDS, leave as 1-KiB wave stores
+  {
+    double2* row = reinterpret_cast<double2*>(stage + (size_t)threadIdx.x * NPROP);
+#pragma unroll
+    for (int j = 0; j < NPROP / 2; ++j) row[j] = make_double2((&acc[0][0])[2 * j], (&acc[0][0])[2 * j + 1]);
+    __syncthreads();
+    const int r0 = blk * 256;
+    const int nrow = (m.nie - r0 < 256) ? m.nie - r0 : 256;
+    const double2* src = reinterpret_cast<const double2*>(stage);
+    double2* dst = reinterpret_cast<double2*>(R + (size_t)r0 * NPROP);
+    const int nvalid = nrow * (NPROP / 2);
+#pragma unroll 5
+    for (int j = 0; j < NPROP / 2; ++j) {
+      const int i = j * 256 + threadIdx.x;
+      if (i < nvalid) dst[i] = src[i];
+    }
+  }
+  if (WITH_DT) {
+    double dte = active ? vol / delt : DBL_MAX;
+    for (int off = 32; off > 0; off >>= 1) dte = fmin(dte, __shfl_down(dte, off, 64));
+    __shared__ double wmin[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) wmin[wv] = dte;
+    __syncthreads();
+    if (threadIdx.x == 0)
+      blockmin[blockIdx.x] = fmin(fmin(wmin[0], wmin[1]), fmin(wmin[2], wmin[3]));
+  }
+}
+
+// ------------------------------------------------- DG-P2 RHS, two lanes per tet
+// The one-lane-per-tet forms above need the tet's row, its accumulators and a neighbour row
+// (3 x 100 registers) and run at ONE wave per SIMD, where the vector unit idles 44 % of the
+// time (profiles/r02_cfg3_nx55_pmc_per_launch.json: fp64 latency and memory waits with nothing
+// to switch to).  Here a tet is worked on by a PAIR of adjacent lanes; lane half h owns the
+// modes k in [5h, 5h+5) of every row: 50 registers each for u, the accumulators and a neighbour
+// half row -> 2 waves per SIMD.
+//  * a state at a point is the sum of the two lanes' partial sums over their modes; the pair
+//    exchanges partial sums with one DPP quad_perm(1,0,3,2) move per 32-bit half;
+//  * the six Gauss points of a face are taken as "slots": lane half h maps slot s to point
+//    (3h + s) mod 6, so each lane's slots 0-2 are the points whose fluxes it computes and its
+//    slots 3-5 are its partner's -- the exchange code is the same for both halves (no selects),
+//    only table addresses differ; the eleven volume points are taken two at a time the same way;
+//  * basis values come from LDS tables indexed by (node permutation of the face, point, h): the
+//    neighbour-side basis needs no evaluation;
+//  * fluxes in the own tet's frame, accumulators visited once per face, G-form volume term and
+//    coalesced row stores as in k_rhs_p2.
+__device__ __forceinline__ double pair_swap(double x)
+{
+  const int lo = __double2loint(x), hi = __double2hiint(x);
+  const int l2 = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true);
+  const int h2 = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true);
+  return __hiloint2double(h2, l2);
+}
+// rank of the ordered triple (m0, m1, m2) of distinct local node ids among the 24 possible
+__host__ __device__ __forceinline__ int perm_rank(int code)
+{
+  const int m0 = code & 3, m1 = (code >> 2) & 3, m2 = (code >> 4) & 3;
+  const int r1 = m1 - (m1 > m0), r2 = m2 - (m2 > m0) - (m2 > m1);
+  return m0 * 6 + r1 * 2 + r2;
+}
+
+template <int PROB, int MODE>
+__global__ __launch_bounds__(256, 2) void k_rhs_p2s(DevMesh m, Phys ph, double t,
+                                                    const double* __restrict__ U,
+                                                    double* __restrict__ R,
+                                                    double* __restrict__ blockmin,
+                                                    double rk_a, double rk_b,
+                                                    const double* __restrict__ dtp,
+                                                    const double* __restrict__ Un)
+{
+  constexpr int NDOF = 10, KH = 5, NPROP = NCOMP * NDOF, TPB = 128;
+  constexpr bool WITH_DT = MODE == 1, FUSE_RK = MODE == 2;
+  __shared__ __attribute__((aligned(16))) P2Split S;
+  __shared__ __attribute__((aligned(16))) double stage[TPB * NPROP];
+  const int tid = threadIdx.x, h = tid & 1, tl = tid >> 1;
+  {
+    const double2* src = reinterpret_cast<const double2*>(&g_p2s);
+    double2* dst = reinterpret_cast<double2*>(&S);
+    for (int i = tid; i < (int)(sizeof(P2Split) / 16); i += 256) dst[i] = src[i];
+  }
+  const int blk = xcd_tile(blockIdx.x, gridDim.x);
+  const int e0 = blk * TPB + tl;
+  const bool active = e0 < m.nie;
+  const int e = active ? e0 : m.nie - 1;       // every lane runs to the barriers
+  const int stride = m.stride;
+  double delt = 0.0;
+
+  double acc[NCOMP][KH], u[NCOMP][KH];
+#pragma unroll
+  for (int c = 0; c < NCOMP; ++c)
+#pragma unroll
+    for (int k = 0; k < KH; ++k) {
+      acc[c][k] = 0.0;
+      u[c][k] = U[(size_t)e * NPROP + c * NDOF + KH * h + k];
+    }
+  ElemGeom g;
+  load_geom(m, e, g);
+  __syncthreads();
+
+  const int gb0 = 3 * h, gb1 = 3 - 3 * h;      // first point of this lane's slots 0-2 / 3-5
+
+  // ---- faces ------------------------------------------------------------
+#pragma unroll 1
+  for (int lf = 0; lf < 4; ++lf) {
+    const int nb = m.nbr[(size_t)lf * stride + e];
+    if (nb == -1 && !WITH_DT) continue;       // boundary face without a BC (dt still counts it)
+    const int info = m.finfo[(size_t)lf * stride + e];
+    const int f = m.fid[(size_t)lf * stride + e];
+    double gq[4];
+    load_row<4>(m.fgeo, f, gq);
+    const bool own_left = (info >> 6) & 1;
+    const double area = gq[0];
+    const double osg = own_left ? 1.0 : -1.0;
+    const double fn[3] = { osg * gq[1], osg * gq[2], osg * gq[3] };
+    const int code_o = lpofa(lf, 0) | (lpofa(lf, 1) << 2) | (lpofa(lf, 2) << 4);
+    const double* To = &S.face[perm_rank(code_o)][0][h][0];
+    const double* Tn = &S.face[perm_rank(info & 63)][0][h][0];
+
+    double so[3][NCOMP], sn[3][NCOMP];
+    if (nb >= 0) {
+      double un[NCOMP][KH];
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c)
+#pragma unroll
+        for (int k = 0; k < KH; ++k) un[c][k] = U[(size_t)nb * NPROP + c * NDOF + KH * h + k];
+      double p[6][NCOMP];
+#pragma unroll
+      for (int s = 0; s < 6; ++s) {
+        const double* B = Tn + (s < 3 ? gb0 + s : gb1 + s - 3) * 12;
+        const double b0 = B[0], b1 = B[1], b2 = B[2], b3 = B[3], b4 = B[4];
+#pragma unroll
+        for (int c = 0; c < NCOMP; ++c)
+          p[s][c] = un[c][0] * b0 + un[c][1] * b1 + un[c][2] * b2 + un[c][3] * b3 + un[c][4] * b4;
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int c = 0; c < NCOMP; ++c) sn[j][c] = p[j][c] + pair_swap(p[j + 3][c]);
+    }
+    {
+      double p[6][NCOMP];
+#pragma unroll
+      for (int s = 0; s < 6; ++s) {
+        const double* B = To + (s < 3 ? gb0 + s : gb1 + s - 3) * 12;
+        const double b0 = B[0], b1 = B[1], b2 = B[2], b3 = B[3], b4 = B[4];
+#pragma unroll
+        for (int c = 0; c < NCOMP; ++c)
+          p[s][c] = u[c][0] * b0 + u[c][1] * b1 + u[c][2] * b2 + u[c][3] * b3 + u[c][4] * b4;
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int c = 0; c < NCOMP; ++c) so[j][c] = p[j][c] + pair_swap(p[j + 3][c]);
+    }
+    if (nb < 0) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const double* q = S.fq[gb0 + j];
+        double P[3];
+        face_point(g, lf, q[0], q[1], q[2], P);
+        bc_state<PROB>(ph, -nb - 1, so[j], P[0], P[1], P[2], t, fn, sn[j]);
+      }
+    }
+    // fluxes at this lane's three points (own frame, weighted: the own tet loses what leaves)
+    const double wsel = (nb == -1) ? 0.0 : 1.0;
+    double F[6][NCOMP];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      Prim qo, qn;
+      primitives(ph, fn, so[j], qo);
+      primitives(ph, fn, sn[j], qn);
+      const double wq = S.fq[gb0 + j][3] * area;
+      if (WITH_DT) {
+        // std::max(dSV_l, dSV_r) as (a < b) ? b : a in STORED (left, right) order
+        const double d_o = wq * (fabs(qo.vn) + qo.a);
+        const double d_n = (nb < 0) ? 0.0 : wq * (fabs(qn.vn) + qn.a);
+        const bool take_n = own_left ? (d_o < d_n) : !(d_n < d_o);
+        delt += take_n ? d_n : d_o;
+      }
+      double fl[NCOMP];
+      if (ph.flux == 1) flux_lf_q(fn, so[j], sn[j], qo, qn, fl);
+      else flux_hllc_own(fn, so[j], sn[j], qo, qn, own_left, fl);
+      const double wt = -wq * wsel;
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) F[j][c] = wt * fl[c];
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) F[j + 3][c] = pair_swap(F[j][c]);
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+      const double* B = To + (s < 3 ? gb0 + s : gb1 + s - 3) * 12;
+      const double b0 = B[0], b1 = B[1], b2 = B[2], b3 = B[3], b4 = B[4];
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) {
+        acc[c][0] = fma(F[s][c], b0, acc[c][0]);
+        acc[c][1] = fma(F[s][c], b1, acc[c][1]);
+        acc[c][2] = fma(F[s][c], b2, acc[c][2]);
+        acc[c][3] = fma(F[s][c], b3, acc[c][3]);
+        acc[c][4] = fma(F[s][c], b4, acc[c][4]);
+      }
+    }
+  }
+
+  const double vol = m.vol[e];
+
+  // ---- volume (+ source) integral, two points per step: this lane's and its partner's ----
+  {
+    double ji[3][3];
+    inverse_jacobian(g, ji);
+#pragma unroll 1
+    for (int s = 0; s < 6; ++s) {
+      const int gm = 2 * s + h, gp = 2 * s + 1 - h;
+      const double* tm = S.vol[gm][h];
+      const double* tp = S.vol[gp][h];
+      double sf[NCOMP];
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) {
+        const double pm = u[c][0] * tm[0] + u[c][1] * tm[1] + u[c][2] * tm[2] + u[c][3] * tm[3] + u[c][4] * tm[4];
+        const double pp = u[c][0] * tp[0] + u[c][1] * tp[1] + u[c][2] * tp[2] + u[c][3] * tp[3] + u[c][4] * tp[4];
+        sf[c] = pm + pair_swap(pp);
+      }
+      const double ir = fast_rcp(sf[0]);
+      const double uu = sf[1] * ir, vv = sf[2] * ir, ww = sf[3] * ir;
+      const double p = eos_pressure(ph, sf[0], uu, vv, ww, sf[4]);
+      const double wt = S.vw[gm] * vol;
+      const double hh = sf[4] + p;
+      // Euler flux F[c][d], src/PDE/CompFlow/DGCompFlow.hpp:599-635
+      const double Fv[NCOMP][3] = {
+        { sf[1], sf[2], sf[3] },
+        { sf[1] * uu + p, sf[2] * uu, sf[3] * uu },
+        { sf[1] * vv, sf[2] * vv + p, sf[3] * vv },
+        { sf[1] * ww, sf[2] * ww, sf[3] * ww + p },
+        { uu * hh, vv * hh, ww * hh } };
+      double Gm[NCOMP][3], Gp[NCOMP][3];
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          Gm[c][j] = wt * (Fv[c][0] * ji[j][0] + Fv[c][1] * ji[j][1] + Fv[c][2] * ji[j][2]);
+          Gp[c][j] = pair_swap(Gm[c][j]);
+        }
+#pragma unroll
+      for (int k = 0; k < KH; ++k) {
+        const double m0 = tm[5 + k], m1 = tm[10 + k], m2 = tm[15 + k];
+        const double p0 = tp[5 + k], p1 = tp[10 + k], p2 = tp[15 + k];
+#pragma unroll
+        for (int c = 0; c < NCOMP; ++c)
+          acc[c][k] += (Gm[c][0] * m0 + Gm[c][1] * m1 + Gm[c][2] * m2)
+                     + (Gp[c][0] * p0 + Gp[c][1] * p1 + Gp[c][2] * p2);
+      }
+      if constexpr (prob_has_source<PROB>()) {
+        // src/PDE/Integrate/Source.cpp:21-141
+        const double xi = S.vc[gm][0], eta = S.vc[gm][1], zeta = S.vc[gm][2];
+        const double w0 = 1.0 - xi - eta - zeta;
+        double P[3], sr[NCOMP];
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+          P[d] = g.p[0][d] * w0 + g.p[1][d] * xi + g.p[2][d] * eta + g.p[3][d] * zeta;
+        prob_src<PROB>(ph, P[0], P[1], P[2], t, sr);
+#pragma unroll
+        for (int c = 0; c < NCOMP; ++c) {
+          const double wm = wt * sr[c];
+          const double wp = pair_swap(wm);
+#pragma unroll
+          for (int k = 0; k < KH; ++k) acc[c][k] += wm * tm[k] + wp * tp[k];
+        }
+      }
+    }
+  }
+
+  if constexpr (FUSE_RK) {
+    const double dtv = dtp[0] / vol;
+    const double imf[KH] = { h ? 21.0 : 1.0, h ? 14.0 : 10.0, h ? 7.0 : 10.0 / 3.0,
+                             h ? 14.0 / 3.0 : 5.0 / 3.0, h ? 7.0 / 3.0 : 35.0 };
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c)
+#pragma unroll
+      for (int k = 0; k < KH; ++k) {
+        const double un = Un[(size_t)e * NPROP + c * NDOF + KH * h + k];
+        acc[c][k] = rk_a * un + rk_b * (u[c][k] + dtv * imf[k] * acc[c][k]);
+      }
+  }
+  // rows out, coalesced (see k_rhs_p1v)
+  {
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c)
+#pragma unroll
+      for (int k = 0; k < KH; ++k) stage[tl * NPROP + c * NDOF + KH * h + k] = acc[c][k];
+    __syncthreads();
+    const int r0 = blk * TPB;
+    const int nrow = (m.nie - r0 < TPB) ? m.nie - r0 : TPB;
+    const double2* src = reinterpret_cast<const double2*>(stage);
+    double2* dst = reinterpret_cast<double2*>(R + (size_t)r0 * NPROP);
+    const int nvalid = nrow * (NPROP / 2);
+#pragma unroll
+    for (int j = 0; j < (TPB * NPROP / 2 + 255) / 256; ++j) {
+      const int i = j * 256 + tid;
+      if (i < nvalid) dst[i] = src[i];
+    }
+  }
+  if (WITH_DT) {
+    delt += pair_swap(delt);
+    double dte = active ? vol / delt : DBL_MAX;
+    for (int off = 32; off > 0; off >>= 1) dte = fmin(dte, __shfl_down(dte, off, 64));
+    __shared__ double wmin[4];
+    const int lane = tid & 63, wv = tid >> 6;
+    if (lane == 0) wmin[wv] = dte;
+    __syncthreads();
+    if (tid == 0)
+      blockmin[blockIdx.x] = fmin(fmin(wmin[0], wmin[1]), fmin(wmin[2], wmin[3]));
+  }
+}
 
 // ------------------------------------------------- DG-P1 RHS (headline kernel)
 // Same algorithm as k_rhs<4>, specialised for throughput:
@@ -3254,7 +3858,51 @@ hipError_t upload_tables(const Tables<1>& t1, const Tables<4>& t4, const Tables<
   if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_tab10), &t10, sizeof(t10))) != hipSuccess) return e;
   if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_qinit), qinit, 3 * sizeof(QuadTet))) != hipSuccess) return e;
   if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_qdiag), qdiag, 3 * sizeof(QuadTet))) != hipSuccess) return e;
+  {
+    // tables of k_rhs_p2s, from the same rules and basis functions as Tables<10>
+    static P2Split ps;
+    std::memset(&ps, 0, sizeof(ps));
+    for (int m0 = 0; m0 < 4; ++m0) for (int m1 = 0; m1 < 4; ++m1) for (int m2 = 0; m2 < 4; ++m2) {
+      if (m0 == m1 || m0 == m2 || m1 == m2) continue;
+      const int code = m0 | (m1 << 2) | (m2 << 4), r = perm_rank(code);
+      for (int gq = 0; gq < 6; ++gq) {
+        double wn[4] = { 0, 0, 0, 0 };
+        wn[m0] += t10.fs[gq][0]; wn[m1] += t10.fs[gq][1]; wn[m2] += t10.fs[gq][2];
+        double B[10];
+        host_basis(10, wn[1], wn[2], wn[3], B);
+        for (int k = 0; k < 10; ++k) ps.face[r][gq][k / 5][k % 5] = B[k];
+      }
+    }
+    for (int gq = 0; gq < 6; ++gq) {
+      for (int j = 0; j < 3; ++j) ps.fq[gq][j] = t10.fs[gq][j];
+      ps.fq[gq][3] = t10.fw[gq];
+    }
+    for (int gv = 0; gv < 12; ++gv) {
+      const int src = gv < 11 ? gv : 0;
+      ps.vw[gv] = gv < 11 ? t10.vw[src] : 0.0;
+      for (int d = 0; d < 3; ++d) ps.vc[gv][d] = t10.vc[src][d];
+      for (int k = 0; k < 10; ++k) {
+        ps.vol[gv][k / 5][k % 5] = t10.vB[src][k];
+        for (int j = 0; j < 3; ++j) ps.vol[gv][k / 5][5 + 5 * j + k % 5] = t10.vdB[src][j][k];
+      }
+    }
+    if ((e = hipMemcpyToSymbol(HIP_SYMBOL(g_p2s), &ps, sizeof(ps))) != hipSuccess) return e;
+  }
   return hipSuccess;
+}
+
+// DG-P2 runs through the face-batched kernel (QDG_P2_GENERIC=1 keeps k_rhs<10> for A/B runs)
+static bool p2_batched(int ndof)
+{
+  static const bool generic = std::getenv("QDG_P2_GENERIC") != nullptr;
+  return ndof == 10 && !generic;
+}
+
+// ... in its two-lanes-per-tet form (QDG_P2_ONE_LANE=1: the one-lane face-batched kernel)
+static bool p2_split()
+{
+  static const bool one = std::getenv("QDG_P2_ONE_LANE") != nullptr;
+  return !one;
 }
 
 void launch_rhs(int ndof, const DevMesh& m, const Phys& ph, double t, const double* U, double* R,
@@ -3265,6 +3913,14 @@ void launch_rhs(int ndof, const DevMesh& m, const Phys& ph, double t, const doub
     QDG_DISPATCH_NDOF(ndof, (tr::k_rhs<N><<<nblk(m.nie, 256), 256, 0, s>>>(m, ph, t, U, R)));
     return;
   }
+  if (p2_batched(ndof)) {
+    if (p2_split()) {
+      QDG_DISPATCH_PROB(ph.problem, (k_rhs_p2s<P, 0><<<nblk(m.nie, 128), 256, 0, s>>>(m, ph, t, U, R, nullptr, 0.0, 0.0, nullptr, nullptr)));
+    } else {
+      QDG_DISPATCH_PROB(ph.problem, (k_rhs_p2<P, 0><<<nblk(m.nie, 256), 256, 0, s>>>(m, ph, t, U, R, nullptr, 0.0, 0.0, nullptr, nullptr)));
+    }
+    return;
+  }
   QDG_DISPATCH_NDOF(ndof, QDG_DISPATCH_PROB(ph.problem, (k_rhs<N, P, 0><<<nblk(m.nie, 256), 256, 0, s>>>(m, ph, t, U, R, nullptr, 0.0, 0.0, nullptr, nullptr))));
 }
 
@@ -3273,9 +3929,16 @@ void launch_rhs_dt(int ndof, const DevMesh& m, const Phys& ph, double t, const d
                    double* blockmin, double scale, double tleft, double* out_raw, double* out_dt,
                    hipStream_t s)
 {
-  const int nb = nblk(m.nie, 256);
+  int nb = nblk(m.nie, 256);
   if (nb == 0) return;
-  QDG_DISPATCH_NDOF(ndof, QDG_DISPATCH_PROB(ph.problem, (k_rhs<N, P, 1><<<nb, 256, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr))));
+  if (p2_batched(ndof) && p2_split()) {
+    nb = nblk(m.nie, 128);
+    QDG_DISPATCH_PROB(ph.problem, (k_rhs_p2s<P, 1><<<nb, 256, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr)));
+  } else if (p2_batched(ndof)) {
+    QDG_DISPATCH_PROB(ph.problem, (k_rhs_p2<P, 1><<<nb, 256, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr)));
+  } else {
+    QDG_DISPATCH_NDOF(ndof, QDG_DISPATCH_PROB(ph.problem, (k_rhs<N, P, 1><<<nb, 256, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr))));
+  }
   k_dt_final<<<1, 256, 0, s>>>(blockmin, nb, scale, tleft, out_raw, out_dt);
 }
 
@@ -3285,6 +3948,14 @@ void launch_rhs_rk(int ndof, const DevMesh& m, const Phys& ph, double t, const d
 {
   const int nb = nblk(m.nie, 256);
   if (nb == 0) return;
+  if (p2_batched(ndof)) {
+    if (p2_split()) {
+      QDG_DISPATCH_PROB(ph.problem, (k_rhs_p2s<P, 2><<<nblk(m.nie, 128), 256, 0, s>>>(m, ph, t, U, Uout, nullptr, a, b, dt, Un)));
+    } else {
+      QDG_DISPATCH_PROB(ph.problem, (k_rhs_p2<P, 2><<<nb, 256, 0, s>>>(m, ph, t, U, Uout, nullptr, a, b, dt, Un)));
+    }
+    return;
+  }
   QDG_DISPATCH_NDOF(ndof, QDG_DISPATCH_PROB(ph.problem, (k_rhs<N, P, 2><<<nb, 256, 0, s>>>(m, ph, t, U, Uout, nullptr, a, b, dt, Un))));
 }
 

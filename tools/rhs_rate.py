@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Resident RHS/step timing of any order on the synthetic box (for DESIGN.md's
 per-order table; bench.py stays on the BASELINE workload).
-Usage (GPU box): python tools/rhs_rate.py <ndof> [nx] [limiter] [problem]"""
+Usage (GPU box): python tools/rhs_rate.py <ndof> [nx] [limiter] [problem] [timed steps]"""
 import os
 import sys
 import time
@@ -29,7 +29,7 @@ for _ in range(3):
     mesh.step(0.0, want_dt=False)
 ctx.synchronize()
 mesh.profile_enable(True)
-n = 10
+n = int(sys.argv[5]) if len(sys.argv) > 5 else 10
 t3 = time.perf_counter()
 for _ in range(n):
     mesh.step(0.0, want_dt=False)
