@@ -1208,6 +1208,8 @@ extern "C" int qdg_stage_rhs_update(qdg_mesh* mesh, int stage, double t)
   QDG_CATCH
 }
 
+static bool can_fuse_update_limit(const qdg_mesh* mesh);
+
 // Fused form.  Stage 0: Un is the current buffer itself (no copy: the update
 // writes the new state to another buffer), R <- rhs(U) and, with a CFL time
 // step, dt from the same kernel.  Stages 1, 2 on the DG-P1 fast path: the RK
@@ -1223,7 +1225,12 @@ extern "C" int qdg_stage_rhs_dt(qdg_mesh* mesh, int stage, double t, double tlef
   const bool cfl_dt = stage == 0 && !(ctx->cfg.dt > 0.0);
   if (stage == 0 && !cfl_dt) if (int rc = qdg_stage_dt(mesh, tleft)) return rc;
   std::pair<hipEvent_t, hipEvent_t>* ev;
-  if (use_p1_fast(mesh) && stage > 0) {
+  // the update is fused into the RHS kernel whenever dt is known before the launch: stages 1, 2
+  // always, stage 0 when the time step is prescribed (Un is then the current buffer itself and
+  // a = 0, b = 1)
+  // (not when the stage-0 update is going to be fused with the limiter of stage 1 instead)
+  const bool fuse = stage > 0 || (!cfl_dt && !can_fuse_update_limit(mesh));
+  if (use_p1_fast(mesh) && fuse) {
     double* out = free_buf(mesh, mesh->Ucur, mesh->Unp);
     if (int rc = prof_begin(mesh, &ev)) return rc;
     if (use_tile(mesh) && mesh->split_rhs) {
@@ -1243,7 +1250,7 @@ extern "C" int qdg_stage_rhs_dt(qdg_mesh* mesh, int stage, double t, double tlef
                        mesh->dt_ptr, mesh->Unp, s);
     if (ev) HIPCHK(hipEventRecord(ev->second, s));
     mesh->Upending = out;
-  } else if (stage > 0 && mesh->dm.ncomp == NCOMP) {
+  } else if (fuse && mesh->dm.ncomp == NCOMP) {
     // P0 / P2 (and the generic P1 path): the same fusion in the generic kernel
     double* out = free_buf(mesh, mesh->Ucur, mesh->Unp);
     if (int rc = prof_begin(mesh, &ev)) return rc;

@@ -1245,8 +1245,6 @@ __global__ __launch_bounds__(256, 2) void k_rhs_p2s(DevMesh m, Phys ph, double t
       acc[c][k] = 0.0;
       u[c][k] = U[(size_t)e * NPROP + c * NDOF + KH * h + k];
     }
-  ElemGeom g;
-  load_geom(m, e, g);
   __syncthreads();
 
   const int gb0 = 3 * h, gb1 = 3 - 3 * h;      // first point of this lane's slots 0-2 / 3-5
@@ -1275,36 +1273,42 @@ __global__ __launch_bounds__(256, 2) void k_rhs_p2s(DevMesh m, Phys ph, double t
       for (int c = 0; c < NCOMP; ++c)
 #pragma unroll
         for (int k = 0; k < KH; ++k) un[c][k] = U[(size_t)nb * NPROP + c * NDOF + KH * h + k];
-      double p[6][NCOMP];
 #pragma unroll
-      for (int s = 0; s < 6; ++s) {
-        const double* B = Tn + (s < 3 ? gb0 + s : gb1 + s - 3) * 12;
-        const double b0 = B[0], b1 = B[1], b2 = B[2], b3 = B[3], b4 = B[4];
+      for (int j = 0; j < 3; ++j) {
+        // slot j (this lane's point) and slot j + 3 (the partner's): partial sums over this
+        // lane's modes, the partner's goes across
+        const double* Ba = Tn + (gb0 + j) * 12;
+        const double* Bb = Tn + (gb1 + j) * 12;
+        const double a0 = Ba[0], a1 = Ba[1], a2 = Ba[2], a3 = Ba[3], a4 = Ba[4];
+        const double b0 = Bb[0], b1 = Bb[1], b2 = Bb[2], b3 = Bb[3], b4 = Bb[4];
 #pragma unroll
-        for (int c = 0; c < NCOMP; ++c)
-          p[s][c] = un[c][0] * b0 + un[c][1] * b1 + un[c][2] * b2 + un[c][3] * b3 + un[c][4] * b4;
+        for (int c = 0; c < NCOMP; ++c) {
+          const double pa = un[c][0] * a0 + un[c][1] * a1 + un[c][2] * a2 + un[c][3] * a3 + un[c][4] * a4;
+          const double pb = un[c][0] * b0 + un[c][1] * b1 + un[c][2] * b2 + un[c][3] * b3 + un[c][4] * b4;
+          sn[j][c] = pa + pair_swap(pb);
+        }
       }
-#pragma unroll
-      for (int j = 0; j < 3; ++j)
-#pragma unroll
-        for (int c = 0; c < NCOMP; ++c) sn[j][c] = p[j][c] + pair_swap(p[j + 3][c]);
     }
     {
-      double p[6][NCOMP];
 #pragma unroll
-      for (int s = 0; s < 6; ++s) {
-        const double* B = To + (s < 3 ? gb0 + s : gb1 + s - 3) * 12;
-        const double b0 = B[0], b1 = B[1], b2 = B[2], b3 = B[3], b4 = B[4];
+      for (int j = 0; j < 3; ++j) {
+        // slot j (this lane's point) and slot j + 3 (the partner's): partial sums over this
+        // lane's modes, the partner's goes across
+        const double* Ba = To + (gb0 + j) * 12;
+        const double* Bb = To + (gb1 + j) * 12;
+        const double a0 = Ba[0], a1 = Ba[1], a2 = Ba[2], a3 = Ba[3], a4 = Ba[4];
+        const double b0 = Bb[0], b1 = Bb[1], b2 = Bb[2], b3 = Bb[3], b4 = Bb[4];
 #pragma unroll
-        for (int c = 0; c < NCOMP; ++c)
-          p[s][c] = u[c][0] * b0 + u[c][1] * b1 + u[c][2] * b2 + u[c][3] * b3 + u[c][4] * b4;
+        for (int c = 0; c < NCOMP; ++c) {
+          const double pa = u[c][0] * a0 + u[c][1] * a1 + u[c][2] * a2 + u[c][3] * a3 + u[c][4] * a4;
+          const double pb = u[c][0] * b0 + u[c][1] * b1 + u[c][2] * b2 + u[c][3] * b3 + u[c][4] * b4;
+          so[j][c] = pa + pair_swap(pb);
+        }
       }
-#pragma unroll
-      for (int j = 0; j < 3; ++j)
-#pragma unroll
-        for (int c = 0; c < NCOMP; ++c) so[j][c] = p[j][c] + pair_swap(p[j + 3][c]);
     }
     if (nb < 0) {
+      ElemGeom g;                             // (not kept across the face loop: 24 registers)
+      load_geom(m, e, g);
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         const double* q = S.fq[gb0 + j];
@@ -1315,7 +1319,7 @@ __global__ __launch_bounds__(256, 2) void k_rhs_p2s(DevMesh m, Phys ph, double t
     }
     // fluxes at this lane's three points (own frame, weighted: the own tet loses what leaves)
     const double wsel = (nb == -1) ? 0.0 : 1.0;
-    double F[6][NCOMP];
+    double F[3][NCOMP];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       Prim qo, qn;
@@ -1337,20 +1341,20 @@ __global__ __launch_bounds__(256, 2) void k_rhs_p2s(DevMesh m, Phys ph, double t
       for (int c = 0; c < NCOMP; ++c) F[j][c] = wt * fl[c];
     }
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-      for (int c = 0; c < NCOMP; ++c) F[j + 3][c] = pair_swap(F[j][c]);
-#pragma unroll
-    for (int s = 0; s < 6; ++s) {
-      const double* B = To + (s < 3 ? gb0 + s : gb1 + s - 3) * 12;
-      const double b0 = B[0], b1 = B[1], b2 = B[2], b3 = B[3], b4 = B[4];
+    for (int j = 0; j < 3; ++j) {
+      // this lane's point (slot j) and the partner's (slot j + 3, its flux comes across)
+      const double* Ba = To + (gb0 + j) * 12;
+      const double* Bb = To + (gb1 + j) * 12;
+      const double a0 = Ba[0], a1 = Ba[1], a2 = Ba[2], a3 = Ba[3], a4 = Ba[4];
+      const double b0 = Bb[0], b1 = Bb[1], b2 = Bb[2], b3 = Bb[3], b4 = Bb[4];
 #pragma unroll
       for (int c = 0; c < NCOMP; ++c) {
-        acc[c][0] = fma(F[s][c], b0, acc[c][0]);
-        acc[c][1] = fma(F[s][c], b1, acc[c][1]);
-        acc[c][2] = fma(F[s][c], b2, acc[c][2]);
-        acc[c][3] = fma(F[s][c], b3, acc[c][3]);
-        acc[c][4] = fma(F[s][c], b4, acc[c][4]);
+        const double fa = F[j][c], fb = pair_swap(F[j][c]);
+        acc[c][0] = fma(fa, a0, fma(fb, b0, acc[c][0]));
+        acc[c][1] = fma(fa, a1, fma(fb, b1, acc[c][1]));
+        acc[c][2] = fma(fa, a2, fma(fb, b2, acc[c][2]));
+        acc[c][3] = fma(fa, a3, fma(fb, b3, acc[c][3]));
+        acc[c][4] = fma(fa, a4, fma(fb, b4, acc[c][4]));
       }
     }
   }
@@ -1359,6 +1363,8 @@ __global__ __launch_bounds__(256, 2) void k_rhs_p2s(DevMesh m, Phys ph, double t
 
   // ---- volume (+ source) integral, two points per step: this lane's and its partner's ----
   {
+    ElemGeom g;
+    load_geom(m, e, g);
     double ji[3][3];
     inverse_jacobian(g, ji);
 #pragma unroll 1
@@ -2779,17 +2785,24 @@ __global__ __launch_bounds__(256) void k_halo_pack_upd(const double* __restrict_
 
 // WENO_P1, src/PDE/Limiter.cpp:29-153 (Jacobi: reads Uin, writes modes 1-3 of
 // Uout; all other planes are copied by the caller)
-template <int NDOF>
-__global__ __launch_bounds__(256) void k_weno(DevMesh m, double cweight,
-                                              const double* __restrict__ Uin,
-                                              double* __restrict__ Uout)
+template <int NDOF, int BS>
+__global__ __launch_bounds__(BS) void k_weno(DevMesh m, double cweight,
+                                             const double* __restrict__ Uin,
+                                             double* __restrict__ Uout)
 {
   // every row of Uout is written here (own row with modes 1-3 replaced; ghost rows
-  // copied), so the Jacobi sweep needs no separate copy of the state
-  const int e = xcd_tile(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
-  if (e >= m.ne) return;
+  // copied), so the Jacobi sweep needs no separate copy of the state.  The kernel is bound by
+  // the number of scattered lane addresses its memory instructions carry, so a neighbour's
+  // three gradient modes of a component (24 contiguous bytes) come as one 8-byte and one
+  // 16-byte load, and the rows leave through LDS as coalesced wave stores.
+  constexpr int NPROP = NCOMP * NDOF;
+  __shared__ __attribute__((aligned(16))) double stage[NDOF > 1 ? BS * NPROP : 2];
+  const int blk = xcd_tile(blockIdx.x, gridDim.x);
+  const int e0 = blk * BS + threadIdx.x;
+  const bool active = e0 < m.ne;
+  const int e = active ? e0 : m.ne - 1;
   double r[NCOMP][NDOF];
-  load_row<NCOMP * NDOF>(Uin, e, &r[0][0]);
+  load_row<NPROP>(Uin, e, &r[0][0]);
   if constexpr (NDOF > 1) {
     if (e < m.nie) {
       const int stride = m.stride;
@@ -2804,9 +2817,14 @@ __global__ __launch_bounds__(256) void k_weno(DevMesh m, double cweight,
 #pragma unroll
         for (int is = 1; is < 5; ++is) {
           const int n = nb[is - 1];
-#pragma unroll
-          for (int d = 0; d < 3; ++d)
-            g[is][d] = (n >= 0) ? Uin[fidx(c * NDOF + 1 + d, n, NCOMP * NDOF)] : 0.0;
+          g[is][0] = g[is][1] = g[is][2] = 0.0;
+          if (n >= 0) {
+            // modes 1, 2, 3 of component c: doubles c*NDOF + 1 .. + 3 of the row; the row is
+            // 16-byte aligned and c*NDOF is even, so the pair (2, 3) is a 16-byte load
+            const double* pn = Uin + (size_t)n * NPROP + c * NDOF + 1;
+            const double2 v = *reinterpret_cast<const double2*>(__builtin_assume_aligned(pn + 1, 16));
+            g[is][0] = pn[0]; g[is][1] = v.x; g[is][2] = v.y;
+          }
         }
 #pragma unroll
         for (int is = 0; is < 5; ++is) {
@@ -2825,8 +2843,25 @@ __global__ __launch_bounds__(256) void k_weno(DevMesh m, double cweight,
         }
       }
     }
+    {
+      double2* row = reinterpret_cast<double2*>(stage + (size_t)threadIdx.x * NPROP);
+#pragma unroll
+      for (int j = 0; j < NPROP / 2; ++j) row[j] = make_double2((&r[0][0])[2 * j], (&r[0][0])[2 * j + 1]);
+      __syncthreads();
+      const int r0 = blk * BS;
+      const int nrow = (m.ne - r0 < BS) ? m.ne - r0 : BS;
+      const double2* src = reinterpret_cast<const double2*>(stage);
+      double2* dst = reinterpret_cast<double2*>(Uout + (size_t)r0 * NPROP);
+      const int nvalid = nrow * (NPROP / 2);
+#pragma unroll 5
+      for (int j = 0; j < NPROP / 2; ++j) {
+        const int i = j * BS + threadIdx.x;
+        if (i < nvalid) dst[i] = src[i];
+      }
+    }
+  } else {
+    if (active) store_row<NPROP>(Uout, e, &r[0][0]);
   }
-  store_row<NCOMP * NDOF>(Uout, e, &r[0][0]);
 }
 
 // ------------------------------------------------------------- time step
@@ -4072,7 +4107,8 @@ void launch_weno(int ndof, const DevMesh& m, double cweight, const double* Uin, 
     QDG_DISPATCH_NDOF(ndof, (tr::k_weno<N><<<nblk(m.ne, 256), 256, 0, s>>>(m, cweight, Uin, Uout)));
     return;
   }
-  QDG_DISPATCH_NDOF(ndof, (k_weno<N><<<nblk(m.ne, 256), 256, 0, s>>>(m, cweight, Uin, Uout)));
+  if (ndof == 10) k_weno<10, 128><<<nblk(m.ne, 128), 128, 0, s>>>(m, cweight, Uin, Uout);
+  else k_weno<4, 256><<<nblk(m.ne, 256), 256, 0, s>>>(m, cweight, Uin, Uout);
 }
 
 void launch_copy_planes(const double* src, double* dst, int nprop, int n, int /*stride*/, hipStream_t s)

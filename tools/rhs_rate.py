@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Resident RHS/step timing of any order on the synthetic box (for DESIGN.md's
 per-order table; bench.py stays on the BASELINE workload).
-Usage (GPU box): python tools/rhs_rate.py <ndof> [nx] [limiter] [problem] [timed steps]"""
+Usage (GPU box): python tools/rhs_rate.py <ndof> [nx] [limiter] [problem] [timed steps] [dt]
+A prescribed dt (config 3: 1e-5 x h / h_fixture) replaces the CFL step."""
 import os
 import sys
 import time
@@ -20,7 +21,9 @@ chunk = dgmesh.build_chunk(ch["coord"], ch["inpoel"], None, ch["sidesets"])
 t1 = time.perf_counter()
 kw = dict(bc_extrapolate=[1, 2], bc_sym=[3, 4, 5, 6]) if problem in ("sod_shocktube",) else \
     dict(bc_dirichlet=[1, 2, 3, 4, 5, 6])
-ctx = capi.Context(ndof, flux="hllc", limiter=limiter, problem=problem, gamma=1.4, cfl=0.3,
+dt = float(sys.argv[6]) if len(sys.argv) > 6 else 0.0
+ctx = capi.Context(ndof, flux="hllc", limiter=limiter, problem=problem, gamma=1.4,
+                   cfl=0.0 if dt > 0.0 else 0.3, dt=dt,
                    alpha=0.1, beta=1.0, p0=10.0, **kw)
 mesh = dgmesh.upload(ctx, chunk)
 t2 = time.perf_counter()
