@@ -1250,12 +1250,18 @@ __global__ __launch_bounds__(256, 2) void k_rhs_p2s(DevMesh m, Phys ph, double t
   const int gb0 = 3 * h, gb1 = 3 - 3 * h;      // first point of this lane's slots 0-2 / 3-5
 
   // ---- faces ------------------------------------------------------------
+  // a face's connectivity is requested one face ahead: neighbour id -> neighbour row would be
+  // two dependent memory latencies per face otherwise
+  int nbN = m.nbr[e], infoN = m.finfo[e], fN = m.fid[e];
 #pragma unroll 1
   for (int lf = 0; lf < 4; ++lf) {
-    const int nb = m.nbr[(size_t)lf * stride + e];
+    const int nb = nbN, info = infoN, f = fN;
+    if (lf < 3) {
+      nbN = m.nbr[(size_t)(lf + 1) * stride + e];
+      infoN = m.finfo[(size_t)(lf + 1) * stride + e];
+      fN = m.fid[(size_t)(lf + 1) * stride + e];
+    }
     if (nb == -1 && !WITH_DT) continue;       // boundary face without a BC (dt still counts it)
-    const int info = m.finfo[(size_t)lf * stride + e];
-    const int f = m.fid[(size_t)lf * stride + e];
     double gq[4];
     load_row<4>(m.fgeo, f, gq);
     const bool own_left = (info >> 6) & 1;
