@@ -9,16 +9,19 @@ export TMPDIR=/tmp
 cd "${root:?}" || exit 1
 out=${2:-gpurun_out/cfg3_nx$nx}
 mkdir -p $out
-timeout -k 10 600 python3 tools/rhs_rate.py 10 $nx wenop1 vortical_flow > $out/rate.txt 2>&1
+# config 3 prescribes the time step (1e-5, scaled with the mesh size; the 1k-tet
+# fixture of the reference case has 10 cells per edge)
+dt=$(python3 -c "print(1e-5 * 10 / $nx)")
+timeout -k 10 600 python3 tools/rhs_rate.py 10 $nx wenop1 vortical_flow 10 $dt > $out/rate.txt 2>&1
 cat $out/rate.txt | tail -2
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 tools/rhs_rate.py 10 $nx wenop1 vortical_flow > $out/stats.log 2>&1
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 tools/rhs_rate.py 10 $nx wenop1 vortical_flow 10 $dt > $out/stats.log 2>&1
 cp $out/stats/*/*kernel_stats.csv $out/kernel_stats.csv 2>/dev/null
 cut -c1-150 $out/kernel_stats.csv | head -8
 [ "$3" = "pmc" ] || exit 0
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "GRBM_GUI_ACTIVE" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS" "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  timeout -k 10 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/pmc$i -- python3 tools/rhs_rate.py 10 $nx wenop1 vortical_flow 3 > $out/pmc$i.log 2>&1 || echo "pmc pass $i failed"
+  timeout -k 10 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/pmc$i -- python3 tools/rhs_rate.py 10 $nx wenop1 vortical_flow 3 $dt > $out/pmc$i.log 2>&1 || echo "pmc pass $i failed"
 done
 python3 - <<PY
 import csv, glob, collections, json
