@@ -63,7 +63,7 @@ def test_single_tet_all_faces_on_the_boundary(ndof):
              bc=dict(bc_extrapolate=[1], bc_sym=[2]))
 
 
-@pytest.mark.parametrize("ndof", [1, 4])
+@pytest.mark.parametrize("ndof", [1, 4, 10])
 def test_six_tets_no_bc_configured(ndof):
     """one Kuhn cube: interior faces only matter, every boundary face is left without a BC"""
     from quinoa_amd import meshgen
@@ -83,6 +83,17 @@ def test_ragged_last_tile_and_last_workgroup():
     assert ch["inpoel"].shape[0] == 258
     _run_rhs(ch["coord"], ch["inpoel"], ch["sidesets"], 4, limiter="superbeep1",
              bc=dict(bc_extrapolate=[1, 2], bc_sym=[3, 4, 5, 6]))
+
+
+def test_ragged_last_workgroup_of_the_p2_kernels():
+    """DG-P2: the lane-pair RHS kernel and the WENO sweep take 128 tets per workgroup; element
+    counts 128 + 4, 128 - 2 and 256 + 2 leave the last workgroup nearly empty / nearly full"""
+    from quinoa_amd import meshgen
+    for nx, ne in ((22, 132), (21, 126), (43, 258)):
+        ch = meshgen.kuhn_box(nx, 1, 1)
+        assert ch["inpoel"].shape[0] == ne
+        _run_rhs(ch["coord"], ch["inpoel"], ch["sidesets"], 10, limiter="wenop1",
+                 bc=dict(bc_extrapolate=[1, 2], bc_sym=[3, 4, 5, 6]))
 
 
 def test_malformed_meshes_are_rejected_on_the_host():
