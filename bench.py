@@ -20,6 +20,8 @@ The same run then times the NORTH-STAR POINT (BASELINE.json north_star: DG-P1 RH
 the roofline fraction of the RHS kernel at 10 M tets at N = 1 and a STRONG-scaling
 value for every N (`--no-north-star` skips it, `--strong-nx M` changes the box).
 BASELINE.md section 5: 5 warm-up + 50 timed steps (the defaults).
+At N = 1 it also times config 5's refine / re-upload loop once (`amr_point`) and config 3 at
+its own size, vortical flow DG-P2 + WENO on 7 986 000 tets (`config3_point`).
 
 Prints ONE JSON line on rank 0.
 """
@@ -214,6 +216,46 @@ def amr_point(local_rank, nx=32, steps=20):
                     "coordinates cross PCIe); transfer = qdg_state_transfer (child <- parent, device)"}
 
 
+def config3_point(local_rank, nx=110, steps=5):
+    """BASELINE config 3 at its own size on one GPU: vortical_flow DG-P2 + wenop1 (alpha 0.1,
+    beta 1, p0 10, gamma 5/3, Dirichlet on all six sides), nx^3 x 6 tets, prescribed dt
+    (1e-5 scaled with the mesh size), `steps` timed SSP-RK3 steps after two warm-up steps."""
+    import numpy as np
+    from quinoa_amd import capi, dgmesh, meshgen
+    ch = meshgen.kuhn_box(nx, nx, nx)
+    chunk = dgmesh.build_chunk(ch["coord"], ch["inpoel"], None, ch["sidesets"])
+    ctx = capi.Context(10, flux="hllc", limiter="wenop1", problem="vortical_flow", gamma=5.0 / 3.0,
+                       cweight=1.0, alpha=0.1, beta=1.0, p0=10.0, dt=1e-5 * 10.0 / nx,
+                       bc_dirichlet=[1, 2, 3, 4, 5, 6], device=local_rank)
+    mesh = dgmesh.upload(ctx, chunk)
+    mesh.state_initialize(0.0)
+    for _ in range(2):
+        mesh.step(0.0, want_dt=False)
+    ctx.synchronize()
+    mesh.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        mesh.step(0.0, want_dt=False)
+    ctx.synchronize()
+    el = (time.perf_counter() - t0) / steps
+    nl, ms = mesh.profile_read()
+    alg = mesh.rhs_algorithmic_bytes()
+    U = mesh.state_download()
+    ok = bool(np.isfinite(U).all())
+    ne = chunk.nielem
+    mesh.close(); ctx.close()
+    ach = alg / (ms / nl * 1e-3) / 1e9
+    return {"workload": "CompFlow vortical_flow DG-P2 + wenop1, Kuhn-tet box %d^3 hexes = %d tets, prescribed dt, "
+                        "%d timed steps" % (nx, ne, steps),
+            "tets_total": ne, "steps": steps, "value": ne * 3 / el / 1e6, "unit": "M element-updates/s",
+            "ms_per_step": el * 1e3, "finite": ok,
+            "roofline": {"bound": "hbm", "kernel": "qdg::k_rhs_p2s (lane pair per tet; RK update fused in; 837 B/tet "
+                                                   "counted per launch)",
+                         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                         "avg_launch_ms": ms / nl, "launches": nl, "algorithmic_bytes_per_launch": alg,
+                         "traffic": None}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -224,6 +266,9 @@ def main():
     ap.add_argument("--no-north-star", action="store_true",
                     help="skip the fixed-size 10.1 M-tet north-star / strong-scaling point")
     ap.add_argument("--no-amr", action="store_true", help="skip the config-5 refinement point (N = 1 only)")
+    ap.add_argument("--no-config3", action="store_true",
+                    help="skip the config-3 point (DG-P2 + WENO at 7.99 M tets, N = 1 only)")
+    ap.add_argument("--config3-nx", type=int, default=110)
     ap.add_argument("--strong-nx", type=int, default=119,
                     help="hexes per direction of the fixed-size box of the strong-scaling point "
                          "(119 -> 10 110 954 tets, 220 -> 63 888 000 tets = config 4)")
@@ -332,6 +377,8 @@ def main():
             }
         if world == 1 and not args.no_amr and not args.self_halo:
             out["amr_point"] = amr_point(local_rank)
+        if world == 1 and not args.no_config3 and not args.self_halo:
+            out["config3_point"] = config3_point(local_rank, args.config3_nx)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
