@@ -23,6 +23,7 @@
 #include <memory>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/qdg.h"
@@ -252,6 +253,23 @@ struct qdg_refined {
   std::vector<double> x, y, z;
 };
 
+// run fn(begin, end, thread) over [0, n) on up to 16 host threads (contiguous ranges in order)
+template <class F> static unsigned par_ranges(size_t n, F&& fn, size_t serial_below = 32768)
+{
+  unsigned nt = std::thread::hardware_concurrency();
+  nt = std::max(1u, std::min(nt, 16u));
+  if (n < serial_below) nt = 1;
+  const size_t chunk = (n + nt - 1) / nt;
+  if (nt == 1) { fn((size_t)0, n, 0u); return 1; }
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < nt; ++t) {
+    const size_t b0 = std::min(n, t * chunk), e0 = std::min(n, b0 + chunk);
+    th.emplace_back([&fn, b0, e0, t] { fn(b0, e0, t); });
+  }
+  for (auto& t : th) t.join();
+  return nt;
+}
+
 extern "C" int qdg_refine_uniform(size_t nelem, size_t nnode, const size_t* inpoel, const double* x,
                                   const double* y, const double* z, size_t ntri, const size_t* tri,
                                   qdg_refined** out)
@@ -261,69 +279,138 @@ extern "C" int qdg_refine_uniform(size_t nelem, size_t nnode, const size_t* inpo
   *out = nullptr;
   if (nnode > (size_t)UINT32_MAX) return fail("qdg_refine_uniform: too many nodes");
   std::unique_ptr<qdg_refined> r(new qdg_refined);
-  r->x.assign(x, x + nnode); r->y.assign(y, y + nnode); r->z.assign(z, z + nnode);
-  // edge (min,max) -> midpoint node: sort-based (no hashing: deterministic and cache friendly)
+  // edge (min,max) -> midpoint node: sort-based (no hashing: deterministic and cache friendly),
+  // on all host cores: the edge slots are dealt into buckets by the edge's smaller node (a range
+  // of node ids per bucket, so the buckets are in key order), each bucket sorted by one thread
   static const int EDG[6][2] = { {0, 1}, {0, 2}, {0, 3}, {1, 2}, {1, 3}, {2, 3} };   // AB AC AD BC BD CD
   struct E { uint64_t key; size_t slot; };
-  std::vector<E> ed(6 * nelem);
-  for (size_t e = 0; e < nelem; ++e)
-    for (int k = 0; k < 6; ++k) {
-      const size_t a = inpoel[4 * e + EDG[k][0]], b = inpoel[4 * e + EDG[k][1]];
-      if (a >= nnode || b >= nnode) return fail("qdg_refine_uniform: inpoel entry out of range");
-      if (a == b) return fail("qdg_refine_uniform: degenerate tet");
-      ed[6 * e + k] = { ((uint64_t)std::min(a, b) << 32) | (uint64_t)std::max(a, b), 6 * e + k };
-    }
-  std::vector<E> sorted = ed;
-  std::sort(sorted.begin(), sorted.end(), [](const E& p, const E& q) { return p.key < q.key || (p.key == q.key && p.slot < q.slot); });
-  // the first slot (in tet order) that meets an edge numbers its midpoint
-  std::vector<size_t> mid(6 * nelem), first(6 * nelem);
-  for (size_t i = 0; i < sorted.size();) {
-    size_t j = i;
-    while (j < sorted.size() && sorted[j].key == sorted[i].key) { first[sorted[j].slot] = sorted[i].slot; ++j; }
-    i = j;
+  const size_t ns = 6 * nelem;
+  std::vector<E> ed(ns);
+  const size_t NB = std::max<size_t>(1, std::min<size_t>(256, nnode / 64 + 1));
+  auto bucket_of = [&](uint64_t key) { return (size_t)((key >> 32) * NB / std::max<size_t>(nnode, 1)); };
+  std::vector<std::vector<size_t>> cnt;          // [thread][bucket]
+  int bad = 0;
+  std::vector<std::pair<size_t, size_t>> range;  // slot range of every thread
+  {
+    unsigned nt_used = 0;
+    std::vector<std::vector<size_t>> c(16, std::vector<size_t>(NB, 0));
+    std::vector<std::pair<size_t, size_t>> rg(16, { 0, 0 });
+    std::vector<int> badt(16, 0);
+    nt_used = par_ranges(nelem, [&](size_t e0, size_t e1, unsigned t) {
+      rg[t] = { 6 * e0, 6 * e1 };
+      for (size_t e = e0; e < e1; ++e)
+        for (int k = 0; k < 6; ++k) {
+          const size_t a = inpoel[4 * e + EDG[k][0]], b = inpoel[4 * e + EDG[k][1]];
+          if (a >= nnode || b >= nnode) { badt[t] = 1; ed[6 * e + k] = { 0, 6 * e + k }; continue; }
+          if (a == b) { badt[t] = 2; ed[6 * e + k] = { 0, 6 * e + k }; continue; }
+          const uint64_t key = ((uint64_t)std::min(a, b) << 32) | (uint64_t)std::max(a, b);
+          ed[6 * e + k] = { key, 6 * e + k };
+          ++c[t][bucket_of(key)];
+        }
+    });
+    for (unsigned t = 0; t < nt_used; ++t) bad = std::max(bad, badt[t]);
+    c.resize(nt_used); rg.resize(nt_used);
+    cnt.swap(c); range.swap(rg);
   }
-  size_t nn = nnode;
-  for (size_t s = 0; s < 6 * nelem; ++s)
-    if (first[s] == s) {
-      const size_t a = (size_t)(ed[s].key >> 32), b = (size_t)(ed[s].key & 0xffffffffu);
-      mid[s] = nn++;
-      r->x.push_back(0.5 * (x[a] + x[b])); r->y.push_back(0.5 * (y[a] + y[b])); r->z.push_back(0.5 * (z[a] + z[b]));
+  if (bad == 1) return fail("qdg_refine_uniform: inpoel entry out of range");
+  if (bad == 2) return fail("qdg_refine_uniform: degenerate tet");
+  // bucket offsets; within a bucket the threads' pieces follow each other in slot order
+  std::vector<size_t> boff(NB + 1, 0);
+  for (size_t b = 0; b < NB; ++b) { size_t n = 0; for (auto& c : cnt) n += c[b]; boff[b + 1] = boff[b] + n; }
+  std::vector<E> sorted(ns);
+  {
+    std::vector<std::vector<size_t>> pos(cnt.size(), std::vector<size_t>(NB));
+    for (size_t b = 0; b < NB; ++b) { size_t o = boff[b]; for (size_t t = 0; t < cnt.size(); ++t) { pos[t][b] = o; o += cnt[t][b]; } }
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < cnt.size(); ++t)
+      th.emplace_back([&, t] {
+        for (size_t i = range[t].first; i < range[t].second; ++i) sorted[pos[t][bucket_of(ed[i].key)]++] = ed[i];
+      });
+    for (auto& t : th) t.join();
+  }
+  std::vector<size_t> mid(ns), first(ns);
+  par_ranges(NB, [&](size_t b0, size_t b1, unsigned) {
+    for (size_t b = b0; b < b1; ++b) {
+      std::sort(sorted.begin() + boff[b], sorted.begin() + boff[b + 1],
+                [](const E& p, const E& q) { return p.key < q.key || (p.key == q.key && p.slot < q.slot); });
+      // the first slot (in tet order) that meets an edge numbers its midpoint
+      for (size_t i = boff[b]; i < boff[b + 1];) {
+        size_t j = i;
+        while (j < boff[b + 1] && sorted[j].key == sorted[i].key) { first[sorted[j].slot] = sorted[i].slot; ++j; }
+        i = j;
+      }
     }
-  for (size_t s = 0; s < 6 * nelem; ++s) mid[s] = mid[first[s]];
+  }, 2);
+  // midpoints numbered in slot order: count per range, offsets, assign
+  size_t nn = nnode;
+  {
+    std::vector<size_t> nnew(17, 0);
+    std::vector<std::pair<size_t, size_t>> rg(16, { 0, 0 });
+    const unsigned nt_used = par_ranges(ns, [&](size_t s0, size_t s1, unsigned t) {
+      rg[t] = { s0, s1 };
+      size_t n = 0;
+      for (size_t q = s0; q < s1; ++q) n += first[q] == q;
+      nnew[t + 1] = n;
+    });
+    for (unsigned t = 0; t < nt_used; ++t) nnew[t + 1] += nnew[t];
+    nn = nnode + nnew[nt_used];
+    r->x.resize(nn); r->y.resize(nn); r->z.resize(nn);
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt_used; ++t)
+      th.emplace_back([&, t] {
+        size_t id = nnode + nnew[t];
+        for (size_t q = rg[t].first; q < rg[t].second; ++q)
+          if (first[q] == q) {
+            const size_t a = (size_t)(ed[q].key >> 32), b = (size_t)(ed[q].key & 0xffffffffu);
+            mid[q] = id;
+            r->x[id] = 0.5 * (x[a] + x[b]); r->y[id] = 0.5 * (y[a] + y[b]); r->z[id] = 0.5 * (z[a] + z[b]);
+            ++id;
+          }
+      });
+    for (auto& t : th) t.join();
+    std::memcpy(r->x.data(), x, nnode * sizeof(double));
+    std::memcpy(r->y.data(), y, nnode * sizeof(double));
+    std::memcpy(r->z.data(), z, nnode * sizeof(double));
+  }
   r->nnode = nn;
   r->inpoel.resize(32 * nelem); r->parent.resize(8 * nelem);
-  for (size_t e = 0; e < nelem; ++e) {
-    const size_t A = inpoel[4 * e], B = inpoel[4 * e + 1], C = inpoel[4 * e + 2], D = inpoel[4 * e + 3];
-    const size_t AB = mid[6 * e], AC = mid[6 * e + 1], AD = mid[6 * e + 2], BC = mid[6 * e + 3],
-                 BD = mid[6 * e + 4], CD = mid[6 * e + 5];
-    const size_t ch[8][4] = { { A, AB, AC, AD }, { B, BC, AB, BD }, { C, AC, BC, CD }, { D, AD, CD, BD },
-                              { BC, CD, AC, BD }, { AB, BD, AC, AD }, { AB, BC, AC, BD }, { AC, BD, CD, AD } };
-    for (int k = 0; k < 8; ++k) {
-      for (int i = 0; i < 4; ++i) r->inpoel[4 * (8 * e + k) + i] = ch[k][i];
-      r->parent[8 * e + k] = e;
+  par_ranges(nelem, [&](size_t e0, size_t e1, unsigned) {
+    for (size_t e = e0; e < e1; ++e) {
+      const size_t A = inpoel[4 * e], B = inpoel[4 * e + 1], C = inpoel[4 * e + 2], D = inpoel[4 * e + 3];
+      size_t M[6];
+      for (int k = 0; k < 6; ++k) M[k] = mid[first[6 * e + k]];
+      const size_t AB = M[0], AC = M[1], AD = M[2], BC = M[3], BD = M[4], CD = M[5];
+      const size_t ch[8][4] = { { A, AB, AC, AD }, { B, BC, AB, BD }, { C, AC, BC, CD }, { D, AD, CD, BD },
+                                { BC, CD, AC, BD }, { AB, BD, AC, AD }, { AB, BC, AC, BD }, { AC, BD, CD, AD } };
+      for (int k = 0; k < 8; ++k) {
+        for (int i = 0; i < 4; ++i) r->inpoel[4 * (8 * e + k) + i] = ch[k][i];
+        r->parent[8 * e + k] = e;
+      }
     }
-  }
-  // boundary triangles: midpoints looked up among the tets' edges
+  });
+  // boundary triangles: midpoints looked up among the tets' edges (the buckets are in key order,
+  // so `sorted` is sorted as a whole)
   if (ntri) {
-    std::vector<std::pair<uint64_t, size_t>> keymid(sorted.size());
-    for (size_t i = 0; i < sorted.size(); ++i) keymid[i] = { sorted[i].key, mid[sorted[i].slot] };
     auto find = [&](size_t a, size_t b, size_t& m) {
       const uint64_t key = ((uint64_t)std::min(a, b) << 32) | (uint64_t)std::max(a, b);
-      auto it = std::lower_bound(keymid.begin(), keymid.end(), std::make_pair(key, (size_t)0));
-      if (it == keymid.end() || it->first != key) return false;
-      m = it->second;
+      auto it = std::lower_bound(sorted.begin(), sorted.end(), key, [](const E& p, uint64_t k) { return p.key < k; });
+      if (it == sorted.end() || it->key != key) return false;
+      m = mid[first[it->slot]];
       return true;
     };
     r->tri.resize(12 * ntri);
-    for (size_t t = 0; t < ntri; ++t) {
-      const size_t a = tri[3 * t], b = tri[3 * t + 1], c = tri[3 * t + 2];
-      size_t ab, bc, ac;
-      if (a >= nnode || b >= nnode || c >= nnode || !find(a, b, ab) || !find(b, c, bc) || !find(a, c, ac))
-        return fail("qdg_refine_uniform: a side-set triangle is not a face of the mesh");
-      const size_t ct[4][3] = { { a, ab, ac }, { b, bc, ab }, { c, ac, bc }, { ab, bc, ac } };
-      for (int k = 0; k < 4; ++k)
-        for (int i = 0; i < 3; ++i) r->tri[3 * (4 * t + k) + i] = ct[k][i];
-    }
+    std::vector<int> badt(16, 0);
+    par_ranges(ntri, [&](size_t t0, size_t t1, unsigned th) {
+      for (size_t t = t0; t < t1; ++t) {
+        const size_t a = tri[3 * t], b = tri[3 * t + 1], c = tri[3 * t + 2];
+        size_t ab = 0, bc = 0, ac = 0;
+        if (a >= nnode || b >= nnode || c >= nnode || !find(a, b, ab) || !find(b, c, bc) || !find(a, c, ac)) { badt[th] = 1; continue; }
+        const size_t ct[4][3] = { { a, ab, ac }, { b, bc, ab }, { c, ac, bc }, { ab, bc, ac } };
+        for (int k = 0; k < 4; ++k)
+          for (int i = 0; i < 3; ++i) r->tri[3 * (4 * t + k) + i] = ct[k][i];
+      }
+    });
+    for (int v : badt) if (v) return fail("qdg_refine_uniform: a side-set triangle is not a face of the mesh");
   }
   *out = r.release();
   return 0;
