@@ -184,7 +184,7 @@ int main(int argc, char** argv)
   const size_t n2 = nd / 2;
   r[k++] = { "axpy_flat",  timeit([&] { k_axpy_flat<<<(unsigned)((n2 + BS - 1) / BS), BS>>>(n2, (const double2*)A, (const double2*)B, (double2*)C, 0.75, 0.25); }, rep), 3 * rowMB };
   printf("{\"rows\": %d, \"row_bytes\": %d", n, NP * 8);
-  for (int i = 0; i < k; ++i) printf(", \"%s\": {\"ms\": %.4f, \"TBps\": %.3f}", r[i].name, r[i].ms, r[i].MB / r[i].ms / 1e6);
+  for (int i = 0; i < k; ++i) printf(", \"%s\": {\"ms\": %.4f, \"TBps\": %.3f}", r[i].name, r[i].ms, r[i].MB / r[i].ms / 1e3);
   printf("}\n");
   return 0;
 }
