@@ -396,6 +396,19 @@ int qdg_mesh_from_connectivity(qdg_ctx* ctx, size_t nelem, size_t nnode, const s
                                const double* x, const double* y, const double* z, size_t ntri,
                                const size_t* tri, const int32_t* tri_set, qdg_mesh** out);
 
+/* The same for one rank's chunk WITH its ghost layer (what the DG chare holds after its ghost
+ * set-up, src/Inciter/DG.cpp:468-712; after a re-mesh on a decomposition, DG.cpp:1536-1612):
+ * tets [0, nielem) are owned, [nielem, nelem) are the face-neighbour ghosts in the order of the
+ * halo plan (qdg_chunk_build), nodes and coordinates cover both.  Everything is derived on the
+ * device: boundary faces of the OWNED tets from the side-set triangles, interior and
+ * chare-boundary faces (a face between two ghosts is none of this chunk's), geometry, the
+ * device order (tets with a ghost neighbour last, for the overlap of halo and interior work),
+ * numbering, face tasks.  Follow with qdg_halo_setup as after qdg_mesh_upload.
+ * nielem == nelem: identical to qdg_mesh_from_connectivity. */
+int qdg_mesh_from_chunk(qdg_ctx* ctx, size_t nielem, size_t nelem, size_t nnode, const size_t* inpoel,
+                        const double* x, const double* y, const double* z, size_t ntri,
+                        const size_t* tri, const int32_t* tri_set, qdg_mesh** out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -481,9 +481,10 @@ class Mesh:
             self.h = C.c_void_p()
 
 
-def mesh_from_connectivity(ctx, inpoel, coord, sidesets):
-    """qdg_mesh_from_connectivity: a Mesh handle for a chunk without ghosts straight from
-    (inpoel, coord, {side set id: triangles}); FaceData and geometry are made on the GPU."""
+def mesh_from_connectivity(ctx, inpoel, coord, sidesets, nielem=None):
+    """qdg_mesh_from_connectivity / qdg_mesh_from_chunk: a Mesh handle straight from
+    (inpoel, coord, {side set id: triangles}); FaceData, geometry and the device layout are
+    made on the GPU.  nielem < number of tets: the trailing tets are the chunk's ghost layer."""
     inpoel = np.ascontiguousarray(inpoel, dtype=np.uint64).reshape(-1)
     coord = np.ascontiguousarray(coord, dtype=np.float64)
     ids = sorted(sidesets)
@@ -495,14 +496,15 @@ def mesh_from_connectivity(ctx, inpoel, coord, sidesets):
     tset = np.ascontiguousarray(tset if tset.size else np.zeros(1, np.int32))
     x, y, z = (np.ascontiguousarray(coord[:, d]) for d in range(3))
     m = Mesh.__new__(Mesh)
-    m.ctx, m.nunk, m.nielem, m.nprop = ctx, inpoel.size // 4, inpoel.size // 4, ctx.nprop
+    m.ctx, m.nunk, m.nprop = ctx, inpoel.size // 4, ctx.nprop
+    m.nielem = m.nunk if nielem is None else int(nielem)
     m.h = C.c_void_p()
     ntri = sum(len(sidesets[s_]) for s_ in ids)
-    _chk(lib().qdg_mesh_from_connectivity(ctx.h, C.c_size_t(m.nunk), C.c_size_t(coord.shape[0]),
-                                          inpoel.ctypes.data_as(c_szp), x.ctypes.data_as(c_f64p),
-                                          y.ctypes.data_as(c_f64p), z.ctypes.data_as(c_f64p),
-                                          C.c_size_t(ntri), tri.ctypes.data_as(c_szp),
-                                          tset.ctypes.data_as(c_i32p), C.byref(m.h)))
+    _chk(lib().qdg_mesh_from_chunk(ctx.h, C.c_size_t(m.nielem), C.c_size_t(m.nunk), C.c_size_t(coord.shape[0]),
+                                   inpoel.ctypes.data_as(c_szp), x.ctypes.data_as(c_f64p),
+                                   y.ctypes.data_as(c_f64p), z.ctypes.data_as(c_f64p),
+                                   C.c_size_t(ntri), tri.ctypes.data_as(c_szp),
+                                   tset.ctypes.data_as(c_i32p), C.byref(m.h)))
     return m
 
 

@@ -96,12 +96,14 @@ __global__ void k_match(const uint32_t* __restrict__ sa, const uint32_t* __restr
   esuel[perm[i]] = v;
 }
 
-__global__ void k_flag(const int* __restrict__ esuel, size_t n4, int* __restrict__ flag)
+// interior and chare-boundary faces: listed by their left (lower-id) tet, which must be an owned
+// one -- a face between two ghosts is none of this chunk's business
+__global__ void k_flag(const int* __restrict__ esuel, size_t n4, size_t nie, int* __restrict__ flag)
 {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4) return;
   const int j = esuel[i];
-  flag[i] = (j != -1 && (int)(i >> 2) < j) ? 1 : 0;
+  flag[i] = (j != -1 && (i >> 2) < nie && (int)(i >> 2) < j) ? 1 : 0;
 }
 
 __global__ void k_interior_faces(const uint64_t* __restrict__ inpoel, const int* __restrict__ esuel,
@@ -200,6 +202,7 @@ struct DevFD {
   Buf<double> x, y, z, geoFace, geoElem;
   Buf<int> esuel, esuf;
   size_t nelem = 0, nnode = 0, nbfac = 0, nipfac = 0;
+  size_t nie = 0;     // owned tets [0, nie); ghosts [nie, nelem) (nie == nelem: a chunk without ghosts)
 };
 
 // connectivity and coordinates of a chunk to the device (validated on the host first)
@@ -214,7 +217,7 @@ static int dev_upload_mesh(qdg_ctx* ctx, size_t nelem, size_t nnode, const size_
     if (inpoel[i] >= nnode) return fail("qdg_dev_facedata: inpoel entry out of range");
   DHIP(hipSetDevice(ctx_device(ctx)));
   hipStream_t s = ctx_stream(ctx);
-  fd.nelem = nelem; fd.nnode = nnode;
+  fd.nelem = nelem; fd.nnode = nnode; fd.nie = nelem;
   static_assert(sizeof(size_t) == sizeof(uint64_t), "size_t is 64 bits in this ABI");
   DHIP(fd.inpoel.alloc(4 * nelem));
   DHIP(fd.x.alloc(nnode)); DHIP(fd.y.alloc(nnode)); DHIP(fd.z.alloc(nnode));
@@ -233,12 +236,13 @@ __constant__ int c_bfa[4][3] = { { 0, 2, 1 }, { 0, 1, 3 }, { 0, 3, 2 }, { 1, 2, 
 
 __global__ void k_bnd_match(const uint64_t* __restrict__ inpoel, size_t n4, const uint32_t* __restrict__ ta,
                             const uint32_t* __restrict__ tb, const uint32_t* __restrict__ tc,
-                            const uint32_t* __restrict__ trank, size_t ntri, uint64_t* __restrict__ okey,
-                            int* __restrict__ count)
+                            const uint32_t* __restrict__ trank, size_t ntri, size_t nie,
+                            uint64_t* __restrict__ okey, int* __restrict__ count)
 {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4) return;
   const size_t e = i >> 2; const int f = (int)(i & 3);
+  if (e >= nie) { okey[i] = ~0ull; return; }          // a ghost's boundary faces belong to its owner
   uint32_t k0 = (uint32_t)inpoel[4 * e + c_bfa[f][0]], k1 = (uint32_t)inpoel[4 * e + c_bfa[f][1]],
            k2 = (uint32_t)inpoel[4 * e + c_bfa[f][2]], t;
   if (k0 > k1) { t = k0; k0 = k1; k1 = t; }
@@ -310,7 +314,7 @@ static int dev_bnd_faces(qdg_ctx* ctx, DevFD& fd, size_t ntri, const size_t* tri
   Buf<int> cnt;
   DHIP(okey.alloc(n4)); DHIP(skey.alloc(n4)); DHIP(cnt.alloc(1));
   DHIP(hipMemsetAsync(cnt.p, 0, sizeof(int), s));
-  k_bnd_match<<<nblk(n4), 256, 0, s>>>(fd.inpoel.p, n4, ta.p, tb.p, tc.p, tr.p, ntri, okey.p, cnt.p);
+  k_bnd_match<<<nblk(n4), 256, 0, s>>>(fd.inpoel.p, n4, ta.p, tb.p, tc.p, tr.p, ntri, fd.nie, okey.p, cnt.p);
   size_t bytes = 0;
   DHIP(rocprim::radix_sort_keys(nullptr, bytes, okey.p, skey.p, n4, 0, 64, s));
   Buf<char> tmp;
@@ -374,7 +378,7 @@ static int dev_facedata_from(qdg_ctx* ctx, DevFD& fd)
   k_match<<<nblk(n4), 256, 0, s>>>(sa.p, sb.p, sc.p, sperm, n4, fd.esuel.p, d_err.p);
 
   // ---- interior faces in the reference's order ---------------------------------------
-  k_flag<<<nblk(n4), 256, 0, s>>>(fd.esuel.p, n4, d_flag.p);
+  k_flag<<<nblk(n4), 256, 0, s>>>(fd.esuel.p, n4, fd.nie, d_flag.p);
   size_t scan_bytes = 0;
   DHIP(rocprim::exclusive_scan(nullptr, scan_bytes, d_flag.p, d_pos.p, 0, n4, rocprim::plus<int>(), s));
   Buf<char> tmp2;
@@ -487,11 +491,16 @@ __device__ __forceinline__ uint64_t spread21d(uint64_t v)
   return v;
 }
 
-__global__ void k_morton(const double* __restrict__ geoElem, size_t ne, double lx, double ly, double lz,
-                         double ext, uint64_t* __restrict__ key, uint32_t* __restrict__ val)
+// owned tets: Morton key of the centroid, bit 63 set for a tet with a ghost neighbour (those go
+// last, still in curve order: launches over the leading rows never touch the halo)
+__global__ void k_morton(const double* __restrict__ geoElem, size_t ne, const int* __restrict__ esuel, double lx,
+                         double ly, double lz, double ext, uint64_t* __restrict__ key, uint32_t* __restrict__ val,
+                         int* __restrict__ ninner)
 {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= ne) return;
+  bool halo = false;
+  for (int lf = 0; lf < 4; ++lf) halo = halo || esuel[4 * e + lf] >= (int)ne;
   const double lo[3] = { lx, ly, lz };
   uint64_t k = 0;
 #pragma unroll
@@ -500,7 +509,14 @@ __global__ void k_morton(const double* __restrict__ geoElem, size_t ne, double l
     const uint64_t q = (uint64_t)fmin(2097151.0, fmax(0.0, t * 2097152.0));
     k |= spread21d(q) << d;
   }
-  key[e] = k; val[e] = (uint32_t)e;
+  key[e] = k | (halo ? 0x8000000000000000ull : 0ull); val[e] = (uint32_t)e;
+  if (!halo) atomicAdd(ninner, 1);
+}
+
+__global__ void k_ghost_ids(uint32_t* __restrict__ val, size_t nie, size_t ne)
+{
+  const size_t e = nie + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < ne) val[e] = (uint32_t)e;
 }
 
 __global__ void k_invert(const uint32_t* __restrict__ d2h, size_t n, int* __restrict__ h2d, int* __restrict__ d2h_i)
@@ -555,7 +571,7 @@ __global__ void k_first_touch(size_t ne, const int* __restrict__ d2h, const uint
   const size_t d = i >> 2; const int k = (int)(i & 3);
   const size_t h = (size_t)d2h[d];
   atomicMin(first_node + inpoel[4 * h + k], (uint32_t)i);
-  atomicMin(first_face + rface[4 * h + k], (uint32_t)i);
+  if (rface[4 * h + k] >= 0) atomicMin(first_face + rface[4 * h + k], (uint32_t)i);   // (-1: a ghost's other faces)
 }
 
 // rank in the order of first touch -> new id; untouched entries (key 0xffffffff) get none
@@ -583,6 +599,7 @@ __global__ void k_layout_rows(size_t ne, int stride, const int* __restrict__ d2h
   o_vol[d] = geoElem[4 * h];
   for (int lf = 0; lf < 4; ++lf) {
     const int f = rface[4 * h + lf];
+    if (f < 0) { *err = 6; continue; }               // free face that no side set lists
     o_fid[(size_t)lf * stride + d] = fmap[f];
     const int nb = esuel[4 * h + lf];
     int info = ((size_t)esuf[2 * f] == h) ? (1 << 6) : 0;
@@ -725,7 +742,8 @@ static int dev_build_layout(qdg_ctx* ctx, DevFD& fd, const std::vector<int>& bcf
   DHIP(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
   Lap lap(s);
-  const size_t ne = fd.nelem, nnode = fd.nnode, nf = fd.nipfac, n4 = 4 * ne;
+  // nie owned tets, ghosts behind them (nie == ne: no ghosts)
+  const size_t ne = fd.nelem, nie = fd.nie, nnode = fd.nnode, nf = fd.nipfac, n4 = 4 * ne;
   const size_t stride = (ne + 63) / 64 * 64;
   if (ne > (size_t)(INT32_MAX - 64) / 4 || nf > (size_t)INT32_MAX) return fail("qdg_mesh_from_connectivity: chunk too large");
   std::unique_ptr<qdg_mesh> m(new qdg_mesh);
@@ -733,12 +751,12 @@ static int dev_build_layout(qdg_ctx* ctx, DevFD& fd, const std::vector<int>& bcf
   m->ndof = ctx->cfg.ndof;
   const int ncomp = ctx->cfg.pde == QDG_PDE_TRANSPORT ? 1 : NCOMP;
   m->nprop = ncomp * m->ndof;
-  m->nie = ne; m->ne = ne; m->stride = stride;
+  m->nie = nie; m->ne = ne; m->stride = stride;
 
   Buf<int> d_err, d_count;
-  DHIP(d_err.alloc(1)); DHIP(d_count.alloc(2));
+  DHIP(d_err.alloc(1)); DHIP(d_count.alloc(3));
   DHIP(hipMemsetAsync(d_err.p, 0, sizeof(int), s));
-  DHIP(hipMemsetAsync(d_count.p, 0, 2 * sizeof(int), s));
+  DHIP(hipMemsetAsync(d_count.p, 0, 3 * sizeof(int), s));
 
   // ---- device order: Morton curve of the centroids (ties by tet id) --------------------
   Buf<unsigned long long> d_mm;
@@ -747,7 +765,7 @@ static int dev_build_layout(qdg_ctx* ctx, DevFD& fd, const std::vector<int>& bcf
     const unsigned long long init[6] = { ~0ull, ~0ull, ~0ull, 0ull, 0ull, 0ull };
     DHIP(hipMemcpyAsync(d_mm.p, init, sizeof init, hipMemcpyHostToDevice, s));
   }
-  k_bbox<<<nblk(ne), 256, 0, s>>>(fd.geoElem.p, ne, d_mm.p);
+  k_bbox<<<nblk(nie), 256, 0, s>>>(fd.geoElem.p, nie, d_mm.p);
   unsigned long long hmm[6];
   DHIP(hipMemcpyAsync(hmm, d_mm.p, sizeof hmm, hipMemcpyDeviceToHost, s));
   DHIP(hipStreamSynchronize(s));
@@ -757,13 +775,15 @@ static int dev_build_layout(qdg_ctx* ctx, DevFD& fd, const std::vector<int>& bcf
   Buf<uint64_t> mkey, mkey2;
   Buf<uint32_t> mval, mval2;
   DHIP(mkey.alloc(ne)); DHIP(mkey2.alloc(ne)); DHIP(mval.alloc(ne)); DHIP(mval2.alloc(ne));
-  k_morton<<<nblk(ne), 256, 0, s>>>(fd.geoElem.p, ne, lo[0], lo[1], lo[2], ext, mkey.p, mval.p);
+  k_morton<<<nblk(nie), 256, 0, s>>>(fd.geoElem.p, nie, fd.esuel.p, lo[0], lo[1], lo[2], ext, mkey.p, mval.p,
+                                    d_count.p + 2);
   {
     size_t bytes = 0;
-    DHIP(rocprim::radix_sort_pairs(nullptr, bytes, mkey.p, mkey2.p, mval.p, mval2.p, ne, 0, 63, s));
+    DHIP(rocprim::radix_sort_pairs(nullptr, bytes, mkey.p, mkey2.p, mval.p, mval2.p, nie, 0, 64, s));
     Buf<char> tmp;
     DHIP(tmp.alloc(bytes));
-    DHIP(rocprim::radix_sort_pairs(tmp.p, bytes, mkey.p, mkey2.p, mval.p, mval2.p, ne, 0, 63, s));
+    DHIP(rocprim::radix_sort_pairs(tmp.p, bytes, mkey.p, mkey2.p, mval.p, mval2.p, nie, 0, 64, s));
+    if (ne > nie) k_ghost_ids<<<nblk(ne - nie), 256, 0, s>>>(mval2.p, nie, ne);   // ghosts keep their rows
     DHIP(hipStreamSynchronize(s));
   }
   lap("Morton order");
@@ -804,10 +824,11 @@ static int dev_build_layout(qdg_ctx* ctx, DevFD& fd, const std::vector<int>& bcf
   DHIP(nnew.alloc(nnode)); DHIP(fmap.alloc(nf));
   k_rank<<<nblk(nnode), 256, 0, s>>>(nnode, fkn2.p, vn2.p, nnew.p, d_count.p);
   k_rank<<<nblk(nf), 256, 0, s>>>(nf, fkf2.p, vf2.p, fmap.p, d_count.p + 1);
-  int hcount[2];
+  int hcount[3];
   DHIP(hipMemcpyAsync(hcount, d_count.p, sizeof hcount, hipMemcpyDeviceToHost, s));
   DHIP(hipStreamSynchronize(s));
   const int ncount = hcount[0], nfd = hcount[1];
+  const size_t ninner = (size_t)hcount[2];
 
   lap("numbering");
   // ---- rows, nodes, faces in device numbering ---------------------------------------------
@@ -825,7 +846,7 @@ static int dev_build_layout(qdg_ctx* ctx, DevFD& fd, const std::vector<int>& bcf
     DHIP(hipMemcpyAsync(m->vol.p, ones.data(), stride * 8, hipMemcpyHostToDevice, s));
     DHIP(hipStreamSynchronize(s));
   }
-  k_layout_rows<<<nblk(ne), 256, 0, s>>>(ne, (int)stride, m->d2h.p, h2d.p, fd.inpoel.p, fd.esuel.p, fd.esuf.p,
+  k_layout_rows<<<nblk(nie), 256, 0, s>>>(nie, (int)stride, m->d2h.p, h2d.p, fd.inpoel.p, fd.esuel.p, fd.esuf.p,
                                          rface.p, nnew.p, fmap.p, d_bc.p, fd.geoElem.p, m->inpoel.p, m->nbr.p,
                                          m->finfo.p, m->fid.p, m->vol.p, d_err.p);
   const size_t nn1 = (size_t)std::max(ncount, 1), nf1 = (size_t)std::max(nfd, 1);
@@ -838,18 +859,20 @@ static int dev_build_layout(qdg_ctx* ctx, DevFD& fd, const std::vector<int>& bcf
   lap("rows / nodes / faces");
   // ---- face tasks of the tile kernels -------------------------------------------------------
   const int tile_rows = TILE;
-  const int ntile = (int)((ne + TILE - 1) / TILE);
+  const int ntile = (int)((nie + TILE - 1) / TILE);
+  const size_t nt4 = 4 * nie;
   Buf<uint32_t> tk, tk2, tv, tv2;
-  DHIP(tk.alloc(n4)); DHIP(tk2.alloc(n4)); DHIP(tv.alloc(n4)); DHIP(tv2.alloc(n4));
+  DHIP(tk.alloc(nt4)); DHIP(tk2.alloc(nt4)); DHIP(tv.alloc(nt4)); DHIP(tv2.alloc(nt4));
   Buf<int> d_nt;
   DHIP(d_nt.alloc(1));
   DHIP(hipMemsetAsync(d_nt.p, 0, sizeof(int), s));
-  k_task_keys<<<nblk(n4), 256, 0, s>>>(ne, (int)stride, tile_rows, m->nbr.p, m->finfo.p, m->fid.p, tk.p, tv.p, d_nt.p);
-  if (int rc = sort32(tk.p, tk2.p, tv.p, tv2.p, n4, s)) return rc;
+  k_task_keys<<<nblk(nt4), 256, 0, s>>>(nie, (int)stride, tile_rows, m->nbr.p, m->finfo.p, m->fid.p, tk.p, tv.p, d_nt.p);
+  if (int rc = sort32(tk.p, tk2.p, tv.p, tv2.p, nt4, s)) return rc;
   int ntask = 0, herr = 0;
   DHIP(hipMemcpyAsync(&ntask, d_nt.p, sizeof(int), hipMemcpyDeviceToHost, s));
   DHIP(hipMemcpyAsync(&herr, d_err.p, sizeof(int), hipMemcpyDeviceToHost, s));
   DHIP(hipStreamSynchronize(s));
+  if (herr == 6) return fail("qdg_mesh_from_connectivity: a free face of an owned tet is in no side set");
   if (herr) return fail("qdg_mesh_from_connectivity: neighbour does not share the face nodes (bad connectivity)");
   const int task_stride = (!std::getenv("QDG_TASK_COMPACT") && !ctx->cfg.pref) ? 4 * TILE_BS : 0;
   const size_t nslot = task_stride ? (size_t)ntile * task_stride : (size_t)ntask;
@@ -860,12 +883,12 @@ static int dev_build_layout(qdg_ctx* ctx, DevFD& fd, const std::vector<int>& bcf
   k_fill_i32<<<nblk(nslot), 256, 0, s>>>(m->task_nb.p, nslot, 0);
   k_fill_i32<<<nblk(nslot), 256, 0, s>>>(m->task_f.p, nslot, 0);
   k_tile_off<<<nblk((size_t)ntask + 1), 256, 0, s>>>((size_t)ntask, ntile, tk2.p, m->tile_off.p);
-  k_task_fill<<<nblk((size_t)ntask), 256, 0, s>>>((size_t)ntask, ne, (int)stride, tile_rows, task_stride, m->nbr.p,
+  k_task_fill<<<nblk((size_t)ntask), 256, 0, s>>>((size_t)ntask, nie, (int)stride, tile_rows, task_stride, m->nbr.p,
                                                   m->finfo.p, m->fid.p, tv2.p, m->tile_off.p, m->task_a.p,
                                                   m->task_nb.p, m->task_f.p);
   {
     std::vector<int> rows(ntile + 1);
-    for (int t = 0; t <= ntile; ++t) rows[t] = (int)std::min((size_t)t * TILE, ne);
+    for (int t = 0; t <= ntile; ++t) rows[t] = (int)std::min((size_t)t * TILE, nie);
     DHIP(hipMemcpyAsync(m->tile_row.p, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice, s));
     DHIP(hipStreamSynchronize(s));
   }
@@ -875,15 +898,17 @@ static int dev_build_layout(qdg_ctx* ctx, DevFD& fd, const std::vector<int>& bcf
   if (int rc = mesh_alloc_state(m.get(), ntile)) return rc;
   m->nnode_used = (size_t)ncount;
   DevMesh& dm = m->dm;
-  dm.nie = (int)ne; dm.ne = (int)ne; dm.stride = (int)stride; dm.nnode = ncount; dm.nfac = nfd;
+  dm.nie = (int)nie; dm.ne = (int)ne; dm.stride = (int)stride; dm.nnode = ncount; dm.nfac = nfd;
   dm.inpoel = m->inpoel.p; dm.nbr = m->nbr.p; dm.finfo = m->finfo.p; dm.fid = m->fid.p;
   dm.x = m->x.p; dm.y = m->y.p; dm.z = m->z.p;
   dm.farea = m->farea.p; dm.fnx = m->fnx.p; dm.fny = m->fny.p; dm.fnz = m->fnz.p;
   dm.vol = m->vol.p; dm.d2h = m->d2h.p; dm.fgeo = m->fgeo.p; dm.xyz4 = m->xyz4.p;
-  dm.ntile = ntile; dm.ntile_inner = ntile; dm.tile_row = m->tile_row.p; dm.task_stride = task_stride;
+  int ntile_inner = 0;
+  while (ntile_inner < ntile && std::min((size_t)(ntile_inner + 1) * TILE, nie) <= ninner) ++ntile_inner;
+  dm.ntile = ntile; dm.ntile_inner = ntile_inner; dm.tile_row = m->tile_row.p; dm.task_stride = task_stride;
   dm.tile_rows = TILE;
   dm.tile_off = m->tile_off.p; dm.task_a = m->task_a.p; dm.task_nb = m->task_nb.p; dm.task_f = m->task_f.p;
-  dm.blk0 = 0; dm.ninner = (int)ne; dm.ncomp = ncomp; dm.ndofel = nullptr;
+  dm.blk0 = 0; dm.ninner = (int)ninner; dm.ncomp = ncomp; dm.ndofel = nullptr;
   if (ctx->cfg.pref) {
     HIPCHK(m->ndofel.alloc(ne)); HIPCHK(m->ndofel2.alloc(ne));
     k_fill_i32<<<nblk(ne), 256, 0, s>>>(m->ndofel.p, ne, 4);
@@ -900,10 +925,20 @@ extern "C" int qdg_mesh_from_connectivity(qdg_ctx* ctx, size_t nelem, size_t nno
                                           size_t ntri, const size_t* tri, const int32_t* tri_set,
                                           qdg_mesh** out)
 {
+  return qdg_mesh_from_chunk(ctx, nelem, nelem, nnode, inpoel, x, y, z, ntri, tri, tri_set, out);
+}
+
+extern "C" int qdg_mesh_from_chunk(qdg_ctx* ctx, size_t nielem, size_t nelem, size_t nnode, const size_t* inpoel,
+                                   const double* x, const double* y, const double* z,
+                                   size_t ntri, const size_t* tri, const int32_t* tri_set, qdg_mesh** out)
+{
   QDG_TRY
   if (!ctx || !out || !inpoel || !x || !y || !z) return fail("qdg_mesh_from_connectivity: null argument");
   if (ntri > 0 && (!tri || !tri_set)) return fail("qdg_mesh_from_connectivity: null side-set arrays");
+  if (nielem == 0 || nielem > nelem) return fail("qdg_mesh_from_chunk: need 0 < nielem <= nelem");
   *out = nullptr;
+  if (nielem < nelem && std::getenv("QDG_HOST_LAYOUT"))
+    return fail("qdg_mesh_from_chunk: QDG_HOST_LAYOUT=1 covers chunks without ghosts only");
   if (!std::getenv("QDG_HOST_LAYOUT")) {
     // Everything on the GPU: boundary faces regenerated from the side-set triangles, FaceData,
     // geometry and the device layout.  Only the connectivity, the coordinates and the side-set
@@ -911,6 +946,7 @@ extern "C" int qdg_mesh_from_connectivity(qdg_ctx* ctx, size_t nelem, size_t nno
     Lap lap(ctx->stream);
     DevFD fd;
     if (int rc = dev_upload_mesh(ctx, nelem, nnode, inpoel, x, y, z, fd)) return rc;
+    fd.nie = nielem;
     lap("validation + upload of inpoel, coord");
     std::vector<int32_t> fset;
     if (int rc = dev_bnd_faces(ctx, fd, ntri, tri, tri_set, fset)) return rc;

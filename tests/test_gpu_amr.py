@@ -129,7 +129,10 @@ def test_config5_partitioned_chunks_refine_on_the_gpu():
         new_chunks, new_meshes = [], []
         for ch, m in zip(chunks, meshes):
             ch2, par = amr.refine_chunk(ch)
-            m2 = upload(ch2)
+            # the re-mesh step of a rank: its refined chunk WITH the new ghost layer rebuilt on
+            # the device from connectivity alone (qdg_mesh_from_chunk)
+            m2 = capi.mesh_from_connectivity(ctx, ch2["inpoel"], ch2["coord"], ch2["sidesets"],
+                                             nielem=ch2["nielem"])
             amr.state_transfer(m, m2, par)
             m.close()
             new_chunks.append(ch2); new_meshes.append(m2)

@@ -18,7 +18,7 @@ def _centroid_order(c):
     return np.lexsort((q[:, 2], q[:, 1], q[:, 0]))
 
 
-def _run(case, fix, nparts, method):
+def _run(case, fix, nparts, method, device_build=False):
     from quinoa_amd import capi, dg, dgmesh, partition
     ss = {int(s): fix["ss_tri_%d" % s] for s in fix["ss_ids"]}
     coord, inpoel = fix["coord"], fix["inpoel"]
@@ -30,8 +30,14 @@ def _run(case, fix, nparts, method):
     meshes, chunks = [], []
     for r in range(nparts):
         ch = partition.build_chunk(coord, inpoel, ss, part, nparts, r)
-        ck = dgmesh.build_chunk(ch["coord"], ch["inpoel"], ch["nielem"], ch["sidesets"])
-        meshes.append(dgmesh.upload(ctx, ck)); chunks.append(ch)
+        if device_build:
+            # FaceData, geometry, ghost-aware device order and face tasks all made on the GPU
+            meshes.append(capi.mesh_from_connectivity(ctx, ch["inpoel"], ch["coord"], ch["sidesets"],
+                                                      nielem=ch["nielem"]))
+        else:
+            ck = dgmesh.build_chunk(ch["coord"], ch["inpoel"], ch["nielem"], ch["sidesets"])
+            meshes.append(dgmesh.upload(ctx, ck))
+        chunks.append(ch)
     try:
         drv = dg.LocalChunks(ctx, meshes, chunks) if nparts > 1 else None
         for m in meshes:
@@ -71,3 +77,20 @@ def test_partitioned_gpu_run_matches_reference_pe4_goldens(name, method, cases):
         assert (np.abs(F4[:, oa] - gold) / scale).max() <= TOL          # == the reference's 4-PE / 40-chare run
         if name == "sedov_pdg":
             assert np.array_equal(F4[6, oa], gold[6])                   # the per-element ndof field
+
+
+@pytest.mark.parametrize("name,method", [("sedov_dgp1", "rcb"), ("sedov_pdg", "morton")])
+def test_chunks_with_ghosts_built_on_the_device(name, method, cases):
+    """qdg_mesh_from_chunk: a rank's chunk WITH its ghost layer from connectivity alone (boundary
+    faces of owned tets, chare-boundary faces, halo-adjacent tets last) -- same run as with the
+    host-built FaceData + qdg_mesh_upload, and within the bar of the reference's 4-PE baseline"""
+    case, fix = cases[name], load_fixture(name)
+    Fh, names, th = _run(case, fix, 4, method)
+    Fd, names_d, td = _run(case, fix, 4, method, device_build=True)
+    assert names == names_d and abs(th - td) <= 1e-13 * th
+    scale = np.maximum(1.0, np.abs(Fh).max(axis=1))[:, None]
+    assert (np.abs(Fd - Fh) / scale).max() <= 1e-12
+    om = O.OracleMesh(fix["coord"], fix["inpoel"], {})
+    cent = om.geoElem.reshape(-1, 4)[:, 1:]
+    oa, ob = _centroid_order(cent), _centroid_order(fix["chunk_centroid"])
+    assert (np.abs(Fd[:, oa] - fix["chunk_vals_last"][:, ob]) / scale).max() <= TOL
