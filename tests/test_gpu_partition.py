@@ -94,3 +94,32 @@ def test_chunks_with_ghosts_built_on_the_device(name, method, cases):
     cent = om.geoElem.reshape(-1, 4)[:, 1:]
     oa, ob = _centroid_order(cent), _centroid_order(fix["chunk_centroid"])
     assert (np.abs(Fd[:, oa] - fix["chunk_vals_last"][:, ob]) / scale).max() <= TOL
+
+
+@pytest.mark.parametrize("ndof", [4, 10])
+def test_device_built_block_chunk_rhs_equals_host_built(ndof):
+    """one chunk of the bench's block decomposition (its analytic ghost layer, 3 neighbours):
+    stateless RHS, dt and limiter of the device-built mesh against the host-built one on the
+    same random state (ghost rows included)"""
+    from quinoa_amd import capi, dgmesh, meshgen
+    ch = meshgen.kuhn_box_chunk(12, 10, 8, lengths=(1.0, 1.0, 1.0), parts=(2, 2, 2), rank=5)
+    lim = "superbeep1" if ndof == 4 else "wenop1"
+    ctx = capi.Context(ndof, flux="hllc", limiter=lim, problem="sod_shocktube", gamma=1.4, cfl=0.3,
+                       bc_extrapolate=[1, 2], bc_sym=[3, 4, 5, 6])
+    mh = dgmesh.upload(ctx, dgmesh.build_chunk(ch["coord"], ch["inpoel"], ch["nielem"], ch["sidesets"]))
+    md = capi.mesh_from_connectivity(ctx, ch["inpoel"], ch["coord"], ch["sidesets"], nielem=ch["nielem"])
+    try:
+        ne = ch["inpoel"].shape[0]
+        rng = np.random.default_rng(11)
+        U = np.zeros((ne, 5 * ndof))
+        U[:, 0] = 1.0 + 0.1 * rng.random(ne)
+        U[:, 4 * ndof] = 2.5 + 0.1 * rng.random(ne)
+        for c in range(5):
+            U[:, c * ndof + 1:(c + 1) * ndof] = 1e-3 * rng.normal(size=(ne, ndof - 1))
+        U = U.reshape(-1)
+        Rh, Rd = mh.rhs(0.0, U), md.rhs(0.0, U)
+        assert np.abs(Rh - Rd).max() <= 1e-13 * max(1.0, np.abs(Rh).max())
+        assert abs(mh.dt(U) - md.dt(U)) <= 1e-14 * mh.dt(U)
+        assert np.abs(mh.limit(U) - md.limit(U)).max() <= 1e-14
+    finally:
+        mh.close(); md.close(); ctx.close()
