@@ -595,6 +595,13 @@ extern "C" int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t 
   dm.tile_rows = fixed_tiles ? TILE : 0;
   dm.tile_off = m->tile_off.p; dm.task_a = m->task_a.p;
   dm.task_nb = m->task_nb.p; dm.task_f = m->task_f.p;
+  dm.tgeo = nullptr;
+  if (task_stride > 0 && ctx->cfg.ndof == 4 && !std::getenv("QDG_NO_TGEO")) {
+    // face records in task order (DG-P1 tile kernel, version 2)
+    HIPCHK(m->tgeo.alloc(4 * h_task_a.size()));
+    launch_task_geo(h_task_a.size(), m->task_a.p, m->task_f.p, m->fgeo.p, m->tgeo.p, s);
+    dm.tgeo = m->tgeo.p;
+  }
   dm.blk0 = 0; dm.ninner = (int)ninner; dm.ncomp = ncomp;
   dm.ndofel = nullptr;
   if (ctx->cfg.pref) {

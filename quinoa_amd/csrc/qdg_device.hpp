@@ -72,6 +72,8 @@ struct DevMesh {
   const int* task_a;   // packed: e_local(8) lf(2) own_left(1) code(6) kind(2) bc(2) partner_local(8)
   const int* task_nb;  // neighbour device row (kind EXT), else 0
   const int* task_f;   // device face id
+  const double* tgeo;  // [task slot][4] the face's {area, nx, ny, nz} in TASK order (padded lists only,
+                       // else null): one coalesced 32-byte record per lane instead of a gather by face id
   // range launches (halo overlap): first workgroup-tile of this launch.  Device
   // rows [0, ninner) are tets without a ghost neighbour, [ninner, nie) the tets
   // next to the halo, so a launch over the leading tiles never reads a ghost row.

@@ -35,6 +35,9 @@ namespace qdg {
 // defined in qdg_api.cpp
 int ctx_device(const qdg_ctx* ctx);
 hipStream_t ctx_stream(const qdg_ctx* ctx);
+// defined in qdg_kernels.hip
+void launch_task_geo(size_t nslot, const int* task_a, const int* task_f, const double* fgeo, double* tgeo,
+                     hipStream_t s);
 }  // namespace qdg
 
 using namespace qdg;
@@ -908,6 +911,12 @@ static int dev_build_layout(qdg_ctx* ctx, DevFD& fd, const std::vector<int>& bcf
   dm.ntile = ntile; dm.ntile_inner = ntile_inner; dm.tile_row = m->tile_row.p; dm.task_stride = task_stride;
   dm.tile_rows = TILE;
   dm.tile_off = m->tile_off.p; dm.task_a = m->task_a.p; dm.task_nb = m->task_nb.p; dm.task_f = m->task_f.p;
+  dm.tgeo = nullptr;
+  if (task_stride > 0 && ctx->cfg.ndof == 4 && !std::getenv("QDG_NO_TGEO")) {
+    HIPCHK(m->tgeo.alloc(4 * nslot));
+    launch_task_geo(nslot, m->task_a.p, m->task_f.p, m->fgeo.p, m->tgeo.p, s);
+    dm.tgeo = m->tgeo.p;
+  }
   dm.blk0 = 0; dm.ninner = (int)ninner; dm.ncomp = ncomp; dm.ndofel = nullptr;
   if (ctx->cfg.pref) {
     HIPCHK(m->ndofel.alloc(ne)); HIPCHK(m->ndofel2.alloc(ne));

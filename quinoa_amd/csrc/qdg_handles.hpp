@@ -69,6 +69,7 @@ struct qdg_mesh {
   qdg::DevBuf<int> inpoel, nbr, finfo, fid, d2h;
   qdg::DevBuf<double> x, y, z, farea, fnx, fny, fnz, vol, fgeo, xyz4;
   qdg::DevBuf<int> tile_row, tile_off, task_a, task_nb, task_f;
+  qdg::DevBuf<double> tgeo;
   // fields (SoA planes [nprop][stride])
   qdg::DevBuf<double> U, Un, R, W;     // W: scratch state (stateless ops, WENO ping-pong)
   qdg::DevBuf<double> aos;             // [ne*nprop] staging in the caller's layout

@@ -2168,7 +2168,8 @@ __global__ __launch_bounds__(TILE_BS, QDG_TILE_WAVES) void k_rhs_p1v(DevMesh m, 
     for (int q = 0; q < MAXT; ++q) {
       const size_t it = base + tid + TILE_BS * q;
       ta[q] = m.task_a[it];
-      tf[q] = m.task_f[it];
+      // with face records in task order (tgeo) the slot itself addresses the record
+      tf[q] = m.tgeo ? (int)it : m.task_f[it];
       tn[q] = m.task_nb[it];
     }
   } else {
@@ -2210,8 +2211,9 @@ __global__ __launch_bounds__(TILE_BS, QDG_TILE_WAVES) void k_rhs_p1v(DevMesh m, 
     if (WITH_DT) sdelt[tid] = 0.0;
   }
   double gnx[4], rnx[NCOMP][NDOF];
+  const double* __restrict__ geo = (m.task_stride > 0 && m.tgeo) ? m.tgeo : m.fgeo;
   if (ta[0] >= 0) {
-    load_row<4>(m.fgeo, tf[0], gnx);
+    load_row<4>(geo, tf[0], gnx);
     if (((ta[0] >> 17) & 3) == TASK_EXT) load_row<NPROP>(U, tn[0], &rnx[0][0]);
   }
   __syncthreads();
@@ -2253,7 +2255,7 @@ __global__ __launch_bounds__(TILE_BS, QDG_TILE_WAVES) void k_rhs_p1v(DevMesh m, 
       const int fq = (q == 0) ? tf[1] : (q == 1) ? tf[2] : tf[3];
       const int nq = (q == 0) ? tn[1] : (q == 1) ? tn[2] : tn[3];
       if (an >= 0) {
-        load_row<4>(m.fgeo, fq, gnx);
+        load_row<4>(geo, fq, gnx);
 #ifndef QDG_KO_EXT
         if (((an >> 17) & 3) == TASK_EXT) load_row<NPROP>(U, nq, &rnx[0][0]);
 #endif
@@ -3362,6 +3364,19 @@ __global__ __launch_bounds__(256) void k_pdg_zero(DevMesh m, const int* __restri
     for (int k = 1; k < 4; ++k) U[((size_t)e * m.ncomp + c) * 4 + k] = 0.0;
 }
 
+// face records in task order: tgeo[slot] = fgeo[task_f[slot]] for the used slots of the padded lists
+__global__ __launch_bounds__(256) void k_task_geo(size_t nslot, const int* __restrict__ task_a,
+                                                  const int* __restrict__ task_f, const double* __restrict__ fgeo,
+                                                  double* __restrict__ tgeo)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nslot) return;
+  double g[4] = { 0.0, 0.0, 0.0, 0.0 };
+  if (task_a[i] >= 0) load_row<4>(fgeo, task_f[i], g);
+  double2* o = reinterpret_cast<double2*>(tgeo + 4 * i);
+  o[0] = make_double2(g[0], g[1]); o[1] = make_double2(g[2], g[3]);
+}
+
 __global__ void k_fill_int(int* __restrict__ p, int n, int v)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -3944,6 +3959,13 @@ static bool p2_split()
 {
   static const bool one = std::getenv("QDG_P2_ONE_LANE") != nullptr;
   return !one;
+}
+
+void launch_task_geo(size_t nslot, const int* task_a, const int* task_f, const double* fgeo, double* tgeo,
+                     hipStream_t s)
+{
+  if (nslot == 0) return;
+  k_task_geo<<<(unsigned)((nslot + 255) / 256), 256, 0, s>>>(nslot, task_a, task_f, fgeo, tgeo);
 }
 
 void launch_rhs(int ndof, const DevMesh& m, const Phys& ph, double t, const double* U, double* R,

@@ -9,6 +9,8 @@ namespace qdg {
 hipError_t upload_tables(const Tables<1>& t1, const Tables<4>& t4, const Tables<10>& t10,
                          const QuadTet* qinit, const QuadTet* qdiag);
 
+void launch_task_geo(size_t nslot, const int* task_a, const int* task_f, const double* fgeo, double* tgeo,
+                     hipStream_t s);
 void launch_rhs(int ndof, const DevMesh& m, const Phys& ph, double t, const double* U, double* R,
                 hipStream_t s);
 void launch_rhs_dt(int ndof, const DevMesh& m, const Phys& ph, double t, const double* U, double* R,
