@@ -11,7 +11,7 @@ out=gpurun_out/${tag}_nx$nx
 mkdir -p $out
 timeout -k 10 900 python3 bench.py --nx $nx --no-north-star --no-amr --no-config3 > $out/bench.json 2> $out/bench.err
 tail -1 $out/bench.json | cut -c1-200
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --nx $nx --steps 10 --warmup 2 --no-cpu-baseline --no-north-star --no-amr --no-config3 > $out/stats.log 2>&1
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --nx $nx --no-cpu-baseline --no-north-star --no-amr --no-config3 > $out/stats.log 2>&1
 cp $out/stats/*/*kernel_stats.csv $out/kernel_stats.csv
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "GRBM_GUI_ACTIVE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum"; do
