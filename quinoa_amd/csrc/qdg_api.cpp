@@ -517,8 +517,7 @@ extern "C" int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t 
             if (!own_left) continue;            // listed by the face's left tet
             kind = TASK_INT; pl = nb - (int)e0;
           } else { kind = TASK_EXT; nbid = nb; }
-          const int a = (int)(d - e0) | (lf << 8) | (own_left << 10) | (code << 11) | (kind << 17) |
-                        (bc << 19) | (pl << 21);
+          const int a = TASK_PACK(d - e0, lf, own_left, code, kind, bc, pl);
           tt.push_back({ (kind << 2) | lf, a, nbid, h_fid[lf * stride + d] });
         }
       // same kind / local face next to each other: fewer divergent branches per wave
@@ -547,7 +546,7 @@ extern "C" int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t 
     lap("face tasks per tile");
     if (stats) {
       size_t cnt[3] = { 0, 0, 0 };
-      for (int a : h_task_a) if (a >= 0) ++cnt[(a >> 17) & 3];
+      for (int a : h_task_a) if (a >= 0) ++cnt[TASK_KIND(a)];
       std::fprintf(stderr, "qdg upload: %zu tets, %d tiles, tasks per tet: interior-in-tile %.3f, "
                    "to other tiles/ghosts %.3f, boundary %.3f; tasks per tile %.1f, rows per tile %.1f\n", nie, ntile,
                    (double)cnt[TASK_INT] / nie, (double)cnt[TASK_EXT] / nie, (double)cnt[TASK_BND] / nie,

@@ -92,7 +92,20 @@ struct DevMesh {
 #endif
 constexpr int TILE = QDG_TILE;
 constexpr int TILE_BS = QDG_TILE_BS;   // workgroup size of the tile kernel
-static_assert(TILE <= TILE_BS && TILE <= 256, "one lane per tet; local ids are 8 bits");
+static_assert(TILE <= TILE_BS && TILE <= 512, "one lane per tet; local ids are 8 or 9 bits");
+// packed task word: e_local(TLB) lf(2) own_left(1) code(6) kind(2) bc(2) partner_local(TLB); TLB = 8
+// bits for tiles of up to 256 rows, 9 beyond (31 bits: the sign stays free for "unused slot")
+constexpr int TLB = TILE > 256 ? 9 : 8;
+#define TASK_PACK(el, lf, own_left, code, kind, bc, pl)                                                   \
+  ((int)(el) | ((lf) << qdg::TLB) | ((own_left) << (qdg::TLB + 2)) | ((code) << (qdg::TLB + 3)) |          \
+   ((kind) << (qdg::TLB + 9)) | ((bc) << (qdg::TLB + 11)) | ((pl) << (qdg::TLB + 13)))
+#define TASK_EL(a) ((a) & ((1 << qdg::TLB) - 1))
+#define TASK_LF(a) (((a) >> qdg::TLB) & 3)
+#define TASK_OWNLEFT(a) (((a) >> (qdg::TLB + 2)) & 1)
+#define TASK_CODE(a) (((a) >> (qdg::TLB + 3)) & 63)
+#define TASK_KIND(a) (((a) >> (qdg::TLB + 9)) & 3)
+#define TASK_BC(a) (((a) >> (qdg::TLB + 11)) & 3)
+#define TASK_PL(a) (((a) >> (qdg::TLB + 13)) & ((1 << qdg::TLB) - 1))
 //   // tets per tile: 2 x (rows + accumulators + dt sums) fit the CU's 160 KiB LDS
 enum { TASK_INT = 0, TASK_EXT = 1, TASK_BND = 2 };
 

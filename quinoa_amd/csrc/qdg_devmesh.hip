@@ -663,7 +663,7 @@ __device__ __forceinline__ bool task_of(size_t d, int lf, int stride, int tile_r
     if (!own_left) return false;
     kind = TASK_INT; pl = nb - (int)e0;
   } else { kind = TASK_EXT; nbid = nb; }
-  a = (int)(d - e0) | (lf << 8) | (own_left << 10) | (code << 11) | (kind << 17) | (bc << 19) | (pl << 21);
+  a = TASK_PACK(d - e0, lf, own_left, code, kind, bc, pl);
   f = fid[(size_t)lf * stride + d];
   key = (uint32_t)(tile << 4) | (uint32_t)((kind << 2) | lf);
   return true;

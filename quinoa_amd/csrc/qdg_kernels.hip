@@ -1826,7 +1826,7 @@ __global__ __launch_bounds__(TILE_BS, QDG_TILE_WAVES) void k_rhs_p1t(DevMesh m, 
   int ndnx = 4;                      // PDG: ndofel of the external neighbour
   if (ta[0] >= 0) {
     load_row<4>(m.fgeo, tf[0], gnx);
-    if (((ta[0] >> 17) & 3) == TASK_EXT) {
+    if (TASK_KIND(ta[0]) == TASK_EXT) {
       load_row<NPROP>(U, tn[0], &rnx[0][0]);
       if constexpr (PDG) ndnx = m.ndofel[tn[0]];
     }
@@ -1840,9 +1840,9 @@ __global__ __launch_bounds__(TILE_BS, QDG_TILE_WAVES) void k_rhs_p1t(DevMesh m, 
   for (int q = 0; q < MAXT; ++q) {
     const int a = (q == 0) ? ta[0] : (q == 1) ? ta[1] : (q == 2) ? ta[2] : ta[3];
     if (a < 0) break;
-    const int el = a & 255, lf = (a >> 8) & 3, code = (a >> 11) & 63, kind = (a >> 17) & 3,
-              bc = (a >> 19) & 3, pl = (a >> 21) & 255;
-    const bool own_left = (a >> 10) & 1;
+    const int el = TASK_EL(a), lf = TASK_LF(a), code = TASK_CODE(a), kind = TASK_KIND(a),
+              bc = TASK_BC(a), pl = TASK_PL(a);
+    const bool own_left = TASK_OWNLEFT(a);
     const double area = gnx[0];
     const double fn[3] = { gnx[1], gnx[2], gnx[3] };
     double rex[NCOMP][NDOF];
@@ -1863,7 +1863,7 @@ __global__ __launch_bounds__(TILE_BS, QDG_TILE_WAVES) void k_rhs_p1t(DevMesh m, 
       const int nq = (q == 0) ? tn[1] : (q == 1) ? tn[2] : tn[3];
       if (an >= 0) {
         load_row<4>(m.fgeo, fq, gnx);
-        if (((an >> 17) & 3) == TASK_EXT) {
+        if (TASK_KIND(an) == TASK_EXT) {
           load_row<NPROP>(U, nq, &rnx[0][0]);
           if constexpr (PDG) ndnx = m.ndofel[nq];
         }
@@ -2214,7 +2214,7 @@ __global__ __launch_bounds__(TILE_BS, QDG_TILE_WAVES) void k_rhs_p1v(DevMesh m, 
   const double* __restrict__ geo = (m.task_stride > 0 && m.tgeo) ? m.tgeo : m.fgeo;
   if (ta[0] >= 0) {
     load_row<4>(geo, tf[0], gnx);
-    if (((ta[0] >> 17) & 3) == TASK_EXT) load_row<NPROP>(U, tn[0], &rnx[0][0]);
+    if (TASK_KIND(ta[0]) == TASK_EXT) load_row<NPROP>(U, tn[0], &rnx[0][0]);
   }
   __syncthreads();
 
@@ -2231,9 +2231,9 @@ __global__ __launch_bounds__(TILE_BS, QDG_TILE_WAVES) void k_rhs_p1v(DevMesh m, 
 #endif
     const int a = (q == 0) ? ta[0] : (q == 1) ? ta[1] : (q == 2) ? ta[2] : ta[3];
     if (a < 0) break;
-    const int el = a & 255, lf = (a >> 8) & 3, code = (a >> 11) & 63, kind = (a >> 17) & 3,
-              bc = (a >> 19) & 3, pl = (a >> 21) & 255;
-    const bool own_left = (a >> 10) & 1;
+    const int el = TASK_EL(a), lf = TASK_LF(a), code = TASK_CODE(a), kind = TASK_KIND(a),
+              bc = TASK_BC(a), pl = TASK_PL(a);
+    const bool own_left = TASK_OWNLEFT(a);
     // everything below works in the OWN tet's frame: left' = own, right' = neighbour,
     // n' = the own tet's outward normal (the stored normal or its negative).  For a face
     // whose stored left tet is the neighbour this is the mirror image of the reference's
@@ -2257,7 +2257,7 @@ __global__ __launch_bounds__(TILE_BS, QDG_TILE_WAVES) void k_rhs_p1v(DevMesh m, 
       if (an >= 0) {
         load_row<4>(geo, fq, gnx);
 #ifndef QDG_KO_EXT
-        if (((an >> 17) & 3) == TASK_EXT) load_row<NPROP>(U, nq, &rnx[0][0]);
+        if (TASK_KIND(an) == TASK_EXT) load_row<NPROP>(U, nq, &rnx[0][0]);
 #endif
       }
     }
