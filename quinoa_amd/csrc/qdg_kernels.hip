@@ -1,16 +1,22 @@
 // qdg_kernels.hip -- hand-written gfx950 (MI355X, CDNA4) kernels of the DG
-// compressible-flow path.  One lane = one tetrahedron; 64 consecutive tets of
-// the Morton-ordered device numbering per wavefront; fields are element-major
-// rows (qdg_device.hpp) read and written with 16-byte accesses, so a
-// face-neighbour gather costs one contiguous row served by the XCD's L2.
+// compressible-flow path.  Fields are element-major rows in the Morton-ordered device
+// numbering (qdg_device.hpp), so a face-neighbour gather is one contiguous row served by
+// the XCD's L2; rows are written back through LDS as coalesced wave stores.
 //
-// The right-hand side is ELEMENT-CENTRIC: every tet visits its 4 faces and
-// gathers the neighbour's DOFs, instead of the reference's face loop that
-// scatters into R[el] and R[er] (src/PDE/Integrate/Surface.cpp:233-271).
-// No atomics, R written exactly once, results independent of scheduling.
-// The Riemann flux of a face is always evaluated in the face's stored
-// orientation (left = esuf[2f], stored normal), by both of its elements, so
-// both sides see the same flux expression.
+// Right-hand side, by scheme order:
+//   DG-P1  k_rhs_p1v / k_rhs_p1t  tile / face-task kernels: a workgroup owns 248 consecutive
+//          rows, keeps their vertex states and flux accumulators in LDS and evaluates every
+//          face between two tets of the tile ONCE (one lane per face task, ds_add_f64 into
+//          both tets); k_rhs_p1 is the element-centric, bitwise reproducible form.
+//   DG-P2  k_rhs_p2s  a LANE PAIR per tet (modes split 5/5, partial sums exchanged by DPP,
+//          basis values from LDS tables, 2 waves per SIMD); k_rhs_p2 one lane per tet with a
+//          face's six Gauss points batched; k_rhs<10> the round-1 reference form.
+//   DG-P0  k_rhs<1>.
+// The element-centric kernels evaluate a face's Riemann flux from both of its tets with the
+// same expression (stored orientation, or the own tet's frame with the mirrored HLLC ladder),
+// so no atomics are needed and R is written exactly once.  Stage 0 fuses the CFL time-step sum
+// of dg::CompFlow::dt into the face loop; whenever dt is known before the launch the SSP-RK3
+// update is fused in as well and R never goes to memory.
 //
 // Reference coordinates of face Gauss points are constant tables: on a
 // straight-sided tet they depend only on the local face id (own side) and on
