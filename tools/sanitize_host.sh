@@ -1,0 +1,44 @@
+#!/bin/bash
+# The host-only sources of libqdg (partitioner / chunk and ghost-plan builder / uniform refinement,
+# FaceData mirrors, ExodusII writer) built WITHOUT HIP under AddressSanitizer + UBSan and under
+# ThreadSanitizer, and the CPU tests that drive them run against those builds.  GPU sanitizers are
+# not available on the pool; this covers the multithreaded host code.   Usage: tools/sanitize_host.sh
+set -e
+root="$(cd "$(dirname "$0")/.." && pwd)"
+out=${TMPDIR:-/tmp}/qdg_sanitize; mkdir -p $out
+cat > $out/err.cpp <<'CPP'
+#include <string>
+#include "qdg_host.hpp"
+namespace qdg {
+static thread_local std::string g_err;
+int fail(const std::string& m) { g_err = m; return 1; }
+void set_error(const std::string& m) { g_err = m; }
+}
+extern "C" const char* qdg_last_error(void) { return qdg::g_err.c_str(); }
+extern "C" const char* qdg_version(void) { return "sanitizer host-only build"; }
+CPP
+src="$root/quinoa_amd/csrc/qdg_partition.cpp $root/quinoa_amd/csrc/qdg_meshdata.cpp $root/quinoa_amd/csrc/qdg_exo.cpp $out/err.cpp"
+inc="-I$root/quinoa_amd/csrc -I$root/include"
+g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -fPIC -shared $inc $src -o $out/libqdg_asan.so -lpthread
+g++ -std=c++17 -O1 -g -fsanitize=thread -fPIC -shared $inc $src -o $out/libqdg_tsan.so -lpthread
+cat > $out/big.py <<'PY'
+import numpy as np
+from quinoa_amd import amr, meshgen, partition
+ch = meshgen.kuhn_box(20, 18, 16)            # large enough for the threaded paths
+c2, i2, s2, par = amr.refine_uniform(ch["coord"], ch["inpoel"], ch["sidesets"])
+def vol(c, i):
+    a = c[i[:, 0]]; b = c[i[:, 1]] - a; cc = c[i[:, 2]] - a; d = c[i[:, 3]] - a
+    return np.einsum('ij,ij->i', b, np.cross(cc, d)) / 6
+v1, v2 = vol(ch["coord"], ch["inpoel"]), vol(c2, i2)
+assert (v2 > 0).all() and abs(v2.sum() - v1.sum()) < 1e-12
+part = partition.partition(ch["coord"], ch["inpoel"], 5, "rcb")
+ck = partition.build_chunk(ch["coord"], ch["inpoel"], ch["sidesets"], part, 5, 2)
+print("refined", i2.shape[0], "tets; chunk", ck["nielem"], "owned,", len(ck["nbr_rank"]), "neighbours")
+PY
+cd "$root"
+echo "== ASan + UBSan"
+LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0 QDG_LIB=$out/libqdg_asan.so \
+  python3 -m pytest tests/test_partition.py tests/test_amr.py tests/test_host_meshdata.py tests/test_exodus.py -x -q -p no:cacheprovider
+LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0 QDG_LIB=$out/libqdg_asan.so PYTHONPATH=$root python3 $out/big.py
+echo "== TSan"
+LD_PRELOAD=$(gcc -print-file-name=libtsan.so) QDG_LIB=$out/libqdg_tsan.so PYTHONPATH=$root python3 $out/big.py
