@@ -21,7 +21,8 @@ the roofline fraction of the RHS kernel at 10 M tets at N = 1 and a STRONG-scali
 value for every N (`--no-north-star` skips it, `--strong-nx M` changes the box).
 BASELINE.md section 5: 5 warm-up + 50 timed steps (the defaults).
 At N = 1 it also times config 5's refine / re-upload loop once (`amr_point`) and config 3 at
-its own size, vortical flow DG-P2 + WENO on 7 986 000 tets (`config3_point`).
+its own size, vortical flow DG-P2 + WENO on 7 986 000 tets (`config3_point`), and one GPU's
+7 986 000-tet share of config 4's Sedov run (`config4_point`).
 
 Prints ONE JSON line on rank 0.
 """
@@ -256,6 +257,42 @@ def config3_point(local_rank, nx=110, steps=5):
                          "traffic": None}}
 
 
+def config4_point(local_rank, nx=110, steps=5):
+    """One GPU's share of BASELINE config 4 (Sedov blast DG-P1 + Superbee, CFL 0.3, 64 M tets over
+    8 GPUs): nx^3 x 6 = 7 986 000 tets on this GPU, no halo (the 8-GPU run is `--gpus 8 --nx 110`)."""
+    import numpy as np
+    from quinoa_amd import capi, dgmesh, meshgen
+    ch = meshgen.kuhn_box(nx, nx, nx)
+    chunk = dgmesh.build_chunk(ch["coord"], ch["inpoel"], None, ch["sidesets"])
+    ctx = capi.Context(4, flux="hllc", limiter="superbeep1", problem="sedov_blastwave", gamma=1.4, cfl=0.3,
+                       bc_sym=[1, 3, 5, 6], bc_extrapolate=[2, 4], device=local_rank)
+    mesh = dgmesh.upload(ctx, chunk)
+    mesh.state_initialize(0.0)
+    for _ in range(2):
+        mesh.step(0.0, want_dt=False)
+    ctx.synchronize()
+    mesh.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        mesh.step(0.0, want_dt=False)
+    ctx.synchronize()
+    el = (time.perf_counter() - t0) / steps
+    nl, ms = mesh.profile_read()
+    alg = mesh.rhs_algorithmic_bytes()
+    U = mesh.state_download()
+    ok = bool(np.isfinite(U).all())
+    ne = chunk.nielem
+    mesh.close(); ctx.close()
+    ach = alg / (ms / nl * 1e-3) / 1e9
+    return {"workload": "CompFlow Sedov blast wave DG-P1 + superbeep1, CFL 0.3, Kuhn-tet box %d^3 hexes = %d tets "
+                        "(one GPU's share of config 4), %d timed steps" % (nx, ne, steps),
+            "tets_total": ne, "steps": steps, "value": ne * 3 / el / 1e6, "unit": "M element-updates/s",
+            "ms_per_step": el * 1e3, "finite": ok,
+            "roofline": {"bound": "hbm", "kernel": "qdg::k_rhs_p1v", "achieved": ach, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "avg_launch_ms": ms / nl, "launches": nl,
+                         "algorithmic_bytes_per_launch": alg, "traffic": None}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -269,6 +306,8 @@ def main():
     ap.add_argument("--no-config3", action="store_true",
                     help="skip the config-3 point (DG-P2 + WENO at 7.99 M tets, N = 1 only)")
     ap.add_argument("--config3-nx", type=int, default=110)
+    ap.add_argument("--no-config4", action="store_true",
+                    help="skip the config-4 point (one GPU's 7.99 M-tet share of the Sedov run, N = 1 only)")
     ap.add_argument("--strong-nx", type=int, default=119,
                     help="hexes per direction of the fixed-size box of the strong-scaling point "
                          "(119 -> 10 110 954 tets, 220 -> 63 888 000 tets = config 4)")
@@ -379,6 +418,8 @@ def main():
             out["amr_point"] = amr_point(local_rank)
         if world == 1 and not args.no_config3 and not args.self_halo:
             out["config3_point"] = config3_point(local_rank, args.config3_nx)
+        if world == 1 and not args.no_config4 and not args.self_halo:
+            out["config4_point"] = config4_point(local_rank)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

@@ -9,14 +9,14 @@ export TMPDIR=/tmp
 cd "${root:?}" || exit 1
 out=gpurun_out/${tag}_nx$nx
 mkdir -p $out
-timeout -k 10 900 python3 bench.py --nx $nx --no-north-star --no-amr --no-config3 > $out/bench.json 2> $out/bench.err
+timeout -k 10 900 python3 bench.py --nx $nx --no-north-star --no-amr --no-config3 --no-config4 > $out/bench.json 2> $out/bench.err
 tail -1 $out/bench.json | cut -c1-200
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --nx $nx --no-cpu-baseline --no-north-star --no-amr --no-config3 > $out/stats.log 2>&1
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --nx $nx --no-cpu-baseline --no-north-star --no-amr --no-config3 --no-config4 > $out/stats.log 2>&1
 cp $out/stats/*/*kernel_stats.csv $out/kernel_stats.csv
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "GRBM_GUI_ACTIVE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum"; do
   i=$((i+1))
-  timeout -k 10 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/pmc$i -- python3 bench.py --nx $nx --steps 3 --warmup 1 --no-cpu-baseline --no-north-star --no-amr --no-config3 > $out/pmc$i.log 2>&1 || echo "pmc pass $i failed"
+  timeout -k 10 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/pmc$i -- python3 bench.py --nx $nx --steps 3 --warmup 1 --no-cpu-baseline --no-north-star --no-amr --no-config3 --no-config4 > $out/pmc$i.log 2>&1 || echo "pmc pass $i failed"
 done
 python3 - <<PY
 import csv, glob, collections, json

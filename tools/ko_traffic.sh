@@ -4,7 +4,7 @@ cd "${GRAFT_REPO_ROOT:?}" || exit 1
 o=gpurun_out/r3j; mkdir -p $o
 for v in "" _koext _kotasks; do
   for c in FETCH_SIZE WRITE_SIZE; do
-    QDG_LIB=$PWD/quinoa_amd/lib/libqdg$v.so timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $o/p${v}_$c -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-north-star --no-amr --no-config3 > $o/p${v}_$c.log 2>&1 || echo fail $v $c
+    QDG_LIB=$PWD/quinoa_amd/lib/libqdg$v.so timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $o/p${v}_$c -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-north-star --no-amr --no-config3 --no-config4 > $o/p${v}_$c.log 2>&1 || echo fail $v $c
   done
 done
 python3 - <<PY
