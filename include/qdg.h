@@ -361,6 +361,29 @@ int qdg_refine_uniform(size_t nelem, size_t nnode, const size_t* inpoel, const d
 int qdg_refined_get(const qdg_refined* r, size_t* nnode, size_t* inpoel, size_t* parent,
                     double* x, double* y, double* z, size_t* tri);
 int qdg_refined_destroy(qdg_refined* r);
+
+/* Uniform refinement of ONE RANK's chunk of a decomposition, by the rank alone (the re-mesh step of
+ * DG::resizePostAMR on a chare, src/Inciter/DG.cpp:1536-1612): in = the chunk as qdg_chunk_build
+ * made it (owned tets [0, nielem), ghosts behind them grouped by owner in the order of nbr_rank
+ * [ascending], gid = global tet ids, side-set triangles in local node ids, recv_counts per
+ * neighbour).  Out: the children of the owned tets (8 * nielem, in order), the new ghost layer
+ * (children of old ghosts that share a face with a new owned tet, grouped by owner, ordered by
+ * global child id 8 * gid(parent) + k), nodes renumbered, side-set triangles of the refined
+ * chunk, the new halo plan (send_off[nnbr + 1], send_list of owned local ids per neighbour ordered
+ * by global child id; recv_counts[nnbr]) and parent[] = old local id of every kept child's
+ * parent (for qdg_state_transfer).  No communication: both ranks of a pair derive the same
+ * sets.  Follow with qdg_mesh_from_chunk + qdg_halo_setup + qdg_state_transfer. */
+typedef struct qdg_chunk_refined qdg_chunk_refined;
+int qdg_refine_chunk(size_t nielem, size_t nunk, size_t nnode, const size_t* inpoel, const double* x,
+                     const double* y, const double* z, const size_t* gid, size_t ntri, const size_t* tri,
+                     const int32_t* tri_set, size_t nnbr, const int32_t* nbr_rank,
+                     const size_t* recv_counts, qdg_chunk_refined** out);
+int qdg_chunk_refined_sizes(const qdg_chunk_refined* c, size_t* nielem, size_t* nunk, size_t* nnode,
+                            size_t* ntri, size_t* nsend);
+int qdg_chunk_refined_get(const qdg_chunk_refined* c, size_t* inpoel, size_t* gid, size_t* parent,
+                          double* x, double* y, double* z, size_t* tri, int32_t* tri_set,
+                          size_t* send_off, size_t* send_list, size_t* recv_counts);
+int qdg_chunk_refined_destroy(qdg_chunk_refined* c);
 int qdg_state_transfer(qdg_mesh* from, qdg_mesh* to, const size_t* parent_of_child);
 
 /* -- element-field output in ExodusII layout -----------------------------------

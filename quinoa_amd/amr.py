@@ -87,6 +87,60 @@ def _rows(a):
 
 
 def refine_chunk(ch):
+    """qdg_refine_chunk (C++, all host cores): uniform 1:8 refinement of ONE RANK's chunk of a
+    partitioned mesh with its new ghost layer and halo plan; see _refine_chunk_numpy for the
+    statement of the algorithm (kept as the cross-check of the tests: about 400x slower).
+    Returns (new chunk dict, parent[nunk_new] old local id of every kept child's parent)."""
+    L = capi.lib()
+    coord = np.ascontiguousarray(ch["coord"], dtype=np.float64)
+    inp, pinp = capi._sz(np.asarray(ch["inpoel"]).reshape(-1))
+    nunk, nie, nn = len(inp) // 4, int(ch["nielem"]), coord.shape[0]
+    x, px = capi._f64(coord[:, 0]); y, py = capi._f64(coord[:, 1]); z, pz = capi._f64(coord[:, 2])
+    gid, pgid = capi._sz(np.asarray(ch["gid"]))
+    ss = ch["sidesets"] or {}
+    ids = sorted(ss)
+    tri = np.concatenate([np.asarray(ss[s]).reshape(-1, 3) for s in ids]) if ids else np.zeros((0, 3))
+    tset = np.concatenate([np.full(len(ss[s]), s, np.int32) for s in ids]) if ids else np.zeros(0, np.int32)
+    ntri = len(tset)
+    tri, ptri = capi._sz(tri.reshape(-1) if ntri else np.zeros(3))
+    tset = np.ascontiguousarray(tset if ntri else np.zeros(1, np.int32), dtype=np.int32)
+    nbr = list(ch["nbr_rank"])
+    nnbr = len(nbr)
+    nb_a = np.ascontiguousarray(nbr or [0], dtype=np.int32)
+    rc_a, prc = capi._sz(np.asarray(list(ch["recv_counts"]) or [0]))
+    h = C.c_void_p()
+    capi._chk(L.qdg_refine_chunk(C.c_size_t(nie), C.c_size_t(nunk), C.c_size_t(nn), pinp, px, py, pz, pgid,
+                                 C.c_size_t(ntri), ptri, tset.ctypes.data_as(capi.c_i32p), C.c_size_t(nnbr),
+                                 nb_a.ctypes.data_as(capi.c_i32p), prc, C.byref(h)))
+    try:
+        n = [C.c_size_t() for _ in range(5)]
+        capi._chk(L.qdg_chunk_refined_sizes(h, *[C.byref(v) for v in n]))
+        nie2, nunk2, nn2, ntri2, nsend = (int(v.value) for v in n)
+        inp2 = np.zeros(4 * nunk2, dtype=np.uint64); gid2 = np.zeros(nunk2, dtype=np.uint64)
+        par = np.zeros(nunk2, dtype=np.uint64)
+        c2 = np.zeros((3, nn2))
+        tri2 = np.zeros(max(1, 3 * ntri2), dtype=np.uint64); tset2 = np.zeros(max(1, ntri2), dtype=np.int32)
+        soff = np.zeros(nnbr + 1, dtype=np.uint64); slist = np.zeros(max(1, nsend), dtype=np.uint64)
+        rc2 = np.zeros(max(1, nnbr), dtype=np.uint64)
+        capi._chk(L.qdg_chunk_refined_get(h, inp2.ctypes.data_as(capi.c_szp), gid2.ctypes.data_as(capi.c_szp),
+                                          par.ctypes.data_as(capi.c_szp), c2[0].ctypes.data_as(capi.c_f64p),
+                                          c2[1].ctypes.data_as(capi.c_f64p), c2[2].ctypes.data_as(capi.c_f64p),
+                                          tri2.ctypes.data_as(capi.c_szp), tset2.ctypes.data_as(capi.c_i32p),
+                                          soff.ctypes.data_as(capi.c_szp), slist.ctypes.data_as(capi.c_szp),
+                                          rc2.ctypes.data_as(capi.c_szp)))
+    finally:
+        L.qdg_chunk_refined_destroy(h)
+    tri2 = tri2[:3 * ntri2].astype(np.int64).reshape(-1, 3); tset2 = tset2[:ntri2]
+    soff = soff.astype(np.int64); slist = slist.astype(np.int64)
+    new = {"coord": np.ascontiguousarray(c2.T), "inpoel": inp2.astype(np.int64).reshape(-1, 4), "nielem": nie2,
+           "sidesets": {int(s_): tri2[tset2 == s_] for s_ in ids if (tset2 == s_).any()},
+           "gid": gid2.astype(np.int64), "nbr_rank": nbr,
+           "send_lists": [slist[soff[i]:soff[i + 1]] for i in range(nnbr)],
+           "recv_counts": [int(v) for v in rc2[:nnbr]]}
+    return new, par.astype(np.int64)
+
+
+def _refine_chunk_numpy(ch):
     """Uniform 1:8 refinement of ONE RANK's chunk of a partitioned mesh (a dict as
     partition.build_chunk / meshgen.kuhn_box_chunk return it), done by the rank alone:
     owned and ghost tets are refined with the same pattern (edge midpoints coincide across the

@@ -417,6 +417,237 @@ extern "C" int qdg_refine_uniform(size_t nelem, size_t nnode, const size_t* inpo
   QDG_CATCH
 }
 
+// ---------------------------------------------------------------- refinement of one rank's chunk
+// Uniform 1:8 refinement of ONE RANK's chunk of a decomposition, done by the rank alone (what
+// DG::resizePostAMR has after the Refiner ran on a chare, src/Inciter/DG.cpp:1536-1612): owned and
+// ghost tets are refined with the same pattern (edge midpoints coincide across the chunk boundary,
+// so the refined mesh stays conforming); the children of the owned tets are the new owned tets;
+// the new ghost layer is the set of children of OLD ghosts that share a face with a new owned tet.
+// The halo plan follows without communication: a child of my tet A touches a child of rank q's
+// tet B only where A and B touched, i.e. only where both ranks already hold the other's tet -- so
+// my send list to q and q's new ghosts from me are the same set, and both sides order it by the
+// global id of the child (8 * parent's global id + child number).
+struct qdg_chunk_refined {
+  size_t nielem = 0, nunk = 0, nnode = 0;
+  std::vector<size_t> inpoel, gid, parent, tri, send_off, send_list, recv_counts;
+  std::vector<int32_t> tri_set;
+  std::vector<double> x, y, z;
+};
+
+namespace {
+struct FK { uint32_t a, b, c, idx; };      // sorted node triple of a face, index of (tet, local face)
+inline bool fk_less(const FK& p, const FK& q)
+{ return p.a != q.a ? p.a < q.a : p.b != q.b ? p.b < q.b : p.c != q.c ? p.c < q.c : p.idx < q.idx; }
+inline bool fk_same(const FK& p, const FK& q) { return p.a == q.a && p.b == q.b && p.c == q.c; }
+inline FK fk_of(size_t n0, size_t n1, size_t n2, size_t idx)
+{
+  uint32_t a = (uint32_t)n0, b = (uint32_t)n1, c = (uint32_t)n2;
+  if (a > b) std::swap(a, b);
+  if (b > c) std::swap(b, c);
+  if (a > b) std::swap(a, b);
+  return { a, b, c, (uint32_t)idx };
+}
+// sort by key on all host cores: buckets by ranges of the smallest node, one thread per bucket
+void fk_sort(std::vector<FK>& v, size_t nnode)
+{
+  const size_t n = v.size();
+  if (n < 65536) { std::sort(v.begin(), v.end(), fk_less); return; }
+  const size_t NB = 256;
+  std::vector<size_t> cnt(NB + 1, 0);
+  auto bk = [&](const FK& f) { return (size_t)((uint64_t)f.a * NB / std::max<size_t>(nnode, 1)); };
+  for (const FK& f : v) ++cnt[bk(f) + 1];
+  for (size_t b = 0; b < NB; ++b) cnt[b + 1] += cnt[b];
+  std::vector<FK> w(n);
+  { std::vector<size_t> pos(cnt.begin(), cnt.end() - 1); for (const FK& f : v) w[pos[bk(f)]++] = f; }
+  par_ranges(NB, [&](size_t b0, size_t b1, unsigned) {
+    for (size_t b = b0; b < b1; ++b) std::sort(w.begin() + cnt[b], w.begin() + cnt[b + 1], fk_less);
+  }, 2);
+  v.swap(w);
+}
+const int FACE_OF[4][3] = { { 1, 2, 3 }, { 2, 0, 3 }, { 3, 0, 1 }, { 0, 2, 1 } };
+}  // namespace
+
+extern "C" int qdg_refine_chunk(size_t nielem, size_t nunk, size_t nnode, const size_t* inpoel,
+                                const double* x, const double* y, const double* z, const size_t* gid,
+                                size_t ntri, const size_t* tri, const int32_t* tri_set, size_t nnbr,
+                                const int32_t* nbr_rank, const size_t* recv_counts, qdg_chunk_refined** out)
+{
+  QDG_TRY
+  if (!inpoel || !x || !y || !z || !gid || !out || (ntri && (!tri || !tri_set)) || (nnbr && (!nbr_rank || !recv_counts)))
+    return fail("qdg_refine_chunk: null argument");
+  *out = nullptr;
+  if (nielem == 0 || nielem > nunk) return fail("qdg_refine_chunk: need 0 < nielem <= nunk");
+  size_t nghost = 0;
+  for (size_t i = 0; i < nnbr; ++i) {
+    nghost += recv_counts[i];
+    if (i > 0 && nbr_rank[i] <= nbr_rank[i - 1]) return fail("qdg_refine_chunk: neighbour ranks must be ascending");
+  }
+  if (nghost != nunk - nielem) return fail("qdg_refine_chunk: receive counts do not add up to the ghost count");
+  for (size_t i = 0; i < 4 * nunk; ++i)
+    if (inpoel[i] >= nnode) return fail("qdg_refine_chunk: inpoel entry out of range");
+
+  // side-set triangles that are faces of a local tet (a triangle can have its three nodes in the
+  // chunk without being one)
+  std::vector<size_t> tri_in; std::vector<int32_t> set_in;
+  if (ntri) {
+    std::vector<FK> all(4 * nunk);
+    par_ranges(nunk, [&](size_t e0, size_t e1, unsigned) {
+      for (size_t e = e0; e < e1; ++e)
+        for (int f = 0; f < 4; ++f)
+          all[4 * e + f] = fk_of(inpoel[4 * e + FACE_OF[f][0]], inpoel[4 * e + FACE_OF[f][1]], inpoel[4 * e + FACE_OF[f][2]], 4 * e + f);
+    });
+    fk_sort(all, nnode);
+    for (size_t t = 0; t < ntri; ++t) {
+      if (tri[3 * t] >= nnode || tri[3 * t + 1] >= nnode || tri[3 * t + 2] >= nnode) continue;
+      FK k = fk_of(tri[3 * t], tri[3 * t + 1], tri[3 * t + 2], 0);
+      auto it = std::lower_bound(all.begin(), all.end(), k, fk_less);
+      if (it != all.end() && fk_same(*it, k)) {
+        tri_in.insert(tri_in.end(), tri + 3 * t, tri + 3 * t + 3);
+        set_in.push_back(tri_set[t]);
+      }
+    }
+  }
+  qdg_refined* rr = nullptr;
+  if (int rc = qdg_refine_uniform(nunk, nnode, inpoel, x, y, z, set_in.size(), tri_in.data(), &rr)) return rc;
+  std::unique_ptr<qdg_refined> r(rr);
+  if (r->nnode > (size_t)UINT32_MAX || 32 * nunk > (size_t)UINT32_MAX) return fail("qdg_refine_chunk: chunk too large");
+  const std::vector<size_t>& i2 = r->inpoel;
+  const size_t nown = 8 * nielem, nall = 8 * nunk;
+
+  // A new ghost is a child of an old ghost that shares a face with a child of an owned tet; such a
+  // face lies on an old owned | ghost face.  So only the children of the tets on the old interface
+  // take part in the matching (a surface-sized set, not all 32 * nunk child faces).
+  std::vector<char> on_iface(nunk, 0);
+  {
+    std::vector<FK> all(4 * nunk);
+    par_ranges(nunk, [&](size_t e0, size_t e1, unsigned) {
+      for (size_t e = e0; e < e1; ++e)
+        for (int f = 0; f < 4; ++f)
+          all[4 * e + f] = fk_of(inpoel[4 * e + FACE_OF[f][0]], inpoel[4 * e + FACE_OF[f][1]], inpoel[4 * e + FACE_OF[f][2]], 4 * e + f);
+    });
+    fk_sort(all, nnode);
+    for (size_t i = 0; i + 1 < all.size(); ++i)
+      if (fk_same(all[i], all[i + 1])) {
+        const size_t ea = all[i].idx >> 2, eb = all[i + 1].idx >> 2;
+        if ((ea < nielem) != (eb < nielem)) on_iface[ea] = on_iface[eb] = 1;
+      }
+  }
+  std::vector<FK> freef;                      // faces of the owned children next to the old interface
+  for (size_t ep = 0; ep < nielem; ++ep)
+    if (on_iface[ep])
+      for (size_t e = 8 * ep; e < 8 * ep + 8; ++e)
+        for (int f = 0; f < 4; ++f)
+          freef.push_back(fk_of(i2[4 * e + FACE_OF[f][0]], i2[4 * e + FACE_OF[f][1]], i2[4 * e + FACE_OF[f][2]], 4 * e + f));
+  fk_sort(freef, r->nnode);
+  // owner (index into nbr_rank) of every old ghost
+  std::vector<int32_t> owner_idx(nunk - nielem);
+  { size_t o = 0; for (size_t i = 0; i < nnbr; ++i) for (size_t k = 0; k < recv_counts[i]; ++k) owner_idx[o++] = (int32_t)i; }
+  // ghost children with a face among the free ones -> new ghosts; the owned child on the other
+  // side of that face goes into the send list of the ghost's owner
+  struct G { int32_t owner; size_t cgid; uint32_t child; };
+  std::vector<G> ghosts;
+  std::vector<std::vector<std::pair<size_t, uint32_t>>> sends(nnbr);   // (global id of the child, owned child)
+  {
+    std::vector<char> taken(nall - nown, 0);
+    for (size_t e = nown; e < nall; ++e) {
+      if (!on_iface[r->parent[e]]) continue;
+      const int32_t ow = owner_idx[r->parent[e] - nielem];
+      for (int f = 0; f < 4; ++f) {
+        const FK k = fk_of(i2[4 * e + FACE_OF[f][0]], i2[4 * e + FACE_OF[f][1]], i2[4 * e + FACE_OF[f][2]], 0);
+        auto it = std::lower_bound(freef.begin(), freef.end(), k, fk_less);
+        if (it != freef.end() && fk_same(*it, k)) {
+          if (!taken[e - nown]) {
+            taken[e - nown] = 1;
+            ghosts.push_back({ ow, 8 * gid[r->parent[e]] + (e & 7), (uint32_t)e });
+          }
+          const uint32_t oc = it->idx >> 2;
+          sends[ow].push_back({ 8 * gid[r->parent[oc]] + (oc & 7), oc });
+        }
+      }
+    }
+  }
+  std::sort(ghosts.begin(), ghosts.end(), [](const G& p, const G& q) { return p.owner != q.owner ? p.owner < q.owner : p.cgid < q.cgid; });
+  std::unique_ptr<qdg_chunk_refined> c(new qdg_chunk_refined);
+  c->nielem = nown; c->nunk = nown + ghosts.size();
+  c->recv_counts.assign(nnbr, 0);
+  for (const G& g : ghosts) ++c->recv_counts[g.owner];
+  c->send_off.assign(nnbr + 1, 0);
+  for (size_t q = 0; q < nnbr; ++q) {
+    auto& v = sends[q];
+    std::sort(v.begin(), v.end());
+    v.erase(std::unique(v.begin(), v.end()), v.end());
+    c->send_off[q + 1] = c->send_off[q] + v.size();
+    for (auto& pr : v) c->send_list.push_back(pr.second);
+  }
+  // kept tets: owned children in order, then the new ghosts; nodes renumbered in ascending order
+  // of their ids in the refined chunk
+  std::vector<uint32_t> keep(c->nunk);
+  for (size_t e = 0; e < nown; ++e) keep[e] = (uint32_t)e;
+  for (size_t i = 0; i < ghosts.size(); ++i) keep[nown + i] = ghosts[i].child;
+  std::vector<int64_t> g2l(r->nnode, -1);
+  for (uint32_t e : keep) for (int i = 0; i < 4; ++i) g2l[i2[4 * (size_t)e + i]] = 0;
+  size_t nn = 0;
+  for (size_t n = 0; n < r->nnode; ++n) if (g2l[n] == 0) g2l[n] = (int64_t)nn++;
+  c->nnode = nn;
+  c->x.resize(nn); c->y.resize(nn); c->z.resize(nn);
+  for (size_t n = 0; n < r->nnode; ++n) if (g2l[n] >= 0) { c->x[g2l[n]] = r->x[n]; c->y[g2l[n]] = r->y[n]; c->z[g2l[n]] = r->z[n]; }
+  c->inpoel.resize(4 * c->nunk); c->gid.resize(c->nunk); c->parent.resize(c->nunk);
+  par_ranges(c->nunk, [&](size_t k0, size_t k1, unsigned) {
+    for (size_t k = k0; k < k1; ++k) {
+      const size_t e = keep[k];
+      for (int i = 0; i < 4; ++i) c->inpoel[4 * k + i] = (size_t)g2l[i2[4 * e + i]];
+      c->gid[k] = 8 * gid[r->parent[e]] + (e & 7);
+      c->parent[k] = r->parent[e];
+    }
+  });
+  for (size_t t = 0; t < r->tri.size() / 3; ++t) {
+    const int64_t a = g2l[r->tri[3 * t]], b = g2l[r->tri[3 * t + 1]], d = g2l[r->tri[3 * t + 2]];
+    if (a >= 0 && b >= 0 && d >= 0) {
+      c->tri.push_back((size_t)a); c->tri.push_back((size_t)b); c->tri.push_back((size_t)d);
+      c->tri_set.push_back(set_in[t / 4]);
+    }
+  }
+  *out = c.release();
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_chunk_refined_sizes(const qdg_chunk_refined* c, size_t* nielem, size_t* nunk, size_t* nnode,
+                                       size_t* ntri, size_t* nsend)
+{
+  QDG_TRY
+  if (!c) return fail("qdg_chunk_refined_sizes: null handle");
+  if (nielem) *nielem = c->nielem;
+  if (nunk) *nunk = c->nunk;
+  if (nnode) *nnode = c->nnode;
+  if (ntri) *ntri = c->tri_set.size();
+  if (nsend) *nsend = c->send_list.size();
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_chunk_refined_get(const qdg_chunk_refined* c, size_t* inpoel, size_t* gid, size_t* parent,
+                                     double* x, double* y, double* z, size_t* tri, int32_t* tri_set,
+                                     size_t* send_off, size_t* send_list, size_t* recv_counts)
+{
+  QDG_TRY
+  if (!c) return fail("qdg_chunk_refined_get: null handle");
+  auto cp = [](auto* dst, const auto& v) { if (dst && !v.empty()) std::memcpy(dst, v.data(), v.size() * sizeof(v[0])); };
+  cp(inpoel, c->inpoel); cp(gid, c->gid); cp(parent, c->parent); cp(x, c->x); cp(y, c->y); cp(z, c->z);
+  cp(tri, c->tri); cp(tri_set, c->tri_set); cp(send_off, c->send_off); cp(send_list, c->send_list);
+  cp(recv_counts, c->recv_counts);
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_chunk_refined_destroy(qdg_chunk_refined* c)
+{
+  QDG_TRY
+  delete c;
+  return 0;
+  QDG_CATCH
+}
+
 extern "C" int qdg_refined_get(const qdg_refined* r, size_t* nnode, size_t* inpoel, size_t* parent,
                                double* x, double* y, double* z, size_t* tri)
 {

@@ -189,3 +189,26 @@ def test_partitioned_run_across_a_refinement_equals_serial_run():
         assert err <= 1e-12, err
         seen += nie
     assert seen == ref.shape[0] and gmap is not None
+
+
+def test_refine_chunk_native_equals_numpy_statement():
+    """qdg_refine_chunk (C++, the one the runs use) against the numpy statement of the same
+    algorithm: every array of the refined chunk, its ghost layer and halo plan identical, for
+    the chunks of a general 3-way cut and for a block chunk with three neighbours"""
+    from quinoa_amd import amr, meshgen, partition
+    g = meshgen.kuhn_box(6, 5, 4)
+    part = partition.partition(g["coord"], g["inpoel"], 3, "rcb")
+    chunks = [partition.build_chunk(g["coord"], g["inpoel"], g["sidesets"], part, 3, r) for r in range(3)]
+    chunks.append(meshgen.kuhn_box_chunk(8, 6, 6, lengths=(1.0, 1.0, 1.0), parts=(2, 2, 2), rank=3))
+    for ch in chunks:
+        a, pa = amr.refine_chunk(ch)
+        b, pb = amr._refine_chunk_numpy(ch)
+        assert a["nielem"] == b["nielem"] and a["nbr_rank"] == b["nbr_rank"] and a["recv_counts"] == b["recv_counts"]
+        for k in ("coord", "inpoel", "gid"):
+            assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
+        assert np.array_equal(pa, pb)
+        for p, q in zip(a["send_lists"], b["send_lists"]):
+            assert np.array_equal(p, q)
+        assert sorted(a["sidesets"]) == sorted(b["sidesets"])
+        for sid in a["sidesets"]:
+            assert np.array_equal(a["sidesets"][sid], b["sidesets"][sid])

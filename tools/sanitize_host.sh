@@ -33,7 +33,10 @@ v1, v2 = vol(ch["coord"], ch["inpoel"]), vol(c2, i2)
 assert (v2 > 0).all() and abs(v2.sum() - v1.sum()) < 1e-12
 part = partition.partition(ch["coord"], ch["inpoel"], 5, "rcb")
 ck = partition.build_chunk(ch["coord"], ch["inpoel"], ch["sidesets"], part, 5, 2)
-print("refined", i2.shape[0], "tets; chunk", ck["nielem"], "owned,", len(ck["nbr_rank"]), "neighbours")
+ck2, par = amr.refine_chunk(ck)             # qdg_refine_chunk: the rank's own re-mesh step
+assert ck2["nielem"] == 8 * ck["nielem"] and len(par) == ck2["inpoel"].shape[0]
+print("refined", i2.shape[0], "tets; chunk", ck["nielem"], "owned,", len(ck["nbr_rank"]), "neighbours ->",
+      ck2["nielem"], "owned,", ck2["inpoel"].shape[0] - ck2["nielem"], "ghosts")
 PY
 cd "$root"
 echo "== ASan + UBSan"
