@@ -210,6 +210,65 @@ def amr_point(local_rank, nx=32, steps=20):
     ne1 = run.mesh.nielem
     ok = bool(np.isfinite(U).all())
     run.mesh.close(); ctx.close()
+    part = amr_partitioned(local_rank, ch, nparts=2, steps=5)
+    return {"on_a_decomposition": part, **_amr_single(nx, steps, ne0, ne1, ms0, ms1, th, tr, tt, ok)}
+
+
+def amr_partitioned(local_rank, g, nparts, steps):
+    """The same re-mesh on a decomposition: `nparts` chunks with ghost halos (all on this one GPU,
+    quinoa_amd.dg.LocalChunks), every chunk refined by its own rank's logic (qdg_refine_chunk: new
+    owned tets, new ghost layer and halo plan without communication), rebuilt on the device WITH
+    its ghosts (qdg_mesh_from_chunk) and handed its state (qdg_state_transfer).  Times are the
+    maximum over the chunks, i.e. what a rank of a one-process-per-GPU run spends."""
+    import numpy as np
+    from quinoa_amd import amr, capi, dg, partition
+    ctx = capi.Context(4, flux="hllc", limiter="superbeep1", problem="sod_shocktube", gamma=1.4,
+                       cfl=0.3, bc_extrapolate=[1, 2], bc_sym=[3, 4, 5, 6], device=local_rank)
+    pt = partition.partition(g["coord"], g["inpoel"], nparts, "rcb")
+    chunks = [partition.build_chunk(g["coord"], g["inpoel"], g["sidesets"], pt, nparts, r) for r in range(nparts)]
+
+    def build(ch):
+        return capi.mesh_from_connectivity(ctx, ch["inpoel"], ch["coord"], ch["sidesets"], nielem=ch["nielem"])
+
+    meshes = [build(ch) for ch in chunks]
+    for m in meshes:
+        m.state_initialize(0.0)
+    drv = dg.LocalChunks(ctx, meshes, chunks)
+    for _ in range(steps):
+        drv.step(0.0)
+    ctx.synchronize()
+    t_ref = t_reb = t_tr = 0.0
+    new_chunks, new_meshes = [], []
+    for ch, m in zip(chunks, meshes):
+        t0 = time.perf_counter()
+        ch2, par = amr.refine_chunk(ch)
+        t1 = time.perf_counter()
+        m2 = build(ch2)
+        ctx.synchronize()
+        t2 = time.perf_counter()
+        amr.state_transfer(m, m2, par)
+        ctx.synchronize()
+        t3 = time.perf_counter()
+        m.close()
+        t_ref, t_reb, t_tr = max(t_ref, t1 - t0), max(t_reb, t2 - t1), max(t_tr, t3 - t2)
+        new_chunks.append(ch2); new_meshes.append(m2)
+    drv = dg.LocalChunks(ctx, new_meshes, new_chunks)
+    for _ in range(steps):
+        drv.step(0.0)
+    ctx.synchronize()
+    ok = all(bool(np.isfinite(m.state_download()).all()) for m in new_meshes)
+    out = {"chunks": nparts, "owned_tets_per_chunk_before": [int(c["nielem"]) for c in chunks],
+           "owned_tets_per_chunk_after": [int(c["nielem"]) for c in new_chunks],
+           "ghost_tets_per_chunk_after": [int(c["inpoel"].shape[0] - c["nielem"]) for c in new_chunks],
+           "refine_chunk_host_ms": t_ref * 1e3, "rebuild_with_ghosts_device_ms": t_reb * 1e3,
+           "state_transfer_ms": t_tr * 1e3, "finite": ok}
+    for m in new_meshes:
+        m.close()
+    ctx.close()
+    return out
+
+
+def _amr_single(nx, steps, ne0, ne1, ms0, ms1, th, tr, tt, ok):
     return {"workload": "Sod DG-P1 + Superbee, %d^3 box: %d steps, uniform 1:8 refinement, %d steps" % (nx, steps, steps),
             "tets_before": ne0, "tets_after": ne1, "ms_per_step_before": ms0, "ms_per_step_after": ms1,
             "refine_host_ms": th * 1e3, "rebuild_upload_ms": tr * 1e3, "state_transfer_ms": tt * 1e3,
