@@ -166,3 +166,34 @@ def test_device_built_layout_equals_host_built_layout(ndof, limiter, problem):
     assert abs(a[4] - b[4]) <= 1e-14 * b[4]
     assert np.abs(a[3] - b[3]).max() <= 1e-12 * max(1.0, np.abs(b[3]).max())
     assert np.abs(a[5] - b[5]).max() <= 1e-12 * max(1.0, np.abs(b[5]).max())
+
+
+def test_device_build_rejects_bad_chunks():
+    """qdg_mesh_from_chunk / qdg_mesh_from_connectivity: argument errors and meshes the kernels must
+    never see -- an owned tet with a free face that no side set lists -- fail on the host side
+    of the call with a message, not in a kernel"""
+    from quinoa_amd import capi, meshgen
+    ch = meshgen.kuhn_box(2, 2, 2)
+    ctx = capi.Context(4, flux="hllc", problem="sod_shocktube", gamma=1.4, cfl=0.3,
+                       bc_extrapolate=[1, 2], bc_sym=[3, 4, 5, 6])
+    try:
+        with pytest.raises(capi.QdgError, match="nielem"):
+            capi.mesh_from_connectivity(ctx, ch["inpoel"], ch["coord"], ch["sidesets"], nielem=0)
+        with pytest.raises(capi.QdgError, match="nielem"):
+            capi.mesh_from_connectivity(ctx, ch["inpoel"], ch["coord"], ch["sidesets"],
+                                        nielem=ch["inpoel"].shape[0] + 1)
+        # drop one side set: its faces become free faces of owned tets without a boundary entry
+        ss = {k: v for k, v in ch["sidesets"].items() if k != 3}
+        with pytest.raises(capi.QdgError, match="free face"):
+            capi.mesh_from_connectivity(ctx, ch["inpoel"], ch["coord"], ss)
+        # the same tets as GHOSTS may have free faces: only owned tets are checked
+        ne = ch["inpoel"].shape[0]
+        cen = ch["coord"][ch["inpoel"]].mean(axis=1)
+        order = np.argsort(cen[:, 1] > 0.5, kind="stable")          # tets with y < 0.5 first
+        nie = int((cen[:, 1] <= 0.5).sum())
+        ss2 = {k: v for k, v in ch["sidesets"].items() if k != 4}    # y-max faces belong to the "ghosts"
+        m = capi.mesh_from_connectivity(ctx, ch["inpoel"][order], ch["coord"], ss2, nielem=nie)
+        assert m.nielem == nie and m.nunk == ne
+        m.close()
+    finally:
+        ctx.close()
