@@ -457,3 +457,40 @@ def test_stiffened_gas_eos_matches_oracle(name, pstiff, cases):
         assert np.abs(fo[ip] - fa[ip]).max() <= 1e-10 * max(1.0, np.abs(fa[ip]).max())
     finally:
         mesh.close(); ctx.close()
+
+
+@pytest.mark.parametrize("name", ["taylor_green_dgp2", "nleg_dgp2", "vortical_flow_dgp1"])
+def test_lax_friedrichs_flux_at_every_order_matches_oracle(name, cases):
+    """LaxFriedrichs::flux (LaxFriedrichs.hpp:34-88) through the DG-P2 lane-pair kernel and the DG-P1
+    tile kernel: the reference only holds Lax-Friedrichs baselines at P0 / P1 (vortical_flow), so the
+    P2 combination is pinned by the oracle -- rhs (with a stiffened gas on top), dt, CFL steps."""
+    from quinoa_amd import capi, dgmesh
+    case, fix = cases[name], load_fixture(name)
+    ss = {int(s): fix["ss_tri_%d" % s] for s in fix["ss_ids"]}
+    chunk = dgmesh.build_chunk(fix["coord"], fix["inpoel"], None, ss)
+    kw = dict(flux="laxfriedrichs", limiter=case["limiter"], problem=case["problem"], gamma=case["gamma"],
+              pstiff=0.2, alpha=case.get("alpha", 0.0), beta=case.get("beta", 0.0), p0=case.get("p0", 0.0),
+              **O.nleg_params(case))
+    ctx = capi.Context(case["ndof"], cfl=0.25, bc_dirichlet=case["bc_dirichlet"], bc_sym=case["bc_sym"],
+                       bc_extrapolate=case["bc_extrapolate"], **kw)
+    mesh = dgmesh.upload(ctx, chunk)
+    om = O.OracleMesh(fix["coord"], fix["inpoel"], ss)
+    orc = O.Oracle(om, O.make_cfg(case["ndof"], **kw), case["bc_dirichlet"], case["bc_sym"], case["bc_extrapolate"])
+    try:
+        Lm = orc.lhs(); U0 = orc.initialize(Lm, 0.0)
+        rng = np.random.default_rng(3)
+        U0 = U0 + 1e-3 * rng.normal(size=U0.shape) * np.abs(U0).max()
+        R = orc.rhs(0.1, U0)
+        assert np.abs(mesh.rhs(0.1, U0) - R).max() <= 1e-11 * max(1.0, np.abs(R).max())
+        dto = orc.dt(U0)
+        assert abs(mesh.dt(U0) - dto) <= 1e-12 * dto
+        mesh.state_upload(U0)
+        U, t = U0.copy(), 0.0
+        for _ in range(3):
+            dtg = mesh.step(t)
+            dtc = orc.step(t, U, Lm, cfl=0.25)
+            assert abs(dtg - dtc) <= 1e-11 * dtc
+            t += dtc
+        assert np.abs(mesh.state_download() - U).max() <= TOL * max(1.0, np.abs(U).max())
+    finally:
+        mesh.close(); ctx.close()
