@@ -2711,8 +2711,9 @@ __global__ __launch_bounds__(256) void k_upd_superbee(DevMesh m, const double* _
 {
   static_assert(NDOF == 4, "fused update + Superbee exists for DG-P1");
   const Tables<NDOF>& T = tab<NDOF>();
-  constexpr int NPROP = NCOMP * NDOF;
+  constexpr int NPROP = NCOMP * NDOF, NCH = NPROP / 2;     // 16-byte chunks per row
   __shared__ double lds[256 * NPROP];
+  __shared__ double sdtv[256];
   const int tid = threadIdx.x;
   const int tile_e0 = (m.blk0 + xcd_tile(blockIdx.x, gridDim.x)) * 256;
   const int e0 = tile_e0 + tid;
@@ -2720,23 +2721,31 @@ __global__ __launch_bounds__(256) void k_upd_superbee(DevMesh m, const double* _
   const int e = active ? e0 : m.nie - 1;
   const int stride = m.stride;
   const double dt = dtp[0];
-  // the lane forms its own row of U1 = U0 + dt R / L from direct row reads (the faster path for
-  // reads, tools/ubench_rowstream.hip); the means of U1 go to LDS for the neighbours in the tile
-  double u[NCOMP][NDOF];
-  {
-    double r[NCOMP][NDOF];
-    load_row<NPROP>(U0, e, &u[0][0]);
-    load_row<NPROP>(R, e, &r[0][0]);
-    const double dtv = dt / m.vol[e];               // the row's dt / vol, as k_rk forms it
-    constexpr double imf[4] = { 1.0, 10.0, 10.0 / 3.0, 5.0 / 3.0 };
-#pragma unroll
-    for (int c = 0; c < NCOMP; ++c)
-#pragma unroll
-      for (int k = 0; k < NDOF; ++k) u[c][k] = u[c][k] + dtv * imf[k] * r[c][k];
-  }
-#pragma unroll
-  for (int c = 0; c < NCOMP; ++c) lds[(size_t)tid * NPROP + c * NDOF] = u[c][0];
+  sdtv[tid] = dt / m.vol[e];                       // the row's dt / vol, as k_rk forms it
   __syncthreads();
+  // the tile's rows of U1 = U0 + dt R / L go to LDS in one coalesced pass over both arrays
+  {
+    const double2* su = reinterpret_cast<const double2*>(U0 + (size_t)tile_e0 * NPROP);
+    const double2* sr = reinterpret_cast<const double2*>(R + (size_t)tile_e0 * NPROP);
+    double2* dst = reinterpret_cast<double2*>(lds);
+    const int nvalid = (m.nie - tile_e0 < 256 ? m.nie - tile_e0 : 256) * NCH;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const int i = j * 256 + tid;
+      double2 v = make_double2(1.0, 1.0);
+      if (i < nvalid) {
+        const double2 a = su[i], b = sr[i];
+        const int row = i / NCH, hi = (i - row * NCH) & 1;     // chunk holds modes (0,1) or (2,3)
+        const double dtv = sdtv[row];
+        const double f0 = hi ? 10.0 / 3.0 : 1.0, f1 = hi ? 5.0 / 3.0 : 10.0;
+        v = make_double2(a.x + dtv * f0 * b.x, a.y + dtv * f1 * b.y);
+      }
+      dst[i] = v;
+    }
+  }
+  __syncthreads();
+  double u[NCOMP][NDOF];
+  lds_row<NPROP>(lds, tid, &u[0][0]);
   double uMin[NCOMP], uMax[NCOMP], phi[NCOMP];
 #pragma unroll
   for (int c = 0; c < NCOMP; ++c) { uMin[c] = uMax[c] = u[c][0]; phi[c] = 1.0; }
