@@ -1772,7 +1772,7 @@ __global__ __launch_bounds__(TILE_BS, QDG_TILE_WAVES) void k_rhs_p1t(DevMesh m, 
   // LDS: the tile's states in NODAL form, nod[e][vertex][c] (a P1 state is
   // affine: its value at a face point is the barycentric mix of its vertex
   // values), and per-vertex flux accumulators accN[e][vertex][c]
-  __shared__ double nod[TILE * NPROP];
+  __shared__ __attribute__((aligned(16))) double nod[TILE * NPROP];
   __shared__ double accN[TILE * NPROP];
   __shared__ double sdelt[WITH_DT ? TILE : 1];
   const int tid = threadIdx.x;
@@ -1789,8 +1789,11 @@ __global__ __launch_bounds__(TILE_BS, QDG_TILE_WAVES) void k_rhs_p1t(DevMesh m, 
   int ta[MAXT], tf[MAXT], tn[MAXT];
 #pragma unroll
   for (int q = 0; q < MAXT; ++q) {
-    const int it = t0 + tid + TILE_BS * q;
-    const bool ok = it < t1;
+    // compact lists: the tile's tasks are [t0, t1); padded lists (QDG_TILE_V1=1 on a mesh built for
+    // version 2): its slots start at tile * stride, unused ones hold -1
+    const size_t it = m.task_stride > 0 ? (size_t)tile * m.task_stride + tid + TILE_BS * q
+                                        : (size_t)(t0 + tid + TILE_BS * q);
+    const bool ok = m.task_stride > 0 || (int)it < t1;
     ta[q] = ok ? m.task_a[it] : -1;
     tf[q] = ok ? m.task_f[it] : 0;
     tn[q] = ok ? m.task_nb[it] : 0;
@@ -2016,9 +2019,9 @@ __global__ __launch_bounds__(TILE_BS, QDG_TILE_WAVES) void k_rhs_p1t(DevMesh m, 
 
   // ---- phase 2: one lane per tet: volume (+source) term, epilogue, store --------
   double dte = DBL_MAX;
+  double acc[NCOMP][NDOF];
   if (tid < nloc) {
     const int e = tile_e0 + tid;
-    double acc[NCOMP][NDOF];
     {
       // R[c][k] = sum_v accN[v][c] * B_k(vertex v)
       double nv[4][NCOMP];
@@ -2111,8 +2114,25 @@ __global__ __launch_bounds__(TILE_BS, QDG_TILE_WAVES) void k_rhs_p1t(DevMesh m, 
         for (int k = 0; k < NDOF; ++k)
           acc[c][k] = rk_a * un[c][k] + rk_b * (u[c][k] + dtv * imf[k] * acc[c][k]);
     }
-    store_row<NPROP>(R, e, &acc[0][0]);
     if (WITH_DT) dte = vol / sdelt[tid];
+  }
+  // rows out through LDS as coalesced wave stores (see k_rhs_p1v)
+  __syncthreads();
+  if (tid < nloc) {
+    double2* row = reinterpret_cast<double2*>(nod + (size_t)tid * NPROP);
+#pragma unroll
+    for (int j = 0; j < NPROP / 2; ++j) row[j] = make_double2((&acc[0][0])[2 * j], (&acc[0][0])[2 * j + 1]);
+  }
+  __syncthreads();
+  {
+    const double2* src = reinterpret_cast<const double2*>(nod);
+    double2* dst = reinterpret_cast<double2*>(R + (size_t)tile_e0 * NPROP);
+    const int nvalid = nloc * (NPROP / 2);
+#pragma unroll
+    for (int j = 0; j < NPROP / 2; ++j) {
+      const int i = j * TILE_BS + tid;
+      if (i < nvalid) dst[i] = src[i];
+    }
   }
 
   if (WITH_DT) {
