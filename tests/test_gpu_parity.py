@@ -494,3 +494,37 @@ def test_lax_friedrichs_flux_at_every_order_matches_oracle(name, cases):
         assert np.abs(mesh.state_download() - U).max() <= TOL * max(1.0, np.abs(U).max())
     finally:
         mesh.close(); ctx.close()
+
+
+def test_tile_kernel_versions_agree(monkeypatch):
+    """the two forms of the DG-P1 tile kernel on the same mesh (version 2 by default; version 1 is
+    what p-adaptive runs use and what QDG_TILE_V1=1 forces): same stateless RHS and same state
+    after fused steps, to rounding (the summation order inside a tile differs)"""
+    from quinoa_amd import capi, dgmesh, meshgen
+    ch = meshgen.kuhn_box(9, 8, 7)
+    chunk = dgmesh.build_chunk(ch["coord"], ch["inpoel"], None, ch["sidesets"])
+    ctx = capi.Context(4, flux="hllc", limiter="superbeep1", problem="sod_shocktube", gamma=1.4, cfl=0.3,
+                       bc_extrapolate=[1, 2], bc_sym=[3, 4, 5, 6])
+    mesh = dgmesh.upload(ctx, chunk)
+    try:
+        rng = np.random.default_rng(2)
+        U0 = mesh.initialize(0.0)
+        U0 = U0 + 1e-3 * rng.normal(size=U0.shape)
+        out = {}
+        for tag, env in (("v2", None), ("v1", "1")):
+            if env is None:
+                monkeypatch.delenv("QDG_TILE_V1", raising=False)
+            else:
+                monkeypatch.setenv("QDG_TILE_V1", env)
+            R = mesh.rhs(0.0, U0)
+            mesh.state_upload(U0)
+            t = 0.0
+            for _ in range(3):
+                t += mesh.step(t)
+            out[tag] = (R, mesh.state_download(), t)
+        assert np.abs(out["v1"][0] - out["v2"][0]).max() <= 1e-12 * max(1.0, np.abs(out["v2"][0]).max())
+        assert np.abs(out["v1"][1] - out["v2"][1]).max() <= 1e-12 * max(1.0, np.abs(out["v2"][1]).max())
+        assert abs(out["v1"][2] - out["v2"][2]) <= 1e-14 * out["v2"][2]
+    finally:
+        monkeypatch.delenv("QDG_TILE_V1", raising=False)
+        mesh.close(); ctx.close()
