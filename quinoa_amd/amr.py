@@ -28,19 +28,19 @@ def refine_uniform(coord, inpoel, sidesets):
         n2 = C.c_size_t()
         capi._chk(L.qdg_refined_get(h, C.byref(n2), None, None, None, None, None, None))
         n2 = int(n2.value)
-        inp2 = np.zeros(32 * ne, dtype=np.uint64)
-        par = np.zeros(8 * ne, dtype=np.uint64)
-        c2 = np.zeros((3, n2))
+        inp2 = np.empty(32 * ne, dtype=np.uint64)          # (filled by the library)
+        par = np.empty(8 * ne, dtype=np.uint64)
+        c2 = np.empty((3, n2))
         tri2 = np.zeros(max(1, 12 * len(tset)), dtype=np.uint64)
         capi._chk(L.qdg_refined_get(h, None, inp2.ctypes.data_as(capi.c_szp), par.ctypes.data_as(capi.c_szp),
                                     c2[0].ctypes.data_as(capi.c_f64p), c2[1].ctypes.data_as(capi.c_f64p),
                                     c2[2].ctypes.data_as(capi.c_f64p), tri2.ctypes.data_as(capi.c_szp)))
     finally:
         L.qdg_refined_destroy(h)
-    tri2 = tri2[:12 * len(tset)].astype(np.int64).reshape(-1, 3)
+    tri2 = tri2[:12 * len(tset)].view(np.int64).reshape(-1, 3)
     tset2 = np.repeat(tset, 4)
     ss2 = {int(s): tri2[tset2 == s] for s in ids}
-    return np.ascontiguousarray(c2.T), inp2.astype(np.int64).reshape(-1, 4), ss2, par.astype(np.int64)
+    return np.ascontiguousarray(c2.T), inp2.view(np.int64).reshape(-1, 4), ss2, par.view(np.int64)
 
 
 def state_transfer(mesh_from, mesh_to, parent):
@@ -116,9 +116,9 @@ def refine_chunk(ch):
         n = [C.c_size_t() for _ in range(5)]
         capi._chk(L.qdg_chunk_refined_sizes(h, *[C.byref(v) for v in n]))
         nie2, nunk2, nn2, ntri2, nsend = (int(v.value) for v in n)
-        inp2 = np.zeros(4 * nunk2, dtype=np.uint64); gid2 = np.zeros(nunk2, dtype=np.uint64)
-        par = np.zeros(nunk2, dtype=np.uint64)
-        c2 = np.zeros((3, nn2))
+        inp2 = np.empty(4 * nunk2, dtype=np.uint64); gid2 = np.empty(nunk2, dtype=np.uint64)
+        par = np.empty(nunk2, dtype=np.uint64)
+        c2 = np.empty((3, nn2))
         tri2 = np.zeros(max(1, 3 * ntri2), dtype=np.uint64); tset2 = np.zeros(max(1, ntri2), dtype=np.int32)
         soff = np.zeros(nnbr + 1, dtype=np.uint64); slist = np.zeros(max(1, nsend), dtype=np.uint64)
         rc2 = np.zeros(max(1, nnbr), dtype=np.uint64)
@@ -130,14 +130,14 @@ def refine_chunk(ch):
                                           rc2.ctypes.data_as(capi.c_szp)))
     finally:
         L.qdg_chunk_refined_destroy(h)
-    tri2 = tri2[:3 * ntri2].astype(np.int64).reshape(-1, 3); tset2 = tset2[:ntri2]
-    soff = soff.astype(np.int64); slist = slist.astype(np.int64)
-    new = {"coord": np.ascontiguousarray(c2.T), "inpoel": inp2.astype(np.int64).reshape(-1, 4), "nielem": nie2,
+    tri2 = tri2[:3 * ntri2].view(np.int64).reshape(-1, 3); tset2 = tset2[:ntri2]
+    soff = soff.view(np.int64); slist = slist.view(np.int64)
+    new = {"coord": np.ascontiguousarray(c2.T), "inpoel": inp2.view(np.int64).reshape(-1, 4), "nielem": nie2,
            "sidesets": {int(s_): tri2[tset2 == s_] for s_ in ids if (tset2 == s_).any()},
-           "gid": gid2.astype(np.int64), "nbr_rank": nbr,
+           "gid": gid2.view(np.int64), "nbr_rank": nbr,
            "send_lists": [slist[soff[i]:soff[i + 1]] for i in range(nnbr)],
            "recv_counts": [int(v) for v in rc2[:nnbr]]}
-    return new, par.astype(np.int64)
+    return new, par.view(np.int64)
 
 
 def _refine_chunk_numpy(ch):

@@ -75,7 +75,11 @@ def _chk(rc):
 
 
 def _sz(a):
-    a = np.ascontiguousarray(a, dtype=np.uint64)
+    a = np.asarray(a)
+    if a.dtype == np.int64 and a.flags.c_contiguous:
+        a = a.view(np.uint64)              # ids are non-negative: same bits, no copy
+    else:
+        a = np.ascontiguousarray(a, dtype=np.uint64)
     return a, a.ctypes.data_as(c_szp)
 
 

@@ -247,10 +247,25 @@ extern "C" int qdg_chunk_destroy(qdg_chunk* c)
 // becomes (a,ab,ac), (b,bc,ab), (c,ac,bc), (ab,bc,ac) on the same side set (Refiner::boundary
 // regenerates the side sets of the children).  New nodes are the edge midpoints, numbered after
 // the old ones in the order the tets meet their edges.
+// large work and result arrays: no value-initialisation on resize, so that their pages are first
+// touched by the threads that fill them (a serial zero-fill of a few hundred MB costs more than
+// the refinement itself)
+template <class T> struct raw_alloc : std::allocator<T> {
+  template <class U> struct rebind { using other = raw_alloc<U>; };
+  raw_alloc() = default;
+  template <class U> raw_alloc(const raw_alloc<U>&) {}
+  template <class U, class... A> void construct(U* p, A&&... a)
+  {
+    if constexpr (sizeof...(A) == 0) ::new ((void*)p) U;
+    else ::new ((void*)p) U(std::forward<A>(a)...);
+  }
+};
+template <class T> using rawvec = std::vector<T, raw_alloc<T>>;
+
 struct qdg_refined {
   size_t nnode = 0;
-  std::vector<size_t> inpoel, parent, tri;
-  std::vector<double> x, y, z;
+  rawvec<size_t> inpoel, parent, tri;
+  rawvec<double> x, y, z;
 };
 
 // run fn(begin, end, thread) over [0, n) on up to 16 host threads (contiguous ranges in order)
@@ -285,7 +300,7 @@ extern "C" int qdg_refine_uniform(size_t nelem, size_t nnode, const size_t* inpo
   static const int EDG[6][2] = { {0, 1}, {0, 2}, {0, 3}, {1, 2}, {1, 3}, {2, 3} };   // AB AC AD BC BD CD
   struct E { uint64_t key; size_t slot; };
   const size_t ns = 6 * nelem;
-  std::vector<E> ed(ns);
+  rawvec<E> ed(ns);
   const size_t NB = std::max<size_t>(1, std::min<size_t>(256, nnode / 64 + 1));
   auto bucket_of = [&](uint64_t key) { return (size_t)((key >> 32) * NB / std::max<size_t>(nnode, 1)); };
   std::vector<std::vector<size_t>> cnt;          // [thread][bucket]
@@ -317,7 +332,7 @@ extern "C" int qdg_refine_uniform(size_t nelem, size_t nnode, const size_t* inpo
   // bucket offsets; within a bucket the threads' pieces follow each other in slot order
   std::vector<size_t> boff(NB + 1, 0);
   for (size_t b = 0; b < NB; ++b) { size_t n = 0; for (auto& c : cnt) n += c[b]; boff[b + 1] = boff[b] + n; }
-  std::vector<E> sorted(ns);
+  rawvec<E> sorted(ns);
   {
     std::vector<std::vector<size_t>> pos(cnt.size(), std::vector<size_t>(NB));
     for (size_t b = 0; b < NB; ++b) { size_t o = boff[b]; for (size_t t = 0; t < cnt.size(); ++t) { pos[t][b] = o; o += cnt[t][b]; } }
@@ -328,7 +343,7 @@ extern "C" int qdg_refine_uniform(size_t nelem, size_t nnode, const size_t* inpo
       });
     for (auto& t : th) t.join();
   }
-  std::vector<size_t> mid(ns), first(ns);
+  rawvec<size_t> mid(ns), first(ns);
   par_ranges(NB, [&](size_t b0, size_t b1, unsigned) {
     for (size_t b = b0; b < b1; ++b) {
       std::sort(sorted.begin() + boff[b], sorted.begin() + boff[b + 1],
@@ -429,9 +444,10 @@ extern "C" int qdg_refine_uniform(size_t nelem, size_t nnode, const size_t* inpo
 // global id of the child (8 * parent's global id + child number).
 struct qdg_chunk_refined {
   size_t nielem = 0, nunk = 0, nnode = 0;
-  std::vector<size_t> inpoel, gid, parent, tri, send_off, send_list, recv_counts;
+  rawvec<size_t> inpoel, gid, parent;
+  std::vector<size_t> tri, send_off, send_list, recv_counts;
   std::vector<int32_t> tri_set;
-  std::vector<double> x, y, z;
+  rawvec<double> x, y, z;
 };
 
 namespace {
@@ -448,7 +464,7 @@ inline FK fk_of(size_t n0, size_t n1, size_t n2, size_t idx)
   return { a, b, c, (uint32_t)idx };
 }
 // sort by key on all host cores: buckets by ranges of the smallest node, one thread per bucket
-void fk_sort(std::vector<FK>& v, size_t nnode)
+template <class V> void fk_sort(V& v, size_t nnode)
 {
   const size_t n = v.size();
   if (n < 65536) { std::sort(v.begin(), v.end(), fk_less); return; }
@@ -457,7 +473,7 @@ void fk_sort(std::vector<FK>& v, size_t nnode)
   auto bk = [&](const FK& f) { return (size_t)((uint64_t)f.a * NB / std::max<size_t>(nnode, 1)); };
   for (const FK& f : v) ++cnt[bk(f) + 1];
   for (size_t b = 0; b < NB; ++b) cnt[b + 1] += cnt[b];
-  std::vector<FK> w(n);
+  V w(n);
   { std::vector<size_t> pos(cnt.begin(), cnt.end() - 1); for (const FK& f : v) w[pos[bk(f)]++] = f; }
   par_ranges(NB, [&](size_t b0, size_t b1, unsigned) {
     for (size_t b = b0; b < b1; ++b) std::sort(w.begin() + cnt[b], w.begin() + cnt[b + 1], fk_less);
@@ -490,7 +506,7 @@ extern "C" int qdg_refine_chunk(size_t nielem, size_t nunk, size_t nnode, const 
   // chunk without being one)
   std::vector<size_t> tri_in; std::vector<int32_t> set_in;
   if (ntri) {
-    std::vector<FK> all(4 * nunk);
+    rawvec<FK> all(4 * nunk);
     par_ranges(nunk, [&](size_t e0, size_t e1, unsigned) {
       for (size_t e = e0; e < e1; ++e)
         for (int f = 0; f < 4; ++f)
@@ -511,7 +527,7 @@ extern "C" int qdg_refine_chunk(size_t nielem, size_t nunk, size_t nnode, const 
   if (int rc = qdg_refine_uniform(nunk, nnode, inpoel, x, y, z, set_in.size(), tri_in.data(), &rr)) return rc;
   std::unique_ptr<qdg_refined> r(rr);
   if (r->nnode > (size_t)UINT32_MAX || 32 * nunk > (size_t)UINT32_MAX) return fail("qdg_refine_chunk: chunk too large");
-  const std::vector<size_t>& i2 = r->inpoel;
+  const rawvec<size_t>& i2 = r->inpoel;
   const size_t nown = 8 * nielem, nall = 8 * nunk;
 
   // A new ghost is a child of an old ghost that shares a face with a child of an owned tet; such a
@@ -519,7 +535,7 @@ extern "C" int qdg_refine_chunk(size_t nielem, size_t nunk, size_t nnode, const 
   // take part in the matching (a surface-sized set, not all 32 * nunk child faces).
   std::vector<char> on_iface(nunk, 0);
   {
-    std::vector<FK> all(4 * nunk);
+    rawvec<FK> all(4 * nunk);
     par_ranges(nunk, [&](size_t e0, size_t e1, unsigned) {
       for (size_t e = e0; e < e1; ++e)
         for (int f = 0; f < 4; ++f)
