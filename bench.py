@@ -274,7 +274,8 @@ def _amr_single(nx, steps, ne0, ne1, ms0, ms1, th, tr, tt, ok):
             "refine_host_ms": th * 1e3, "rebuild_upload_ms": tr * 1e3, "state_transfer_ms": tt * 1e3,
             "rebuild_upload_ms_per_Mtet": tr * 1e3 / (ne1 / 1e6),
             "steps_of_new_mesh_per_rebuild": tr * 1e3 / ms1, "finite": ok,
-            "note": "refine = qdg_refine_uniform on the host (AMR bookkeeping stays host-side); rebuild = "
+            "note": "refine (key refine_host_ms) = qdg_refine_uniform_device: edge sort + scans on the GPU, the "
+                    "refined mesh copied back to the host, where AMR bookkeeping stays; rebuild = "
                     "qdg_mesh_from_connectivity on the refined mesh, all on the device: boundary faces, "
                     "FaceData, geometry, Morton order, numbering, face tasks (only connectivity + "
                     "coordinates cross PCIe); transfer = qdg_state_transfer (child <- parent, device)"}

@@ -361,6 +361,11 @@ int qdg_refine_uniform(size_t nelem, size_t nnode, const size_t* inpoel, const d
 int qdg_refined_get(const qdg_refined* r, size_t* nnode, size_t* inpoel, size_t* parent,
                     double* x, double* y, double* z, size_t* tri);
 int qdg_refined_destroy(qdg_refined* r);
+/* The same refinement computed on the context's GPU (one radix sort of the edge keys and two
+ * scans) and copied back: identical arrays, for meshes whose host-side refinement time matters. */
+int qdg_refine_uniform_device(qdg_ctx* ctx, size_t nelem, size_t nnode, const size_t* inpoel,
+                              const double* x, const double* y, const double* z, size_t ntri,
+                              const size_t* tri, qdg_refined** out);
 
 /* Uniform refinement of ONE RANK's chunk of a decomposition, by the rank alone (the re-mesh step of
  * DG::resizePostAMR on a chare, src/Inciter/DG.cpp:1536-1612): in = the chunk as qdg_chunk_build

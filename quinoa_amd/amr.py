@@ -10,8 +10,9 @@ import numpy as np
 from . import capi
 
 
-def refine_uniform(coord, inpoel, sidesets):
-    """-> coord2[nnode2,3], inpoel2[8*ne,4], sidesets2 {id: tri[4*n,3]}, parent[8*ne]"""
+def refine_uniform(coord, inpoel, sidesets, ctx=None):
+    """-> coord2[nnode2,3], inpoel2[8*ne,4], sidesets2 {id: tri[4*n,3]}, parent[8*ne]
+    ctx: compute on that context's GPU (qdg_refine_uniform_device: same arrays)"""
     L = capi.lib()
     coord = np.asarray(coord, dtype=np.float64)
     inp, pinp = capi._sz(np.asarray(inpoel).reshape(-1))
@@ -22,8 +23,12 @@ def refine_uniform(coord, inpoel, sidesets):
     tset = np.concatenate([np.full(len(sidesets[s]), s, np.int64) for s in ids]) if ids else np.zeros(0, np.int64)
     tri, ptri = capi._sz(tri.reshape(-1))
     h = C.c_void_p()
-    capi._chk(L.qdg_refine_uniform(C.c_size_t(ne), C.c_size_t(nn), pinp, px, py, pz, C.c_size_t(len(tset)),
-                                   ptri, C.byref(h)))
+    if ctx is not None:
+        capi._chk(L.qdg_refine_uniform_device(ctx.h, C.c_size_t(ne), C.c_size_t(nn), pinp, px, py, pz,
+                                              C.c_size_t(len(tset)), ptri, C.byref(h)))
+    else:
+        capi._chk(L.qdg_refine_uniform(C.c_size_t(ne), C.c_size_t(nn), pinp, px, py, pz, C.c_size_t(len(tset)),
+                                       ptri, C.byref(h)))
     try:
         n2 = C.c_size_t()
         capi._chk(L.qdg_refined_get(h, C.byref(n2), None, None, None, None, None, None))
@@ -52,17 +57,20 @@ class RefinedRun:
     """One chunk without ghosts that is refined uniformly while it runs: holds the host mesh
     (what Discretization holds), the device mesh handle and the resident state."""
 
-    def __init__(self, ctx, coord, inpoel, sidesets):
+    def __init__(self, ctx, coord, inpoel, sidesets, device_refine=True):
         self.ctx = ctx
+        self.device_refine = device_refine
         self.coord, self.inpoel, self.sidesets = np.asarray(coord, dtype=np.float64), np.asarray(inpoel), sidesets
         self.mesh = capi.mesh_from_connectivity(ctx, self.inpoel, self.coord, self.sidesets)
         self.timings = []
 
     def refine(self):
-        """uniform 1:8 refinement + rebuild on the device + state transfer; returns the seconds
-        spent in (host refinement, device mesh rebuild incl. upload, state transfer)"""
+        """uniform 1:8 refinement (on the device by default, copied back for the host's book-keeping)
+        + rebuild on the device + state transfer; returns the seconds spent in (refinement, device
+        mesh rebuild incl. upload, state transfer)"""
         t0 = time.perf_counter()
-        c2, i2, s2, par = refine_uniform(self.coord, self.inpoel, self.sidesets)
+        c2, i2, s2, par = refine_uniform(self.coord, self.inpoel, self.sidesets,
+                                         ctx=self.ctx if self.device_refine else None)
         t1 = time.perf_counter()
         new = capi.mesh_from_connectivity(self.ctx, i2, c2, s2)
         self.ctx.synchronize()

@@ -929,6 +929,195 @@ static int dev_build_layout(qdg_ctx* ctx, DevFD& fd, const std::vector<int>& bcf
   return 0;
 }
 
+// ======================================================================================
+// Uniform 1:8 refinement on the device: same result, array for array, as qdg_refine_uniform
+// (qdg_partition.cpp: children order of src/Inciter/AMR/refinement.hpp, midpoints numbered after
+// the old nodes in the order the tets meet their edges), computed with one radix sort of the
+// 6 * nelem edge keys and two scans, then copied back into a qdg_refined handle.  What a re-mesh
+// of ~10 M tets spends on the host otherwise (0.3 s) takes a few tens of ms here.
+namespace {
+__constant__ int c_edg[6][2] = { {0, 1}, {0, 2}, {0, 3}, {1, 2}, {1, 3}, {2, 3} };   // AB AC AD BC BD CD
+
+__global__ void k_edge_keys(const uint64_t* __restrict__ inpoel, size_t ns, size_t nnode, uint64_t* __restrict__ key,
+                            uint32_t* __restrict__ slot, int* __restrict__ err)
+{
+  const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= ns) return;
+  const size_t e = s / 6; const int k = (int)(s - 6 * e);
+  const uint64_t a = inpoel[4 * e + c_edg[k][0]], b = inpoel[4 * e + c_edg[k][1]];
+  if (a >= nnode || b >= nnode) { *err = 1; key[s] = 0; slot[s] = (uint32_t)s; return; }
+  if (a == b) { *err = 2; key[s] = 0; slot[s] = (uint32_t)s; return; }
+  key[s] = ((a < b ? a : b) << 32) | (a < b ? b : a);
+  slot[s] = (uint32_t)s;
+}
+// position of the head of every run of equal keys (0 elsewhere; an inclusive max-scan spreads it)
+__global__ void k_run_heads(const uint64_t* __restrict__ skey, size_t ns, int* __restrict__ headpos)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ns) return;
+  headpos[i] = (i == 0 || skey[i] != skey[i - 1]) ? (int)i : 0;
+}
+// first[slot] = the smallest slot with the same edge (the sort is stable: the head of the run);
+// ishead[slot] = 1 where the slot itself is that one
+__global__ void k_first_slot(const uint32_t* __restrict__ sslot, const int* __restrict__ headpos, size_t ns,
+                             uint32_t* __restrict__ first, int* __restrict__ ishead)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ns) return;
+  const uint32_t s = sslot[i], f = sslot[headpos[i]];
+  first[s] = f;
+  ishead[s] = (f == s) ? 1 : 0;
+}
+__global__ void k_midpoints(const uint64_t* __restrict__ key, const uint32_t* __restrict__ first,
+                            const int* __restrict__ ishead, const int* __restrict__ rank, size_t ns, size_t nnode,
+                            const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ z,
+                            double* __restrict__ x2, double* __restrict__ y2, double* __restrict__ z2)
+{
+  const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= ns || !ishead[s]) return;
+  const size_t id = nnode + (size_t)rank[s];
+  const uint64_t a = key[s] >> 32, b = key[s] & 0xffffffffu;
+  x2[id] = 0.5 * (x[a] + x[b]); y2[id] = 0.5 * (y[a] + y[b]); z2[id] = 0.5 * (z[a] + z[b]);
+}
+__global__ void k_children(const uint64_t* __restrict__ inpoel, const uint32_t* __restrict__ first,
+                           const int* __restrict__ rank, size_t nelem, size_t nnode, uint64_t* __restrict__ out,
+                           uint64_t* __restrict__ parent)
+{
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nelem) return;
+  const uint64_t A = inpoel[4 * e], B = inpoel[4 * e + 1], C = inpoel[4 * e + 2], D = inpoel[4 * e + 3];
+  uint64_t M[6];
+  for (int k = 0; k < 6; ++k) M[k] = nnode + (uint64_t)rank[first[6 * e + k]];
+  const uint64_t AB = M[0], AC = M[1], AD = M[2], BC = M[3], BD = M[4], CD = M[5];
+  const uint64_t ch[8][4] = { { A, AB, AC, AD }, { B, BC, AB, BD }, { C, AC, BC, CD }, { D, AD, CD, BD },
+                              { BC, CD, AC, BD }, { AB, BD, AC, AD }, { AB, BC, AC, BD }, { AC, BD, CD, AD } };
+  for (int k = 0; k < 8; ++k) {
+    for (int i = 0; i < 4; ++i) out[4 * (8 * e + k) + i] = ch[k][i];
+    parent[8 * e + k] = e;
+  }
+}
+__device__ bool edge_mid(const uint64_t* skey, const uint32_t* sslot, const uint32_t* first, const int* rank,
+                         size_t ns, size_t nnode, uint64_t a, uint64_t b, uint64_t& m)
+{
+  const uint64_t key = ((a < b ? a : b) << 32) | (a < b ? b : a);
+  size_t lo = 0, hi = ns;
+  while (lo < hi) { const size_t mid = (lo + hi) >> 1; if (skey[mid] < key) lo = mid + 1; else hi = mid; }
+  if (lo >= ns || skey[lo] != key) return false;
+  m = nnode + (uint64_t)rank[first[sslot[lo]]];
+  return true;
+}
+__global__ void k_child_tris(const uint64_t* __restrict__ tri, size_t ntri, const uint64_t* __restrict__ skey,
+                             const uint32_t* __restrict__ sslot, const uint32_t* __restrict__ first,
+                             const int* __restrict__ rank, size_t ns, size_t nnode, uint64_t* __restrict__ out,
+                             int* __restrict__ err)
+{
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ntri) return;
+  const uint64_t a = tri[3 * t], b = tri[3 * t + 1], c = tri[3 * t + 2];
+  uint64_t ab = 0, bc = 0, ac = 0;
+  if (a >= nnode || b >= nnode || c >= nnode || !edge_mid(skey, sslot, first, rank, ns, nnode, a, b, ab) ||
+      !edge_mid(skey, sslot, first, rank, ns, nnode, b, c, bc) || !edge_mid(skey, sslot, first, rank, ns, nnode, a, c, ac)) {
+    *err = 3;
+    return;
+  }
+  const uint64_t ct[4][3] = { { a, ab, ac }, { b, bc, ab }, { c, ac, bc }, { ab, bc, ac } };
+  for (int k = 0; k < 4; ++k)
+    for (int i = 0; i < 3; ++i) out[3 * (4 * t + k) + i] = ct[k][i];
+}
+}  // namespace
+
+extern "C" int qdg_refine_uniform_device(qdg_ctx* ctx, size_t nelem, size_t nnode, const size_t* inpoel,
+                                         const double* x, const double* y, const double* z, size_t ntri,
+                                         const size_t* tri, qdg_refined** out)
+{
+  QDG_TRY
+  if (!ctx || !inpoel || !x || !y || !z || !out || (ntri && !tri)) return fail("qdg_refine_uniform_device: null argument");
+  *out = nullptr;
+  const size_t ns = 6 * nelem;
+  if (nelem == 0) return fail("qdg_refine_uniform_device: empty mesh");
+  if (nnode > (size_t)UINT32_MAX / 2 || ns > (size_t)INT32_MAX) return fail("qdg_refine_uniform_device: mesh too large for 32-bit slots");
+  DHIP(hipSetDevice(ctx_device(ctx)));
+  hipStream_t s = ctx_stream(ctx);
+  Buf<uint64_t> d_inp, d_tri, key, skey, d_out, d_par, d_tri2;
+  Buf<uint32_t> slot, sslot, first;
+  Buf<int> headpos, headscan, ishead, rank, d_err;
+  Buf<double> dx, dy, dz, x2, y2, z2;
+  DHIP(d_inp.alloc(4 * nelem)); DHIP(dx.alloc(nnode)); DHIP(dy.alloc(nnode)); DHIP(dz.alloc(nnode));
+  DHIP(key.alloc(ns)); DHIP(skey.alloc(ns)); DHIP(slot.alloc(ns)); DHIP(sslot.alloc(ns)); DHIP(first.alloc(ns));
+  DHIP(headpos.alloc(ns)); DHIP(headscan.alloc(ns)); DHIP(ishead.alloc(ns)); DHIP(rank.alloc(ns)); DHIP(d_err.alloc(1));
+  DHIP(hipMemcpyAsync(d_inp.p, inpoel, 4 * nelem * 8, hipMemcpyHostToDevice, s));
+  DHIP(hipMemcpyAsync(dx.p, x, nnode * 8, hipMemcpyHostToDevice, s));
+  DHIP(hipMemcpyAsync(dy.p, y, nnode * 8, hipMemcpyHostToDevice, s));
+  DHIP(hipMemcpyAsync(dz.p, z, nnode * 8, hipMemcpyHostToDevice, s));
+  DHIP(hipMemsetAsync(d_err.p, 0, sizeof(int), s));
+  k_edge_keys<<<nblk(ns), 256, 0, s>>>(d_inp.p, ns, nnode, key.p, slot.p, d_err.p);
+  {
+    unsigned bits = 1;
+    while (bits < 32 && ((size_t)1 << bits) < nnode) ++bits;
+    size_t bytes = 0;
+    DHIP(rocprim::radix_sort_pairs(nullptr, bytes, key.p, skey.p, slot.p, sslot.p, ns, 0, 32 + bits, s));
+    Buf<char> tmp;
+    DHIP(tmp.alloc(bytes));
+    DHIP(rocprim::radix_sort_pairs(tmp.p, bytes, key.p, skey.p, slot.p, sslot.p, ns, 0, 32 + bits, s));
+    DHIP(hipStreamSynchronize(s));
+  }
+  k_run_heads<<<nblk(ns), 256, 0, s>>>(skey.p, ns, headpos.p);
+  {
+    size_t bytes = 0;
+    DHIP(rocprim::inclusive_scan(nullptr, bytes, headpos.p, headscan.p, ns, rocprim::maximum<int>(), s));
+    Buf<char> tmp;
+    DHIP(tmp.alloc(bytes));
+    DHIP(rocprim::inclusive_scan(tmp.p, bytes, headpos.p, headscan.p, ns, rocprim::maximum<int>(), s));
+    DHIP(hipStreamSynchronize(s));
+  }
+  k_first_slot<<<nblk(ns), 256, 0, s>>>(sslot.p, headscan.p, ns, first.p, ishead.p);
+  {
+    size_t bytes = 0;
+    DHIP(rocprim::exclusive_scan(nullptr, bytes, ishead.p, rank.p, 0, ns, rocprim::plus<int>(), s));
+    Buf<char> tmp;
+    DHIP(tmp.alloc(bytes));
+    DHIP(rocprim::exclusive_scan(tmp.p, bytes, ishead.p, rank.p, 0, ns, rocprim::plus<int>(), s));
+    DHIP(hipStreamSynchronize(s));
+  }
+  int last_rank = 0, last_head = 0, herr = 0;
+  DHIP(hipMemcpyAsync(&last_rank, rank.p + (ns - 1), sizeof(int), hipMemcpyDeviceToHost, s));
+  DHIP(hipMemcpyAsync(&last_head, ishead.p + (ns - 1), sizeof(int), hipMemcpyDeviceToHost, s));
+  DHIP(hipMemcpyAsync(&herr, d_err.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  DHIP(hipStreamSynchronize(s));
+  if (herr == 1) return fail("qdg_refine_uniform: inpoel entry out of range");
+  if (herr == 2) return fail("qdg_refine_uniform: degenerate tet");
+  const size_t nn = nnode + (size_t)last_rank + (size_t)last_head;
+  std::unique_ptr<qdg_refined> r(new qdg_refined);
+  r->nnode = nn;
+  r->x.resize(nn); r->y.resize(nn); r->z.resize(nn);
+  r->inpoel.resize(32 * nelem); r->parent.resize(8 * nelem); r->tri.resize(12 * ntri);
+  DHIP(x2.alloc(nn)); DHIP(y2.alloc(nn)); DHIP(z2.alloc(nn));
+  DHIP(d_out.alloc(32 * nelem)); DHIP(d_par.alloc(8 * nelem));
+  DHIP(hipMemcpyAsync(x2.p, dx.p, nnode * 8, hipMemcpyDeviceToDevice, s));
+  DHIP(hipMemcpyAsync(y2.p, dy.p, nnode * 8, hipMemcpyDeviceToDevice, s));
+  DHIP(hipMemcpyAsync(z2.p, dz.p, nnode * 8, hipMemcpyDeviceToDevice, s));
+  k_midpoints<<<nblk(ns), 256, 0, s>>>(key.p, first.p, ishead.p, rank.p, ns, nnode, dx.p, dy.p, dz.p, x2.p, y2.p, z2.p);
+  k_children<<<nblk(nelem), 256, 0, s>>>(d_inp.p, first.p, rank.p, nelem, nnode, d_out.p, d_par.p);
+  if (ntri) {
+    DHIP(d_tri.alloc(3 * ntri)); DHIP(d_tri2.alloc(12 * ntri));
+    DHIP(hipMemcpyAsync(d_tri.p, tri, 3 * ntri * 8, hipMemcpyHostToDevice, s));
+    k_child_tris<<<nblk(ntri), 256, 0, s>>>(d_tri.p, ntri, skey.p, sslot.p, first.p, rank.p, ns, nnode, d_tri2.p, d_err.p);
+    DHIP(hipMemcpyAsync(r->tri.data(), d_tri2.p, 12 * ntri * 8, hipMemcpyDeviceToHost, s));
+  }
+  DHIP(hipMemcpyAsync(r->inpoel.data(), d_out.p, 32 * nelem * 8, hipMemcpyDeviceToHost, s));
+  DHIP(hipMemcpyAsync(r->parent.data(), d_par.p, 8 * nelem * 8, hipMemcpyDeviceToHost, s));
+  DHIP(hipMemcpyAsync(r->x.data(), x2.p, nn * 8, hipMemcpyDeviceToHost, s));
+  DHIP(hipMemcpyAsync(r->y.data(), y2.p, nn * 8, hipMemcpyDeviceToHost, s));
+  DHIP(hipMemcpyAsync(r->z.data(), z2.p, nn * 8, hipMemcpyDeviceToHost, s));
+  DHIP(hipMemcpyAsync(&herr, d_err.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  DHIP(hipStreamSynchronize(s));
+  DHIP(hipGetLastError());
+  if (herr == 3) return fail("qdg_refine_uniform: a side-set triangle is not a face of the mesh");
+  *out = r.release();
+  return 0;
+  QDG_CATCH
+}
+
 extern "C" int qdg_mesh_from_connectivity(qdg_ctx* ctx, size_t nelem, size_t nnode, const size_t* inpoel,
                                           const double* x, const double* y, const double* z,
                                           size_t ntri, const size_t* tri, const int32_t* tri_set,

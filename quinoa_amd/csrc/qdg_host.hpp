@@ -3,6 +3,8 @@
 #include <cstddef>
 #include <cstdint>
 #include <exception>
+#include <memory>
+#include <utility>
 #include <string>
 #include <vector>
 
@@ -25,3 +27,25 @@ void set_error(const std::string& msg);
   }
 
 }  // namespace qdg
+
+// large work and result arrays: no value-initialisation on resize, so that their pages are first
+// touched by the threads that fill them (a serial zero-fill of a few hundred MB costs more than
+// the refinement itself)
+template <class T> struct raw_alloc : std::allocator<T> {
+  template <class U> struct rebind { using other = raw_alloc<U>; };
+  raw_alloc() = default;
+  template <class U> raw_alloc(const raw_alloc<U>&) {}
+  template <class U, class... A> void construct(U* p, A&&... a)
+  {
+    if constexpr (sizeof...(A) == 0) ::new ((void*)p) U;
+    else ::new ((void*)p) U(std::forward<A>(a)...);
+  }
+};
+template <class T> using rawvec = std::vector<T, raw_alloc<T>>;
+
+struct qdg_refined {
+  size_t nnode = 0;
+  rawvec<size_t> inpoel, parent, tri;
+  rawvec<double> x, y, z;
+};
+

@@ -247,27 +247,6 @@ extern "C" int qdg_chunk_destroy(qdg_chunk* c)
 // becomes (a,ab,ac), (b,bc,ab), (c,ac,bc), (ab,bc,ac) on the same side set (Refiner::boundary
 // regenerates the side sets of the children).  New nodes are the edge midpoints, numbered after
 // the old ones in the order the tets meet their edges.
-// large work and result arrays: no value-initialisation on resize, so that their pages are first
-// touched by the threads that fill them (a serial zero-fill of a few hundred MB costs more than
-// the refinement itself)
-template <class T> struct raw_alloc : std::allocator<T> {
-  template <class U> struct rebind { using other = raw_alloc<U>; };
-  raw_alloc() = default;
-  template <class U> raw_alloc(const raw_alloc<U>&) {}
-  template <class U, class... A> void construct(U* p, A&&... a)
-  {
-    if constexpr (sizeof...(A) == 0) ::new ((void*)p) U;
-    else ::new ((void*)p) U(std::forward<A>(a)...);
-  }
-};
-template <class T> using rawvec = std::vector<T, raw_alloc<T>>;
-
-struct qdg_refined {
-  size_t nnode = 0;
-  rawvec<size_t> inpoel, parent, tri;
-  rawvec<double> x, y, z;
-};
-
 // run fn(begin, end, thread) over [0, n) on up to 16 host threads (contiguous ranges in order)
 template <class F> static unsigned par_ranges(size_t n, F&& fn, size_t serial_below = 32768)
 {

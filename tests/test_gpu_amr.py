@@ -152,3 +152,25 @@ def test_config5_partitioned_chunks_refine_on_the_gpu():
         for m in meshes:
             m.close()
         one.mesh.close(); ctx.close(); ctx1.close()
+
+
+def test_device_refinement_equals_host_refinement():
+    """qdg_refine_uniform_device: every array identical to the host's qdg_refine_uniform (children
+    order, midpoint numbering in the order the tets meet their edges, side-set triangles), on a
+    jittered Kuhn box and on the reference's own fixture mesh"""
+    from quinoa_amd import amr, capi, meshgen
+    ctx = capi.Context(4, flux="hllc", problem="sod_shocktube", gamma=1.4, cfl=0.3)
+    try:
+        meshes = [meshgen.kuhn_box(9, 7, 5)]
+        fix = load_fixture("sedov_dgp1")
+        meshes.append({"coord": fix["coord"], "inpoel": fix["inpoel"],
+                       "sidesets": {int(s): fix["ss_tri_%d" % s] for s in fix["ss_ids"]}})
+        for g in meshes:
+            ch, ih, sh, ph = amr.refine_uniform(g["coord"], g["inpoel"], g["sidesets"])
+            cd, idv, sd, pd = amr.refine_uniform(g["coord"], g["inpoel"], g["sidesets"], ctx=ctx)
+            assert np.array_equal(ih, idv) and np.array_equal(ph, pd) and np.array_equal(ch, cd)
+            assert sorted(sh) == sorted(sd)
+            for k in sh:
+                assert np.array_equal(sh[k], sd[k])
+    finally:
+        ctx.close()
