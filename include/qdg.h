@@ -417,9 +417,11 @@ int qdg_dev_facedata(qdg_ctx* ctx, size_t nelem, size_t nnode, const size_t* inp
 
 /* One call from connectivity to a mesh handle, for a chunk WITHOUT ghosts (serial run,
  * or the re-build after mesh refinement, DG::resizePostAMR src/Inciter/DG.cpp:1536-1612):
- * boundary faces regenerated from the side-set triangles (qdg_bnd_faces), FaceData and
- * geometry on the device (qdg_dev_facedata), then qdg_mesh_upload.  tri_set[i] is the side
- * set id of triangle i. */
+ * boundary faces regenerated from the side-set triangles (the order of qdg_bnd_faces), FaceData
+ * and geometry (the arrays of qdg_dev_facedata), device order, numbering and face tasks (what
+ * qdg_mesh_upload derives on the host) -- all on the device; only connectivity, coordinates and
+ * the side-set triangles cross PCIe.  tri_set[i] is the side set id of triangle i.
+ * (QDG_HOST_LAYOUT=1: FaceData on the device, layout by qdg_mesh_upload, for equivalence tests.) */
 int qdg_mesh_from_connectivity(qdg_ctx* ctx, size_t nelem, size_t nnode, const size_t* inpoel,
                                const double* x, const double* y, const double* z, size_t ntri,
                                const size_t* tri, const int32_t* tri_set, qdg_mesh** out);
