@@ -129,6 +129,19 @@ int qdg_ctx_destroy(qdg_ctx* ctx);
 /* run all kernels of this context on an existing HIP stream (hipStream_t) */
 int qdg_ctx_set_stream(qdg_ctx* ctx, void* hip_stream);
 int qdg_ctx_synchronize(qdg_ctx* ctx);
+/* Tuning / A-B switches, by name; nothing but QDG_UPLOAD_STATS (timings on stderr) is read from
+ * the process environment.  Set before the meshes they concern are created.  Unknown name: -1.
+ *   "p1_rhs"        0 (default) tile / face-task kernels: every in-tile face once, LDS atomics
+ *                   (results reproducible to rounding); 1 element-centric kernel, bitwise
+ *                   reproducible run to run
+ *   "p1_variant"    form of the uniform-order DG-P1 tile kernel: 0 k_rhs_p1v (256 lanes, 2 waves
+ *                   per SIMD), 1 / 2 k_rhs_p1w with 384 / 512 lanes (3 / 4 waves per SIMD)
+ *   "fused_update"  1 (default) stage-0 RK update fused with the Superbee limiter of stage 1
+ *   "halo_overlap"  1: qdg_step_comm exchanges on a second stream behind the halo-free rows
+ *   "renumber"      1 (default) Morton order of the device rows; 0 keeps the caller's order
+ *   "host_layout"   1: qdg_mesh_from_connectivity runs qdg_mesh_upload's host layout code (A/B) */
+int qdg_ctx_set_option(qdg_ctx* ctx, const char* name, int value);
+int qdg_ctx_get_option(qdg_ctx* ctx, const char* name, int* value);
 /* Problem::solution at n points (DGPDE::analyticSolution, src/PDE/DGPDE.hpp:141-144;
  * also the Dirichlet state and the initial condition): out[i*ncomp + c], ncomp = 5
  * (CompFlow) or 1 (Transport); evaluated by the device functors of the context's problem */

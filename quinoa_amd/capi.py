@@ -168,12 +168,17 @@ def gen_geoelem(inpoel, coord):
 
 # ------------------------------------------------------------------ device side
 
+# options applied to every new Context (qdg_ctx_set_option); tests use it to run a whole
+# golden case through another kernel form
+default_options = {}
+
+
 class Context:
     def __init__(self, ndof, flux="hllc", limiter="nolimiter", problem="sod_shocktube",
                  gamma=1.4, pstiff=0.0, cv=717.5, cweight=1.0, alpha=0.0, beta=0.0, p0=0.0,
                  cfl=0.0, dt=0.0, bc_dirichlet=(), bc_sym=(), bc_extrapolate=(), device=0,
                  pde="compflow", bc_inlet=(), bc_outlet=(), pref=False, tolref=0.1,
-                 betax=0.0, betay=0.0, betaz=0.0, r0=0.0, ce=0.0, kappa=0.0):
+                 betax=0.0, betay=0.0, betaz=0.0, r0=0.0, ce=0.0, kappa=0.0, options=None):
         L = lib()
         ss = list(bc_dirichlet) + list(bc_sym) + list(bc_extrapolate) + list(bc_inlet) + list(bc_outlet)
         ty = [BC_DIRICHLET] * len(bc_dirichlet) + [BC_SYMMETRY] * len(bc_sym) + \
@@ -191,6 +196,8 @@ class Context:
         _chk(L.qdg_ctx_create(C.byref(self.cfg), C.byref(self.h)))
         self.ndof = ndof
         self.nprop = (1 if pde == "transport" else 5) * ndof
+        for k, v in {**default_options, **(options or {})}.items():
+            self.set_option(k, v)
 
     def solution(self, pts, t):
         """Problem::solution at points [n,3] -> [n, ncomp]"""
@@ -252,6 +259,16 @@ class Context:
 
     def synchronize(self):
         _chk(lib().qdg_ctx_synchronize(self.h))
+
+    def set_option(self, name, value):
+        """qdg_ctx_set_option: tuning / A-B switch by name (see include/qdg.h); set before the
+        meshes it concerns are created"""
+        _chk(lib().qdg_ctx_set_option(self.h, name.encode(), C.c_int(int(value))))
+
+    def get_option(self, name):
+        v = C.c_int()
+        _chk(lib().qdg_ctx_get_option(self.h, name.encode(), C.byref(v)))
+        return v.value
 
     def close(self):
         if self.h:

@@ -137,7 +137,7 @@ extern "C" int qdg_ctx_create(const qdg_config* cfg, qdg_ctx** out)
   HIPCHK(hipSetDevice(cfg->device));
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, cfg->device));
-  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !std::getenv("QDG_ALLOW_ANY_ARCH"))
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return fail(std::string("qdg_ctx_create: device is ") + prop.gcnArchName +
                 ", this library is built for gfx950 (MI355X) only");
   std::unique_ptr<qdg_ctx> c(new qdg_ctx);
@@ -192,6 +192,41 @@ extern "C" int qdg_ctx_set_stream(qdg_ctx* ctx, void* s)
   }
   ctx->stream = (hipStream_t)s;
   ctx->own_stream = false;
+  return 0;
+  QDG_CATCH
+}
+
+// tuning / A-B switches by name (no behaviour is read from the process environment)
+static int* option_slot(qdg_ctx* ctx, const char* name)
+{
+  static const struct { const char* n; int qdg::Options::*p; } tab[] = {
+    { "p1_rhs", &qdg::Options::p1_rhs },           { "p1_variant", &qdg::Options::p1_variant },
+    { "fused_update", &qdg::Options::fused_update }, { "halo_overlap", &qdg::Options::halo_overlap },
+    { "renumber", &qdg::Options::renumber },       { "host_layout", &qdg::Options::host_layout },
+  };
+  for (const auto& t : tab)
+    if (std::strcmp(name, t.n) == 0) return &(ctx->opt.*(t.p));
+  return nullptr;
+}
+
+extern "C" int qdg_ctx_set_option(qdg_ctx* ctx, const char* name, int value)
+{
+  QDG_TRY
+  if (!ctx || !name) return fail("qdg_ctx_set_option: null argument");
+  int* p = option_slot(ctx, name);
+  if (!p) return fail(std::string("qdg_ctx_set_option: unknown option '") + name + "'");
+  *p = value;
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_ctx_get_option(qdg_ctx* ctx, const char* name, int* value)
+{
+  QDG_TRY
+  if (!ctx || !name || !value) return fail("qdg_ctx_get_option: null argument");
+  const int* p = option_slot(ctx, name);
+  if (!p) return fail(std::string("qdg_ctx_get_option: unknown option '") + name + "'");
+  *value = *p;
   return 0;
   QDG_CATCH
 }
@@ -304,7 +339,7 @@ extern "C" int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t 
   // ---- device order of interior tets: Morton curve of the centroids ------
   std::vector<int> d2h(ne), h2d(ne);
   std::iota(d2h.begin(), d2h.end(), 0);
-  if (!std::getenv("QDG_NO_RENUMBER")) {
+  if (ctx->opt.renumber) {
     double lo[3] = { DBL_MAX, DBL_MAX, DBL_MAX }, hi[3] = { -DBL_MAX, -DBL_MAX, -DBL_MAX };
     for (size_t e = 0; e < nie; ++e)
       for (int d = 0; d < 3; ++d) {
@@ -466,36 +501,13 @@ extern "C" int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t 
     }
 
   lap("device arrays (host side)");
-  // ---- face tasks per tile (k_rhs_p1t) -----------------------------------------
-  // Tiles are runs of consecutive device rows: TILE rows each, or (QDG_TILE_TASKS=n) cut when
-  // the face tasks of a run would exceed n.  Measured (round 2, 1 M tets): runs cut at 512 tasks
-  // -- two full rounds of the workgroup's 256 lanes instead of 2.4 -- are no faster than plain
-  // 248-row tiles (0.204 vs 0.201 ms; 576: 0.198), so fixed tiles stay the default.
+  // ---- face tasks per tile (tile kernels of qdg_rhs_p1.hip) ---------------------
+  // Tiles are runs of TILE consecutive device rows.  (Round 2 also measured runs cut at a task
+  // count -- two full rounds of the workgroup's lanes: no faster; not kept.)
   std::vector<int> h_tile_row(1, 0);
-  {
-    const char* lim = std::getenv("QDG_TILE_TASKS");
-    const int limit = lim ? std::atoi(lim) : 0;
-    if (limit <= 0) {
-      for (size_t r = TILE; r < nie; r += TILE) h_tile_row.push_back((int)r);
-    } else {
-      int start = 0, ntask = 0;
-      for (size_t d = 0; d < nie; ++d) {
-        int k = 0;
-        for (int lf = 0; lf < 4; ++lf) {
-          const int nb = h_nbr[lf * stride + d];
-          if (nb >= start && nb < (int)d) ++k;
-        }
-        if ((int)d - start >= TILE || (d > (size_t)start && ntask + 4 - k > limit)) {
-          h_tile_row.push_back((int)d);
-          start = (int)d; ntask = 0; k = 0;
-        }
-        ntask += 4 - k;
-      }
-    }
-    h_tile_row.push_back((int)nie);
-  }
+  for (size_t r = TILE; r < nie; r += TILE) h_tile_row.push_back((int)r);
+  h_tile_row.push_back((int)nie);
   const int ntile = (int)h_tile_row.size() - 1;
-  const bool fixed_tiles = [&] { const char* l = std::getenv("QDG_TILE_TASKS"); return !(l && std::atoi(l) > 0); }();
   int ntile_inner = 0;
   while (ntile_inner < ntile && (size_t)h_tile_row[ntile_inner + 1] <= ninner) ++ntile_inner;
   std::vector<int> h_tile_off(ntile + 1, 0), h_task_a, h_task_nb, h_task_f;
@@ -518,7 +530,10 @@ extern "C" int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t 
             kind = TASK_INT; pl = nb - (int)e0;
           } else { kind = TASK_EXT; nbid = nb; }
           const int a = TASK_PACK(d - e0, lf, own_left, code, kind, bc, pl);
-          tt.push_back({ (kind << 2) | lf, a, nbid, h_fid[lf * stride + d] });
+          // faces to other tiles first (their neighbour rows are requested at kernel entry),
+          // then in-tile faces, then boundary faces
+          const int rank = kind == TASK_EXT ? 0 : kind == TASK_INT ? 1 : 2;
+          tt.push_back({ (rank << 2) | lf, a, nbid, h_fid[lf * stride + d] });
         }
       // same kind / local face next to each other: fewer divergent branches per wave
       std::stable_sort(tt.begin(), tt.end(), [](const Task& p, const Task& q) { return p.key < q.key; });
@@ -529,10 +544,10 @@ extern "C" int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t 
     }, 256);
     for (int t = 0; t < ntile; ++t) h_tile_off[t + 1] += h_tile_off[t];
     const size_t ntask = (size_t)h_tile_off[ntile];
-    // fixed-stride task lists for the v2 tile kernel (4 rounds of the workgroup per tile, unused
-    // slots -1): no offset load in front of the descriptors, 1-2 % on the kernel (round 2:
-    // 1.608 -> 1.581 ms at 10.1 M tets); QDG_TASK_COMPACT=1 keeps the compact lists
-    task_stride = (!std::getenv("QDG_TASK_COMPACT") && !ctx->cfg.pref) ? 4 * TILE_BS : 0;
+    // fixed-stride task lists for the uniform-order tile kernels (4 * TILE_BS slots per tile,
+    // unused slots -1): no offset load in front of the descriptors, 1-2 % on the kernel (round 2:
+    // 1.608 -> 1.581 ms at 10.1 M tets); p-adaptive runs (k_rhs_p1t) keep compact lists
+    task_stride = !ctx->cfg.pref ? 4 * TILE_BS : 0;
     const size_t nslot = task_stride ? (size_t)ntile * task_stride : ntask;
     h_task_a.assign(nslot, -1); h_task_nb.assign(nslot, 0); h_task_f.assign(nslot, 0);
     parallel_for((size_t)ntile, [&](size_t t0, size_t t1) {
@@ -591,11 +606,11 @@ extern "C" int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t 
   HIPCHK(m->tile_off.upload(h_tile_off, s)); HIPCHK(m->task_a.upload(h_task_a, s));
   HIPCHK(m->task_nb.upload(h_task_nb, s)); HIPCHK(m->task_f.upload(h_task_f, s));
   dm.ntile = ntile; dm.ntile_inner = ntile_inner; dm.tile_row = m->tile_row.p; dm.task_stride = task_stride;
-  dm.tile_rows = fixed_tiles ? TILE : 0;
+  dm.tile_rows = TILE;
   dm.tile_off = m->tile_off.p; dm.task_a = m->task_a.p;
   dm.task_nb = m->task_nb.p; dm.task_f = m->task_f.p;
   dm.tgeo = nullptr;
-  if (task_stride > 0 && ctx->cfg.ndof == 4 && !std::getenv("QDG_NO_TGEO")) {
+  if (task_stride > 0 && ctx->cfg.ndof == 4) {
     // face records in task order (DG-P1 tile kernel, version 2)
     HIPCHK(m->tgeo.alloc(4 * h_task_a.size()));
     launch_task_geo(h_task_a.size(), m->task_a.p, m->task_f.p, m->fgeo.p, m->tgeo.p, s);
@@ -707,20 +722,17 @@ static int run_limiter(qdg_mesh* mesh, double*& Ucur, double* Ualt_in)
   return 0;
 }
 
-// RHS dispatch: DG-P1 runs the specialised kernel (QDG_GENERIC_RHS=1 forces the
-// generic one, for A/B parity runs)
+// RHS dispatch: CompFlow DG-P1 has kernels of its own (qdg_rhs_p1.hip)
 static bool use_p1_fast(const qdg_mesh* mesh)
 {
-  static const bool generic = std::getenv("QDG_GENERIC_RHS") != nullptr;
-  return mesh->ndof == 4 && mesh->dm.ncomp == NCOMP && (!generic || mesh->dm.ndofel);
+  return mesh->ndof == 4 && mesh->dm.ncomp == NCOMP;
 }
 
 // tile / face-task kernel (each in-tile face evaluated once, LDS accumulation with
-// ds_add_f64) unless bitwise run-to-run reproducibility is requested
+// ds_add_f64) unless bitwise run-to-run reproducibility is requested (option "p1_rhs" = 1)
 static bool use_tile(const qdg_mesh* mesh)
 {
-  static const bool det = std::getenv("QDG_DETERMINISTIC_RHS") != nullptr;
-  return !det || mesh->dm.ndofel;      // p-adaptive DG exists in the tile kernel only
+  return mesh->ctx->opt.p1_rhs == 0 || mesh->dm.ndofel;      // p-adaptive DG exists in the tile kernel only
 }
 
 static void run_rhs(qdg_mesh* mesh, double t, const double* U, double* R)
@@ -729,13 +741,13 @@ static void run_rhs(qdg_mesh* mesh, double t, const double* U, double* R)
   if (use_p1_fast(mesh) && use_tile(mesh) && mesh->split_rhs) {
     const int inner = mesh->dm.ntile_inner;
     launch_rhs_p1t(mesh->dm, ctx->ph, t, U, R, false, mesh->blockmin.p, 1.0, DBL_MAX,
-                   mesh->dtraw.p, mesh->dt_ptr, ctx->stream, 0, inner);
+                   mesh->dtraw.p, mesh->dt_ptr, ctx->stream, 0, inner, ctx->opt.p1_variant);
     (void)hipStreamWaitEvent(ctx->stream, mesh->split_rhs, 0);
     launch_rhs_p1t(mesh->dm, ctx->ph, t, U, R, false, mesh->blockmin.p, 1.0, DBL_MAX,
-                   mesh->dtraw.p, mesh->dt_ptr, ctx->stream, inner, -1);
+                   mesh->dtraw.p, mesh->dt_ptr, ctx->stream, inner, -1, ctx->opt.p1_variant);
   } else if (use_p1_fast(mesh) && use_tile(mesh))
     launch_rhs_p1t(mesh->dm, ctx->ph, t, U, R, false, mesh->blockmin.p, 1.0, DBL_MAX,
-                   mesh->dtraw.p, mesh->dt_ptr, ctx->stream);
+                   mesh->dtraw.p, mesh->dt_ptr, ctx->stream, 0, -1, ctx->opt.p1_variant);
   else if (use_p1_fast(mesh))
     launch_rhs_p1(mesh->dm, ctx->ph, t, U, R, false, mesh->blockmin.p, 1.0, DBL_MAX,
                   mesh->dtraw.p, mesh->dt_ptr, ctx->stream);
@@ -1242,15 +1254,15 @@ extern "C" int qdg_stage_rhs_dt(qdg_mesh* mesh, int stage, double t, double tlef
     if (use_tile(mesh) && mesh->split_rhs) {
       const int inner = mesh->dm.ntile_inner;
       launch_rhs_p1t_rk(mesh->dm, ctx->ph, t, mesh->Ucur, out, RK[0][stage], RK[1][stage],
-                        mesh->dt_ptr, mesh->Unp, s, 0, inner);
+                        mesh->dt_ptr, mesh->Unp, s, 0, inner, ctx->opt.p1_variant);
       if (ev) HIPCHK(hipEventRecord(ev->second, s));
       HIPCHK(hipStreamWaitEvent(s, mesh->split_rhs, 0));
       if (int rc = prof_begin(mesh, &ev, true)) return rc;
       launch_rhs_p1t_rk(mesh->dm, ctx->ph, t, mesh->Ucur, out, RK[0][stage], RK[1][stage],
-                        mesh->dt_ptr, mesh->Unp, s, inner, -1);
+                        mesh->dt_ptr, mesh->Unp, s, inner, -1, ctx->opt.p1_variant);
     } else if (use_tile(mesh))
       launch_rhs_p1t_rk(mesh->dm, ctx->ph, t, mesh->Ucur, out, RK[0][stage], RK[1][stage],
-                        mesh->dt_ptr, mesh->Unp, s);
+                        mesh->dt_ptr, mesh->Unp, s, 0, -1, ctx->opt.p1_variant);
     else
       launch_rhs_p1_rk(mesh->dm, ctx->ph, t, mesh->Ucur, out, RK[0][stage], RK[1][stage],
                        mesh->dt_ptr, mesh->Unp, s);
@@ -1271,15 +1283,15 @@ extern "C" int qdg_stage_rhs_dt(qdg_mesh* mesh, int stage, double t, double tlef
     if (use_tile(mesh) && mesh->split_rhs) {
       const int inner = mesh->dm.ntile_inner;
       launch_rhs_p1t(mesh->dm, ctx->ph, t, mesh->Ucur, mesh->R.p, true, mesh->blockmin.p, scale,
-                     tleft, mesh->dtraw.p, mesh->dt_ptr, s, 0, inner);
+                     tleft, mesh->dtraw.p, mesh->dt_ptr, s, 0, inner, ctx->opt.p1_variant);
       if (ev) HIPCHK(hipEventRecord(ev->second, s));
       HIPCHK(hipStreamWaitEvent(s, mesh->split_rhs, 0));
       if (int rc = prof_begin(mesh, &ev, true)) return rc;
       launch_rhs_p1t(mesh->dm, ctx->ph, t, mesh->Ucur, mesh->R.p, true, mesh->blockmin.p, scale,
-                     tleft, mesh->dtraw.p, mesh->dt_ptr, s, inner, -1);
+                     tleft, mesh->dtraw.p, mesh->dt_ptr, s, inner, -1, ctx->opt.p1_variant);
     } else if (use_tile(mesh))
       launch_rhs_p1t(mesh->dm, ctx->ph, t, mesh->Ucur, mesh->R.p, true, mesh->blockmin.p, scale,
-                     tleft, mesh->dtraw.p, mesh->dt_ptr, s);
+                     tleft, mesh->dtraw.p, mesh->dt_ptr, s, 0, -1, ctx->opt.p1_variant);
     else
       launch_rhs_p1(mesh->dm, ctx->ph, t, mesh->Ucur, mesh->R.p, true, mesh->blockmin.p, scale,
                     tleft, mesh->dtraw.p, mesh->dt_ptr, s);
@@ -1413,10 +1425,10 @@ extern "C" int qdg_ndofel_set(qdg_mesh* mesh, const size_t* ndofel)
 }
 
 // Stage-0 update fused with the limiter of stage 1 (k_upd_superbee): DG-P1 CompFlow with
-// Superbee, uniform order.  QDG_NO_FUSED_UPDATE=1 keeps the two kernels (A/B runs).
+// Superbee, uniform order.  Option "fused_update" = 0 keeps the two kernels (A/B runs).
 static bool can_fuse_update_limit(const qdg_mesh* mesh)
 {
-  static const bool off = std::getenv("QDG_NO_FUSED_UPDATE") != nullptr;
+  const bool off = !mesh->ctx->opt.fused_update;
   return !off && use_p1_fast(mesh) && mesh->ctx->cfg.limiter == QDG_LIMITER_SUPERBEEP1 && !mesh->dm.ndofel;
 }
 
@@ -1847,7 +1859,7 @@ extern "C" int qdg_stage_dt_allreduce(qdg_mesh* mesh, qdg_comm* comm)
 // DESIGN.md "Multi-GPU").  It pays only where the exchange is long.
 static bool can_overlap(const qdg_mesh* mesh)
 {
-  static const bool on = std::getenv("QDG_OVERLAP") != nullptr;
+  const bool on = mesh->ctx->opt.halo_overlap != 0;
   return on && mesh->nnbr > 0 && !mesh->dm.ndofel && use_p1_fast(mesh) && use_tile(mesh) &&
          mesh->ctx->cfg.limiter != QDG_LIMITER_WENOP1 && mesh->dm.ntile_inner > 0 &&
          mesh->dm.ninner / 256 > 0;
@@ -1959,13 +1971,3 @@ extern "C" int qdg_rhs_algorithmic_bytes(qdg_mesh* mesh, double* bytes)
   QDG_CATCH
 }
 
-#ifdef QDG_STAMPS
-namespace qdg { hipError_t read_stamps(unsigned long long* out16, bool reset); }
-extern "C" int qdg_debug_stamps(double* out16, int reset)
-{
-  unsigned long long v[16];
-  if (qdg::read_stamps(v, reset != 0) != hipSuccess) return fail("qdg_debug_stamps failed");
-  for (int i = 0; i < 16; ++i) out16[i] = (double)v[i];
-  return 0;
-}
-#endif

@@ -665,7 +665,9 @@ __device__ __forceinline__ bool task_of(size_t d, int lf, int stride, int tile_r
   } else { kind = TASK_EXT; nbid = nb; }
   a = TASK_PACK(d - e0, lf, own_left, code, kind, bc, pl);
   f = fid[(size_t)lf * stride + d];
-  key = (uint32_t)(tile << 4) | (uint32_t)((kind << 2) | lf);
+  // faces to other tiles first, then in-tile faces, then boundary faces (as qdg_mesh_upload)
+  const int rank = kind == TASK_EXT ? 0 : kind == TASK_INT ? 1 : 2;
+  key = (uint32_t)(tile << 4) | (uint32_t)((rank << 2) | lf);
   return true;
 }
 
@@ -877,7 +879,7 @@ static int dev_build_layout(qdg_ctx* ctx, DevFD& fd, const std::vector<int>& bcf
   DHIP(hipStreamSynchronize(s));
   if (herr == 6) return fail("qdg_mesh_from_connectivity: a free face of an owned tet is in no side set");
   if (herr) return fail("qdg_mesh_from_connectivity: neighbour does not share the face nodes (bad connectivity)");
-  const int task_stride = (!std::getenv("QDG_TASK_COMPACT") && !ctx->cfg.pref) ? 4 * TILE_BS : 0;
+  const int task_stride = !ctx->cfg.pref ? 4 * TILE_BS : 0;
   const size_t nslot = task_stride ? (size_t)ntile * task_stride : (size_t)ntask;
   HIPCHK(m->tile_off.alloc(ntile + 1)); HIPCHK(m->tile_row.alloc(ntile + 1));
   HIPCHK(m->task_a.alloc(std::max<size_t>(nslot, 1))); HIPCHK(m->task_nb.alloc(std::max<size_t>(nslot, 1)));
@@ -912,7 +914,7 @@ static int dev_build_layout(qdg_ctx* ctx, DevFD& fd, const std::vector<int>& bcf
   dm.tile_rows = TILE;
   dm.tile_off = m->tile_off.p; dm.task_a = m->task_a.p; dm.task_nb = m->task_nb.p; dm.task_f = m->task_f.p;
   dm.tgeo = nullptr;
-  if (task_stride > 0 && ctx->cfg.ndof == 4 && !std::getenv("QDG_NO_TGEO")) {
+  if (task_stride > 0 && ctx->cfg.ndof == 4) {
     HIPCHK(m->tgeo.alloc(4 * nslot));
     launch_task_geo(nslot, m->task_a.p, m->task_f.p, m->fgeo.p, m->tgeo.p, s);
     dm.tgeo = m->tgeo.p;
@@ -1135,9 +1137,9 @@ extern "C" int qdg_mesh_from_chunk(qdg_ctx* ctx, size_t nielem, size_t nelem, si
   if (ntri > 0 && (!tri || !tri_set)) return fail("qdg_mesh_from_connectivity: null side-set arrays");
   if (nielem == 0 || nielem > nelem) return fail("qdg_mesh_from_chunk: need 0 < nielem <= nelem");
   *out = nullptr;
-  if (nielem < nelem && std::getenv("QDG_HOST_LAYOUT"))
-    return fail("qdg_mesh_from_chunk: QDG_HOST_LAYOUT=1 covers chunks without ghosts only");
-  if (!std::getenv("QDG_HOST_LAYOUT")) {
+  if (nielem < nelem && ctx->opt.host_layout)
+    return fail("qdg_mesh_from_chunk: option host_layout covers chunks without ghosts only");
+  if (!ctx->opt.host_layout) {
     // Everything on the GPU: boundary faces regenerated from the side-set triangles, FaceData,
     // geometry and the device layout.  Only the connectivity, the coordinates and the side-set
     // triangles cross PCIe.

@@ -43,8 +43,21 @@ template <class T> struct DevBuf {
 }  // namespace qdg
 
 
+namespace qdg {
+// qdg_ctx_set_option: tuning / A-B switches (defaults = the product path)
+struct Options {
+  int p1_rhs = 0;        // DG-P1 RHS: 0 tile / face-task kernels (LDS atomics), 1 element-centric (bitwise reproducible)
+  int p1_variant = 0;    // uniform-order tile kernel: 0 k_rhs_p1v, 1 k_rhs_p1w<384>, 2 k_rhs_p1w<512>
+  int fused_update = 1;  // stage-0 RK update fused with the Superbee limiter of stage 1
+  int halo_overlap = 0;  // qdg_step_comm: exchange on a second stream behind the halo-free rows
+  int renumber = 1;      // Morton order of the interior tets (0: caller's order; layout experiments)
+  int host_layout = 0;   // qdg_mesh_from_connectivity: 1 routes through qdg_mesh_upload's host code (A/B)
+};
+}  // namespace qdg
+
 struct qdg_ctx {
   qdg_config cfg;
+  qdg::Options opt;
   std::vector<int32_t> bc_sideset, bc_type;
   qdg::Phys ph;
   int device = 0;

@@ -1,5 +1,5 @@
 // qdg_kernels.hpp -- host-callable launchers of the gfx950 kernels
-// (definitions in qdg_kernels.hip).
+// (definitions in qdg_kernels.hip, qdg_rhs_p1.hip, qdg_rhs_p2.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "qdg_device.hpp"
@@ -18,16 +18,24 @@ void launch_rhs_dt(int ndof, const DevMesh& m, const Phys& ph, double t, const d
                    hipStream_t s);
 void launch_rhs_rk(int ndof, const DevMesh& m, const Phys& ph, double t, const double* U, double* Uout,
                    double a, double b, const double* dt, const double* Un, hipStream_t s);
+void launch_dt_final(const double* blockmin, int n, double scale, double tleft, double* out_raw,
+                     double* out_dt, hipStream_t s);
+// DG-P2 (qdg_rhs_p2.hip): mode 0 R = rhs(U); 1 + per-workgroup min(vol/delt) into blockmin
+// [p2_rhs_blocks(m)]; 2 SSP-RK3 update fused in
+int p2_rhs_blocks(const DevMesh& m);
+void launch_rhs_p2(const DevMesh& m, const Phys& ph, double t, const double* U, double* R, int mode,
+                   double* blockmin, double a, double b, const double* dt, const double* Un, hipStream_t s);
 void launch_rhs_p1(const DevMesh& m, const Phys& ph, double t, const double* U, double* R,
                    bool with_dt, double* blockmin, double scale, double tleft, double* out_raw,
                    double* out_dt, hipStream_t s);
-// range launches: workgroup tiles [first, first+count), count < 0 = all the rest
+// range launches: workgroup tiles [first, first+count), count < 0 = all the rest; variant: which
+// form of the uniform-order tile kernel (context option "p1_variant")
 void launch_rhs_p1t(const DevMesh& m, const Phys& ph, double t, const double* U, double* R,
                     bool with_dt, double* blockmin, double scale, double tleft, double* out_raw,
-                    double* out_dt, hipStream_t s, int first = 0, int count = -1);
+                    double* out_dt, hipStream_t s, int first = 0, int count = -1, int variant = 0);
 void launch_rhs_p1t_rk(const DevMesh& m, const Phys& ph, double t, const double* U, double* Uout,
                        double a, double b, const double* dt, const double* Un, hipStream_t s,
-                       int first = 0, int count = -1);
+                       int first = 0, int count = -1, int variant = 0);
 void launch_superbee(int ndof, const DevMesh& m, double* U, hipStream_t s, int first = 0,
                      int count = -1);
 // stage-0 RK update fused with the Superbee limiter of stage 1 (DG-P1), and its halo pack

@@ -127,7 +127,7 @@ def test_mesh_from_connectivity_equals_the_hand_assembled_chunk(cases):
                                                     (1, "nolimiter", "sod_shocktube")])
 def test_device_built_layout_equals_host_built_layout(ndof, limiter, problem):
     """qdg_mesh_from_connectivity builds the whole device layout (Morton order, node / face
-    numbering, neighbour and face-code planes, face tasks) on the GPU; QDG_HOST_LAYOUT=1 routes
+    numbering, neighbour and face-code planes, face tasks) on the GPU; option host_layout = 1 routes
     the same call through qdg_mesh_upload's host code.  Same ordering rules => the same mesh:
     stateless operators and a few resident steps agree to rounding (the tile kernel's LDS
     atomics leave last-bit differences), on a mesh with ragged tiles and all six side sets."""
@@ -142,13 +142,8 @@ def test_device_built_layout_equals_host_built_layout(ndof, limiter, problem):
                   dt=1e-4, bc_dirichlet=[1, 2, 3, 4, 5, 6])
     res = {}
     for mode in ("device", "host"):
-        if mode == "host":
-            os.environ["QDG_HOST_LAYOUT"] = "1"
-        try:
-            ctx = capi.Context(ndof, **kw)
-            mesh = capi.mesh_from_connectivity(ctx, ch["inpoel"], ch["coord"], ch["sidesets"])
-        finally:
-            os.environ.pop("QDG_HOST_LAYOUT", None)
+        ctx = capi.Context(ndof, options={"host_layout": 1 if mode == "host" else 0}, **kw)
+        mesh = capi.mesh_from_connectivity(ctx, ch["inpoel"], ch["coord"], ch["sidesets"])
         try:
             U0 = mesh.initialize(0.0)
             R = mesh.rhs(0.0, U0)

@@ -102,7 +102,7 @@ def _self_halo_run(kind, out, pref=False, parts=(2, 1, 1)):
     ctx = capi.Context(4, cfl=0.3, device=0, pref=pref, tolref=0.1, **KW, **BC)
     mesh = dgmesh.upload(ctx, ck)
     if kind == "rccl_overlap":
-        os.environ["QDG_OVERLAP"] = "1"          # read once per process by libqdg
+        ctx.set_option("halo_overlap", 1)
     comm = dg.SelfComm() if kind == "copy" else \
         dg.RcclComm(ctx, rank=0, size=1, unique_id=capi.Comm.unique_id())
     drv = dg.DGDriver(ctx, mesh, [0] * len(ch["nbr_rank"]), ch["send_lists"], ch["recv_counts"], comm)
@@ -125,7 +125,7 @@ def test_rccl_transport_self_halo(tmp_path, parts):
     unpack, ncclAllReduce(min) of dt) on the one GPU of the test box: the rank's
     neighbour is the rank itself, and the result must equal the same plan moved
     by a plain device copy through the per-stage Python driver -- both for the
-    default one-stream sequence and for the overlapped step (QDG_OVERLAP=1:
+    default one-stream sequence and for the overlapped step (option halo_overlap:
     exchange on a second stream behind the halo-free rows)."""
     import torch.multiprocessing as mp
     outs = {}

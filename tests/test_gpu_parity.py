@@ -271,27 +271,19 @@ def test_errors_are_reported_not_thrown():
         capi.Context(4, gamma=0.5)
 
 
-def test_element_centric_rhs_kernel_still_matches(cases):
-    """QDG_DETERMINISTIC_RHS=1 selects the element-centric P1 kernel (no LDS
-    atomics, bitwise reproducible); it must pass the same golden run.  Runs in a
-    child process because the choice is read once per process."""
-    import os
-    import subprocess
-    import sys
-    code = (
-        "import sys, json, numpy as np\n"
-        "sys.path.insert(0, 'tests'); sys.path.insert(0, '.')\n"
-        "import test_gpu_parity as T\n"
-        "cases = json.load(open('tests/golden/cases.json'))\n"
-        "T.test_time_stepping_matches_reference_golden('sedov_dgp1', cases)\n"
-        "T.test_operators_match_oracle('sedov_dgp1', cases)\n"
-        "T.test_time_stepping_matches_reference_golden('vortical_flow_dgp1', cases)\n"
-        "print('ok')\n")
-    env = dict(os.environ, QDG_DETERMINISTIC_RHS="1")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True,
-                       timeout=600)
-    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+@pytest.mark.parametrize("opts", [{"p1_rhs": 1}, {"p1_variant": 1}, {"p1_variant": 2}, {"p1_variant": 3}],
+                         ids=["element_centric", "lean384", "lean512", "persistent"])
+def test_other_p1_rhs_kernels_pass_the_same_golden_runs(cases, opts, monkeypatch):
+    """The other forms of the DG-P1 RHS -- option p1_rhs = 1: the element-centric kernel (no LDS
+    atomics, bitwise reproducible); p1_variant = 1 / 2: the register-lean tile kernel at 384 / 512
+    lanes -- must pass the same golden runs and operator checks as the default."""
+    from quinoa_amd import capi
+    monkeypatch.setattr(capi, "default_options", dict(opts))
+    test_time_stepping_matches_reference_golden("sedov_dgp1", cases)
+    test_operators_match_oracle("sedov_dgp1", cases)
+    test_time_stepping_matches_reference_golden("vortical_flow_dgp1", cases)
+    test_operators_match_oracle("vortical_flow_dgp1", cases)
+    test_time_stepping_matches_reference_golden("vortical_flow_dgp1_lf", cases)
 
 
 def test_tile_kernel_run_to_run_spread_is_rounding_only(cases):
@@ -496,10 +488,10 @@ def test_lax_friedrichs_flux_at_every_order_matches_oracle(name, cases):
         mesh.close(); ctx.close()
 
 
-def test_tile_kernel_versions_agree(monkeypatch):
-    """the two forms of the DG-P1 tile kernel on the same mesh (version 2 by default; version 1 is
-    what p-adaptive runs use and what QDG_TILE_V1=1 forces): same stateless RHS and same state
-    after fused steps, to rounding (the summation order inside a tile differs)"""
+def test_p1_rhs_kernel_forms_agree():
+    """all forms of the DG-P1 RHS on the same mesh (ragged last tile): the default tile kernel, the
+    register-lean tile kernel at 384 and 512 lanes, and the element-centric kernel -- same
+    stateless RHS and same state after fused steps, to rounding (the summation order differs)"""
     from quinoa_amd import capi, dgmesh, meshgen
     ch = meshgen.kuhn_box(9, 8, 7)
     chunk = dgmesh.build_chunk(ch["coord"], ch["inpoel"], None, ch["sidesets"])
@@ -511,20 +503,20 @@ def test_tile_kernel_versions_agree(monkeypatch):
         U0 = mesh.initialize(0.0)
         U0 = U0 + 1e-3 * rng.normal(size=U0.shape)
         out = {}
-        for tag, env in (("v2", None), ("v1", "1")):
-            if env is None:
-                monkeypatch.delenv("QDG_TILE_V1", raising=False)
-            else:
-                monkeypatch.setenv("QDG_TILE_V1", env)
+        for tag, opts in (("v2", {}), ("lean384", {"p1_variant": 1}), ("lean512", {"p1_variant": 2}),
+                          ("persistent", {"p1_variant": 3}), ("element", {"p1_rhs": 1})):
+            ctx.set_option("p1_variant", 0); ctx.set_option("p1_rhs", 0)
+            for k, v in opts.items():
+                ctx.set_option(k, v)
             R = mesh.rhs(0.0, U0)
             mesh.state_upload(U0)
             t = 0.0
             for _ in range(3):
                 t += mesh.step(t)
             out[tag] = (R, mesh.state_download(), t)
-        assert np.abs(out["v1"][0] - out["v2"][0]).max() <= 1e-12 * max(1.0, np.abs(out["v2"][0]).max())
-        assert np.abs(out["v1"][1] - out["v2"][1]).max() <= 1e-12 * max(1.0, np.abs(out["v2"][1]).max())
-        assert abs(out["v1"][2] - out["v2"][2]) <= 1e-14 * out["v2"][2]
+        for tag in ("lean384", "lean512", "persistent", "element"):
+            assert np.abs(out[tag][0] - out["v2"][0]).max() <= 1e-12 * max(1.0, np.abs(out["v2"][0]).max()), tag
+            assert np.abs(out[tag][1] - out["v2"][1]).max() <= 1e-12 * max(1.0, np.abs(out["v2"][1]).max()), tag
+            assert abs(out[tag][2] - out["v2"][2]) <= 1e-14 * out["v2"][2], tag
     finally:
-        monkeypatch.delenv("QDG_TILE_V1", raising=False)
         mesh.close(); ctx.close()

@@ -1,15 +1,13 @@
 #!/bin/bash
-# Build quinoa_amd/lib/libqdg_<name>.so with extra -D flags on the kernel file and the host
-# layer (tile constants are shared through qdg_device.hpp); the other objects of the regular
-# build are reused.  Usage: tools/build_variant.sh NAME "-DFOO=1 -DBAR"
-# Select it at run time with QDG_LIB=quinoa_amd/lib/libqdg_NAME.so (A/B and knock-out runs).
-set -e
-name=$1; flags=$2
+# Builds a VARIANT of libqdg.so with extra compiler flags (A/B runs of compile-time parameters such
+# as the tile size): tools/build_variant.sh NAME -DQDG_TILE=160 ...  ->  quinoa_amd/lib/variants/NAME/libqdg.so
+# (git-ignored, travels with gpurun); select it with QDG_LIB=<path> (quinoa_amd/capi.py).
+name=$1; shift
 root="$(cd "$(dirname "$0")/.." && pwd)"
-obj=$root/quinoa_amd/lib/obj
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $flags -c $root/quinoa_amd/csrc/qdg_kernels.hip -o $obj/qdg_kernels_$name.o &
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $flags -c $root/quinoa_amd/csrc/qdg_api.cpp -o $obj/qdg_api_$name.o &
+out=$root/quinoa_amd/lib/variants/$name; mkdir -p $out
+cd $root/quinoa_amd/csrc || exit 1
+for f in qdg_rhs_p1.hip qdg_rhs_p2.hip qdg_kernels.hip qdg_devmesh.hip qdg_api.cpp qdg_meshdata.cpp qdg_partition.cpp qdg_exo.cpp; do
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" -c $f -o $out/${f%.*}.o &
+done
 wait
-hipcc --offload-arch=gfx950 -fPIC -shared -o $root/quinoa_amd/lib/libqdg_$name.so $obj/qdg_kernels_$name.o \
-  $obj/qdg_devmesh.o $obj/qdg_api_$name.o $obj/qdg_meshdata.o $obj/qdg_partition.o $obj/qdg_exo.o -ldl
-echo built libqdg_$name.so
+hipcc --offload-arch=gfx950 -fPIC -shared -o $out/libqdg.so $out/*.o -ldl && rm -f $out/*.o && echo "built $out/libqdg.so"
