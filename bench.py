@@ -71,6 +71,9 @@ def cpu_baseline(budget_s=10.0, budget_all_s=5.0):
     el = time.perf_counter() - t0
     out = {"value": om.nelem * 3 * steps / el / 1e6, "unit": "M element-updates/s",
            "cores": 1, "kind": "port",
+           # the reference's own DG-P1 RHS kernels timed in isolation on one
+           # Xeon core (the reference itself cannot be built in this image; quoted, not measured here)
+           "reference_kernels_M_per_s_per_core": 0.37,
            "sample": "oracle/dg_oracle.c, Sod DG-P1+Superbee CFL 0.3, %d-tet Kuhn box, %d full "
                      "RK3 steps in %.1f s" % (om.nelem, steps, el)}
     # all cores: one partition per thread
@@ -101,19 +104,21 @@ def run_workload(args, rank, world, local_rank, dims, lengths, parts, steps, war
     into `parts`; returns the measurements of this rank's chunk (max/sum over ranks done)."""
     import numpy as np
     import torch
-    from quinoa_amd import capi, dg, dgmesh, meshgen
+    from quinoa_amd import capi, dg, meshgen
     self_halo = args.self_halo
     ch = meshgen.kuhn_box_chunk(dims[0], dims[1], dims[2], lengths=lengths, parts=parts, rank=rank)
     if self_halo:
         ch["nbr_rank"] = [0 for _ in ch["nbr_rank"]]
-    chunk = dgmesh.build_chunk(ch["coord"], ch["inpoel"], ch["nielem"], ch["sidesets"])
+    nielem = int(ch["nielem"])
     if args.workload == "sedov":     # config 4's physics (symmetry on x-min, y-min and the z faces)
         ctx = capi.Context(4, flux="hllc", limiter="superbeep1", problem="sedov_blastwave", gamma=1.4,
                            cfl=0.3, bc_extrapolate=[2, 4], bc_sym=[1, 3, 5, 6], device=local_rank)
     else:
         ctx = capi.Context(4, flux="hllc", limiter="superbeep1", problem="sod_shocktube", gamma=1.4,
                            cfl=0.3, bc_extrapolate=[1, 2], bc_sym=[3, 4, 5, 6], device=local_rank)
-    mesh = dgmesh.upload(ctx, chunk)
+    # FaceData, geometry and the device layout of the chunk (with its ghost layer) are built on
+    # the GPU: only connectivity, coordinates and side-set triangles cross PCIe
+    mesh = capi.mesh_from_connectivity(ctx, ch["inpoel"], ch["coord"], ch["sidesets"], nielem=nielem)
     comm = None
     if use_dist:
         if comm_kind == "rccl":
@@ -128,10 +133,10 @@ def run_workload(args, rank, world, local_rank, dims, lengths, parts, steps, war
     # outside the timed region: total mass and energy before / after the run.  Between
     # symmetry walls and (still undisturbed) extrapolation faces they are conserved, and a
     # flux that does not match across a chunk boundary would show up here.
-    vol = chunk.geoElem[0:4 * chunk.nielem:4]
+    vol = _tet_volumes(ch["coord"], ch["inpoel"][:nielem])
 
     def totals():
-        Uh = mesh.state_download().reshape(-1, 20)[:chunk.nielem]
+        Uh = mesh.state_download().reshape(-1, 20)[:nielem]
         v = np.array([(Uh[:, 0] * vol).sum(), (Uh[:, 16] * vol).sum()])
         if world > 1:
             tv = torch.tensor(v, dtype=torch.float64, device="cuda")
@@ -164,13 +169,13 @@ def run_workload(args, rank, world, local_rank, dims, lengths, parts, steps, war
     drift = np.abs(totals() - tot0) / np.abs(tot0)
     if not self_halo and not (drift.max() <= 1e-9):
         raise SystemExit("invalid run: mass / energy drift %r (halo or flux mismatch)" % (drift,))
-    ntet = chunk.nielem
+    ntet = nielem
     if world > 1:
         tt = torch.tensor([el, float(ntet)], dtype=torch.float64, device="cuda")
         mx = tt.clone(); torch.distributed.all_reduce(mx, op=torch.distributed.ReduceOp.MAX)
         sm = tt.clone(); torch.distributed.all_reduce(sm, op=torch.distributed.ReduceOp.SUM)
         el, ntet = float(mx[0]), int(round(float(sm[1])))
-    res = {"el": el, "ntet": ntet, "ntet_local": chunk.nielem, "avg_ms": ms / max(nl, 1), "launches": nl,
+    res = {"el": el, "ntet": ntet, "ntet_local": nielem, "avg_ms": ms / max(nl, 1), "launches": nl,
            "alg": mesh.rhs_algorithmic_bytes(), "dt_last": dt_last, "drift": drift,
            "backend": None if comm is None else comm.backend}
     mesh.close()
@@ -178,6 +183,15 @@ def run_workload(args, rank, world, local_rank, dims, lengths, parts, steps, war
         comm.close()
     ctx.close()
     return res
+
+
+def _tet_volumes(coord, inpoel):
+    """tet volumes (tk::triple / 6, src/Mesh/DerivedData.cpp:genGeoElemTet) for the conservation check"""
+    import numpy as np
+    c = np.asarray(coord, dtype=np.float64)
+    t = np.asarray(inpoel).reshape(-1, 4)
+    a, b, d = c[t[:, 1]] - c[t[:, 0]], c[t[:, 2]] - c[t[:, 0]], c[t[:, 3]] - c[t[:, 0]]
+    return np.einsum("ij,ij->i", a, np.cross(b, d)) / 6.0
 
 
 def amr_point(local_rank, nx=32, steps=20):
@@ -281,18 +295,17 @@ def _amr_single(nx, steps, ne0, ne1, ms0, ms1, th, tr, tt, ok):
                     "coordinates cross PCIe); transfer = qdg_state_transfer (child <- parent, device)"}
 
 
-def config3_point(local_rank, nx=110, steps=5):
+def config3_point(local_rank, nx=110, steps=20):
     """BASELINE config 3 at its own size on one GPU: vortical_flow DG-P2 + wenop1 (alpha 0.1,
     beta 1, p0 10, gamma 5/3, Dirichlet on all six sides), nx^3 x 6 tets, prescribed dt
     (1e-5 scaled with the mesh size), `steps` timed SSP-RK3 steps after two warm-up steps."""
     import numpy as np
-    from quinoa_amd import capi, dgmesh, meshgen
+    from quinoa_amd import capi, meshgen
     ch = meshgen.kuhn_box(nx, nx, nx)
-    chunk = dgmesh.build_chunk(ch["coord"], ch["inpoel"], None, ch["sidesets"])
     ctx = capi.Context(10, flux="hllc", limiter="wenop1", problem="vortical_flow", gamma=5.0 / 3.0,
                        cweight=1.0, alpha=0.1, beta=1.0, p0=10.0, dt=1e-5 * 10.0 / nx,
                        bc_dirichlet=[1, 2, 3, 4, 5, 6], device=local_rank)
-    mesh = dgmesh.upload(ctx, chunk)
+    mesh = capi.mesh_from_connectivity(ctx, ch["inpoel"], ch["coord"], ch["sidesets"])
     mesh.state_initialize(0.0)
     for _ in range(2):
         mesh.step(0.0, want_dt=False)
@@ -307,7 +320,7 @@ def config3_point(local_rank, nx=110, steps=5):
     alg = mesh.rhs_algorithmic_bytes()
     U = mesh.state_download()
     ok = bool(np.isfinite(U).all())
-    ne = chunk.nielem
+    ne = mesh.nielem
     mesh.close(); ctx.close()
     ach = alg / (ms / nl * 1e-3) / 1e9
     return {"workload": "CompFlow vortical_flow DG-P2 + wenop1, Kuhn-tet box %d^3 hexes = %d tets, prescribed dt, "
@@ -321,16 +334,15 @@ def config3_point(local_rank, nx=110, steps=5):
                          "traffic": None}}
 
 
-def config4_point(local_rank, nx=110, steps=5):
+def config4_point(local_rank, nx=110, steps=20):
     """One GPU's share of BASELINE config 4 (Sedov blast DG-P1 + Superbee, CFL 0.3, 64 M tets over
     8 GPUs): nx^3 x 6 = 7 986 000 tets on this GPU, no halo (the 8-GPU run is `--gpus 8 --nx 110`)."""
     import numpy as np
-    from quinoa_amd import capi, dgmesh, meshgen
+    from quinoa_amd import capi, meshgen
     ch = meshgen.kuhn_box(nx, nx, nx)
-    chunk = dgmesh.build_chunk(ch["coord"], ch["inpoel"], None, ch["sidesets"])
     ctx = capi.Context(4, flux="hllc", limiter="superbeep1", problem="sedov_blastwave", gamma=1.4, cfl=0.3,
                        bc_sym=[1, 3, 5, 6], bc_extrapolate=[2, 4], device=local_rank)
-    mesh = dgmesh.upload(ctx, chunk)
+    mesh = capi.mesh_from_connectivity(ctx, ch["inpoel"], ch["coord"], ch["sidesets"])
     mesh.state_initialize(0.0)
     for _ in range(2):
         mesh.step(0.0, want_dt=False)
@@ -345,14 +357,14 @@ def config4_point(local_rank, nx=110, steps=5):
     alg = mesh.rhs_algorithmic_bytes()
     U = mesh.state_download()
     ok = bool(np.isfinite(U).all())
-    ne = chunk.nielem
+    ne = mesh.nielem
     mesh.close(); ctx.close()
     ach = alg / (ms / nl * 1e-3) / 1e9
     return {"workload": "CompFlow Sedov blast wave DG-P1 + superbeep1, CFL 0.3, Kuhn-tet box %d^3 hexes = %d tets "
                         "(one GPU's share of config 4), %d timed steps" % (nx, ne, steps),
             "tets_total": ne, "steps": steps, "value": ne * 3 / el / 1e6, "unit": "M element-updates/s",
             "ms_per_step": el * 1e3, "finite": ok,
-            "roofline": {"bound": "hbm", "kernel": "qdg::k_rhs_p1v", "achieved": ach, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "qdg::k_rhs_p1w", "achieved": ach, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "avg_launch_ms": ms / nl, "launches": nl,
                          "algorithmic_bytes_per_launch": alg, "traffic": None}}
 
@@ -422,7 +434,7 @@ def main():
     ns = None
     if not args.no_north_star and not args.self_halo:
         sx = args.strong_nx
-        ns_steps, ns_warm = max(3, args.steps // 5), max(1, args.warmup // 2)
+        ns_steps, ns_warm = max(20, args.steps // 2), max(2, args.warmup // 2)   # >= 20 timed steps whatever --steps says
         ns = run_workload(args, rank, world, local_rank, (sx, sx, sx), (1.0, 1.0, 1.0), parts, ns_steps, ns_warm,
                           args.comm, use_dist)
         ns["steps"], ns["warmup"] = ns_steps, ns_warm
@@ -458,7 +470,7 @@ def main():
                                       + ("" if w["backend"] is None else ", transport " + w["backend"])
                                       + (" (SELF-HALO TEST: the neighbour is this rank)" if args.self_halo else ""),
                        "step": "SSP-RK3 time step = 3 x (halo, limiter, halo, [dt], rhs, update)"},
-            "roofline": {"bound": "hbm", "kernel": "qdg::k_rhs_p1v (tile/face-task RHS, version 2; stage 0: + CFL dt; stages 1,2: + fused RK update; 357 B/tet counted for every launch)", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "qdg::k_rhs_p1w (tile / face-task RHS; stage 0: + CFL dt; stages 1,2: + fused RK update; 357 B/tet counted for every launch)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac,
                          "traffic": traffic, "traffic_source": traffic_source,
                          "avg_launch_ms": w["avg_ms"], "launches": w["launches"],
@@ -478,7 +490,7 @@ def main():
                 "steps": ns["steps"], "warmup": ns["warmup"],
                 "value": ns["ntet"] * 3 * ns["steps"] / ns["el"] / 1e6, "unit": "M element-updates/s",
                 "ms_per_step": ns["el"] / ns["steps"] * 1e3,
-                "roofline": {"bound": "hbm", "kernel": "qdg::k_rhs_p1v on rank 0's chunk", "achieved": a2,
+                "roofline": {"bound": "hbm", "kernel": "qdg::k_rhs_p1w on rank 0's chunk", "achieved": a2,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": f2, "avg_launch_ms": ns["avg_ms"],
                              "launches": ns["launches"], "algorithmic_bytes_per_launch": ns["alg"],
                              "traffic": None},

@@ -134,10 +134,7 @@ int qdg_ctx_synchronize(qdg_ctx* ctx);
  *   "p1_rhs"        0 (default) tile / face-task kernels: every in-tile face once, LDS atomics
  *                   (results reproducible to rounding); 1 element-centric kernel, bitwise
  *                   reproducible run to run
- *   "p1_variant"    form of the uniform-order DG-P1 tile kernel: 0 k_rhs_p1v (256 lanes, 2 waves
- *                   per SIMD), 1 / 2 k_rhs_p1w with 384 / 512 lanes (3 / 4 waves per SIMD)
  *   "fused_update"  1 (default) stage-0 RK update fused with the Superbee limiter of stage 1
- *   "halo_overlap"  1: qdg_step_comm exchanges on a second stream behind the halo-free rows
  *   "renumber"      1 (default) Morton order of the device rows; 0 keeps the caller's order
  *   "host_layout"   1: qdg_mesh_from_connectivity runs qdg_mesh_upload's host layout code (A/B) */
 int qdg_ctx_set_option(qdg_ctx* ctx, const char* name, int value);
@@ -445,7 +442,7 @@ int qdg_mesh_from_connectivity(qdg_ctx* ctx, size_t nelem, size_t nnode, const s
  * halo plan (qdg_chunk_build), nodes and coordinates cover both.  Everything is derived on the
  * device: boundary faces of the OWNED tets from the side-set triangles, interior and
  * chare-boundary faces (a face between two ghosts is none of this chunk's), geometry, the
- * device order (tets with a ghost neighbour last, for the overlap of halo and interior work),
+ * device order (tets with a ghost neighbour last: the halo's send rows are the trailing rows),
  * numbering, face tasks.  Follow with qdg_halo_setup as after qdg_mesh_upload.
  * nielem == nelem: identical to qdg_mesh_from_connectivity. */
 int qdg_mesh_from_chunk(qdg_ctx* ctx, size_t nielem, size_t nelem, size_t nnode, const size_t* inpoel,

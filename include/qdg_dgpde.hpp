@@ -25,6 +25,8 @@
 
 #include <array>
 #include <cstddef>
+#include <cstdint>
+#include <cstring>
 #include <algorithm>
 #include <map>
 #include <memory>
@@ -37,6 +39,23 @@
 
 #include "qdg.h"
 
+// -- shared by both configurations ---------------------------------------------------------------
+namespace qdg {
+class Exception : public std::runtime_error {
+ public:
+  explicit Exception(const std::string& m) : std::runtime_error(m) {}
+};
+inline void check(int rc)
+{
+  if (rc != 0) throw Exception(std::string("qdg: ") + qdg_last_error());
+}
+}  // namespace qdg
+
+// -- the ONLY configuration-dependent part: where real, Fields, FaceData and Coords come from.
+// Inside a Quinoa build (-DQDG_WITH_QUINOA) they are the reference's own types; otherwise the
+// mirrors below (same members) stand in, so everything after this block -- InputDeck, the Problem
+// traits, DeviceDG and the CompFlowHIP / TransportHIP adapters -- is the SAME code in both
+// configurations: what tests/cpp drives is what a Quinoa build compiles.
 #ifdef QDG_WITH_QUINOA
 #include "Fields.hpp"
 #include "FaceData.hpp"
@@ -73,16 +92,6 @@ class Fields {
   std::vector<real> m_vec;
   ncomp_t m_nunk = 0, m_nprop = 0;
 };
-
-class Exception : public std::runtime_error {
- public:
-  explicit Exception(const std::string& m) : std::runtime_error(m) {}
-};
-
-inline void check(int rc)
-{
-  if (rc != 0) throw Exception(std::string("qdg: ") + qdg_last_error());
-}
 
 // inciter::FaceData (src/Inciter/FaceData.hpp:41-106): same constructor
 // arguments and accessors; built by libqdg's host mirrors.
@@ -148,17 +157,6 @@ inline Fields genGeoElemTet(const std::vector<std::size_t>& inpoel, const Coords
 #endif  // QDG_WITH_QUINOA
 
 namespace qdg {
-
-#ifdef QDG_WITH_QUINOA
-class Exception : public std::runtime_error {
- public:
-  explicit Exception(const std::string& m) : std::runtime_error(m) {}
-};
-inline void check(int rc)
-{
-  if (rc != 0) throw Exception(std::string("qdg: ") + qdg_last_error());
-}
-#endif
 
 // what dg::CompFlow's constructor reads from g_inputdeck
 // (src/PDE/CompFlow/DGCompFlow.hpp:80-93; defaults InputDeck.hpp:191-238)
@@ -267,13 +265,16 @@ class DeviceDG {
               const std::vector<std::size_t>& inpoel, const Coords& coord) const
   {
     std::lock_guard<std::mutex> lock(m_state->mtx);
+    const std::uint64_t sig = signature(inpoel, coord, fd);
     {
-      // same storage, same sizes: the chare's mesh is already on the device.  A vector that was
-      // re-allocated at the same address with other sizes (AMR, migration) is re-uploaded.
+      // same storage, same sizes AND same content signature: the chare's mesh is already on the
+      // device.  A vector re-allocated at the same address (AMR, migration, a new chare reusing a
+      // freed block) is recognised by its sizes or, at equal sizes, by the sampled checksum of
+      // connectivity, coordinates and face-element pairs, and re-uploaded.
       auto it = m_state->meshes.find(inpoel.data());
       if (it != m_state->meshes.end()) {
         if (it->second.nunk == inpoel.size() / 4 && it->second.nnode == coord[0].size() &&
-            it->second.nfac == fd.Esuf().size() / 2) return;
+            it->second.nfac == fd.Esuf().size() / 2 && it->second.sig == sig) return;
         qdg_mesh_destroy(it->second.h);
         m_state->meshes.erase(it);
       }
@@ -293,7 +294,30 @@ class DeviceDG {
                           coord[1].data(), coord[2].data(), fd.Nbfac(), fd.Esuf().size() / 2,
                           fd.Esuf().data(), fd.Esuel().data(), fd.Inpofa().data(),
                           geoFace.data().data(), geoElem.data().data(), &bf, &m));
-    m_state->meshes[inpoel.data()] = Cached{ m, nunk, coord[0].size(), fd.Esuf().size() / 2 };
+    m_state->meshes[inpoel.data()] = Cached{ m, nunk, coord[0].size(), fd.Esuf().size() / 2, sig };
+  }
+
+  //! Content signature of a chare's mesh: FNV-1a over the sizes and up to 4096 evenly spaced
+  //! entries each of inpoel, the three coordinate arrays (bit patterns) and esuf -- O(1) per call,
+  //! so it can guard every rhs()/dt().  Two different meshes of equal sizes in the same storage
+  //! that also agree on all sampled entries are not told apart: call release() when a chare's
+  //! mesh changes (DG::resizePostAMR, migration), as INTEGRATION.md asks.
+  static std::uint64_t signature(const std::vector<std::size_t>& inpoel, const Coords& coord, const FaceData& fd)
+  {
+    std::uint64_t h = 1469598103934665603ull;
+    auto mix = [&h](std::uint64_t v) { for (int b = 0; b < 8; ++b) { h ^= (v >> (8 * b)) & 0xffu; h *= 1099511628211ull; } };
+    auto sample = [&mix](const auto& a) {
+      const std::size_t n = a.size(), step = n > 4096 ? n / 4096 : 1;
+      mix(n);
+      for (std::size_t i = 0; i < n; i += step) {
+        std::uint64_t v = 0;
+        std::memcpy(&v, &a[i], sizeof(a[i]) < 8 ? sizeof(a[i]) : 8);
+        mix(v);
+      }
+      if (n) { std::uint64_t v = 0; std::memcpy(&v, &a[n - 1], sizeof(a[n - 1]) < 8 ? sizeof(a[n - 1]) : 8); mix(v); }
+    };
+    sample(inpoel); sample(coord[0]); sample(coord[1]); sample(coord[2]); sample(fd.Esuf());
+    return h;
   }
 
   //! Forget a chare's mesh (DG dtor, before resizePostAMR / migration)
@@ -416,7 +440,7 @@ class DeviceDG {
   }
 
  private:
-  struct Cached { qdg_mesh* h; std::size_t nunk, nnode, nfac; };
+  struct Cached { qdg_mesh* h; std::size_t nunk, nnode, nfac; std::uint64_t sig; };
   struct State {
     qdg_ctx* ctx = nullptr;
     std::mutex mtx;

@@ -200,8 +200,8 @@ extern "C" int qdg_ctx_set_stream(qdg_ctx* ctx, void* s)
 static int* option_slot(qdg_ctx* ctx, const char* name)
 {
   static const struct { const char* n; int qdg::Options::*p; } tab[] = {
-    { "p1_rhs", &qdg::Options::p1_rhs },           { "p1_variant", &qdg::Options::p1_variant },
-    { "fused_update", &qdg::Options::fused_update }, { "halo_overlap", &qdg::Options::halo_overlap },
+    { "p1_rhs", &qdg::Options::p1_rhs },
+    { "fused_update", &qdg::Options::fused_update },
     { "renumber", &qdg::Options::renumber },       { "host_layout", &qdg::Options::host_layout },
   };
   for (const auto& t : tab)
@@ -361,7 +361,7 @@ extern "C" int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t 
     for (size_t d = 0; d < nie; ++d) d2h[d] = key[d].second;
   }
   // tets with a ghost neighbour go last (still in curve order): launches over the
-  // leading rows never touch the halo and can overlap the exchange (qdg_step_comm)
+  // leading rows never touch the halo (the send rows of the halo exchange are the trailing ones)
   size_t ninner = nie;
   if (ne > nie) {
     auto at_halo = [&](int e) {
@@ -706,14 +706,7 @@ static int run_limiter(qdg_mesh* mesh, double*& Ucur, double* Ualt_in)
   hipStream_t s = ctx->stream;
   if (mesh->ndof == 1) return 0;          // DG.cpp:1251: rdof > 1 only
   if (ctx->cfg.limiter == QDG_LIMITER_SUPERBEEP1) {
-    if (mesh->split_lim) {
-      const int inner = mesh->dm.ninner / 256;
-      launch_superbee(mesh->ndof, mesh->dm, Ucur, s, 0, inner);
-      HIPCHK(hipStreamWaitEvent(s, mesh->split_lim, 0));
-      launch_superbee(mesh->ndof, mesh->dm, Ucur, s, inner, -1);
-    } else {
-      launch_superbee(mesh->ndof, mesh->dm, Ucur, s);
-    }
+    launch_superbee(mesh->ndof, mesh->dm, Ucur, s);
   } else if (ctx->cfg.limiter == QDG_LIMITER_WENOP1) {
     launch_weno(mesh->ndof, mesh->dm, ctx->ph.cweight, Ucur, Ualt, s);    // writes every row of Ualt
     std::swap(Ucur, Ualt);
@@ -738,16 +731,9 @@ static bool use_tile(const qdg_mesh* mesh)
 static void run_rhs(qdg_mesh* mesh, double t, const double* U, double* R)
 {
   qdg_ctx* ctx = mesh->ctx;
-  if (use_p1_fast(mesh) && use_tile(mesh) && mesh->split_rhs) {
-    const int inner = mesh->dm.ntile_inner;
+  if (use_p1_fast(mesh) && use_tile(mesh))
     launch_rhs_p1t(mesh->dm, ctx->ph, t, U, R, false, mesh->blockmin.p, 1.0, DBL_MAX,
-                   mesh->dtraw.p, mesh->dt_ptr, ctx->stream, 0, inner, ctx->opt.p1_variant);
-    (void)hipStreamWaitEvent(ctx->stream, mesh->split_rhs, 0);
-    launch_rhs_p1t(mesh->dm, ctx->ph, t, U, R, false, mesh->blockmin.p, 1.0, DBL_MAX,
-                   mesh->dtraw.p, mesh->dt_ptr, ctx->stream, inner, -1, ctx->opt.p1_variant);
-  } else if (use_p1_fast(mesh) && use_tile(mesh))
-    launch_rhs_p1t(mesh->dm, ctx->ph, t, U, R, false, mesh->blockmin.p, 1.0, DBL_MAX,
-                   mesh->dtraw.p, mesh->dt_ptr, ctx->stream, 0, -1, ctx->opt.p1_variant);
+                   mesh->dtraw.p, mesh->dt_ptr, ctx->stream);
   else if (use_p1_fast(mesh))
     launch_rhs_p1(mesh->dm, ctx->ph, t, U, R, false, mesh->blockmin.p, 1.0, DBL_MAX,
                   mesh->dtraw.p, mesh->dt_ptr, ctx->stream);
@@ -1251,18 +1237,9 @@ extern "C" int qdg_stage_rhs_dt(qdg_mesh* mesh, int stage, double t, double tlef
   if (use_p1_fast(mesh) && fuse) {
     double* out = free_buf(mesh, mesh->Ucur, mesh->Unp);
     if (int rc = prof_begin(mesh, &ev)) return rc;
-    if (use_tile(mesh) && mesh->split_rhs) {
-      const int inner = mesh->dm.ntile_inner;
+    if (use_tile(mesh))
       launch_rhs_p1t_rk(mesh->dm, ctx->ph, t, mesh->Ucur, out, RK[0][stage], RK[1][stage],
-                        mesh->dt_ptr, mesh->Unp, s, 0, inner, ctx->opt.p1_variant);
-      if (ev) HIPCHK(hipEventRecord(ev->second, s));
-      HIPCHK(hipStreamWaitEvent(s, mesh->split_rhs, 0));
-      if (int rc = prof_begin(mesh, &ev, true)) return rc;
-      launch_rhs_p1t_rk(mesh->dm, ctx->ph, t, mesh->Ucur, out, RK[0][stage], RK[1][stage],
-                        mesh->dt_ptr, mesh->Unp, s, inner, -1, ctx->opt.p1_variant);
-    } else if (use_tile(mesh))
-      launch_rhs_p1t_rk(mesh->dm, ctx->ph, t, mesh->Ucur, out, RK[0][stage], RK[1][stage],
-                        mesh->dt_ptr, mesh->Unp, s, 0, -1, ctx->opt.p1_variant);
+                        mesh->dt_ptr, mesh->Unp, s);
     else
       launch_rhs_p1_rk(mesh->dm, ctx->ph, t, mesh->Ucur, out, RK[0][stage], RK[1][stage],
                        mesh->dt_ptr, mesh->Unp, s);
@@ -1280,18 +1257,9 @@ extern "C" int qdg_stage_rhs_dt(qdg_mesh* mesh, int stage, double t, double tlef
     const double scale = ctx->cfg.cfl / 3.0;     // cfl/(2p+1), p = 1 (DG.cpp:1404-1418)
     if (int rc = prof_begin(mesh, &ev)) return rc;
     // here the event pair also covers the 1-block dt reduction (~5 us)
-    if (use_tile(mesh) && mesh->split_rhs) {
-      const int inner = mesh->dm.ntile_inner;
+    if (use_tile(mesh))
       launch_rhs_p1t(mesh->dm, ctx->ph, t, mesh->Ucur, mesh->R.p, true, mesh->blockmin.p, scale,
-                     tleft, mesh->dtraw.p, mesh->dt_ptr, s, 0, inner, ctx->opt.p1_variant);
-      if (ev) HIPCHK(hipEventRecord(ev->second, s));
-      HIPCHK(hipStreamWaitEvent(s, mesh->split_rhs, 0));
-      if (int rc = prof_begin(mesh, &ev, true)) return rc;
-      launch_rhs_p1t(mesh->dm, ctx->ph, t, mesh->Ucur, mesh->R.p, true, mesh->blockmin.p, scale,
-                     tleft, mesh->dtraw.p, mesh->dt_ptr, s, inner, -1, ctx->opt.p1_variant);
-    } else if (use_tile(mesh))
-      launch_rhs_p1t(mesh->dm, ctx->ph, t, mesh->Ucur, mesh->R.p, true, mesh->blockmin.p, scale,
-                     tleft, mesh->dtraw.p, mesh->dt_ptr, s, 0, -1, ctx->opt.p1_variant);
+                     tleft, mesh->dtraw.p, mesh->dt_ptr, s);
     else
       launch_rhs_p1(mesh->dm, ctx->ph, t, mesh->Ucur, mesh->R.p, true, mesh->blockmin.p, scale,
                     tleft, mesh->dtraw.p, mesh->dt_ptr, s);
@@ -1322,8 +1290,9 @@ extern "C" int qdg_stage_update(qdg_mesh* mesh, int stage)
   if (stage < 0 || stage > 2) return fail("qdg_stage_update: stage must be 0,1,2");
   if (!mesh->Unp) return fail("qdg_stage_update: no stage in flight");
   if (mesh->Upending) {                       // the fused kernel already wrote the new state
-    // ghost rows are not written by the update: carry them over, as the unfused path does
-    if (mesh->ne > mesh->nie)
+    // ghost rows are not written by the update: carry them over, as the unfused path does --
+    // except inside qdg_step_comm before a stage whose first action is to receive them again
+    if (mesh->ne > mesh->nie && !mesh->skip_ghost_carry)
       HIPCHK(hipMemcpyAsync(mesh->Upending + mesh->nie * (size_t)mesh->nprop,
                             mesh->Ucur + mesh->nie * (size_t)mesh->nprop,
                             (mesh->ne - mesh->nie) * (size_t)mesh->nprop * sizeof(double),
@@ -1698,9 +1667,6 @@ RcclApi* rccl_api()
 struct qdg_comm {
   ncclComm_t comm = nullptr;
   int nranks = 1, rank = 0, device = 0;
-  // communication stream and events of the overlapped step (qdg_step_comm)
-  hipStream_t cs = nullptr;
-  hipEvent_t ev_ready = nullptr, ev_x1 = nullptr, ev_x2 = nullptr;
   qdg_comm() = default;
   qdg_comm(const qdg_comm&) = delete;
   qdg_comm& operator=(const qdg_comm&) = delete;
@@ -1708,8 +1674,6 @@ struct qdg_comm {
   ~qdg_comm()
   {
     (void)hipSetDevice(device);
-    if (cs) { (void)hipStreamSynchronize(cs); (void)hipStreamDestroy(cs); }
-    for (hipEvent_t e : { ev_ready, ev_x1, ev_x2 }) if (e) (void)hipEventDestroy(e);
     if (comm) (void)rccl_api()->CommDestroy(comm);
   }
 };
@@ -1741,10 +1705,6 @@ extern "C" int qdg_comm_create(qdg_ctx* ctx, int nranks, int rank, const void* i
   std::unique_ptr<qdg_comm> c(new qdg_comm);
   c->nranks = nranks; c->rank = rank; c->device = ctx->device;
   RCCLCHK(a->CommInitRank(&c->comm, nranks, id, rank));
-  HIPCHK(hipStreamCreateWithFlags(&c->cs, hipStreamNonBlocking));
-  HIPCHK(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
-  HIPCHK(hipEventCreateWithFlags(&c->ev_x1, hipEventDisableTiming));
-  HIPCHK(hipEventCreateWithFlags(&c->ev_x2, hipEventDisableTiming));
   *out = c.release();
   return 0;
   QDG_CATCH
@@ -1848,81 +1808,35 @@ extern "C" int qdg_stage_dt_allreduce(qdg_mesh* mesh, qdg_comm* comm)
   QDG_CATCH
 }
 
-// Optional (QDG_OVERLAP=1): the exchanges of a stage hide behind the work on tets
-// that have no ghost neighbour (device rows [0, ninner)):
-//   comm stream:  [exchange U]            [exchange limited U]        [min dt]
-//   main stream:  limiter(inner) | wait | limiter(halo side)  RHS(inner tiles) | wait | RHS(rest)
-// for the DG-P1 tile kernel with Superbee / no limiter (in-place state).
-// Off by default: at ~1 M tets per GPU an exchange costs ~17 us on the stream
-// while each cross-stream event edge costs more than that on this runtime
-// (measured, self-halo bench: 1.37 ms/step overlapped vs 1.12 ms in sequence;
-// DESIGN.md "Multi-GPU").  It pays only where the exchange is long.
-static bool can_overlap(const qdg_mesh* mesh)
-{
-  const bool on = mesh->ctx->opt.halo_overlap != 0;
-  return on && mesh->nnbr > 0 && !mesh->dm.ndofel && use_p1_fast(mesh) && use_tile(mesh) &&
-         mesh->ctx->cfg.limiter != QDG_LIMITER_WENOP1 && mesh->dm.ntile_inner > 0 &&
-         mesh->dm.ninner / 256 > 0;
-}
-
 extern "C" int qdg_step_comm(qdg_mesh* mesh, qdg_comm* comm, double t, double tleft, double* dt_taken)
 {
   QDG_TRY
   MESH_ENTER("qdg_step_comm");
   if (!comm) return fail("qdg_step_comm: null communicator");
   const bool limited = ctx->cfg.limiter != QDG_LIMITER_NONE && mesh->ndof > 1;
-  const bool overlap = can_overlap(mesh);
-  const bool fuse = !overlap && can_fuse_update_limit(mesh);
-  hipStream_t cs = comm->cs;
+  const bool fuse = can_fuse_update_limit(mesh);
   for (int stage = 0; stage < 3; ++stage) {
-    if (!overlap) {
-      const bool pdg0 = stage == 0 && mesh->dm.ndofel;
-      const bool fused1 = fuse && stage == 1;        // comsol + limiter of stage 1 ran with the update
-      if (pdg0) if (int rc = qdg_stage_pdg_eval(mesh)) return rc;          // DG::next: eval_ndof
-      if (!fused1) if (int rc = exchange_on(mesh, comm, s)) return rc;    // DG::next -> comsol
-      if (pdg0) if (int rc = qdg_stage_pdg_propagate(mesh)) return rc;     // DG::lim: propagate_ndof
-      if (!fused1) if (int rc = qdg_stage_limit(mesh)) return rc;          // DG::lim
-      if (limited || pdg0) if (int rc = exchange_on(mesh, comm, s)) return rc;   // -> comlim
-      if (int rc = qdg_stage_rhs_dt(mesh, stage, t, tleft)) return rc;     // DG::dt, DG::solve
-      if (stage == 0) if (int rc = qdg_stage_dt_allreduce(mesh, comm)) return rc;
-      if (fuse && stage == 0) {
-        // update of stage 0 + comsol + limiter of stage 1 in one pass over the state
-        double* out = free_buf(mesh, mesh->Ucur, mesh->Unp);
-        if (int rc = exchange_upd(mesh, comm, s, out)) return rc;
-        if (int rc = stage0_update_and_limit(mesh)) return rc;
-      } else if (int rc = qdg_stage_update(mesh, stage)) return rc;
-      continue;
-    }
-    HIPCHK(hipEventRecord(comm->ev_ready, s));
-    HIPCHK(hipStreamWaitEvent(cs, comm->ev_ready, 0));
-    if (int rc = exchange_on(mesh, comm, cs)) return rc;
-    HIPCHK(hipEventRecord(comm->ev_x1, cs));
-    int rc = 0;
-    if (limited) {
-      mesh->split_lim = comm->ev_x1;
-      rc = qdg_stage_limit(mesh);
-      mesh->split_lim = nullptr;
-      if (rc) return rc;
-      HIPCHK(hipEventRecord(comm->ev_ready, s));
-      HIPCHK(hipStreamWaitEvent(cs, comm->ev_ready, 0));
-      if ((rc = exchange_on(mesh, comm, cs))) return rc;
-      HIPCHK(hipEventRecord(comm->ev_x2, cs));
-      mesh->split_rhs = comm->ev_x2;
+    const bool pdg0 = stage == 0 && mesh->dm.ndofel;
+    const bool fused1 = fuse && stage == 1;        // comsol + limiter of stage 1 ran with the update
+    if (pdg0) if (int rc = qdg_stage_pdg_eval(mesh)) return rc;          // DG::next: eval_ndof
+    if (!fused1) if (int rc = exchange_on(mesh, comm, s)) return rc;    // DG::next -> comsol
+    if (pdg0) if (int rc = qdg_stage_pdg_propagate(mesh)) return rc;     // DG::lim: propagate_ndof
+    if (!fused1) if (int rc = qdg_stage_limit(mesh)) return rc;          // DG::lim
+    if (limited || pdg0) if (int rc = exchange_on(mesh, comm, s)) return rc;   // -> comlim
+    if (int rc = qdg_stage_rhs_dt(mesh, stage, t, tleft)) return rc;     // DG::dt, DG::solve
+    if (stage == 0) if (int rc = qdg_stage_dt_allreduce(mesh, comm)) return rc;
+    if (fuse && stage == 0) {
+      // update of stage 0 + comsol + limiter of stage 1 in one pass over the state
+      double* out = free_buf(mesh, mesh->Ucur, mesh->Unp);
+      if (int rc = exchange_upd(mesh, comm, s, out)) return rc;
+      if (int rc = stage0_update_and_limit(mesh)) return rc;
     } else {
-      mesh->split_rhs = comm->ev_x1;
+      // stages 0, 1: the next stage starts by receiving the ghost rows of the new state
+      mesh->skip_ghost_carry = stage < 2 && mesh->nnbr > 0;
+      const int rc = qdg_stage_update(mesh, stage);
+      mesh->skip_ghost_carry = false;
+      if (rc) return rc;
     }
-    rc = qdg_stage_rhs_dt(mesh, stage, t, tleft);
-    mesh->split_rhs = nullptr;
-    if (rc) return rc;
-    if (stage == 0) {
-      // every RCCL call of the overlapped step is issued on the communication stream
-      HIPCHK(hipEventRecord(comm->ev_ready, s));
-      HIPCHK(hipStreamWaitEvent(cs, comm->ev_ready, 0));
-      RCCLCHK(rccl_api()->AllReduce(mesh->dt_ptr, mesh->dt_ptr, 1, ncclDouble, ncclMin, comm->comm, cs));
-      HIPCHK(hipEventRecord(comm->ev_x1, cs));
-      HIPCHK(hipStreamWaitEvent(s, comm->ev_x1, 0));
-    }
-    if ((rc = qdg_stage_update(mesh, stage))) return rc;
   }
   if (dt_taken) return qdg_stage_dt_get(mesh, dt_taken);
   return 0;

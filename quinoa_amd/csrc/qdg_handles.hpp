@@ -47,9 +47,7 @@ namespace qdg {
 // qdg_ctx_set_option: tuning / A-B switches (defaults = the product path)
 struct Options {
   int p1_rhs = 0;        // DG-P1 RHS: 0 tile / face-task kernels (LDS atomics), 1 element-centric (bitwise reproducible)
-  int p1_variant = 0;    // uniform-order tile kernel: 0 k_rhs_p1v, 1 k_rhs_p1w<384>, 2 k_rhs_p1w<512>
   int fused_update = 1;  // stage-0 RK update fused with the Superbee limiter of stage 1
-  int halo_overlap = 0;  // qdg_step_comm: exchange on a second stream behind the halo-free rows
   int renumber = 1;      // Morton order of the interior tets (0: caller's order; layout experiments)
   int host_layout = 0;   // qdg_mesh_from_connectivity: 1 routes through qdg_mesh_upload's host code (A/B)
 };
@@ -93,6 +91,7 @@ struct qdg_mesh {
   double* Ucur = nullptr;
   double* Unp = nullptr;
   double* Upending = nullptr;     // output of a fused RHS+RK launch, adopted by qdg_stage_update
+  bool skip_ghost_carry = false;  // set by qdg_step_comm around an update whose ghost rows are received next
   qdg::DevBuf<double> S1, S2;          // scratch of the stateless operators (allocated on first use)
   qdg::DevBuf<int> ndofel, ndofel2;    // p-adaptive DG: DG::m_ndof per device row (+ Jacobi copy)
   qdg::DevBuf<double> fout;            // field output staging (allocated on first use)
@@ -106,10 +105,6 @@ struct qdg_mesh {
   double* recv_ptr = nullptr;
   double* dt_ptr = nullptr;       // dt scalar in use
   size_t nnode_used = 0;
-  // halo overlap (qdg_step_comm): when set, the limiter / the tile RHS run the
-  // rows without a ghost neighbour first, then wait for this event (end of the
-  // exchange on the communication stream) before the rows next to the halo
-  hipEvent_t split_lim = nullptr, split_rhs = nullptr;
   // measurement: event pairs around the RHS kernel (cont: second part of a split launch)
   bool prof = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;

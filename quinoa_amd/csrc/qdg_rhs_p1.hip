@@ -1,42 +1,15 @@
 // qdg_rhs_p1.hip -- the DG-P1 right-hand side of dg::CompFlow::rhs
-// (src/PDE/CompFlow/DGCompFlow.hpp:130-195) for gfx950, hand-written HIP.
-#include <algorithm>
+// (src/PDE/CompFlow/DGCompFlow.hpp:130-195) for gfx950, hand-written HIP:
+//   k_rhs_p1w  tile / face-task kernel, uniform order (the default and the headline kernel)
+//   k_rhs_p1t  tile / face-task kernel of p-adaptive meshes (per-element ndof in {1, 4})
+//   k_rhs_p1   element-centric form: every tet visits its four faces, R written once, bitwise
+//              reproducible run to run (context option "p1_rhs" = 1)
 #include "qdg_devfn.hpp"
-
-#ifndef QDG_TILE_WAVES
-#define QDG_TILE_WAVES 2
-#endif
-#ifndef QDG_TILE_GP_SERIAL
-#define QDG_TILE_GP_SERIAL 1
-#endif
-#ifndef QDG_P1_WAVES
-#define QDG_P1_WAVES 2   // waves per SIMD the element-centric DG-P1 RHS kernel is register-budgeted for
-#endif
 
 namespace qdg {
 
-#ifdef QDG_P1_STAMPS
-// DIAGNOSTIC build only (tools/stamps_p1.sh; never part of a timed or shipped build): lane 0 of
-// every wave adds the s_memtime difference of each segment of k_rhs_p1w; slots [0,16) waves
-// 0-1 of a workgroup, [16,32) waves 2 and up
-__device__ unsigned long long g_stamp[32];
-#define STAMP_INIT unsigned long long tprev_ = __builtin_amdgcn_s_memtime()
-#define STAMP(i)                                                                                   \
-  do {                                                                                             \
-    __builtin_amdgcn_sched_barrier(0);                                                             \
-    const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                    \
-    __builtin_amdgcn_s_waitcnt(0xC07F);                                                            \
-    if ((threadIdx.x & 63) == 0) atomicAdd(&g_stamp[(i) + ((threadIdx.x >> 6) >= 2 ? 16 : 0)], t_ - tprev_); \
-    tprev_ = __builtin_amdgcn_s_memtime();                                                         \
-    __builtin_amdgcn_sched_barrier(0);                                                             \
-  } while (0)
-#else
-#define STAMP_INIT do {} while (0)
-#define STAMP(i) do {} while (0)
-#endif
-
-// ------------------------------------------------- DG-P1 RHS (headline kernel)
-// Same algorithm as k_rhs<4>, specialised for throughput:
+// ------------------------------------------------- DG-P1 RHS, element-centric form
+// One lane per tet, specialised for throughput:
 //  * own DOFs live in registers (one coalesced pass), the neighbour's 20 DOFs
 //    of face lf+1 are gathered while face lf is computed (software prefetch),
 //    so each wave has ~25 independent loads in flight instead of a dependent
@@ -48,7 +21,7 @@ __device__ unsigned long long g_stamp[32];
 //    (DGCompFlow.hpp:206-406) is accumulated from the wave speeds the Riemann
 //    solver already has -- the separate dt face loop disappears.
 template <bool WITH_DT, bool FUSE_RK, int PROB>
-__global__ __launch_bounds__(256, QDG_P1_WAVES) void k_rhs_p1(DevMesh m, Phys ph, double t,
+__global__ __launch_bounds__(256, 2) void k_rhs_p1(DevMesh m, Phys ph, double t,
                                                 const double* __restrict__ U,
                                                 double* __restrict__ R,
                                                 double* __restrict__ blockmin,
@@ -297,7 +270,7 @@ __global__ __launch_bounds__(256, QDG_P1_WAVES) void k_rhs_p1(DevMesh m, Phys ph
 // (Surface.cpp:81-86): between two P0 tets both states are constant, so the 1-
 // and the 3-point sums agree to rounding.
 template <bool WITH_DT, bool FUSE_RK, int PROB, bool PDG>
-__global__ __launch_bounds__(TILE_BS, QDG_TILE_WAVES) void k_rhs_p1t(DevMesh m, Phys ph, double t,
+__global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1t(DevMesh m, Phys ph, double t,
                                                      const double* __restrict__ U,
                                                      double* __restrict__ R,
                                                      double* __restrict__ blockmin,
@@ -654,441 +627,7 @@ __global__ __launch_bounds__(TILE_BS, QDG_TILE_WAVES) void k_rhs_p1t(DevMesh m, 
     }
     if (WITH_DT) dte = vol / sdelt[tid];
   }
-  // rows out through LDS as coalesced wave stores (see k_rhs_p1v)
-  __syncthreads();
-  if (tid < nloc) {
-    double2* row = reinterpret_cast<double2*>(nod + (size_t)tid * NPROP);
-#pragma unroll
-    for (int j = 0; j < NPROP / 2; ++j) row[j] = make_double2((&acc[0][0])[2 * j], (&acc[0][0])[2 * j + 1]);
-  }
-  __syncthreads();
-  {
-    const double2* src = reinterpret_cast<const double2*>(nod);
-    double2* dst = reinterpret_cast<double2*>(R + (size_t)tile_e0 * NPROP);
-    const int nvalid = nloc * (NPROP / 2);
-#pragma unroll
-    for (int j = 0; j < NPROP / 2; ++j) {
-      const int i = j * TILE_BS + tid;
-      if (i < nvalid) dst[i] = src[i];
-    }
-  }
-
-  if (WITH_DT) {
-    for (int off = 32; off > 0; off >>= 1) dte = fmin(dte, __shfl_down(dte, off, 64));
-    __shared__ double wmin[TILE_BS / 64];
-    const int lane = tid & 63, wv = tid >> 6;
-    if (lane == 0) wmin[wv] = dte;
-    __syncthreads();
-    if (tid == 0) {
-      double mn = wmin[0];
-      for (int w = 1; w < TILE_BS / 64; ++w) mn = fmin(mn, wmin[w]);
-      blockmin[tile] = mn;
-    }
-  }
-}
-
-// ------------------------------------------- DG-P1 RHS, tile / face-task form, version 2
-// Same tiles, task lists, LDS layout and phases as k_rhs_p1t; the face task is leaner:
-//  * own-frame evaluation with the mirrored HLLC ladder instead of swapping the two states
-//    into stored (left, right) order at every Gauss point (20 selects per point);
-//  * the 3-point rule's structure (one heavy vertex per point, equal weights): one FMA per
-//    state component per point, and the vertex-weighted flux sums formed once after the
-//    point loop from the three raw fluxes;
-//  * uniform order only (p-adaptive runs use k_rhs_p1t).
-template <bool WITH_DT, bool FUSE_RK, int PROB>
-__global__ __launch_bounds__(TILE_BS, QDG_TILE_WAVES) void k_rhs_p1v(DevMesh m, Phys ph, double t,
-                                                     const double* __restrict__ U,
-                                                     double* __restrict__ R,
-                                                     double* __restrict__ blockmin,
-                                                     double rk_a, double rk_b,
-                                                     const double* __restrict__ dtp,
-                                                     const double* __restrict__ Un)
-{
-  constexpr int NDOF = 4, NGF = 3, NGV = 5, NPROP = NCOMP * NDOF;
-  const Tables<4>& T = c_tab4;
-  // LDS: the tile's states in NODAL form, nod[e][vertex][c] (a P1 state is
-  // affine: its value at a face point is the barycentric mix of its vertex
-  // values), and per-vertex flux accumulators accN[e][vertex][c]
-  __shared__ __attribute__((aligned(16))) double nod[TILE * NPROP];
-  __shared__ double accN[TILE * NPROP];
-  __shared__ double sdelt[WITH_DT ? TILE : 1];
-  const int tid = threadIdx.x;
-  const int tile = m.blk0 + xcd_tile(blockIdx.x, gridDim.x);
-  const int tile_e0 = m.tile_rows ? tile * m.tile_rows : m.tile_row[tile];
-  const int nloc = m.tile_rows ? ((m.nie - tile_e0 < m.tile_rows) ? m.nie - tile_e0 : m.tile_rows)
-                               : m.tile_row[tile + 1] - tile_e0;
-
-  // this lane's task descriptors (up to MAXT rounds) and the first task's face
-  // geometry / external row are requested before anything waits on LDS
-  constexpr int MAXT = 4;
-  int ta[MAXT], tf[MAXT], tn[MAXT];
-  int t0 = 0, t1 = 0;
-  if (m.task_stride > 0) {
-    // padded task lists (unused slots hold -1): a tile's slots start at tile * stride, so the
-    // descriptors need no offset load in front of them (one dependent memory latency less on
-    // the way to the first neighbour row)
-    const size_t base = (size_t)tile * m.task_stride;
-#pragma unroll
-    for (int q = 0; q < MAXT; ++q) {
-      const size_t it = base + tid + TILE_BS * q;
-      ta[q] = m.task_a[it];
-      // with face records in task order (tgeo) the slot itself addresses the record
-      tf[q] = m.tgeo ? (int)it : m.task_f[it];
-      tn[q] = m.task_nb[it];
-    }
-  } else {
-    t0 = m.tile_off[tile]; t1 = m.tile_off[tile + 1];
-#pragma unroll
-    for (int q = 0; q < MAXT; ++q) {
-      const int it = t0 + tid + TILE_BS * q;
-      const bool ok = it < t1;
-      ta[q] = ok ? m.task_a[it] : -1;
-      tf[q] = ok ? m.task_f[it] : 0;
-      tn[q] = ok ? m.task_nb[it] : 0;
-    }
-  }
-
-  // ---- phase 0: modal row -> the 4 vertex states, accumulators = 0 ------------
-  if (tid < TILE) {
-    double r[NCOMP][NDOF];
-    if (tid < nloc) load_row<NPROP>(U, tile_e0 + tid, &r[0][0]);
-    else {
-#pragma unroll
-      for (int c = 0; c < NCOMP; ++c) { r[c][0] = 1.0; r[c][1] = r[c][2] = r[c][3] = 0.0; }
-    }
-    double v[4][NCOMP];
-#pragma unroll
-    for (int c = 0; c < NCOMP; ++c) {
-      // B at the vertices: v0 (-1,-1,-1), v1 (1,-1,-1), v2 (0,2,-1), v3 (0,0,3)
-      const double a = r[c][0] - r[c][3];
-      v[0][c] = a - r[c][1] - r[c][2];
-      v[1][c] = a + r[c][1] - r[c][2];
-      v[2][c] = a + 2.0 * r[c][2];
-      v[3][c] = r[c][0] + 3.0 * r[c][3];
-    }
-    // LDS planes [vertex][component][tet]: lanes of a wave work on different tets at the
-    // same (vertex, component), so tet-fastest storage is free of bank conflicts
-#pragma unroll
-    for (int vx = 0; vx < 4; ++vx)
-#pragma unroll
-      for (int c = 0; c < NCOMP; ++c) { nod[LIDX(tid, vx, c)] = v[vx][c]; accN[LIDX(tid, vx, c)] = 0.0; }
-    if (WITH_DT) sdelt[tid] = 0.0;
-  }
-  double gnx[4], rnx[NCOMP][NDOF];
-  const double* __restrict__ geo = (m.task_stride > 0 && m.tgeo) ? m.tgeo : m.fgeo;
-  if (ta[0] >= 0) {
-    load_row<4>(geo, tf[0], gnx);
-    if (TASK_KIND(ta[0]) == TASK_EXT) load_row<NPROP>(U, tn[0], &rnx[0][0]);
-  }
-  __syncthreads();
-
-  // ---- phase 1: one lane per face task ------------------------------------------
-  constexpr bool HAS_DIRICHLET = (PROB == 3 || PROB == 4 || PROB == 0 || PROB == 7 || PROB == 10);
-  if ((t1 - t0) > TILE_BS * MAXT) __builtin_trap();   // cannot happen: <= 4*TILE tasks per tile
-#pragma unroll 1
-  for (int q = 0; q < MAXT; ++q) {
-    const int a = (q == 0) ? ta[0] : (q == 1) ? ta[1] : (q == 2) ? ta[2] : ta[3];
-    if (a < 0) break;
-    const int el = TASK_EL(a), lf = TASK_LF(a), code = TASK_CODE(a), kind = TASK_KIND(a),
-              bc = TASK_BC(a), pl = TASK_PL(a);
-    const bool own_left = TASK_OWNLEFT(a);
-    // everything below works in the OWN tet's frame: left' = own, right' = neighbour,
-    // n' = the own tet's outward normal (the stored normal or its negative).  For a face
-    // whose stored left tet is the neighbour this is the mirror image of the reference's
-    // evaluation: wave speeds change sign (Sl' = -Sr, Sm' = -Sm, Sr' = -Sl), so the
-    // reference's ladder (HLLC.hpp:93-124) is applied in its mirrored form -- same four
-    // fluxes, same fall-through of a NaN wave speed to the STORED right state -- and the
-    // own tet always loses what the neighbour gains.
-    const double area = gnx[0];
-    const double osg = own_left ? 1.0 : -1.0;
-    const double fn[3] = { osg * gnx[1], osg * gnx[2], osg * gnx[3] };
-    double rex[NCOMP][NDOF];
-#pragma unroll
-    for (int c = 0; c < NCOMP; ++c)
-#pragma unroll
-      for (int k = 0; k < NDOF; ++k) rex[c][k] = rnx[c][k];
-    {
-      // prefetch the next task of this lane
-      const int an = (q == 0) ? ta[1] : (q == 1) ? ta[2] : (q == 2) ? ta[3] : -1;
-      const int fq = (q == 0) ? tf[1] : (q == 1) ? tf[2] : tf[3];
-      const int nq = (q == 0) ? tn[1] : (q == 1) ? tn[2] : tn[3];
-      if (an >= 0) {
-        load_row<4>(geo, fq, gnx);
-        if (TASK_KIND(an) == TASK_EXT) load_row<NPROP>(U, nq, &rnx[0][0]);
-      }
-    }
-    const bool bnd = kind == TASK_BND;
-
-    // vertex states of both tets at the three face vertices
-    double Vo[3][NCOMP], Vn[3][NCOMP];
-    int no[3], nn[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) { no[j] = lpofa(lf, j); nn[j] = (code >> (2 * j)) & 3; }
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-#pragma unroll
-      for (int c = 0; c < NCOMP; ++c) Vo[j][c] = nod[LIDX(el, no[j], c)];
-    }
-    if (kind == TASK_INT) {
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-#pragma unroll
-        for (int c = 0; c < NCOMP; ++c) Vn[j][c] = nod[LIDX(pl, nn[j], c)];
-      }
-    } else if (kind == TASK_EXT) {
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        double b1, b2, b3;
-        vertex_basis(nn[j], b1, b2, b3);
-#pragma unroll
-        for (int c = 0; c < NCOMP; ++c)
-          Vn[j][c] = rex[c][0] + rex[c][1] * b1 + rex[c][2] * b2 + rex[c][3] * b3;
-      }
-    } else {
-      // Extrapolate: u_r = u_l; Symmetry: mirrored momentum (DGCompFlow.hpp:672-690),
-      // a linear map, applied to the vertex states
-      const double refl = (bc == 2) ? 2.0 : 0.0;
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const double vn2 = refl * (Vo[j][1] * fn[0] + Vo[j][2] * fn[1] + Vo[j][3] * fn[2]);
-        Vn[j][0] = Vo[j][0];
-        Vn[j][1] = Vo[j][1] - vn2 * fn[0];
-        Vn[j][2] = Vo[j][2] - vn2 * fn[1];
-        Vn[j][3] = Vo[j][3] - vn2 * fn[2];
-        Vn[j][4] = Vo[j][4];
-      }
-    }
-    const double wsel = (bnd && bc == 0) ? 0.0 : 1.0;   // boundary face without a BC: no flux
-
-    // The 3-point rule (Quadrature.cpp:261-339) puts weight 2/3 on one face vertex and 1/6
-    // on the other two, all three points weigh 1/3: with B = (V0+V1+V2)/6 the state at point g
-    // is B + V_h(g)/2, h(g) = (g+1)%3, and the vertex-weighted flux sums are
-    //   W_j = A/18 (F_0+F_1+F_2) + A/6 F_g(j),  g(j) = (j+2)%3
-    // -- one FMA per state component and no arithmetic on the fluxes inside the point loop.
-    double Bo[NCOMP], Bn[NCOMP], Fg[3][NCOMP], dsum = 0.0;
-#pragma unroll
-    for (int c = 0; c < NCOMP; ++c) {
-      Bo[c] = (Vo[0][c] + Vo[1][c] + Vo[2][c]) * (1.0 / 6.0);
-      Bn[c] = (Vn[0][c] + Vn[1][c] + Vn[2][c]) * (1.0 / 6.0);
-    }
-    [[maybe_unused]] ElemGeom gdir;
-    if constexpr (HAS_DIRICHLET) {
-      if (bnd && bc == 1) load_geom(m, tile_e0 + el, gdir);
-    }
-#pragma unroll
-    for (int ig = 0; ig < NGF; ++ig) {
-      constexpr int H[3] = { 1, 2, 0 };
-      const int h = H[ig];
-      double so[NCOMP], sn[NCOMP];
-#pragma unroll
-      for (int c = 0; c < NCOMP; ++c) {
-        so[c] = fma(0.5, Vo[h][c], Bo[c]);
-        sn[c] = fma(0.5, Vn[h][c], Bn[c]);
-      }
-      if constexpr (HAS_DIRICHLET) {
-        if (bnd && bc == 1) {
-          double P[3];
-          face_point(gdir, lf, T.fs[ig][0], T.fs[ig][1], T.fs[ig][2], P);
-          prob_solution<PROB>(ph, P[0], P[1], P[2], t, sn);
-        }
-      }
-      Prim qo, qn;
-      primitives(ph, fn, so, qo);
-      primitives(ph, fn, sn, qn);
-      if (WITH_DT) {
-        // delt += std::max(dSV_l, dSV_r) = (a < b) ? b : a in STORED (left, right) order;
-        // boundary faces: dSV_r = 0
-        const double d_o = fabs(qo.vn) + qo.a;
-        const double d_n = bnd ? 0.0 : fabs(qn.vn) + qn.a;
-        const bool take_n = own_left ? (d_o < d_n) : !(d_n < d_o);
-        dsum += take_n ? d_n : d_o;
-      }
-      if (ph.flux == 1) {
-        // Lax-Friedrichs is symmetric under the mirror image (LaxFriedrichs.hpp:34-88)
-        flux_lf_q(fn, so, sn, qo, qn, Fg[ig]);
-      } else {
-        const double rlr = fast_sqrt(sn[0] * qo.ir);
-        const double irlr1 = fast_rcp(1.0 + rlr);
-        const double vnroe = (qn.vn * rlr + qo.vn) * irlr1;
-        const double aroe = (qn.a * rlr + qo.a) * irlr1;
-        const double Sl = fmin(qo.vn - qo.a, vnroe - aroe);
-        const double Sr = fmax(qn.vn + qn.a, vnroe + aroe);
-        const double ml = so[0] * (Sl - qo.vn), mr = sn[0] * (Sr - qn.vn);
-        const double Sm = (mr * qn.vn - ml * qo.vn + qo.p - qn.p) * fast_rcp(mr - ml);
-        const double pStar = so[0] * (qo.vn - Sl) * (qo.vn - Sm) + qo.p;
-        // stored orientation = own frame:  Sl>0: own | Sl<=0,Sm>0: own* | Sm<=0,Sr>=0: nbr* | else nbr
-        // mirrored:                        Sr<0: nbr | Sr>=0,Sm<0: nbr* | Sm>=0,Sl<=0: own* | else own
-        const bool c1 = Sl > 0.0;
-        const bool c2 = !c1 && (Sl <= 0.0) && (Sm > 0.0);
-        const bool c3 = !c1 && !c2 && (Sm <= 0.0) && (Sr >= 0.0);
-        const bool m1 = Sr < 0.0;
-        const bool m2 = !m1 && (Sr >= 0.0) && (Sm < 0.0);
-        const bool m3 = !m1 && !m2 && (Sm >= 0.0) && (Sl <= 0.0);
-        const bool left = own_left ? (c1 || c2) : !(m1 || m2);
-        const bool star = own_left ? (c2 || c3) : (m2 || m3);
-        const double S = left ? Sl : Sr;
-        const double vn = left ? qo.vn : qn.vn;
-        const double p = left ? qo.p : qn.p;
-        const double u0 = left ? so[0] : sn[0], u1 = left ? so[1] : sn[1], u2 = left ? so[2] : sn[2],
-                     u3 = left ? so[3] : sn[3], u4 = left ? so[4] : sn[4];
-        const double id = star ? fast_rcp(S - Sm) : 1.0;
-        const double sv = star ? (S - vn) * id * Sm : vn;
-        const double dp = star ? (pStar - p) * id * Sm + pStar : p;
-        const double e4 = star ? ((pStar * Sm - p * vn) * id + pStar) * Sm : p * vn;
-        Fg[ig][0] = sv * u0;
-        Fg[ig][1] = sv * u1 + dp * fn[0];
-        Fg[ig][2] = sv * u2 + dp * fn[1];
-        Fg[ig][3] = sv * u3 + dp * fn[2];
-        Fg[ig][4] = sv * u4 + e4;
-      }
-#if QDG_TILE_GP_SERIAL
-      __builtin_amdgcn_sched_barrier(0);     // keep the three points in sequence (register pressure)
-#endif
-    }
-
-    // ---- scatter the vertex-weighted flux sums: the own tet loses, the neighbour gains ---
-    {
-      const double k1 = area * wsel * (1.0 / 18.0), k2 = area * wsel * (1.0 / 6.0);
-      double W[3][NCOMP];
-#pragma unroll
-      for (int c = 0; c < NCOMP; ++c) {
-        const double Ssum = k1 * ((Fg[0][c] + Fg[1][c]) + Fg[2][c]);
-        W[0][c] = fma(k2, Fg[2][c], Ssum);
-        W[1][c] = fma(k2, Fg[0][c], Ssum);
-        W[2][c] = fma(k2, Fg[1][c], Ssum);
-      }
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-#pragma unroll
-        for (int c = 0; c < NCOMP; ++c)
-          __hip_atomic_fetch_add(accN + LIDX(el, no[j], c), -W[j][c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-      if (WITH_DT) {
-        dsum *= area * (1.0 / 3.0);
-        __hip_atomic_fetch_add(sdelt + el, dsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-      if (kind == TASK_INT) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-#pragma unroll
-          for (int c = 0; c < NCOMP; ++c)
-            __hip_atomic_fetch_add(accN + LIDX(pl, nn[j], c), W[j][c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        if (WITH_DT) __hip_atomic_fetch_add(sdelt + pl, dsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-    }
-  }
-  // phase-2 inputs are requested before the barrier (their latency overlaps the
-  // other waves' last tasks)
-  double u[NCOMP][NDOF], un[NCOMP][NDOF];
-  double vol = 1.0;
-  ElemGeom g;
-  if (tid < nloc) {
-    const int e = tile_e0 + tid;
-    load_row<NPROP>(U, e, &u[0][0]);          // modal row again
-    if (FUSE_RK) load_row<NPROP>(Un, e, &un[0][0]);
-    vol = m.vol[e];
-    const int stride = m.stride;
-    const int n0 = m.inpoel[e], n1 = m.inpoel[(size_t)stride + e], n2 = m.inpoel[(size_t)2 * stride + e],
-              n3 = m.inpoel[(size_t)3 * stride + e];
-    double q[4];
-    load_row<4>(m.xyz4, n0, q); g.p[0][0] = q[0]; g.p[0][1] = q[1]; g.p[0][2] = q[2];
-    load_row<4>(m.xyz4, n1, q); g.p[1][0] = q[0]; g.p[1][1] = q[1]; g.p[1][2] = q[2];
-    load_row<4>(m.xyz4, n2, q); g.p[2][0] = q[0]; g.p[2][1] = q[1]; g.p[2][2] = q[2];
-    load_row<4>(m.xyz4, n3, q); g.p[3][0] = q[0]; g.p[3][1] = q[1]; g.p[3][2] = q[2];
-  }
-  __syncthreads();
-
-  // ---- phase 2: one lane per tet: volume (+source) term, epilogue, store --------
-  double dte = DBL_MAX;
-  double acc[NCOMP][NDOF];
-  if (tid < nloc) {
-    {
-      // R[c][k] = sum_v accN[v][c] * B_k(vertex v)
-      double nv[4][NCOMP];
-#pragma unroll
-      for (int vx = 0; vx < 4; ++vx)
-#pragma unroll
-        for (int c = 0; c < NCOMP; ++c) nv[vx][c] = accN[LIDX(tid, vx, c)];
-#pragma unroll
-      for (int c = 0; c < NCOMP; ++c) {
-        acc[c][0] = (nv[0][c] + nv[1][c]) + (nv[2][c] + nv[3][c]);
-        acc[c][1] = nv[1][c] - nv[0][c];
-        acc[c][2] = 2.0 * nv[2][c] - nv[0][c] - nv[1][c];
-        acc[c][3] = 3.0 * nv[3][c] - nv[0][c] - nv[1][c] - nv[2][c];
-      }
-    }
-    {
-      double ji[3][3];
-      inverse_jacobian(g, ji);
-      double Fs[NCOMP][3];
-#pragma unroll
-      for (int c = 0; c < NCOMP; ++c) Fs[c][0] = Fs[c][1] = Fs[c][2] = 0.0;
-#pragma unroll
-      for (int ig = 0; ig < NGV; ++ig) {
-        double s[NCOMP];
-        state_from<NDOF>(u, T.vB[ig], s);
-        const double ir = fast_rcp(s[0]);
-        const double uu = s[1] * ir, vv = s[2] * ir, ww = s[3] * ir;
-        const double p = eos_pressure(ph, s[0], uu, vv, ww, s[4]);
-        const double wg = T.vw[ig];
-        const double h = s[4] + p;
-        Fs[0][0] += wg * s[1];            Fs[0][1] += wg * s[2];            Fs[0][2] += wg * s[3];
-        Fs[1][0] += wg * (s[1] * uu + p); Fs[1][1] += wg * (s[2] * uu);     Fs[1][2] += wg * (s[3] * uu);
-        Fs[2][0] += wg * (s[1] * vv);     Fs[2][1] += wg * (s[2] * vv + p); Fs[2][2] += wg * (s[3] * vv);
-        Fs[3][0] += wg * (s[1] * ww);     Fs[3][1] += wg * (s[2] * ww);     Fs[3][2] += wg * (s[3] * ww + p);
-        Fs[4][0] += wg * (uu * h);        Fs[4][1] += wg * (vv * h);        Fs[4][2] += wg * (ww * h);
-      }
-#pragma unroll
-      for (int k = 1; k < NDOF; ++k) {
-        const double g0 = T.vdB[0][0][k], g1 = T.vdB[0][1][k], g2 = T.vdB[0][2][k];
-        const double dx = vol * (g0 * ji[0][0] + g1 * ji[1][0] + g2 * ji[2][0]);
-        const double dy = vol * (g0 * ji[0][1] + g1 * ji[1][1] + g2 * ji[2][1]);
-        const double dz = vol * (g0 * ji[0][2] + g1 * ji[1][2] + g2 * ji[2][2]);
-#pragma unroll
-        for (int c = 0; c < NCOMP; ++c) acc[c][k] += Fs[c][0] * dx + Fs[c][1] * dy + Fs[c][2] * dz;
-      }
-    }
-    if constexpr (prob_has_source<PROB>()) {
-      const int ngs = NGV;
-#pragma unroll 1
-      for (int ig = 0; ig < ngs; ++ig) {
-        constexpr bool one = false;
-        const double xi = one ? 0.25 : T.vc[ig][0], eta = one ? 0.25 : T.vc[ig][1],
-                     zeta = one ? 0.25 : T.vc[ig][2];
-        const double w0 = 1.0 - xi - eta - zeta;
-        double P[3], s[NCOMP];
-#pragma unroll
-        for (int d = 0; d < 3; ++d)
-          P[d] = g.p[0][d] * w0 + g.p[1][d] * xi + g.p[2][d] * eta + g.p[3][d] * zeta;
-        prob_src<PROB>(ph, P[0], P[1], P[2], t, s);
-        const double wt = (one ? 1.0 : T.vw[ig]) * vol;
-#pragma unroll
-        for (int c = 0; c < NCOMP; ++c) {
-          const double ws = wt * s[c];
-          acc[c][0] += ws;
-          if (!one) {
-#pragma unroll
-            for (int k = 1; k < NDOF; ++k) acc[c][k] += ws * T.vB[ig][k];
-          }
-        }
-      }
-    }
-    if (FUSE_RK) {
-      constexpr double imf[4] = { 1.0, 10.0, 10.0 / 3.0, 5.0 / 3.0 };
-      const double dtv = dtp[0] / vol;
-#pragma unroll
-      for (int c = 0; c < NCOMP; ++c)
-#pragma unroll
-        for (int k = 0; k < NDOF; ++k)
-          acc[c][k] = rk_a * un[c][k] + rk_b * (u[c][k] + dtv * imf[k] * acc[c][k]);
-    }
-    if (WITH_DT) dte = vol / sdelt[tid];
-  }
-  // rows out, coalesced: a lane storing its own 160-B row issues 64 separate 16-B write
-  // requests per wave instruction (3.4 TB/s measured, tools/ubench_rowstream.hip); the tile's
-  // rows are one contiguous span, so they go through LDS (row-major over the vertex states,
-  // which nobody reads any more) and leave as 1-KiB wave stores (6.1 TB/s)
+  // rows out through LDS as coalesced wave stores (see k_rhs_p1w)
   __syncthreads();
   if (tid < nloc) {
     double2* row = reinterpret_cast<double2*>(nod + (size_t)tid * NPROP);
@@ -1122,19 +661,23 @@ __global__ __launch_bounds__(TILE_BS, QDG_TILE_WAVES) void k_rhs_p1v(DevMesh m, 
 }
 
 // ------------------------------------------- the lean face task of the tile kernels below
-// One face of a tile, evaluated once in the own tet's frame (see k_rhs_p1v for the mirrored HLLC
-// ladder and the 3-point-rule algebra), budgeted for registers: vertex states are NOT held
+// One face of a tile, evaluated once, budgeted for registers: vertex states are NOT held
 // across the Gauss points -- the face means Bo, Bn stay in registers (one pass over the 2 x 15
 // LDS values) and the heavy vertex of each point is read again from LDS when its point is
 // evaluated.  `a` is the packed task word, g4 the face record {area, n}, *nbrow the neighbour's
-// device row (faces to other tiles; read only by lanes that have such a face, so rounds without
-// one issue no load); ROWREADY: rnx already holds that row (prefetched).
-template <bool WITH_DT, int PROB, bool ROWREADY>
+// device row (faces to other tiles; read only by lanes that have such a face -- they are listed
+// first, so later rounds issue no load).  Everything is evaluated in the OWN tet's frame: left' =
+// own, right' = neighbour, n' = the own tet's outward normal (the stored normal or its negative);
+// for a face whose stored left tet is the neighbour this is the mirror image of the reference's
+// evaluation (Sl' = -Sr, Sm' = -Sm, Sr' = -Sl), so HLLC's ladder (HLLC.hpp:93-124) is applied in
+// its mirrored form (flux_hllc_own) -- same four fluxes, same fall-through of a NaN wave speed to
+// the STORED right state -- and the own tet always loses what the neighbour gains.
+template <bool WITH_DT, int PROB>
 __device__ __forceinline__ void face_task_lean(const DevMesh& m, const Phys& ph, double t,
                                                const double* __restrict__ U, double* __restrict__ nod,
                                                double* __restrict__ accN, double* __restrict__ sdelt,
                                                int a, const int* __restrict__ nbrow, int tile_e0,
-                                               const double (&g4)[4], const double (&rnx)[NCOMP][4])
+                                               const double (&g4)[4])
 {
   constexpr int NDOF = 4, NGF = 3, NPROP = NCOMP * NDOF;
   constexpr bool HAS_DIRICHLET = (PROB == 3 || PROB == 4 || PROB == 0 || PROB == 7 || PROB == 10);
@@ -1168,11 +711,10 @@ __device__ __forceinline__ void face_task_lean(const DevMesh& m, const Phys& ph,
 #pragma unroll
     for (int j = 0; j < 3; ++j) vertex_basis((code >> (2 * j)) & 3, b1[j], b2[j], b3[j]);
     double rl[NCOMP][NDOF];
-    if constexpr (!ROWREADY) load_row<NPROP>(U, *nbrow, &rl[0][0]);
+    load_row<NPROP>(U, *nbrow, &rl[0][0]);
 #pragma unroll
     for (int c = 0; c < NCOMP; ++c) {
-      const double x0 = ROWREADY ? rnx[c][0] : rl[c][0], x1 = ROWREADY ? rnx[c][1] : rl[c][1],
-                   x2 = ROWREADY ? rnx[c][2] : rl[c][2], x3 = ROWREADY ? rnx[c][3] : rl[c][3];
+      const double x0 = rl[c][0], x1 = rl[c][1], x2 = rl[c][2], x3 = rl[c][3];
       const double v0 = x0 + x1 * b1[0] + x2 * b2[0] + x3 * b3[0];
       const double v1 = x0 + x1 * b1[1] + x2 * b2[1] + x3 * b3[1];
       const double v2 = x0 + x1 * b1[2] + x2 * b2[2] + x3 * b3[2];
@@ -1338,7 +880,7 @@ __device__ __forceinline__ void tet_volume_lean(const Phys& ph, double t, const 
   }
 }
 
-// SSP-RK3 update fused into the epilogue, rows in registers (requested before the barrier)
+// SSP-RK3 update fused into the epilogue: acc <- a*Un + b*(U + dt*acc/L), rows in registers
 __device__ __forceinline__ void rk_epilogue_rows(const double (&u)[NCOMP][4], const double (&un)[NCOMP][4],
                                                  double dtv, double rk_a, double rk_b, double (&acc)[NCOMP][4])
 {
@@ -1349,48 +891,38 @@ __device__ __forceinline__ void rk_epilogue_rows(const double (&u)[NCOMP][4], co
     for (int k = 0; k < 4; ++k) acc[c][k] = rk_a * un[c][k] + rk_b * (u[c][k] + dtv * imf[k] * acc[c][k]);
 }
 
-// SSP-RK3 update fused into the epilogue: acc <- a*Un + b*(U + dt*acc/L); U and Un stream
-// through (two 16-byte loads per pair of modes, consumed at once)
-__device__ __forceinline__ void rk_epilogue_lean(const double* __restrict__ U, const double* __restrict__ Un,
-                                                 int e, double dtv, double rk_a, double rk_b,
-                                                 double (&acc)[NCOMP][4])
+// ------------------------------------------- DG-P1 RHS, tile / face-task form (uniform order)
+// A workgroup of 256 lanes owns a tile of TILE = 248 consecutive device rows (Morton-compact),
+// two workgroups per CU (2 x 79 KB of LDS), in three phases separated by two barriers:
+//  0. every load that depends on nothing goes out at kernel entry in one burst (the tet's own
+//     modal row, the task words of all rounds, round 0's face record, node ids, volume); the row
+//     is written to LDS in NODAL form, nod[vertex][c][tet], and STAYS in registers for the RK
+//     epilogue (re-read in phase 2 it misses the L2 at size: 160 B per tet of extra HBM reads);
+//  1. one lane per face task (face_task_lean): every face of the tile once, both tets of an
+//     in-tile face served by one evaluation through ds_add_f64;
+//  2. one lane per tet (tet_volume_lean): accumulators -> modal R, volume term from the vertex
+//     states in LDS, source; WITH_DT: CFL sum -> vol/sum, block minimum (stage 0); FUSE_RK:
+//     Uout = a*Un + b*(U + dt*R/L) written instead of R (stages 1, 2); rows leave through LDS as
+//     coalesced 1-KiB wave stores.
+// Round 3 measured the alternatives on this kernel (profiles/r03_p1_experiments.log): 384 / 320
+// lanes per tile get ONE workgroup per CU from the dispatcher (2.7 ms against 1.6 ms at 10.1 M
+// tets), 512 lanes need 128 registers (spills: scratch traffic costs more than the waves hide),
+// 160-row tiles with three workgroups per CU at 158 registers 1.67 ms, persistent workgroups
+// prefetching the next tile's rows through the face rounds 2.1 ms (256 registers, in-order vmcnt
+// couples the prefetch to every later load), the round-2 form of the face task (vertex states
+// held across the Gauss points, 206 registers, the row re-read in phase 2) 1.60-1.65 ms.
+template <bool WITH_DT, bool FUSE_RK, int PROB>
+__global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1w(DevMesh m, Phys ph, double t,
+                                                        const double* __restrict__ U,
+                                                        double* __restrict__ R,
+                                                        double* __restrict__ blockmin,
+                                                        double rk_a, double rk_b,
+                                                        const double* __restrict__ dtp,
+                                                        const double* __restrict__ Un)
 {
-  constexpr double imf[4] = { 1.0, 10.0, 10.0 / 3.0, 5.0 / 3.0 };
-  const double2* pu = reinterpret_cast<const double2*>(U + (size_t)e * (NCOMP * 4));
-  const double2* pn = reinterpret_cast<const double2*>(Un + (size_t)e * (NCOMP * 4));
-#pragma unroll
-  for (int c = 0; c < NCOMP; ++c)
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const double2 a = pu[c * 2 + kk], b = pn[c * 2 + kk];
-      acc[c][2 * kk] = rk_a * b.x + rk_b * (a.x + dtv * imf[2 * kk] * acc[c][2 * kk]);
-      acc[c][2 * kk + 1] = rk_a * b.y + rk_b * (a.y + dtv * imf[2 * kk + 1] * acc[c][2 * kk + 1]);
-    }
-}
-
-// ------------------------------------------- DG-P1 RHS, tile / face-task form, version 3
-// Same tiles, task words, LDS planes and phases as k_rhs_p1v with the lean face task above and
-// BS = 384 or 512 lanes on the same 248-row tile, register-budgeted for 3 / 4 waves per SIMD.
-// Kept as the MEASURED answer to "is it occupancy?": at 1 M tets 0.27 / 0.24 ms per launch
-// against 0.19 ms of k_rhs_p1v -- more waves on the same two tiles per CU add no bytes in
-// flight (profiles/r03_p1_experiments.log).
-#ifndef QDG_P1W_WAVES256
-#define QDG_P1W_WAVES256 2      // waves per SIMD the 256-lane form is budgeted for (3: tiles of <= 166 rows)
-#endif
-template <bool WITH_DT, bool FUSE_RK, int PROB, int BS, bool EXTPF = false>
-__global__ __launch_bounds__(BS, (BS == 256 ? QDG_P1W_WAVES256 : BS / 128)) void k_rhs_p1w(DevMesh m, Phys ph, double t,
-                                                           const double* __restrict__ U,
-                                                           double* __restrict__ R,
-                                                           double* __restrict__ blockmin,
-                                                           double rk_a, double rk_b,
-                                                           const double* __restrict__ dtp,
-                                                           const double* __restrict__ Un)
-{
-  constexpr int NDOF = 4, NPROP = NCOMP * NDOF;
-  constexpr int STRIDE = 4 * TILE_BS;                 // slots per tile of the padded task lists
-  constexpr int NR = (STRIDE + BS - 1) / BS;          // rounds of the workgroup over the slots
-  // the modal row stays in registers for the RK epilogue where the register budget allows
-  constexpr bool KEEP_ROW = BS <= 256 && QDG_P1W_WAVES256 == 2;
+  constexpr int NDOF = 4, NPROP = NCOMP * NDOF, BS = TILE_BS;
+  constexpr int NR = 4;                               // rounds of the workgroup over the padded task slots
+  static_assert(TILE_BS == 256, "task_stride = 4 * TILE_BS slots per tile, 4 rounds of 256 lanes");
   __shared__ __attribute__((aligned(16))) double nod[TILE * NPROP];
   __shared__ double accN[TILE * NPROP];
   __shared__ double sdelt[WITH_DT ? TILE : 1];
@@ -1398,46 +930,30 @@ __global__ __launch_bounds__(BS, (BS == 256 ? QDG_P1W_WAVES256 : BS / 128)) void
   const int tile = m.blk0 + xcd_tile(blockIdx.x, gridDim.x);
   const int tile_e0 = tile * TILE;
   const int nloc = (m.nie - tile_e0 < TILE) ? m.nie - tile_e0 : TILE;
-  STAMP_INIT;
 
-  // Kernel entry: EVERY load that depends on nothing goes out in one burst -- the tet's own row,
-  // the task words and neighbour rows ids of all rounds, round 0's face record, the tet's node
-  // ids and volume (in-kernel stamps, round 3: with the chains task word -> neighbour id ->
-  // neighbour row in front of the own row, and node ids -> coordinates before the second
-  // barrier, a wave spent 43 % of its life in those dependent latencies).
-  const size_t slot0 = (size_t)tile * STRIDE + tid;
-  // With 256 lanes the modal row STAYS in registers for the RK epilogue: re-reading it in phase 2
-  // misses the L2 at size (round 3, 10.1 M tets: 160 B per tet of extra HBM reads per launch).
+  // kernel entry: everything that depends on nothing
+  const size_t slot0 = (size_t)tile * (4 * TILE_BS) + tid;
   double r[NCOMP][NDOF];
-  const int erow = tile_e0 + ((tid < nloc) ? tid : 0);          // lanes beyond the tile read row 0 of it
+  const int erow = tile_e0 + ((tid < nloc) ? tid : 0);          // lanes beyond the tile read its row 0
   load_row<NPROP>(U, erow, &r[0][0]);
   int ta[NR];
-  [[maybe_unused]] int tn[NR];
 #pragma unroll
-  for (int q = 0; q < NR; ++q) {
-    const bool in = tid + BS * q < STRIDE;
-    ta[q] = in ? m.task_a[slot0 + BS * q] : -1;
-    if constexpr (EXTPF) tn[q] = in ? m.task_nb[slot0 + BS * q] : 0;
-  }
+  for (int q = 0; q < NR; ++q) ta[q] = m.task_a[slot0 + BS * q];
   double gnx[4];
   load_row<4>(m.tgeo, slot0, gnx);                               // (zeros behind unused slots)
   int in4[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) in4[i] = m.inpoel[(size_t)i * m.stride + erow];
   const double vol = m.vol[erow];
-  // second wave of requests: round 0's neighbour row (needs its id)
-  [[maybe_unused]] double rnx[NCOMP][NDOF];
-  if constexpr (EXTPF) {
-    if (ta[0] >= 0 && TASK_KIND(ta[0]) == TASK_EXT) load_row<NPROP>(U, tn[0], &rnx[0][0]);
-  }
 
-  // ---- phase 0: modal row -> the 4 vertex states; accumulators = 0 (all lanes) ---------
-  for (int i = tid; i < TILE * NPROP; i += BS) accN[i] = 0.0;
+  // ---- phase 0: modal row -> the 4 vertex states; accumulators = 0 ---------------------
   if (tid < TILE) {
     if (tid >= nloc) {
 #pragma unroll
       for (int c = 0; c < NCOMP; ++c) { r[c][0] = 1.0; r[c][1] = r[c][2] = r[c][3] = 0.0; }
     }
+    // LDS planes [vertex][component][tet]: lanes of a wave work on different tets at the same
+    // (vertex, component), so tet-fastest storage is free of bank conflicts
 #pragma unroll
     for (int c = 0; c < NCOMP; ++c) {
       // B at the vertices: v0 (-1,-1,-1), v1 (1,-1,-1), v2 (0,2,-1), v3 (0,0,3)
@@ -1446,50 +962,29 @@ __global__ __launch_bounds__(BS, (BS == 256 ? QDG_P1W_WAVES256 : BS / 128)) void
       nod[LIDX(tid, 1, c)] = a + r[c][1] - r[c][2];
       nod[LIDX(tid, 2, c)] = a + 2.0 * r[c][2];
       nod[LIDX(tid, 3, c)] = r[c][0] + 3.0 * r[c][3];
+#pragma unroll
+      for (int vx = 0; vx < 4; ++vx) accN[LIDX(tid, vx, c)] = 0.0;
     }
     if (WITH_DT) sdelt[tid] = 0.0;
   }
-  STAMP(0);      // task words, rows in, nodal transform, LDS stores
   __syncthreads();
-  STAMP(1);      // barrier 1
 
   // ---- phase 1: one lane per face task ------------------------------------------
 #pragma unroll 1
   for (int q = 0; q < NR; ++q) {
-    int a = ta[0];
-#pragma unroll
-    for (int i = 1; i < NR; ++i) a = (q == i) ? ta[i] : a;
+    const int a = (q == 0) ? ta[0] : (q == 1) ? ta[1] : (q == 2) ? ta[2] : ta[3];
     if (a < 0) break;
     const double g4[4] = { gnx[0], gnx[1], gnx[2], gnx[3] };
-    int an_ = -1;
-#pragma unroll
-    for (int i = 1; i < NR; ++i) an_ = (q + 1 == i) ? ta[i] : an_;
-    if (an_ >= 0) load_row<4>(m.tgeo, slot0 + (size_t)BS * (q + 1), gnx);
-    if constexpr (EXTPF) {
-      double rc[NCOMP][NDOF];
-#pragma unroll
-      for (int c = 0; c < NCOMP; ++c)
-#pragma unroll
-        for (int k = 0; k < NDOF; ++k) rc[c][k] = rnx[c][k];
-      int nn_ = 0;
-#pragma unroll
-      for (int i = 1; i < NR; ++i) nn_ = (q + 1 == i) ? tn[i] : nn_;
-      if (an_ >= 0 && TASK_KIND(an_) == TASK_EXT) load_row<NPROP>(U, nn_, &rnx[0][0]);
-      face_task_lean<WITH_DT, PROB, true>(m, ph, t, U, nod, accN, sdelt, a, nullptr, tile_e0, g4, rc);
-    } else {
-      double none[NCOMP][NDOF];
-      face_task_lean<WITH_DT, PROB, false>(m, ph, t, U, nod, accN, sdelt, a, m.task_nb + slot0 + (size_t)BS * q,
-                                           tile_e0, g4, none);
-    }
-    STAMP(2 + q);    // rounds 0..3
+    const int an_ = (q == 0) ? ta[1] : (q == 1) ? ta[2] : (q == 2) ? ta[3] : -1;
+    if (an_ >= 0) load_row<4>(m.tgeo, slot0 + (size_t)BS * (q + 1), gnx);    // the next round's face record
+    face_task_lean<WITH_DT, PROB>(m, ph, t, U, nod, accN, sdelt, a, m.task_nb + slot0 + (size_t)BS * q, tile_e0, g4);
   }
 
   // phase-2 inputs are requested before the barrier (the node ids are here already)
   ElemGeom g;
   [[maybe_unused]] double un[NCOMP][NDOF];
   if (tid < nloc) {
-    const int e = tile_e0 + tid;
-    if constexpr (FUSE_RK && KEEP_ROW) load_row<NPROP>(Un, e, &un[0][0]);
+    if constexpr (FUSE_RK) load_row<NPROP>(Un, tile_e0 + tid, &un[0][0]);
     double q[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -1497,23 +992,21 @@ __global__ __launch_bounds__(BS, (BS == 256 ? QDG_P1W_WAVES256 : BS / 128)) void
       g.p[i][0] = q[0]; g.p[i][1] = q[1]; g.p[i][2] = q[2];
     }
   }
-  STAMP(6);      // phase-2 requests issued
   __syncthreads();
-  STAMP(7);      // barrier 2 (includes the wait for the slower waves' last round)
 
   // ---- phase 2: one lane per tet: volume (+source) term, epilogue, store --------
   double dte = DBL_MAX;
   double acc[NCOMP][NDOF];
   if (tid < nloc) {
     tet_volume_lean<PROB>(ph, t, nod, accN, tid, vol, g, acc);
-    if constexpr (FUSE_RK && KEEP_ROW) rk_epilogue_rows(r, un, dtp[0] / vol, rk_a, rk_b, acc);
-    else if constexpr (FUSE_RK) rk_epilogue_lean(U, Un, tile_e0 + tid, dtp[0] / vol, rk_a, rk_b, acc);
+    if constexpr (FUSE_RK) rk_epilogue_rows(r, un, dtp[0] / vol, rk_a, rk_b, acc);
     if (WITH_DT) dte = vol / sdelt[tid];
   }
-  STAMP(8);      // phase 2: waits for its inputs, volume term, epilogue
-  // rows out through LDS as coalesced 1-KiB wave stores (see k_rhs_p1v)
+  // rows out, coalesced: a lane storing its own 160-B row issues 64 separate 16-B write
+  // requests per wave instruction (3.4 TB/s measured, tools/ubench_rowstream.hip); the tile's
+  // rows are one contiguous span, so they go through LDS (row-major over the vertex states,
+  // which nobody reads any more) and leave as 1-KiB wave stores (6.1 TB/s)
   __syncthreads();
-  STAMP(9);      // barrier 3
   if (tid < nloc) {
     double2* row = reinterpret_cast<double2*>(nod + (size_t)tid * NPROP);
 #pragma unroll
@@ -1524,9 +1017,12 @@ __global__ __launch_bounds__(BS, (BS == 256 ? QDG_P1W_WAVES256 : BS / 128)) void
     const double2* src = reinterpret_cast<const double2*>(nod);
     double2* dst = reinterpret_cast<double2*>(R + (size_t)tile_e0 * NPROP);
     const int nvalid = nloc * (NPROP / 2);
-    for (int i = tid; i < nvalid; i += BS) dst[i] = src[i];
+#pragma unroll
+    for (int j = 0; j < NPROP / 2; ++j) {
+      const int i = j * BS + tid;
+      if (i < nvalid) dst[i] = src[i];
+    }
   }
-  STAMP(10);     // staging + stores issued
 
   if (WITH_DT) {
     for (int off = 32; off > 0; off >>= 1) dte = fmin(dte, __shfl_down(dte, off, 64));
@@ -1542,204 +1038,8 @@ __global__ __launch_bounds__(BS, (BS == 256 ? QDG_P1W_WAVES256 : BS / 128)) void
   }
 }
 
-// ------------------------------------------- DG-P1 RHS, tile / face-task form, PERSISTENT
-// The tile kernels above are serialised per workgroup: rows in (memory latency), face tasks
-// (arithmetic, no memory requests), rows in again, volume term, rows out -- and only two
-// workgroups fit a CU (LDS), so the CU's memory pipe idles whenever both compute.
-// Here a workgroup is PERSISTENT and software-pipelined over its tiles:
-//  * while the face tasks of tile i run, the modal rows of tile i+1 are in flight into
-//    registers (20 doubles per lane; the lean face task leaves room for them at 2 waves per
-//    SIMD) together with tile i+1's task words, node ids and volumes, so the next tile starts
-//    without a memory wait and without a dependent address load;
-//  * the first face record of tile i+1 is requested at the end of tile i; neighbour rows of
-//    faces to other tiles are read when their task starts (carrying a second prefetched row
-//    through the loop costs more registers than two waves per SIMD have);
-//  * XCD x walks its contiguous tile range with all its workgroups side by side (workgroup j of
-//    the XCD takes tiles j, j + G/8, ...), so the tiles in flight on an XCD stay neighbours.
-// row `idx` (a small unsigned lane offset) behind a wave-uniform base: the address is
-// base + zext(32-bit byte offset), i.e. the scalar-base form of global_load -- no 64-bit
-// per-lane pointer is formed or kept
-template <int NPROP>
-__device__ __forceinline__ void load_row_u(const double* __restrict__ base, unsigned idx, double* r)
-{
-  const double2* q = reinterpret_cast<const double2*>(__builtin_assume_aligned(base, 16)) + idx * (unsigned)(NPROP / 2);
-#pragma unroll
-  for (int i = 0; i < NPROP / 2; ++i) { const double2 v = q[i]; r[2 * i] = v.x; r[2 * i + 1] = v.y; }
-}
-
-template <bool WITH_DT, bool FUSE_RK, int PROB>
-__global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1x(DevMesh m, Phys ph, double t, int ntiles,
-                                                        const double* __restrict__ U,
-                                                        double* __restrict__ R,
-                                                        double* __restrict__ blockmin,
-                                                        double rk_a, double rk_b,
-                                                        const double* __restrict__ dtp,
-                                                        const double* __restrict__ Un)
-{
-  constexpr int NDOF = 4, NPROP = NCOMP * NDOF, BS = TILE_BS;
-  constexpr int STRIDE = 4 * TILE_BS, NR = 4;
-  __shared__ __attribute__((aligned(16))) double nod[TILE * NPROP];
-  __shared__ double accN[TILE * NPROP];
-  __shared__ double sdelt[WITH_DT ? TILE : 1];
-  __shared__ double wmin[BS / 64];
-  const int tid = threadIdx.x;
-  const unsigned utid = threadIdx.x;
-  // this workgroup's tiles: local index j0, j0 + G8, ... of its XCD's contiguous range
-  constexpr int NXCD = 8;
-  const int G8 = gridDim.x / NXCD;                      // workgroups per XCD (grid is a multiple of 8)
-  const int xcd = blockIdx.x % NXCD, j0 = blockIdx.x / NXCD;
-  const int per = ntiles / NXCD, rem = ntiles - per * NXCD;
-  const int xbase = m.blk0 + xcd * per + (xcd < rem ? xcd : rem), xcount = per + (xcd < rem ? 1 : 0);
-  if (j0 >= xcount) return;
-
-  // prologue: what the first tile needs
-  double rnext[NCOMP][NDOF];
-  int tan[NR];
-  double gnx[4];
-  {
-    const int tile = xbase + j0, e0 = tile * TILE;
-    const int* ta_t = m.task_a + (size_t)tile * STRIDE;
-#pragma unroll
-    for (int q = 0; q < NR; ++q) tan[q] = ta_t[utid + BS * q];
-    // unconditional loads with clamped rows (lanes beyond the tile's rows read a valid row
-    // they never use): no control flow around the in-flight registers
-    load_row_u<NPROP>(U + (size_t)e0 * NPROP, min(utid, (unsigned)(m.nie - 1 - e0)), &rnext[0][0]);
-    load_row_u<4>(m.tgeo + (size_t)tile * STRIDE * 4, utid, gnx);
-  }
-
-#pragma unroll 1
-  for (int j = j0; j < xcount; j += G8) {
-    const int tile = xbase + j;
-    const int tile_e0 = tile * TILE;
-    const int nloc = (m.nie - tile_e0 < TILE) ? m.nie - tile_e0 : TILE;
-    const int* tn_t = m.task_nb + (size_t)tile * STRIDE;
-    const double* tg_t = m.tgeo + (size_t)tile * STRIDE * 4;
-    const bool more = j + G8 < xcount;
-    int ta[NR];
-#pragma unroll
-    for (int q = 0; q < NR; ++q) ta[q] = tan[q];
-
-    // ---- phase 0: modal row (prefetched) -> the 4 vertex states; accumulators = 0 ---------
-    if (tid < TILE) {
-#pragma unroll
-      for (int c = 0; c < NCOMP; ++c) {
-        const bool in = tid < nloc;
-        const double r0 = in ? rnext[c][0] : 1.0, r1 = in ? rnext[c][1] : 0.0,
-                     r2 = in ? rnext[c][2] : 0.0, r3 = in ? rnext[c][3] : 0.0;
-        // B at the vertices: v0 (-1,-1,-1), v1 (1,-1,-1), v2 (0,2,-1), v3 (0,0,3)
-        const double a = r0 - r3;
-        nod[LIDX(tid, 0, c)] = a - r1 - r2;
-        nod[LIDX(tid, 1, c)] = a + r1 - r2;
-        nod[LIDX(tid, 2, c)] = a + 2.0 * r2;
-        nod[LIDX(tid, 3, c)] = r0 + 3.0 * r3;
-#pragma unroll
-        for (int vx = 0; vx < 4; ++vx) accN[LIDX(tid, vx, c)] = 0.0;
-      }
-      if (WITH_DT) sdelt[tid] = 0.0;
-    }
-    __syncthreads();
-
-    // the NEXT tile's task words and rows go in flight now and land while this tile's face
-    // tasks compute (the last tile of a workgroup reads its own tile again: harmless, keeps the
-    // loads free of control flow)
-    {
-      const int tnext = more ? tile + G8 : tile;
-      const int* ta_n = m.task_a + (size_t)tnext * STRIDE;
-#pragma unroll
-      for (int q = 0; q < NR; ++q) tan[q] = ta_n[utid + BS * q];
-      load_row_u<NPROP>(U + (size_t)tnext * TILE * NPROP, min(utid, (unsigned)(m.nie - 1 - tnext * TILE)), &rnext[0][0]);
-    }
-    // ---- phase 1: one lane per face task ----------------------------------------------------
-#pragma unroll 1
-    for (int q = 0; q < NR; ++q) {
-      const int a = (q == 0) ? ta[0] : (q == 1) ? ta[1] : (q == 2) ? ta[2] : ta[3];
-      if (a < 0) break;
-      const double g4[4] = { gnx[0], gnx[1], gnx[2], gnx[3] };
-      const int an_ = (q == 0) ? ta[1] : (q == 1) ? ta[2] : (q == 2) ? ta[3] : -1;
-      if (an_ >= 0) load_row_u<4>(tg_t, utid + BS * (q + 1), gnx);
-      double none[NCOMP][NDOF];
-      face_task_lean<WITH_DT, PROB, false>(m, ph, t, U, nod, accN, sdelt, a, tn_t + (utid + BS * q), tile_e0, g4, none);
-    }
-
-    // node ids and volume of this lane's tet are requested before the barrier; the coordinates
-    // (L2-resident gathers) after it -- requested before it, the register allocator spills them
-    int in4[4];
-    double vol = 1.0;
-    {
-      const unsigned el = min(utid, (unsigned)(nloc - 1));
-#pragma unroll
-      for (int i = 0; i < 4; ++i) in4[i] = (m.inpoel + (size_t)i * m.stride + tile_e0)[el];
-      vol = (m.vol + tile_e0)[el];
-    }
-    __syncthreads();
-
-    // ---- phase 2: one lane per tet: volume (+source) term, epilogue, store --------
-    double dte = DBL_MAX;
-    double acc[NCOMP][NDOF];
-    if (tid < nloc) {
-      ElemGeom g;
-      double q4[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        load_row<4>(m.xyz4, in4[i], q4);
-        g.p[i][0] = q4[0]; g.p[i][1] = q4[1]; g.p[i][2] = q4[2];
-      }
-      tet_volume_lean<PROB>(ph, t, nod, accN, tid, vol, g, acc);
-      if (FUSE_RK) rk_epilogue_lean(U, Un, tile_e0 + tid, dtp[0] / vol, rk_a, rk_b, acc);
-      if (WITH_DT) dte = vol / sdelt[tid];
-    }
-    // the next tile's first face record and neighbour row (its task words have landed)
-    {
-      const int tnext = more ? tile + G8 : tile;
-      load_row_u<4>(m.tgeo + (size_t)tnext * STRIDE * 4, utid, gnx);
-    }
-    // rows out through LDS as coalesced 1-KiB wave stores
-    __syncthreads();
-    if (tid < nloc) {
-      double2* row = reinterpret_cast<double2*>(nod + (size_t)tid * NPROP);
-#pragma unroll
-      for (int jj = 0; jj < NPROP / 2; ++jj) row[jj] = make_double2((&acc[0][0])[2 * jj], (&acc[0][0])[2 * jj + 1]);
-    }
-    __syncthreads();
-    {
-      const double2* src = reinterpret_cast<const double2*>(nod);
-      double2* dst = reinterpret_cast<double2*>(R + (size_t)tile_e0 * NPROP);
-      const int nvalid = nloc * (NPROP / 2);
-#pragma unroll
-      for (int jj = 0; jj < NPROP / 2; ++jj) {
-        const int i = jj * BS + tid;
-        if (i < nvalid) dst[i] = src[i];
-      }
-    }
-    if (WITH_DT) {
-      for (int off = 32; off > 0; off >>= 1) dte = fmin(dte, __shfl_down(dte, off, 64));
-      const int lane = tid & 63, wv = tid >> 6;
-      if (lane == 0) wmin[wv] = dte;
-    }
-    __syncthreads();      // nod (staging) and wmin are read; the next tile's phase 0 may write
-    if (WITH_DT && tid == 0) {
-      double mn = wmin[0];
-      for (int w = 1; w < BS / 64; ++w) mn = fmin(mn, wmin[w]);
-      blockmin[tile] = mn;
-    }
-  }
-}
-
 // ================================================================ launchers
 
-#ifdef QDG_P1_STAMPS
-extern "C" int qdg_debug_stamps(double* out32, int reset)
-{
-  unsigned long long v[32];
-  if (hipMemcpyFromSymbol(v, HIP_SYMBOL(g_stamp), sizeof(v)) != hipSuccess) return -1;
-  for (int i = 0; i < 32; ++i) out32[i] = (double)v[i];
-  if (reset) {
-    unsigned long long z[32] = { 0 };
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z)) != hipSuccess) return -1;
-  }
-  return 0;
-}
-#endif
 
 hipError_t upload_tables_p1(const Tables<1>& t1, const Tables<4>& t4, const Tables<10>& t10,
                             const QuadTet* qinit, const QuadTet* qdiag)
@@ -1764,58 +1064,21 @@ void launch_rhs_p1(const DevMesh& m, const Phys& ph, double t, const double* U, 
 }
 
 // tile / face-task form of the P1 RHS; tiles [first, first+count) (count < 0: all).
-// Uniform order runs k_rhs_p1v, p-adaptive meshes (m.ndofel) k_rhs_p1t.  With with_dt the
+// Uniform order runs k_rhs_p1w, p-adaptive meshes (m.ndofel) k_rhs_p1t.  With with_dt the
 // launch that ends at the last tile also reduces the per-tile minima to the time step.
 void launch_rhs_p1t(const DevMesh& m0, const Phys& ph, double t, const double* U, double* R,
                     bool with_dt, double* blockmin, double scale, double tleft, double* out_raw,
-                    double* out_dt, hipStream_t s, int first, int count, int variant)
+                    double* out_dt, hipStream_t s, int first, int count)
 {
   if (m0.ntile == 0) return;
   DevMesh m = m0;
   m.blk0 = first;
   const int nb = count < 0 ? m.ntile - first : count;
-  const bool lean = variant > 0 && !m.ndofel && m.tgeo && m.task_stride == 4 * TILE_BS && m.tile_rows == TILE;
-  if (nb > 0 && lean && variant == 3) {
-    // persistent, software-pipelined over tiles: 2 workgroups per CU, a multiple of 8 in all
-    const int g8 = std::min(64, (nb + 7) / 8);
+  if (nb > 0 && !m.ndofel) {
     if (with_dt) {
-      QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1x<true, false, P><<<8 * g8, TILE_BS, 0, s>>>(m, ph, t, nb, U, R, blockmin, 0.0, 0.0, nullptr, nullptr)));
+      QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1w<true, false, P><<<nb, TILE_BS, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr)));
     } else {
-      QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1x<false, false, P><<<8 * g8, TILE_BS, 0, s>>>(m, ph, t, nb, U, R, blockmin, 0.0, 0.0, nullptr, nullptr)));
-    }
-  } else if (nb > 0 && lean) {
-    // version 3 (k_rhs_p1w): 384 lanes at 3 waves per SIMD (variant 1) or 512 at 4 (variant 2);
-    // 256 lanes without / with the neighbour row prefetched a round ahead (variants 4 / 5)
-    if (variant == 4) {
-      if (with_dt) {
-        QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1w<true, false, P, 256><<<nb, 256, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr)));
-      } else {
-        QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1w<false, false, P, 256><<<nb, 256, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr)));
-      }
-    } else if (variant == 5) {
-      if (with_dt) {
-        QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1w<true, false, P, 256, true><<<nb, 256, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr)));
-      } else {
-        QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1w<false, false, P, 256, true><<<nb, 256, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr)));
-      }
-    } else if (variant == 1) {
-      if (with_dt) {
-        QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1w<true, false, P, 384><<<nb, 384, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr)));
-      } else {
-        QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1w<false, false, P, 384><<<nb, 384, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr)));
-      }
-    } else {
-      if (with_dt) {
-        QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1w<true, false, P, 512><<<nb, 512, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr)));
-      } else {
-        QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1w<false, false, P, 512><<<nb, 512, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr)));
-      }
-    }
-  } else if (nb > 0 && !m.ndofel) {
-    if (with_dt) {
-      QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1v<true, false, P><<<nb, TILE_BS, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr)));
-    } else {
-      QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1v<false, false, P><<<nb, TILE_BS, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr)));
+      QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1w<false, false, P><<<nb, TILE_BS, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr)));
     }
   } else if (nb > 0) {
     if (with_dt) {
@@ -1830,37 +1093,15 @@ void launch_rhs_p1t(const DevMesh& m0, const Phys& ph, double t, const double* U
 
 void launch_rhs_p1t_rk(const DevMesh& m0, const Phys& ph, double t, const double* U, double* Uout,
                        double a, double b, const double* dt, const double* Un, hipStream_t s,
-                       int first, int count, int variant)
+                       int first, int count)
 {
   if (m0.ntile == 0) return;
   DevMesh m = m0;
   m.blk0 = first;
   const int nb = count < 0 ? m.ntile - first : count;
   if (nb <= 0) return;
-  const bool lean = variant > 0 && !m.ndofel && m.tgeo && m.task_stride == 4 * TILE_BS && m.tile_rows == TILE;
-  if (lean && variant == 3) {
-    const int g8 = std::min(64, (nb + 7) / 8);
-    QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1x<false, true, P><<<8 * g8, TILE_BS, 0, s>>>(m, ph, t, nb, U, Uout, nullptr, a, b, dt, Un)));
-    return;
-  }
-  if (lean && variant == 4) {
-    QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1w<false, true, P, 256><<<nb, 256, 0, s>>>(m, ph, t, U, Uout, nullptr, a, b, dt, Un)));
-    return;
-  }
-  if (lean && variant == 5) {
-    QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1w<false, true, P, 256, true><<<nb, 256, 0, s>>>(m, ph, t, U, Uout, nullptr, a, b, dt, Un)));
-    return;
-  }
-  if (lean && variant == 1) {
-    QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1w<false, true, P, 384><<<nb, 384, 0, s>>>(m, ph, t, U, Uout, nullptr, a, b, dt, Un)));
-    return;
-  }
-  if (lean) {
-    QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1w<false, true, P, 512><<<nb, 512, 0, s>>>(m, ph, t, U, Uout, nullptr, a, b, dt, Un)));
-    return;
-  }
   if (!m.ndofel) {
-    QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1v<false, true, P><<<nb, TILE_BS, 0, s>>>(m, ph, t, U, Uout, nullptr, a, b, dt, Un)));
+    QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1w<false, true, P><<<nb, TILE_BS, 0, s>>>(m, ph, t, U, Uout, nullptr, a, b, dt, Un)));
     return;
   }
   QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1t<false, true, P, true><<<nb, TILE_BS, 0, s>>>(m, ph, t, U, Uout, nullptr, a, b, dt, Un)));

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Interleaved A/B timing of DG-P1 RHS kernel forms on ONE resident mesh (GPU box).
-Usage: python tools/ab_p1.py NX [ROUNDS] "p1_variant=0" "p1_variant=1" "p1_rhs=1" ...
+Usage: python tools/ab_p1.py NX [ROUNDS] "p1_rhs=0" "p1_rhs=1" "fused_update=0" ...
 Every configuration is a comma-separated list of qdg_ctx_set_option settings applied to the
 same context (the options are read at launch time); ROUNDS interleaved rounds of 3 + 10 steps
 of the Sod DG-P1 + Superbee workload each; RHS kernel time from the library's event pairs;
@@ -19,8 +19,8 @@ args = sys.argv[2:]
 rounds = 3
 if args and args[0].isdigit():
     rounds = int(args[0]); args = args[1:]
-cfgs = args or ["p1_variant=0"]
-BASE = {"p1_variant": 0, "p1_rhs": 0, "fused_update": 1}
+cfgs = args or ["p1_rhs=0"]
+BASE = {"p1_rhs": 0, "fused_update": 1}
 
 ch = meshgen.kuhn_box(nx, nx, nx)
 ctx = capi.Context(4, flux="hllc", limiter="superbeep1", problem="sod_shocktube", gamma=1.4, cfl=0.3,
