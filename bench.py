@@ -20,7 +20,8 @@ The same run then times the NORTH-STAR POINT (BASELINE.json north_star: DG-P1 RH
 the roofline fraction of the RHS kernel at 10 M tets at N = 1 and a STRONG-scaling
 value for every N (`--no-north-star` skips it, `--strong-nx M` changes the box).
 BASELINE.md section 5: 5 warm-up + 50 timed steps (the defaults).
-At N = 1 it also times config 5's refine / re-upload loop once (`amr_point`) and config 3 at
+At N = 1 it also times config 5's refine / re-upload loop (`amr_point`: a small box incl. a
+decomposition, and the north-star box refined 10.1 M -> 80.9 M tets) and config 3 at
 its own size, vortical flow DG-P2 + WENO on 7 986 000 tets (`config3_point`), and one GPU's
 7 986 000-tet share of config 4's Sedov run (`config4_point`).
 
@@ -194,7 +195,7 @@ def _tet_volumes(coord, inpoel):
     return np.einsum("ij,ij->i", a, np.cross(b, d)) / 6.0
 
 
-def amr_point(local_rank, nx=32, steps=20):
+def amr_point(local_rank, nx=32, steps=20, with_partition=True):
     """BASELINE config 5's loop once, on one GPU: Sod DG-P1 on an nx^3 Kuhn box, `steps` time
     steps, uniform 1:8 refinement (the refinement the reference's DG scheme performs during
     time stepping), mesh-derived data of the new mesh on the device, state handed over on the
@@ -224,8 +225,10 @@ def amr_point(local_rank, nx=32, steps=20):
     ne1 = run.mesh.nielem
     ok = bool(np.isfinite(U).all())
     run.mesh.close(); ctx.close()
-    part = amr_partitioned(local_rank, ch, nparts=2, steps=5)
-    return {"on_a_decomposition": part, **_amr_single(nx, steps, ne0, ne1, ms0, ms1, th, tr, tt, ok)}
+    out = _amr_single(nx, steps, ne0, ne1, ms0, ms1, th, tr, tt, ok)
+    if with_partition:
+        out = {"on_a_decomposition": amr_partitioned(local_rank, ch, nparts=2, steps=5), **out}
+    return out
 
 
 def amr_partitioned(local_rank, g, nparts, steps):
@@ -498,6 +501,9 @@ def main():
             }
         if world == 1 and not args.no_amr and not args.self_halo:
             out["amr_point"] = amr_point(local_rank)
+            # config 5 at the north-star box: 119^3 x 6 = 10.1 M -> 80.9 M tets on one GPU
+            out["amr_point"]["at_north_star_size"] = amr_point(local_rank, nx=args.strong_nx, steps=5,
+                                                               with_partition=False)
         if world == 1 and not args.no_config3 and not args.self_halo:
             out["config3_point"] = config3_point(local_rank, args.config3_nx)
         if world == 1 and not args.no_config4 and not args.self_halo:

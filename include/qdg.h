@@ -400,6 +400,25 @@ int qdg_chunk_refined_get(const qdg_chunk_refined* c, size_t* inpoel, size_t* gi
                           size_t* send_off, size_t* send_list, size_t* recv_counts);
 int qdg_chunk_refined_destroy(qdg_chunk_refined* c);
 int qdg_state_transfer(qdg_mesh* from, qdg_mesh* to, const size_t* parent_of_child);
+/* The child mesh need not come from qdg_refine_*: ANY conforming tetrahedron mesh with a parent
+ * per tet is accepted -- what Refiner hands DG::resizePostAMR (src/Inciter/DG.cpp:1537-1612), e.g. a
+ * region refined 1:8 and closed with the 1:2 / 1:4 templates of src/Inciter/AMR/refinement.hpp:78-424;
+ * build `to` with qdg_mesh_from_connectivity / qdg_mesh_from_chunk.  An entry QDG_NO_ROW leaves
+ * that row of `to` as it is.
+ *
+ * State migration after a re-partition (the load balancing behind DG::resizePostAMR,
+ * src/Inciter/DG.cpp:1658-1664, Partitioner.cpp:137-170): rows travel by GLOBAL tet id.
+ *   qdg_state_migrate   both chunks in one context (one GPU): every owned row of `to` whose
+ *                       global id is owned by `from` is copied device to device; call it for
+ *                       every (from, to) pair; *nmoved (may be NULL) = rows copied
+ *   qdg_state_rows_get / _put   the two halves for chunks of DIFFERENT processes: n rows (caller's
+ *                       numbering) <-> a packed device buffer of n * nprop doubles that the caller
+ *                       moves (ncclSend / ncclRecv, MPI, hipMemcpyPeer) */
+#define QDG_NO_ROW ((size_t)-1)
+int qdg_state_migrate(qdg_mesh* from, const size_t* from_gid, qdg_mesh* to, const size_t* to_gid,
+                      size_t* nmoved);
+int qdg_state_rows_get(qdg_mesh* mesh, size_t n, const size_t* rows, void* packed_dev);
+int qdg_state_rows_put(qdg_mesh* mesh, size_t n, const size_t* rows, const void* packed_dev);
 
 /* -- element-field output in ExodusII layout -----------------------------------
  * What DG::writeFields hands tk::ExodusIIMeshWriter (src/Inciter/DG.cpp:1165-1215,
@@ -431,7 +450,8 @@ int qdg_dev_facedata(qdg_ctx* ctx, size_t nelem, size_t nnode, const size_t* inp
  * and geometry (the arrays of qdg_dev_facedata), device order, numbering and face tasks (what
  * qdg_mesh_upload derives on the host) -- all on the device; only connectivity, coordinates and
  * the side-set triangles cross PCIe.  tri_set[i] is the side set id of triangle i.
- * (QDG_HOST_LAYOUT=1: FaceData on the device, layout by qdg_mesh_upload, for equivalence tests.) */
+ * (context option "host_layout" = 1: FaceData on the device, layout by qdg_mesh_upload, for
+ * equivalence tests.) */
 int qdg_mesh_from_connectivity(qdg_ctx* ctx, size_t nelem, size_t nnode, const size_t* inpoel,
                                const double* x, const double* y, const double* z, size_t ntri,
                                const size_t* tri, const int32_t* tri_set, qdg_mesh** out);

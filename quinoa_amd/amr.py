@@ -53,6 +53,16 @@ def state_transfer(mesh_from, mesh_to, parent):
     capi._chk(capi.lib().qdg_state_transfer(mesh_from.h, mesh_to.h, ppar))
 
 
+def state_migrate(mesh_from, gid_from, mesh_to, gid_to):
+    """qdg_state_migrate: owned rows of `mesh_to` whose global tet id is owned by `mesh_from` are
+    copied device to device (both chunks under one context); returns the number of rows moved"""
+    gf, pgf = capi._sz(np.asarray(gid_from))
+    gt, pgt = capi._sz(np.asarray(gid_to))
+    n = C.c_size_t()
+    capi._chk(capi.lib().qdg_state_migrate(mesh_from.h, pgf, mesh_to.h, pgt, C.byref(n)))
+    return n.value
+
+
 class RefinedRun:
     """One chunk without ghosts that is refined uniformly while it runs: holds the host mesh
     (what Discretization holds), the device mesh handle and the resident state."""

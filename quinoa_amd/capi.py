@@ -460,6 +460,15 @@ class Mesh:
     def stage_dt_use_buffer(self, ptr):
         _chk(lib().qdg_stage_dt_use_buffer(self.h, C.c_void_p(ptr)))
 
+    def state_rows_get(self, rows, packed_dev):
+        """rows (caller's numbering) of the resident state -> packed device buffer (address)"""
+        r, pr = _sz(np.asarray(rows))
+        _chk(lib().qdg_state_rows_get(self.h, C.c_size_t(len(r)), pr, C.c_void_p(int(packed_dev))))
+
+    def state_rows_put(self, rows, packed_dev):
+        r, pr = _sz(np.asarray(rows))
+        _chk(lib().qdg_state_rows_put(self.h, C.c_size_t(len(r)), pr, C.c_void_p(int(packed_dev))))
+
     def profile_enable(self, on=True):
         _chk(lib().qdg_profile_enable(self.h, C.c_int(1 if on else 0)))
 

@@ -20,6 +20,7 @@
 #include <atomic>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/qdg.h"
@@ -1465,6 +1466,7 @@ extern "C" int qdg_state_transfer(qdg_mesh* from, qdg_mesh* to, const size_t* pa
   hipStream_t s = ctx->stream;
   std::vector<int> par(to->ne), d2h(from->ne), h2d(from->ne);
   for (size_t c = 0; c < to->ne; ++c) {
+    if (parent_of_child[c] == QDG_NO_ROW) { par[c] = -1; continue; }     // row left as it is
     if (parent_of_child[c] >= from->ne) return fail("qdg_state_transfer: parent id out of range");
     par[c] = (int)parent_of_child[c];
   }
@@ -1477,6 +1479,72 @@ extern "C" int qdg_state_transfer(qdg_mesh* from, qdg_mesh* to, const size_t* pa
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(s));
   to->Unp = nullptr; to->Upending = nullptr;
+  return 0;
+  QDG_CATCH
+}
+
+// State migration after a re-partition (DG::resizePostAMR + the load balancing that follows it,
+// src/Inciter/DG.cpp:1537-1664): rows travel between chunks by GLOBAL tet id.
+extern "C" int qdg_state_migrate(qdg_mesh* from, const size_t* from_gid, qdg_mesh* to, const size_t* to_gid,
+                                 size_t* nmoved)
+{
+  QDG_TRY
+  if (!from || !to || !from_gid || !to_gid) return fail("qdg_state_migrate: null argument");
+  std::unordered_map<size_t, size_t> own;
+  own.reserve(from->nie * 2);
+  for (size_t e = 0; e < from->nie; ++e) own.emplace(from_gid[e], e);      // owned rows only
+  std::vector<size_t> par(to->ne, QDG_NO_ROW);
+  size_t n = 0;
+  for (size_t e = 0; e < to->nie; ++e) {
+    auto it = own.find(to_gid[e]);
+    if (it != own.end()) { par[e] = it->second; ++n; }
+  }
+  if (nmoved) *nmoved = n;
+  if (n == 0) return 0;
+  return qdg_state_transfer(from, to, par.data());
+  QDG_CATCH
+}
+
+static int rows_to_device(qdg_mesh* mesh, size_t n, const size_t* rows, DevBuf<int>& drow, const char* who)
+{
+  std::vector<int> d2h(mesh->ne), h2d(mesh->ne), dr(n);
+  HIPCHK(hipMemcpy(d2h.data(), mesh->d2h.p, mesh->ne * sizeof(int), hipMemcpyDeviceToHost));
+  for (size_t d = 0; d < mesh->ne; ++d) h2d[d2h[d]] = (int)d;
+  for (size_t j = 0; j < n; ++j) {
+    if (rows[j] >= mesh->ne) return fail(std::string(who) + ": row id out of range");
+    dr[j] = h2d[rows[j]];
+  }
+  HIPCHK(drow.upload(dr, mesh->ctx->stream));
+  return 0;
+}
+
+extern "C" int qdg_state_rows_get(qdg_mesh* mesh, size_t n, const size_t* rows, void* packed_dev)
+{
+  QDG_TRY
+  MESH_ENTER("qdg_state_rows_get");
+  if (n == 0) return 0;
+  if (!rows || !packed_dev) return fail("qdg_state_rows_get: null argument");
+  DevBuf<int> drow;
+  if (int rc = rows_to_device(mesh, n, rows, drow, "qdg_state_rows_get")) return rc;
+  launch_rows_gather(n, mesh->nprop, drow.p, mesh->Ucur, static_cast<double*>(packed_dev), s);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(s));        // drow is released on return
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_state_rows_put(qdg_mesh* mesh, size_t n, const size_t* rows, const void* packed_dev)
+{
+  QDG_TRY
+  MESH_ENTER("qdg_state_rows_put");
+  if (n == 0) return 0;
+  if (!rows || !packed_dev) return fail("qdg_state_rows_put: null argument");
+  DevBuf<int> drow;
+  if (int rc = rows_to_device(mesh, n, rows, drow, "qdg_state_rows_put")) return rc;
+  launch_rows_scatter(n, mesh->nprop, drow.p, static_cast<const double*>(packed_dev), mesh->Ucur, s);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(s));
+  mesh->Unp = nullptr; mesh->Upending = nullptr;
   return 0;
   QDG_CATCH
 }

@@ -298,6 +298,15 @@ static int dev_bnd_faces(qdg_ctx* ctx, DevFD& fd, size_t ntri, const size_t* tri
   }
   std::sort(keys.begin(), keys.end(), [](const K& p, const K& q) {
     return p.a != q.a ? p.a < q.a : p.b != q.b ? p.b < q.b : p.c != q.c ? p.c < q.c : p.set < q.set; });
+  // The reference keeps one boundary face per side-set ENTRY (a triangle listed in two side sets is
+  // integrated once per set, src/Inciter/Partitioner.cpp:357-393); here a triangle gets one boundary
+  // face, so such input is refused instead of silently dropping a condition.
+  for (size_t i = 0; i + 1 < ntri; ++i)
+    if (keys[i].a == keys[i + 1].a && keys[i].b == keys[i + 1].b && keys[i].c == keys[i + 1].c)
+      return fail(keys[i].set == keys[i + 1].set
+                  ? "qdg_mesh_from_connectivity: a side-set triangle is listed twice"
+                  : "qdg_mesh_from_connectivity: a triangle is listed in two side sets (not supported "
+                    "by the device mesh build; use qdg_mesh_upload with the reference's bface)");
   std::sort(sets.begin(), sets.end());
   sets.erase(std::unique(sets.begin(), sets.end()), sets.end());
   if (sets.size() >= (1u << 20)) return fail("qdg_mesh_from_connectivity: too many side sets");

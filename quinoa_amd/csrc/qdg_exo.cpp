@@ -80,7 +80,8 @@ extern "C" int qdg_exo_write(const char* path, const char* title, size_t nnode, 
   QDG_TRY
   if (!path || !x || !y || !z || !inpoel) return fail("qdg_exo_write: null argument");
   if (nss && (!ss_id || !ss_off || !ss_elem || !ss_side)) return fail("qdg_exo_write: null side-set arrays");
-  if (nvar && (!var_names || (ntime && (!times || !vals)))) return fail("qdg_exo_write: null field arrays");
+  if (ntime && !times) return fail("qdg_exo_write: null times");          // written for every record, fields or not
+  if (nvar && (!var_names || (ntime && !vals))) return fail("qdg_exo_write: null field arrays");
   if (nelem > (size_t)INT32_MAX / 4 || nnode > (size_t)INT32_MAX) return fail("qdg_exo_write: mesh too large for 32-bit ids");
   const size_t LEN_STRING = 33, LEN_NAME = 33;
   // ---- dimensions --------------------------------------------------------------------------

