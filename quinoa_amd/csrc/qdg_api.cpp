@@ -201,7 +201,7 @@ extern "C" int qdg_ctx_set_stream(qdg_ctx* ctx, void* s)
 static int* option_slot(qdg_ctx* ctx, const char* name)
 {
   static const struct { const char* n; int qdg::Options::*p; } tab[] = {
-    { "p1_rhs", &qdg::Options::p1_rhs },           { "p1_persistent", &qdg::Options::p1_persistent },
+    { "p1_rhs", &qdg::Options::p1_rhs },
     { "fused_update", &qdg::Options::fused_update },
     { "renumber", &qdg::Options::renumber },       { "host_layout", &qdg::Options::host_layout },
   };
@@ -734,7 +734,7 @@ static void run_rhs(qdg_mesh* mesh, double t, const double* U, double* R)
   qdg_ctx* ctx = mesh->ctx;
   if (use_p1_fast(mesh) && use_tile(mesh))
     launch_rhs_p1t(mesh->dm, ctx->ph, t, U, R, false, mesh->blockmin.p, 1.0, DBL_MAX,
-                   mesh->dtraw.p, mesh->dt_ptr, ctx->stream, 0, -1, ctx->opt.p1_persistent != 0);
+                   mesh->dtraw.p, mesh->dt_ptr, ctx->stream);
   else if (use_p1_fast(mesh))
     launch_rhs_p1(mesh->dm, ctx->ph, t, U, R, false, mesh->blockmin.p, 1.0, DBL_MAX,
                   mesh->dtraw.p, mesh->dt_ptr, ctx->stream);
@@ -1240,7 +1240,7 @@ extern "C" int qdg_stage_rhs_dt(qdg_mesh* mesh, int stage, double t, double tlef
     if (int rc = prof_begin(mesh, &ev)) return rc;
     if (use_tile(mesh))
       launch_rhs_p1t_rk(mesh->dm, ctx->ph, t, mesh->Ucur, out, RK[0][stage], RK[1][stage],
-                        mesh->dt_ptr, mesh->Unp, s, 0, -1, ctx->opt.p1_persistent != 0);
+                        mesh->dt_ptr, mesh->Unp, s);
     else
       launch_rhs_p1_rk(mesh->dm, ctx->ph, t, mesh->Ucur, out, RK[0][stage], RK[1][stage],
                        mesh->dt_ptr, mesh->Unp, s);
@@ -1260,7 +1260,7 @@ extern "C" int qdg_stage_rhs_dt(qdg_mesh* mesh, int stage, double t, double tlef
     // here the event pair also covers the 1-block dt reduction (~5 us)
     if (use_tile(mesh))
       launch_rhs_p1t(mesh->dm, ctx->ph, t, mesh->Ucur, mesh->R.p, true, mesh->blockmin.p, scale,
-                     tleft, mesh->dtraw.p, mesh->dt_ptr, s, 0, -1, ctx->opt.p1_persistent != 0);
+                     tleft, mesh->dtraw.p, mesh->dt_ptr, s);
     else
       launch_rhs_p1(mesh->dm, ctx->ph, t, mesh->Ucur, mesh->R.p, true, mesh->blockmin.p, scale,
                     tleft, mesh->dtraw.p, mesh->dt_ptr, s);

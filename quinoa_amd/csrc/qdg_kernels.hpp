@@ -31,10 +31,10 @@ void launch_rhs_p1(const DevMesh& m, const Phys& ph, double t, const double* U, 
 // range launches: workgroup tiles [first, first+count), count < 0 = all the rest
 void launch_rhs_p1t(const DevMesh& m, const Phys& ph, double t, const double* U, double* R,
                     bool with_dt, double* blockmin, double scale, double tleft, double* out_raw,
-                    double* out_dt, hipStream_t s, int first = 0, int count = -1, bool persistent = false);
+                    double* out_dt, hipStream_t s, int first = 0, int count = -1);
 void launch_rhs_p1t_rk(const DevMesh& m, const Phys& ph, double t, const double* U, double* Uout,
                        double a, double b, const double* dt, const double* Un, hipStream_t s,
-                       int first = 0, int count = -1, bool persistent = false);
+                       int first = 0, int count = -1);
 void launch_superbee(int ndof, const DevMesh& m, double* U, hipStream_t s, int first = 0,
                      int count = -1);
 // stage-0 RK update fused with the Superbee limiter of stage 1 (DG-P1), and its halo pack

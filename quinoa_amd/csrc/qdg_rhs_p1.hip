@@ -4,7 +4,6 @@
 //   k_rhs_p1t  tile / face-task kernel of p-adaptive meshes (per-element ndof in {1, 4})
 //   k_rhs_p1   element-centric form: every tet visits its four faces, R written once, bitwise
 //              reproducible run to run (context option "p1_rhs" = 1)
-#include <algorithm>
 #include "qdg_devfn.hpp"
 
 namespace qdg {
@@ -914,9 +913,10 @@ __device__ __forceinline__ void rk_epilogue_rows(const double (&u)[NCOMP][4], co
 // lanes per tile get ONE workgroup per CU from the dispatcher (2.7 ms against 1.6 ms at 10.1 M
 // tets), 512 lanes need 128 registers (spills: scratch traffic costs more than the waves hide),
 // 160-row tiles with three workgroups per CU at 158 registers 1.67 ms, persistent workgroups
-// prefetching the next tile's rows through the face rounds 2.1 ms (256 registers, in-order vmcnt
-// couples the prefetch to every later load), the round-2 form of the face task (vertex states
-// held across the Gauss points, 206 registers, the row re-read in phase 2) 1.60-1.65 ms.
+// prefetching the next tile's rows into registers through the face rounds 2.1 ms (256 registers,
+// in-order vmcnt couples the prefetch to every later load) or by LDS-DMA into the accumulator
+// planes during phase 2 1.84 ms, the round-2 form of the face task (vertex states held across
+// the Gauss points, 206 registers, the row re-read in phase 2) 1.60-1.65 ms.
 template <bool WITH_DT, bool FUSE_RK, int PROB>
 __global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1w(DevMesh m, Phys ph, double t,
                                                         const double* __restrict__ U,
@@ -1045,222 +1045,6 @@ __global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1w(DevMesh m, Phys ph, doub
   }
 }
 
-// ------------------------------------------- DG-P1 RHS, tile / face-task form, persistent + LDS-DMA
-// k_rhs_p1w with the one wait it cannot hide taken out of the tile's critical path: a wave's life
-// there starts with its rows in flight and nothing else to do (in-kernel stamps, round 3: 28 % of a
-// wave's cycles in phase 0), and two workgroups per CU are too few to cover it.  Here a workgroup
-// is PERSISTENT over its XCD-contiguous tiles and the NEXT tile's modal rows are copied by
-// LDS-DMA (global_load_lds, no registers) into the accumulator planes as soon as phase 2 has read
-// them -- the accumulators are dead from there to the next tile's phase 0, exactly the span in
-// which the volume term, the RK epilogue and the row stores run.  Registers carry only the next
-// tile's task words and first face record.  In-order vmcnt is respected by construction: every
-// ordinary load of a tile is consumed before that tile's DMA is issued (so no wait on a later load
-// drags the DMA in), and the DMA is waited for at the top of the next tile.
-// workgroup barrier for LDS traffic only: waits for this wave's LDS operations, not for its
-// vector-memory counter (an LDS-DMA or a row store may stay in flight across it)
-__device__ __forceinline__ void lds_barrier()
-{
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-__device__ __forceinline__ void dma_tile_rows(const double* __restrict__ src, double* lds_dst, int nbytes, int tid)
-{
-  // 1-KiB pieces (one wave instruction each, LDS destination = piece base + 16 * lane), dealt to
-  // the waves round-robin; nbytes is a multiple of 160, so the last piece may be partial
-  const int wave = tid >> 6, lane = tid & 63;
-  for (int p = wave; p * 1024 < nbytes; p += TILE_BS / 64) {
-    const int off = p * 1024 + lane * 16;
-    if (off < nbytes)
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(src) + off),
-          (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(lds_dst) + p * 1024), 16, 0, 0);
-  }
-}
-
-template <bool WITH_DT, bool FUSE_RK, int PROB>
-__global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1d(DevMesh m, Phys ph, double t, int ntiles,
-                                                        const double* __restrict__ U,
-                                                        double* __restrict__ R,
-                                                        double* __restrict__ blockmin,
-                                                        double rk_a, double rk_b,
-                                                        const double* __restrict__ dtp,
-                                                        const double* __restrict__ Un)
-{
-  constexpr int NDOF = 4, NPROP = NCOMP * NDOF, BS = TILE_BS, NR = 4, STRIDE = 4 * TILE_BS;
-  __shared__ __attribute__((aligned(16))) double nod[TILE * NPROP];
-  __shared__ __attribute__((aligned(16))) double accN[TILE * NPROP];     // also: landing zone of the next tile's rows
-  __shared__ double sdelt[WITH_DT ? TILE : 1];
-  __shared__ double wmin[BS / 64];
-  const int tid = threadIdx.x;
-  // this workgroup's tiles: local index j0, j0 + G8, ... of its XCD's contiguous range
-  constexpr int NXCD = 8;
-  const int G8 = gridDim.x / NXCD;
-  const int xcd = blockIdx.x % NXCD, j0 = blockIdx.x / NXCD;
-  const int per = ntiles / NXCD, rem = ntiles - per * NXCD;
-  const int xbase = m.blk0 + xcd * per + (xcd < rem ? xcd : rem), xcount = per + (xcd < rem ? 1 : 0);
-  if (j0 >= xcount) return;
-
-  // prologue: the first tile's task words and first face record (ordinary loads), then its rows (DMA)
-  int tan[NR];
-  double gnn[4];
-  {
-    const int tile = xbase + j0, e0 = tile * TILE;
-    const size_t slot0 = (size_t)tile * STRIDE + tid;
-#pragma unroll
-    for (int q = 0; q < NR; ++q) tan[q] = m.task_a[slot0 + BS * q];
-    load_row<4>(m.tgeo, slot0, gnn);
-    const int nl = (m.nie - e0 < TILE) ? m.nie - e0 : TILE;
-    dma_tile_rows(U + (size_t)e0 * NPROP, accN, nl * NPROP * 8, tid);
-  }
-
-#pragma unroll 1
-  for (int j = j0; j < xcount; j += G8) {
-    const int tile = xbase + j;
-    const int tile_e0 = tile * TILE;
-    const int nloc = (m.nie - tile_e0 < TILE) ? m.nie - tile_e0 : TILE;
-    const size_t slot0 = (size_t)tile * STRIDE + tid;
-    const bool more = j + G8 < xcount;
-
-    // this wave's DMA pieces (and the task words / face record) have landed; the barrier covers
-    // the other waves' pieces and the previous tile's last LDS reads
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int ta[NR];
-#pragma unroll
-    for (int q = 0; q < NR; ++q) ta[q] = tan[q];
-    double gnx[4] = { gnn[0], gnn[1], gnn[2], gnn[3] };
-
-    // ---- phase 0: modal row out of the landing zone; it stays in registers for the RK epilogue ----
-    double r[NCOMP][NDOF];
-    if (tid < nloc) {
-      const double2* row = reinterpret_cast<const double2*>(accN + (size_t)tid * NPROP);
-#pragma unroll
-      for (int i = 0; i < NPROP / 2; ++i) { const double2 v = row[i]; (&r[0][0])[2 * i] = v.x; (&r[0][0])[2 * i + 1] = v.y; }
-    } else {
-#pragma unroll
-      for (int c = 0; c < NCOMP; ++c) { r[c][0] = 1.0; r[c][1] = r[c][2] = r[c][3] = 0.0; }
-    }
-    __syncthreads();           // every row is in registers: the planes may be overwritten
-    if (tid < TILE) {
-#pragma unroll
-      for (int c = 0; c < NCOMP; ++c) {
-        // B at the vertices: v0 (-1,-1,-1), v1 (1,-1,-1), v2 (0,2,-1), v3 (0,0,3)
-        const double a = r[c][0] - r[c][3];
-        nod[LIDX(tid, 0, c)] = a - r[c][1] - r[c][2];
-        nod[LIDX(tid, 1, c)] = a + r[c][1] - r[c][2];
-        nod[LIDX(tid, 2, c)] = a + 2.0 * r[c][2];
-        nod[LIDX(tid, 3, c)] = r[c][0] + 3.0 * r[c][3];
-#pragma unroll
-        for (int vx = 0; vx < 4; ++vx) accN[LIDX(tid, vx, c)] = 0.0;
-      }
-      if (WITH_DT) sdelt[tid] = 0.0;
-    }
-    __syncthreads();
-
-    // ---- phase 1: one lane per face task ------------------------------------------
-#pragma unroll 1
-    for (int q = 0; q < NR; ++q) {
-      const int a = (q == 0) ? ta[0] : (q == 1) ? ta[1] : (q == 2) ? ta[2] : ta[3];
-      if (a < 0) break;
-      const double g4[4] = { gnx[0], gnx[1], gnx[2], gnx[3] };
-      const int an_ = (q == 0) ? ta[1] : (q == 1) ? ta[2] : (q == 2) ? ta[3] : -1;
-      if (an_ >= 0) load_row<4>(m.tgeo, slot0 + (size_t)BS * (q + 1), gnx);
-      face_task_lean<WITH_DT, PROB>(m, ph, t, U, nod, accN, sdelt, a, m.task_nb + slot0 + (size_t)BS * q, tile_e0, g4);
-    }
-
-    // phase-2 inputs (ordinary loads), requested before the barrier and ALL consumed before the DMA
-    const int erow = tile_e0 + ((tid < nloc) ? tid : 0);
-    double vol = m.vol[erow];
-    ElemGeom g;
-    [[maybe_unused]] double un[NCOMP][NDOF];
-    {
-      if constexpr (FUSE_RK) load_row<NPROP>(Un, erow, &un[0][0]);
-      double q4[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        load_row<4>(m.xyz4, m.inpoel[(size_t)i * m.stride + erow], q4);
-        g.p[i][0] = q4[0]; g.p[i][1] = q4[1]; g.p[i][2] = q4[2];
-      }
-    }
-    __syncthreads();
-
-    // ---- phase 2: face sums out of the planes, then the planes become the landing zone ----------
-    double acc[NCOMP][NDOF];
-    if (tid < TILE) tet_face_sums(accN, tid, acc);
-    const double dtv = (WITH_DT && tid < nloc) ? sdelt[tid] : 1.0;
-    // the next tile's task words and first face record: ordinary loads, older than the DMA
-    {
-      const int tnext = more ? tile + G8 : tile;
-      const size_t s1 = (size_t)tnext * STRIDE + tid;
-#pragma unroll
-      for (int q = 0; q < NR; ++q) tan[q] = m.task_a[s1 + BS * q];
-      load_row<4>(m.tgeo, s1, gnn);
-    }
-    // every ordinary load of this tile must have been consumed before the DMA goes out (a wait
-    // on it afterwards would be a wait for the DMA too): pin the values
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(vol), "+v"(tan[0]), "+v"(tan[1]), "+v"(tan[2]), "+v"(tan[3]),
-                                       "+v"(gnn[0]), "+v"(gnn[1]), "+v"(gnn[2]), "+v"(gnn[3]) :: "memory");
-    if constexpr (FUSE_RK) {
-      // a*Un + b*U now (Un is dead afterwards: 40 registers less through the volume term); the
-      // epilogue adds b*dt*R/L
-#pragma unroll
-      for (int c = 0; c < NCOMP; ++c)
-#pragma unroll
-        for (int kk = 0; kk < NDOF; ++kk) r[c][kk] = rk_a * un[c][kk] + rk_b * r[c][kk];
-    }
-    __syncthreads();           // all face sums are in registers
-    if (more) {
-      const int e1 = (tile + G8) * TILE;
-      const int nl = (m.nie - e1 < TILE) ? m.nie - e1 : TILE;
-      dma_tile_rows(U + (size_t)e1 * NPROP, accN, nl * NPROP * 8, tid);
-    }
-    double dte = DBL_MAX;
-    if (tid < nloc) {
-      tet_volume_lean<PROB>(ph, t, nod, tid, vol, g, acc);
-      if constexpr (FUSE_RK) {
-        constexpr double imf[4] = { 1.0, 10.0, 10.0 / 3.0, 5.0 / 3.0 };
-        const double bdt = rk_b * (dtp[0] / vol);
-#pragma unroll
-        for (int c = 0; c < NCOMP; ++c)
-#pragma unroll
-          for (int kk = 0; kk < NDOF; ++kk) acc[c][kk] = fma(bdt * imf[kk], acc[c][kk], r[c][kk]);
-      }
-      if (WITH_DT) dte = vol / dtv;
-    }
-    // rows out through LDS as coalesced 1-KiB wave stores.  The DMA is in flight: __syncthreads()
-    // would drain it (hipcc waits vmcnt(0) in front of a barrier while an LDS-DMA is pending), so
-    // these are LDS-only barriers
-    lds_barrier();
-    if (tid < nloc) {
-      double2* row = reinterpret_cast<double2*>(nod + (size_t)tid * NPROP);
-#pragma unroll
-      for (int jj = 0; jj < NPROP / 2; ++jj) row[jj] = make_double2((&acc[0][0])[2 * jj], (&acc[0][0])[2 * jj + 1]);
-    }
-    lds_barrier();
-    {
-      const double2* src = reinterpret_cast<const double2*>(nod);
-      double2* dst = reinterpret_cast<double2*>(R + (size_t)tile_e0 * NPROP);
-      const int nvalid = nloc * (NPROP / 2);
-#pragma unroll
-      for (int jj = 0; jj < NPROP / 2; ++jj) {
-        const int i = jj * BS + tid;
-        if (i < nvalid) dst[i] = src[i];
-      }
-    }
-    if (WITH_DT) {
-      for (int off = 32; off > 0; off >>= 1) dte = fmin(dte, __shfl_down(dte, off, 64));
-      const int lane = tid & 63, wv = tid >> 6;
-      if (lane == 0) wmin[wv] = dte;
-      lds_barrier();
-      if (tid == 0) {
-        double mn = wmin[0];
-        for (int w = 1; w < BS / 64; ++w) mn = fmin(mn, wmin[w]);
-        blockmin[tile] = mn;
-      }
-    }
-  }
-}
-
 // ================================================================ launchers
 
 
@@ -1291,20 +1075,13 @@ void launch_rhs_p1(const DevMesh& m, const Phys& ph, double t, const double* U, 
 // launch that ends at the last tile also reduces the per-tile minima to the time step.
 void launch_rhs_p1t(const DevMesh& m0, const Phys& ph, double t, const double* U, double* R,
                     bool with_dt, double* blockmin, double scale, double tleft, double* out_raw,
-                    double* out_dt, hipStream_t s, int first, int count, bool persistent)
+                    double* out_dt, hipStream_t s, int first, int count)
 {
   if (m0.ntile == 0) return;
   DevMesh m = m0;
   m.blk0 = first;
   const int nb = count < 0 ? m.ntile - first : count;
-  if (nb > 0 && !m.ndofel && persistent) {
-    const int g8 = std::min(64, (nb + 7) / 8);          // 2 workgroups per CU, a multiple of 8 in all
-    if (with_dt) {
-      QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1d<true, false, P><<<8 * g8, TILE_BS, 0, s>>>(m, ph, t, nb, U, R, blockmin, 0.0, 0.0, nullptr, nullptr)));
-    } else {
-      QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1d<false, false, P><<<8 * g8, TILE_BS, 0, s>>>(m, ph, t, nb, U, R, blockmin, 0.0, 0.0, nullptr, nullptr)));
-    }
-  } else if (nb > 0 && !m.ndofel) {
+  if (nb > 0 && !m.ndofel) {
     if (with_dt) {
       QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1w<true, false, P><<<nb, TILE_BS, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr)));
     } else {
@@ -1323,18 +1100,13 @@ void launch_rhs_p1t(const DevMesh& m0, const Phys& ph, double t, const double* U
 
 void launch_rhs_p1t_rk(const DevMesh& m0, const Phys& ph, double t, const double* U, double* Uout,
                        double a, double b, const double* dt, const double* Un, hipStream_t s,
-                       int first, int count, bool persistent)
+                       int first, int count)
 {
   if (m0.ntile == 0) return;
   DevMesh m = m0;
   m.blk0 = first;
   const int nb = count < 0 ? m.ntile - first : count;
   if (nb <= 0) return;
-  if (!m.ndofel && persistent) {
-    const int g8 = std::min(64, (nb + 7) / 8);
-    QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1d<false, true, P><<<8 * g8, TILE_BS, 0, s>>>(m, ph, t, nb, U, Uout, nullptr, a, b, dt, Un)));
-    return;
-  }
   if (!m.ndofel) {
     QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1w<false, true, P><<<nb, TILE_BS, 0, s>>>(m, ph, t, U, Uout, nullptr, a, b, dt, Un)));
     return;

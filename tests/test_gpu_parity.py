@@ -522,16 +522,15 @@ def test_p1_rhs_kernel_forms_agree():
         U0 = mesh.initialize(0.0)
         U0 = U0 + 1e-3 * rng.normal(size=U0.shape)
         out = {}
-        for tag, v, pers in (("tile", 0, 0), ("element", 1, 0), ("persistent", 0, 1)):
+        for tag, v in (("tile", 0), ("element", 1)):
             ctx.set_option("p1_rhs", v)
-            ctx.set_option("p1_persistent", pers)
             R = mesh.rhs(0.0, U0)
             mesh.state_upload(U0)
             t = 0.0
             for _ in range(3):
                 t += mesh.step(t)
             out[tag] = (R, mesh.state_download(), t)
-        for tag in ("element", "persistent"):
+        for tag in ("element",):
             assert np.abs(out[tag][0] - out["tile"][0]).max() <= 1e-12 * max(1.0, np.abs(out["tile"][0]).max()), tag
             assert np.abs(out[tag][1] - out["tile"][1]).max() <= 1e-12 * max(1.0, np.abs(out["tile"][1]).max()), tag
             assert abs(out[tag][2] - out["tile"][2]) <= 1e-14 * out["tile"][2], tag

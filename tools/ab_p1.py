@@ -20,7 +20,7 @@ rounds = 3
 if args and args[0].isdigit():
     rounds = int(args[0]); args = args[1:]
 cfgs = args or ["p1_rhs=0"]
-BASE = {"p1_rhs": 0, "p1_persistent": 0, "fused_update": 1}
+BASE = {"p1_rhs": 0, "fused_update": 1}
 
 ch = meshgen.kuhn_box(nx, nx, nx)
 ctx = capi.Context(4, flux="hllc", limiter="superbeep1", problem="sod_shocktube", gamma=1.4, cfl=0.3,
