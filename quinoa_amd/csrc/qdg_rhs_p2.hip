@@ -7,7 +7,7 @@ namespace qdg {
 __device__ P2Split g_p2s;          // copied to LDS by every workgroup of k_rhs_p2s
 
 // ------------------------------------------------- DG-P2 RHS, two lanes per tet
-// The one-lane-per-tet forms above need the tet's row, its accumulators and a neighbour row
+// A one-lane-per-tet form needs the tet's row, its accumulators and a neighbour row
 // (3 x 100 registers) and run at ONE wave per SIMD, where the vector unit idles 44 % of the
 // time (profiles/r02_cfg3_nx55_pmc_per_launch.json: fp64 latency and memory waits with nothing
 // to switch to).  Here a tet is worked on by a PAIR of adjacent lanes; lane half h owns the
@@ -194,12 +194,43 @@ __global__ __launch_bounds__(256, 2) void k_rhs_p2s(DevMesh m, Phys ph, double t
 
   const double vol = m.vol[e];
 
-  // ---- volume (+ source) integral, two points per step: this lane's and its partner's ----
+  // ---- source and volume integrals, two points per step: this lane's and its partner's ----
+  // The source term (a function of position and time alone) has a loop of its own IN FRONT of the
+  // flux loop: it needs the tet's twelve node coordinates, the flux loop their inverse Jacobian and
+  // 60 registers of contracted fluxes -- together they spilled 88 bytes per lane to scratch, and a
+  // kernel with scratch runs at a fraction of its speed on this chip (round 3).
   {
     ElemGeom g;
     load_geom(m, e, g);
+    if constexpr (prob_has_source<PROB>()) {
+      // src/PDE/Integrate/Source.cpp:21-141
+#pragma unroll 1
+      for (int s = 0; s < 6; ++s) {
+        const int gm = 2 * s + h, gp = 2 * s + 1 - h;
+        const double* tm = S.vol[gm][h];
+        const double* tp = S.vol[gp][h];
+        const double wt = S.vw[gm] * vol;
+        const double xi = S.vc[gm][0], eta = S.vc[gm][1], zeta = S.vc[gm][2];
+        const double w0 = 1.0 - xi - eta - zeta;
+        double P[3], sr[NCOMP];
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+          P[d] = g.p[0][d] * w0 + g.p[1][d] * xi + g.p[2][d] * eta + g.p[3][d] * zeta;
+        prob_src<PROB>(ph, P[0], P[1], P[2], t, sr);
+#pragma unroll
+        for (int c = 0; c < NCOMP; ++c) {
+          const double wm = wt * sr[c];
+          const double wp = pair_swap(wm);
+#pragma unroll
+          for (int k = 0; k < KH; ++k) acc[c][k] += wm * tm[k] + wp * tp[k];
+        }
+      }
+    }
     double ji[3][3];
     inverse_jacobian(g, ji);
+    // (an opaque use: the coordinates are dead from here on)
+    asm volatile("" : "+v"(ji[0][0]), "+v"(ji[0][1]), "+v"(ji[0][2]), "+v"(ji[1][0]), "+v"(ji[1][1]),
+                      "+v"(ji[1][2]), "+v"(ji[2][0]), "+v"(ji[2][1]), "+v"(ji[2][2]));
 #pragma unroll 1
     for (int s = 0; s < 6; ++s) {
       const int gm = 2 * s + h, gp = 2 * s + 1 - h;
@@ -240,23 +271,6 @@ __global__ __launch_bounds__(256, 2) void k_rhs_p2s(DevMesh m, Phys ph, double t
         for (int c = 0; c < NCOMP; ++c)
           acc[c][k] += (Gm[c][0] * m0 + Gm[c][1] * m1 + Gm[c][2] * m2)
                      + (Gp[c][0] * p0 + Gp[c][1] * p1 + Gp[c][2] * p2);
-      }
-      if constexpr (prob_has_source<PROB>()) {
-        // src/PDE/Integrate/Source.cpp:21-141
-        const double xi = S.vc[gm][0], eta = S.vc[gm][1], zeta = S.vc[gm][2];
-        const double w0 = 1.0 - xi - eta - zeta;
-        double P[3], sr[NCOMP];
-#pragma unroll
-        for (int d = 0; d < 3; ++d)
-          P[d] = g.p[0][d] * w0 + g.p[1][d] * xi + g.p[2][d] * eta + g.p[3][d] * zeta;
-        prob_src<PROB>(ph, P[0], P[1], P[2], t, sr);
-#pragma unroll
-        for (int c = 0; c < NCOMP; ++c) {
-          const double wm = wt * sr[c];
-          const double wp = pair_swap(wm);
-#pragma unroll
-          for (int k = 0; k < KH; ++k) acc[c][k] += wm * tm[k] + wp * tp[k];
-        }
       }
     }
   }
