@@ -661,12 +661,14 @@ __global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1t(DevMesh m, Phys ph, doub
 }
 
 // ------------------------------------------- the lean face task of the tile kernels below
-// One face of a tile, evaluated once, budgeted for registers: vertex states are NOT held
-// across the Gauss points -- the face means Bo, Bn stay in registers (one pass over the 2 x 15
-// LDS values) and the heavy vertex of each point is read again from LDS when its point is
-// evaluated.  `a` is the packed task word, g4 the face record {area, n}, *nbrow the neighbour's
-// device row (faces to other tiles; read only by lanes that have such a face -- they are listed
-// first, so later rounds issue no load).  Everything is evaluated in the OWN tet's frame: left' =
+// One face of a tile, evaluated once.  The two tets' vertex states at the face (2 x 15 LDS values)
+// are read ONCE, at the top, and turned into the six point states at once (Y own side, X
+// neighbour); nothing else is held across the Gauss points.  (Round 3 measured the forms: vertex
+// states re-read per point 1.58 ms at 10.1 M tets, the neighbour's read once -- the reads that meet
+// bank conflicts, partner tets are scattered over the tile -- 1.52 ms, both once 1.50 ms.)
+// `a` is the packed task word, g4 the face record {area, n}, *nbrow the neighbour's device row
+// (faces to other tiles; read only by lanes that have such a face -- they are listed first, so
+// later rounds issue no load).  Everything is evaluated in the OWN tet's frame: left' =
 // own, right' = neighbour, n' = the own tet's outward normal (the stored normal or its negative);
 // for a face whose stored left tet is the neighbour this is the mirror image of the reference's
 // evaluation (Sl' = -Sr, Sm' = -Sm, Sr' = -Sl), so HLLC's ladder (HLLC.hpp:93-124) is applied in
@@ -696,16 +698,24 @@ __device__ __forceinline__ void face_task_lean(const DevMesh& m, const Phys& ph,
     ao[j] = LIDX(el, lpofa(lf, j), 0);
     an[j] = LIDX(pl, (code >> (2 * j)) & 3, 0);
   }
-  // X: neighbour side.  in-tile face: X[0] = the face mean Bn (heavy vertices re-read per
-  // point); face to another tile: X[g] = the neighbour's state at point g, from its modal row
-  double Bo[NCOMP], X[3][NCOMP];
+  // X[g]: the neighbour's state at point g -- in-tile face: from its three vertex states in LDS,
+  // read ONCE (the partner tets of a wave's lanes are scattered over the tile, so these are the
+  // reads that meet bank conflicts; the own side's, consecutive tets, are conflict-free and are
+  // read again per point); face to another tile: from the neighbour's modal row
+  double Y[3][NCOMP], X[3][NCOMP];
 #pragma unroll
-  for (int c = 0; c < NCOMP; ++c)
-    Bo[c] = (nod[ao[0] + c * TILE] + nod[ao[1] + c * TILE] + nod[ao[2] + c * TILE]) * (1.0 / 6.0);
+  for (int c = 0; c < NCOMP; ++c) {
+    const double v0 = nod[ao[0] + c * TILE], v1 = nod[ao[1] + c * TILE], v2 = nod[ao[2] + c * TILE];
+    const double bo = (v0 + v1 + v2) * (1.0 / 6.0);
+    Y[0][c] = fma(0.5, v1, bo); Y[1][c] = fma(0.5, v2, bo); Y[2][c] = fma(0.5, v0, bo);
+  }
   if (kind == TASK_INT) {
 #pragma unroll
-    for (int c = 0; c < NCOMP; ++c)
-      X[0][c] = (nod[an[0] + c * TILE] + nod[an[1] + c * TILE] + nod[an[2] + c * TILE]) * (1.0 / 6.0);
+    for (int c = 0; c < NCOMP; ++c) {
+      const double v0 = nod[an[0] + c * TILE], v1 = nod[an[1] + c * TILE], v2 = nod[an[2] + c * TILE];
+      const double bn = (v0 + v1 + v2) * (1.0 / 6.0);
+      X[0][c] = fma(0.5, v1, bn); X[1][c] = fma(0.5, v2, bn); X[2][c] = fma(0.5, v0, bn);
+    }
   } else if (kind == TASK_EXT) {
     double b1[3], b2[3], b3[3];
 #pragma unroll
@@ -734,15 +744,10 @@ __device__ __forceinline__ void face_task_lean(const DevMesh& m, const Phys& ph,
   double Fg[3][NCOMP], dsum = 0.0;
 #pragma unroll
   for (int ig = 0; ig < NGF; ++ig) {
-    constexpr int H[3] = { 1, 2, 0 };
-    const int h = H[ig];
     double so[NCOMP], sn[NCOMP];
 #pragma unroll
-    for (int c = 0; c < NCOMP; ++c) so[c] = fma(0.5, nod[ao[h] + c * TILE], Bo[c]);
-    if (kind == TASK_INT) {
-#pragma unroll
-      for (int c = 0; c < NCOMP; ++c) sn[c] = fma(0.5, nod[an[h] + c * TILE], X[0][c]);
-    } else if (kind == TASK_EXT) {
+    for (int c = 0; c < NCOMP; ++c) so[c] = Y[ig][c];
+    if (kind != TASK_BND) {
 #pragma unroll
       for (int c = 0; c < NCOMP; ++c) sn[c] = X[ig][c];
     } else {
@@ -928,7 +933,7 @@ __global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1w(DevMesh m, Phys ph, doub
 {
   constexpr int NDOF = 4, NPROP = NCOMP * NDOF, BS = TILE_BS;
   constexpr int NR = 4;                               // rounds of the workgroup over the padded task slots
-  static_assert(TILE_BS == 256, "task_stride = 4 * TILE_BS slots per tile, 4 rounds of 256 lanes");
+  static_assert(TILE <= TILE_BS, "task_stride = 4 * TILE_BS slots per tile: 4 rounds of the workgroup's lanes");
   __shared__ __attribute__((aligned(16))) double nod[TILE * NPROP];
   __shared__ double accN[TILE * NPROP];
   __shared__ double sdelt[WITH_DT ? TILE : 1];
@@ -1033,13 +1038,13 @@ __global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1w(DevMesh m, Phys ph, doub
 
   if (WITH_DT) {
     for (int off = 32; off > 0; off >>= 1) dte = fmin(dte, __shfl_down(dte, off, 64));
-    __shared__ double wmin[BS / 64];
+    __shared__ double wmin[(BS + 63) / 64];
     const int lane = tid & 63, wv = tid >> 6;
     if (lane == 0) wmin[wv] = dte;
     __syncthreads();
     if (tid == 0) {
       double mn = wmin[0];
-      for (int w = 1; w < BS / 64; ++w) mn = fmin(mn, wmin[w]);
+      for (int w = 1; w < (BS + 63) / 64; ++w) mn = fmin(mn, wmin[w]);
       blockmin[tile] = mn;
     }
   }
