@@ -350,6 +350,11 @@ __device__ __forceinline__ void prob_solution(const Phys& ph, double x, double y
 
 // Problem::src: VorticalFlow.cpp:80-115, TaylorGreen.cpp:77-90 (zero otherwise)
 template <int PROB> constexpr bool prob_has_source() { return PROB == 3 || PROB == 4 || PROB == 7 || PROB == 10; }
+// components whose source is identically zero (their projection is skipped)
+template <int PROB> constexpr bool prob_src_is_zero(int c)
+{
+  return PROB == 3 ? (c == 0 || c == 3) : PROB == 4 ? c < 4 : !prob_has_source<PROB>();
+}
 template <int PROB>
 __device__ __forceinline__ void prob_src(const Phys& ph, double x, double y, double z,
                                          double t, double* r)

@@ -219,6 +219,7 @@ __global__ __launch_bounds__(256, 2) void k_rhs_p2s(DevMesh m, Phys ph, double t
         prob_src<PROB>(ph, P[0], P[1], P[2], t, sr);
 #pragma unroll
         for (int c = 0; c < NCOMP; ++c) {
+          if (prob_src_is_zero<PROB>(c)) continue;
           const double wm = wt * sr[c];
           const double wp = pair_swap(wm);
 #pragma unroll
