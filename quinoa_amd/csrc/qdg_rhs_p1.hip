@@ -687,9 +687,30 @@ __device__ __forceinline__ void face_task_lean(const DevMesh& m, const Phys& ph,
   const int el = TASK_EL(a), lf = TASK_LF(a), code = TASK_CODE(a), kind = TASK_KIND(a),
             bc = TASK_BC(a), pl = TASK_PL(a);
   const bool own_left = TASK_OWNLEFT(a);
+#if defined(QDG_X_GEO)
+  // experiment (round 3, measured): the face record recomputed from the own tet's node coordinates
+  // (three node ids + three 32-byte node records, cache hits) instead of the 32-byte record per task
+  double area, fn[3];
+  {
+    const int e = tile_e0 + el;
+    const int n0 = m.inpoel[(size_t)lpofa(lf, 0) * m.stride + e], n1 = m.inpoel[(size_t)lpofa(lf, 1) * m.stride + e],
+              n2 = m.inpoel[(size_t)lpofa(lf, 2) * m.stride + e];
+    double p0[4], p1[4], p2[4];
+    load_row<4>(m.xyz4, n0, p0); load_row<4>(m.xyz4, n1, p1); load_row<4>(m.xyz4, n2, p2);
+    const double ax = p1[0] - p0[0], ay = p1[1] - p0[1], az = p1[2] - p0[2];
+    const double bx = p2[0] - p0[0], by = p2[1] - p0[1], bz = p2[2] - p0[2];
+    const double cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx;
+    const double l2 = cx * cx + cy * cy + cz * cz;
+    const double il = fast_rcp(fast_sqrt(l2));
+    fn[0] = cx * il; fn[1] = cy * il; fn[2] = cz * il;
+    area = 0.5 * l2 * il;
+    (void)g4;
+  }
+#else
   const double area = g4[0];
   const double osg = own_left ? 1.0 : -1.0;
   const double fn[3] = { osg * g4[1], osg * g4[2], osg * g4[3] };
+#endif
   const bool bnd = kind == TASK_BND;
   // LDS word index of (tet, face vertex j, component 0); components are TILE words apart
   int ao[3], an[3];
@@ -943,7 +964,14 @@ __global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1w(DevMesh m, Phys ph, doub
   const int nloc = (m.nie - tile_e0 < TILE) ? m.nie - tile_e0 : TILE;
 
   // kernel entry: everything that depends on nothing
+#if defined(QDG_X_ALT)
+  const size_t slot0 = (size_t)tile * (4 * TILE_BS) + (tid ^ ((tile & 1) << 7));
+#else
   const size_t slot0 = (size_t)tile * (4 * TILE_BS) + tid;
+#endif
+#if defined(QDG_X_PRIO)
+  __builtin_amdgcn_s_setprio(QDG_X_PRIO == 1 ? 3 : 0);
+#endif
   double r[NCOMP][NDOF];
   const int erow = tile_e0 + ((tid < nloc) ? tid : 0);          // lanes beyond the tile read its row 0
   load_row<NPROP>(U, erow, &r[0][0]);
@@ -951,7 +979,11 @@ __global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1w(DevMesh m, Phys ph, doub
 #pragma unroll
   for (int q = 0; q < NR; ++q) ta[q] = m.task_a[slot0 + BS * q];
   double gnx[4];
+#if defined(QDG_X_GEO)
+  gnx[0] = gnx[1] = gnx[2] = gnx[3] = 0.0;
+#else
   load_row<4>(m.tgeo, slot0, gnx);                               // (zeros behind unused slots)
+#endif
   int in4[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) in4[i] = m.inpoel[(size_t)i * m.stride + erow];
@@ -979,6 +1011,9 @@ __global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1w(DevMesh m, Phys ph, doub
     if (WITH_DT) sdelt[tid] = 0.0;
   }
   __syncthreads();
+#if defined(QDG_X_PRIO)
+  __builtin_amdgcn_s_setprio(QDG_X_PRIO == 1 ? 0 : 3);
+#endif
 
   // ---- phase 1: one lane per face task ------------------------------------------
 #pragma unroll 1
@@ -987,10 +1022,17 @@ __global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1w(DevMesh m, Phys ph, doub
     if (a < 0) break;
     const double g4[4] = { gnx[0], gnx[1], gnx[2], gnx[3] };
     const int an_ = (q == 0) ? ta[1] : (q == 1) ? ta[2] : (q == 2) ? ta[3] : -1;
+#if !defined(QDG_X_GEO)
     if (an_ >= 0) load_row<4>(m.tgeo, slot0 + (size_t)BS * (q + 1), gnx);    // the next round's face record
+#else
+    (void)an_;
+#endif
     face_task_lean<WITH_DT, PROB>(m, ph, t, U, nod, accN, sdelt, a, m.task_nb + slot0 + (size_t)BS * q, tile_e0, g4);
   }
 
+#if defined(QDG_X_PRIO)
+  __builtin_amdgcn_s_setprio(QDG_X_PRIO == 1 ? 3 : 0);
+#endif
   // phase-2 inputs are requested before the barrier (the node ids are here already)
   ElemGeom g;
   [[maybe_unused]] double un[NCOMP][NDOF];
@@ -1003,6 +1045,30 @@ __global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1w(DevMesh m, Phys ph, doub
       g.p[i][0] = q[0]; g.p[i][1] = q[1]; g.p[i][2] = q[2];
     }
   }
+#if defined(QDG_X_VOLFIRST)
+  // the volume term needs the vertex states only: it runs BEFORE the barrier, in the time the
+  // waves with fewer face rounds would wait for the others
+  double dte = DBL_MAX;
+  double acc[NCOMP][NDOF];
+  if (tid < nloc) {
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c)
+#pragma unroll
+      for (int k = 0; k < NDOF; ++k) acc[c][k] = 0.0;
+    tet_volume_lean<PROB>(ph, t, nod, tid, vol, g, acc);
+  }
+  __syncthreads();
+  if (tid < nloc) {
+    double fs[NCOMP][NDOF];
+    tet_face_sums(accN, tid, fs);
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c)
+#pragma unroll
+      for (int k = 0; k < NDOF; ++k) acc[c][k] += fs[c][k];
+    if constexpr (FUSE_RK) rk_epilogue_rows(r, un, dtp[0] / vol, rk_a, rk_b, acc);
+    if (WITH_DT) dte = vol / sdelt[tid];
+  }
+#else
   __syncthreads();
 
   // ---- phase 2: one lane per tet: volume (+source) term, epilogue, store --------
@@ -1014,6 +1080,7 @@ __global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1w(DevMesh m, Phys ph, doub
     if constexpr (FUSE_RK) rk_epilogue_rows(r, un, dtp[0] / vol, rk_a, rk_b, acc);
     if (WITH_DT) dte = vol / sdelt[tid];
   }
+#endif
   // rows out, coalesced: a lane storing its own 160-B row issues 64 separate 16-B write
   // requests per wave instruction (3.4 TB/s measured, tools/ubench_rowstream.hip); the tile's
   // rows are one contiguous span, so they go through LDS (row-major over the vertex states,
