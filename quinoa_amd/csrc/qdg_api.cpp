@@ -201,7 +201,7 @@ extern "C" int qdg_ctx_set_stream(qdg_ctx* ctx, void* s)
 static int* option_slot(qdg_ctx* ctx, const char* name)
 {
   static const struct { const char* n; int qdg::Options::*p; } tab[] = {
-    { "p1_rhs", &qdg::Options::p1_rhs },           { "p1_wide", &qdg::Options::p1_wide },
+    { "p1_rhs", &qdg::Options::p1_rhs },
     { "fused_update", &qdg::Options::fused_update },
     { "renumber", &qdg::Options::renumber },       { "host_layout", &qdg::Options::host_layout },
   };
@@ -724,14 +724,6 @@ static bool use_p1_fast(const qdg_mesh* mesh)
 
 // tile / face-task kernel (each in-tile face evaluated once, LDS accumulation with
 // ds_add_f64) unless bitwise run-to-run reproducibility is requested (option "p1_rhs" = 1)
-// the mesh view of a DG-P1 tile launch: the launch-time options ride in it
-static qdg::DevMesh dm_p1(const qdg_mesh* mesh)
-{
-  qdg::DevMesh d = mesh->dm;
-  d.p1_wide = mesh->ctx->opt.p1_wide;
-  return d;
-}
-
 static bool use_tile(const qdg_mesh* mesh)
 {
   return mesh->ctx->opt.p1_rhs == 0 || mesh->dm.ndofel;      // p-adaptive DG exists in the tile kernel only
@@ -741,7 +733,7 @@ static void run_rhs(qdg_mesh* mesh, double t, const double* U, double* R)
 {
   qdg_ctx* ctx = mesh->ctx;
   if (use_p1_fast(mesh) && use_tile(mesh))
-    launch_rhs_p1t(dm_p1(mesh), ctx->ph, t, U, R, false, mesh->blockmin.p, 1.0, DBL_MAX,
+    launch_rhs_p1t(mesh->dm, ctx->ph, t, U, R, false, mesh->blockmin.p, 1.0, DBL_MAX,
                    mesh->dtraw.p, mesh->dt_ptr, ctx->stream);
   else if (use_p1_fast(mesh))
     launch_rhs_p1(mesh->dm, ctx->ph, t, U, R, false, mesh->blockmin.p, 1.0, DBL_MAX,
@@ -1247,7 +1239,7 @@ extern "C" int qdg_stage_rhs_dt(qdg_mesh* mesh, int stage, double t, double tlef
     double* out = free_buf(mesh, mesh->Ucur, mesh->Unp);
     if (int rc = prof_begin(mesh, &ev)) return rc;
     if (use_tile(mesh))
-      launch_rhs_p1t_rk(dm_p1(mesh), ctx->ph, t, mesh->Ucur, out, RK[0][stage], RK[1][stage],
+      launch_rhs_p1t_rk(mesh->dm, ctx->ph, t, mesh->Ucur, out, RK[0][stage], RK[1][stage],
                         mesh->dt_ptr, mesh->Unp, s);
     else
       launch_rhs_p1_rk(mesh->dm, ctx->ph, t, mesh->Ucur, out, RK[0][stage], RK[1][stage],
@@ -1267,7 +1259,7 @@ extern "C" int qdg_stage_rhs_dt(qdg_mesh* mesh, int stage, double t, double tlef
     if (int rc = prof_begin(mesh, &ev)) return rc;
     // here the event pair also covers the 1-block dt reduction (~5 us)
     if (use_tile(mesh))
-      launch_rhs_p1t(dm_p1(mesh), ctx->ph, t, mesh->Ucur, mesh->R.p, true, mesh->blockmin.p, scale,
+      launch_rhs_p1t(mesh->dm, ctx->ph, t, mesh->Ucur, mesh->R.p, true, mesh->blockmin.p, scale,
                      tleft, mesh->dtraw.p, mesh->dt_ptr, s);
     else
       launch_rhs_p1(mesh->dm, ctx->ph, t, mesh->Ucur, mesh->R.p, true, mesh->blockmin.p, scale,

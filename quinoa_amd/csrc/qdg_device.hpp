@@ -82,7 +82,6 @@ struct DevMesh {
   int ncomp;        // 5: CompFlow, 1: scalar Transport (rows of ncomp*ndof doubles)
   // p-adaptive DG (scheme pdg): DG::m_ndof per device row, 1 or 4; null otherwise
   const int* ndofel;
-  int p1_wide;      // DG-P1 tile kernel with 512 lanes per tile (option "p1_wide"), set per launch
 };
 
 #ifndef QDG_TILE

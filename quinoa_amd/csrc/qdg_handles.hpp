@@ -47,7 +47,6 @@ namespace qdg {
 // qdg_ctx_set_option: tuning / A-B switches (defaults = the product path)
 struct Options {
   int p1_rhs = 0;        // DG-P1 RHS: 0 tile / face-task kernels (LDS atomics), 1 element-centric (bitwise reproducible)
-  int p1_wide = 0;       // DG-P1 tile kernel with 512 lanes per tile / 4 waves per SIMD (k_rhs_p1h; A/B)
   int fused_update = 1;  // stage-0 RK update fused with the Superbee limiter of stage 1
   int renumber = 1;      // Morton order of the interior tets (0: caller's order; layout experiments)
   int host_layout = 0;   // qdg_mesh_from_connectivity: 1 routes through qdg_mesh_upload's host code (A/B)

@@ -674,7 +674,7 @@ __global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1t(DevMesh m, Phys ph, doub
 // evaluation (Sl' = -Sr, Sm' = -Sm, Sr' = -Sl), so HLLC's ladder (HLLC.hpp:93-124) is applied in
 // its mirrored form (flux_hllc_own) -- same four fluxes, same fall-through of a NaN wave speed to
 // the STORED right state -- and the own tet always loses what the neighbour gains.
-template <bool WITH_DT, int PROB, bool OWN_ONCE = true>
+template <bool WITH_DT, int PROB>
 __device__ __forceinline__ void face_task_lean(const DevMesh& m, const Phys& ph, double t,
                                                const double* __restrict__ U, double* __restrict__ nod,
                                                double* __restrict__ accN, double* __restrict__ sdelt,
@@ -702,17 +702,12 @@ __device__ __forceinline__ void face_task_lean(const DevMesh& m, const Phys& ph,
   // read ONCE (the partner tets of a wave's lanes are scattered over the tile, so these are the
   // reads that meet bank conflicts; the own side's, consecutive tets, are conflict-free and are
   // read again per point); face to another tile: from the neighbour's modal row
-  // (OWN_ONCE = false, the 128-register kernel k_rhs_p1h: the own side's states are NOT held but
-  // re-read per point -- consecutive tets, conflict-free reads -- which frees 30 registers)
-  [[maybe_unused]] double Y[3][NCOMP];
-  double X[3][NCOMP];
-  if constexpr (OWN_ONCE) {
+  double Y[3][NCOMP], X[3][NCOMP];
 #pragma unroll
-    for (int c = 0; c < NCOMP; ++c) {
-      const double v0 = nod[ao[0] + c * TILE], v1 = nod[ao[1] + c * TILE], v2 = nod[ao[2] + c * TILE];
-      const double bo = (v0 + v1 + v2) * (1.0 / 6.0);
-      Y[0][c] = fma(0.5, v1, bo); Y[1][c] = fma(0.5, v2, bo); Y[2][c] = fma(0.5, v0, bo);
-    }
+  for (int c = 0; c < NCOMP; ++c) {
+    const double v0 = nod[ao[0] + c * TILE], v1 = nod[ao[1] + c * TILE], v2 = nod[ao[2] + c * TILE];
+    const double bo = (v0 + v1 + v2) * (1.0 / 6.0);
+    Y[0][c] = fma(0.5, v1, bo); Y[1][c] = fma(0.5, v2, bo); Y[2][c] = fma(0.5, v0, bo);
   }
   if (kind == TASK_INT) {
 #pragma unroll
@@ -750,21 +745,8 @@ __device__ __forceinline__ void face_task_lean(const DevMesh& m, const Phys& ph,
 #pragma unroll
   for (int ig = 0; ig < NGF; ++ig) {
     double so[NCOMP], sn[NCOMP];
-    if constexpr (OWN_ONCE) {
 #pragma unroll
-      for (int c = 0; c < NCOMP; ++c) so[c] = Y[ig][c];
-    } else {
-      // (the addresses pass through an opaque statement: the compiler would otherwise merge the
-      // three points' reads into one set held across the loop)
-      int a0 = ao[0], a1 = ao[1], a2 = ao[2];
-      asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2));
-#pragma unroll
-      for (int c = 0; c < NCOMP; ++c) {
-        const double v0 = nod[a0 + c * TILE], v1 = nod[a1 + c * TILE], v2 = nod[a2 + c * TILE];
-        const double bo = (v0 + v1 + v2) * (1.0 / 6.0);
-        so[c] = fma(0.5, (ig == 0) ? v1 : (ig == 1) ? v2 : v0, bo);
-      }
-    }
+    for (int c = 0; c < NCOMP; ++c) so[c] = Y[ig][c];
     if (kind != TASK_BND) {
 #pragma unroll
       for (int c = 0; c < NCOMP; ++c) sn[c] = X[ig][c];
@@ -1021,30 +1003,6 @@ __global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1w(DevMesh m, Phys ph, doub
       g.p[i][0] = q[0]; g.p[i][1] = q[1]; g.p[i][2] = q[2];
     }
   }
-#if defined(QDG_X_VOLFIRST)
-  // the volume term needs the vertex states only: it runs BEFORE the barrier, in the time the
-  // waves with fewer face rounds would wait for the others
-  double dte = DBL_MAX;
-  double acc[NCOMP][NDOF];
-  if (tid < nloc) {
-#pragma unroll
-    for (int c = 0; c < NCOMP; ++c)
-#pragma unroll
-      for (int k = 0; k < NDOF; ++k) acc[c][k] = 0.0;
-    tet_volume_lean<PROB>(ph, t, nod, tid, vol, g, acc);
-  }
-  __syncthreads();
-  if (tid < nloc) {
-    double fs[NCOMP][NDOF];
-    tet_face_sums(accN, tid, fs);
-#pragma unroll
-    for (int c = 0; c < NCOMP; ++c)
-#pragma unroll
-      for (int k = 0; k < NDOF; ++k) acc[c][k] += fs[c][k];
-    if constexpr (FUSE_RK) rk_epilogue_rows(r, un, dtp[0] / vol, rk_a, rk_b, acc);
-    if (WITH_DT) dte = vol / sdelt[tid];
-  }
-#else
   __syncthreads();
 
   // ---- phase 2: one lane per tet: volume (+source) term, epilogue, store --------
@@ -1056,7 +1014,6 @@ __global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1w(DevMesh m, Phys ph, doub
     if constexpr (FUSE_RK) rk_epilogue_rows(r, un, dtp[0] / vol, rk_a, rk_b, acc);
     if (WITH_DT) dte = vol / sdelt[tid];
   }
-#endif
   // rows out, coalesced: a lane storing its own 160-B row issues 64 separate 16-B write
   // requests per wave instruction (3.4 TB/s measured, tools/ubench_rowstream.hip); the tile's
   // rows are one contiguous span, so they go through LDS (row-major over the vertex states,
@@ -1088,249 +1045,6 @@ __global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1w(DevMesh m, Phys ph, doub
     if (tid == 0) {
       double mn = wmin[0];
       for (int w = 1; w < (BS + 63) / 64; ++w) mn = fmin(mn, wmin[w]);
-      blockmin[tile] = mn;
-    }
-  }
-}
-
-// ------------------------------------------- DG-P1 RHS, tile / face-task form, 512 lanes per tile
-// The same tile, LDS planes, task lists and face task as k_rhs_p1w, with TWICE the lanes (option
-// "p1_wide" = 1): 8 waves per 248-row tile, two tiles per CU = 4 waves per SIMD, which caps the
-// kernel at 128 registers.  To fit, nothing is carried across the face rounds (the modal row is
-// rebuilt from the tile's vertex states in LDS for the RK epilogue, node ids and volume are read
-// in phase 2), and the per-tet phases are split over two lanes BY COMPONENT: lane half h = tid / 256
-// (wave-uniform) owns rho, rho*u, rho*v (h = 0) or rho*w, rho*E (h = 1) of tet tid % 256 -- its
-// part of the row in phase 0, of the flux sums, volume term, RK update and store in phase 2 (the
-// primitive variables at the five volume points are evaluated by both).  The 620 face tasks of a
-// tile take 1.2 rounds of the 512 lanes.
-template <int C0, int NC>
-__device__ __forceinline__ void p1h_rows_to_lds(const double* __restrict__ U, int erow, bool valid, int tl,
-                                                double* __restrict__ nod, double* __restrict__ accN)
-{
-  double r[NC][4];
-  const double2* q = reinterpret_cast<const double2*>(__builtin_assume_aligned(U + (size_t)erow * 20 + C0 * 4, 16));
-#pragma unroll
-  for (int i = 0; i < NC * 2; ++i) { const double2 v = q[i]; r[i >> 1][(i & 1) * 2] = v.x; r[i >> 1][(i & 1) * 2 + 1] = v.y; }
-  if (!valid) {
-#pragma unroll
-    for (int c = 0; c < NC; ++c) { r[c][0] = 1.0; r[c][1] = r[c][2] = r[c][3] = 0.0; }
-  }
-#pragma unroll
-  for (int c = 0; c < NC; ++c) {
-    const double a = r[c][0] - r[c][3];
-    nod[LIDX(tl, 0, C0 + c)] = a - r[c][1] - r[c][2];
-    nod[LIDX(tl, 1, C0 + c)] = a + r[c][1] - r[c][2];
-    nod[LIDX(tl, 2, C0 + c)] = a + 2.0 * r[c][2];
-    nod[LIDX(tl, 3, C0 + c)] = r[c][0] + 3.0 * r[c][3];
-#pragma unroll
-    for (int vx = 0; vx < 4; ++vx) accN[LIDX(tl, vx, C0 + c)] = 0.0;
-  }
-}
-
-// phase 2 of one lane half: components [C0, C0+NC) of tet tl; acc/un are [3][4], rows [0, NC) used
-template <int C0, int NC, bool FUSE_RK, int PROB>
-__device__ __forceinline__ void p1h_tet_half(const DevMesh& m, const Phys& ph, double t, const double* __restrict__ nod,
-                                             const double* __restrict__ accN, int tl, int erow, double vol,
-                                             const double (&ji)[3][3], const double* __restrict__ Un,
-                                             const double* __restrict__ dtp, double rk_a, double rk_b,
-                                             double (&acc)[3][4])
-{
-  const Tables<4>& T = c_tab4;
-  double SV[NCOMP], Fs[NC][3];
-#pragma unroll
-  for (int c = 0; c < NCOMP; ++c)
-    SV[c] = (nod[LIDX(tl, 0, c)] + nod[LIDX(tl, 1, c)]) + (nod[LIDX(tl, 2, c)] + nod[LIDX(tl, 3, c)]);
-#pragma unroll
-  for (int c = 0; c < NC; ++c) Fs[c][0] = Fs[c][1] = Fs[c][2] = 0.0;
-#pragma unroll
-  for (int ig = 0; ig < 5; ++ig) {
-    double s[NCOMP];
-#pragma unroll
-    for (int c = 0; c < NCOMP; ++c)
-      s[c] = (ig == 0) ? 0.25 * SV[c] : fma(1.0 / 3.0, nod[LIDX(tl, (ig + 3) & 3, c)], SV[c] * (1.0 / 6.0));
-    const double ir = fast_rcp(s[0]);
-    const double uu = s[1] * ir, vv = s[2] * ir, ww = s[3] * ir;
-    const double p = eos_pressure(ph, s[0], uu, vv, ww, s[4]);
-    const double wg = T.vw[ig];
-    const double h = s[4] + p;
-    const double F[NCOMP][3] = { { s[1], s[2], s[3] },
-                                 { s[1] * uu + p, s[2] * uu, s[3] * uu },
-                                 { s[1] * vv, s[2] * vv + p, s[3] * vv },
-                                 { s[1] * ww, s[2] * ww, s[3] * ww + p },
-                                 { uu * h, vv * h, ww * h } };
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      Fs[c][0] += wg * F[C0 + c][0]; Fs[c][1] += wg * F[C0 + c][1]; Fs[c][2] += wg * F[C0 + c][2];
-    }
-  }
-  // the own part of the Un row is requested here (its registers are not live through the flux loop)
-  [[maybe_unused]] double un[NC][4];
-  if constexpr (FUSE_RK) {
-    const double2* q = reinterpret_cast<const double2*>(__builtin_assume_aligned(Un + (size_t)erow * 20 + C0 * 4, 16));
-#pragma unroll
-    for (int i = 0; i < NC * 2; ++i) { const double2 v = q[i]; un[i >> 1][(i & 1) * 2] = v.x; un[i >> 1][(i & 1) * 2 + 1] = v.y; }
-  }
-  // face sums of the own components in modal form, + vol * F_c . grad B_k
-#pragma unroll
-  for (int c = 0; c < NC; ++c) {
-    const double n0 = accN[LIDX(tl, 0, C0 + c)], n1 = accN[LIDX(tl, 1, C0 + c)], n2 = accN[LIDX(tl, 2, C0 + c)],
-                 n3 = accN[LIDX(tl, 3, C0 + c)];
-    acc[c][0] = (n0 + n1) + (n2 + n3);
-    acc[c][1] = n1 - n0;
-    acc[c][2] = 2.0 * n2 - n0 - n1;
-    acc[c][3] = 3.0 * n3 - n0 - n1 - n2;
-  }
-#pragma unroll
-  for (int k = 1; k < 4; ++k) {
-    const double g0 = T.vdB[0][0][k], g1 = T.vdB[0][1][k], g2 = T.vdB[0][2][k];
-    const double dx = vol * (g0 * ji[0][0] + g1 * ji[1][0] + g2 * ji[2][0]);
-    const double dy = vol * (g0 * ji[0][1] + g1 * ji[1][1] + g2 * ji[2][1]);
-    const double dz = vol * (g0 * ji[0][2] + g1 * ji[1][2] + g2 * ji[2][2]);
-#pragma unroll
-    for (int c = 0; c < NC; ++c) acc[c][k] += Fs[c][0] * dx + Fs[c][1] * dy + Fs[c][2] * dz;
-  }
-  if constexpr (prob_has_source<PROB>()) {
-    ElemGeom gs;                         // the node coordinates again (cache hits)
-    load_geom(m, erow, gs);
-#pragma unroll 1
-    for (int ig = 0; ig < 5; ++ig) {
-      const double xi = T.vc[ig][0], eta = T.vc[ig][1], zeta = T.vc[ig][2];
-      const double w0 = 1.0 - xi - eta - zeta;
-      double P[3], sr[NCOMP];
-#pragma unroll
-      for (int d = 0; d < 3; ++d)
-        P[d] = gs.p[0][d] * w0 + gs.p[1][d] * xi + gs.p[2][d] * eta + gs.p[3][d] * zeta;
-      prob_src<PROB>(ph, P[0], P[1], P[2], t, sr);
-      const double wt = T.vw[ig] * vol;
-#pragma unroll
-      for (int c = 0; c < NC; ++c) {
-        const double ws = wt * sr[C0 + c];
-        acc[c][0] += ws;
-#pragma unroll
-        for (int k = 1; k < 4; ++k) acc[c][k] += ws * T.vB[ig][k];
-      }
-    }
-  }
-  if constexpr (FUSE_RK) {
-    // Uout = a*Un + b*(U + dt*R/L); the modal U rebuilt from the vertex states (exact to rounding)
-    constexpr double imf[4] = { 1.0, 10.0, 10.0 / 3.0, 5.0 / 3.0 };
-    const double dtv = dtp[0] / vol;
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const double v0 = nod[LIDX(tl, 0, C0 + c)], v1 = nod[LIDX(tl, 1, C0 + c)], v2 = nod[LIDX(tl, 2, C0 + c)],
-                   v3 = nod[LIDX(tl, 3, C0 + c)];
-      const double u[4] = { 0.25 * ((v0 + v1) + (v2 + v3)), 0.5 * (v1 - v0), (2.0 * v2 - v0 - v1) * (1.0 / 6.0),
-                            (3.0 * v3 - v0 - v1 - v2) * (1.0 / 12.0) };
-#pragma unroll
-      for (int k = 0; k < 4; ++k) acc[c][k] = rk_a * un[c][k] + rk_b * (u[k] + dtv * imf[k] * acc[c][k]);
-    }
-  }
-}
-
-constexpr int WIDE_BS = 512;
-template <bool WITH_DT, bool FUSE_RK, int PROB>
-__global__ __launch_bounds__(WIDE_BS, 4) void k_rhs_p1h(DevMesh m, Phys ph, double t,
-                                                        const double* __restrict__ U,
-                                                        double* __restrict__ R,
-                                                        double* __restrict__ blockmin,
-                                                        double rk_a, double rk_b,
-                                                        const double* __restrict__ dtp,
-                                                        const double* __restrict__ Un)
-{
-  constexpr int NPROP = NCOMP * 4, BS = WIDE_BS;
-  static_assert(TILE <= 256 && 4 * TILE_BS == 2 * BS, "two lanes per tet, two rounds over the 4 x 256 padded task slots");
-  __shared__ __attribute__((aligned(16))) double nod[TILE * NPROP];
-  __shared__ double accN[TILE * NPROP];
-  __shared__ double sdelt[WITH_DT ? TILE : 1];
-  const int tid = threadIdx.x;
-  const int h = tid >> 8, tl = tid & 255;            // lane half (wave-uniform), local tet
-  const int tile = m.blk0 + xcd_tile(blockIdx.x, gridDim.x);
-  const int tile_e0 = tile * TILE;
-  const int nloc = (m.nie - tile_e0 < TILE) ? m.nie - tile_e0 : TILE;
-  const bool valid = tl < nloc;
-  const int erow = tile_e0 + (valid ? tl : 0);
-  const int slot0 = tile * (4 * TILE_BS) + tid;          // < 2^31: the padded task lists of <= 2 M tiles
-
-  // kernel entry: the own part of the row, the task words of both rounds, round 0's face record
-  int ta[2];
-  ta[0] = m.task_a[slot0]; ta[1] = m.task_a[slot0 + BS];
-  double g4[4];
-  load_row<4>(m.tgeo, slot0, g4);
-  if (tl < TILE) {
-    if (h == 0) p1h_rows_to_lds<0, 3>(U, erow, valid, tl, nod, accN);
-    else p1h_rows_to_lds<3, 2>(U, erow, valid, tl, nod, accN);
-    if (WITH_DT && h == 0) sdelt[tl] = 0.0;
-  }
-  __syncthreads();
-
-  // ---- phase 1: one lane per face task, two rounds ---------------------------------
-#pragma unroll 1
-  for (int q = 0; q < 2; ++q) {
-    const int a = (q == 0) ? ta[0] : ta[1];
-    if (a < 0) break;
-    if (q == 1) load_row<4>(m.tgeo, slot0 + BS, g4);
-    face_task_lean<WITH_DT, PROB, false>(m, ph, t, U, nod, accN, sdelt, a, m.task_nb + slot0 + BS * q, tile_e0, g4);
-  }
-
-  // phase-2 inputs: node ids -> coordinates -> inverse Jacobian before the barrier (9 values cross it)
-  double ji[3][3];
-  double vol = 1.0;
-  if (valid) {
-    ElemGeom g;
-    int in4[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) in4[i] = m.inpoel[(size_t)i * m.stride + erow];
-    vol = m.vol[erow];
-    double q4[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      load_row<4>(m.xyz4, in4[i], q4);
-      g.p[i][0] = q4[0]; g.p[i][1] = q4[1]; g.p[i][2] = q4[2];
-    }
-    inverse_jacobian(g, ji);
-  }
-  __syncthreads();
-
-  // ---- phase 2: two lanes per tet, split by component ---------------------------------
-  double dte = DBL_MAX;
-  double acc[3][4];
-  if (valid) {
-    if (h == 0) p1h_tet_half<0, 3, FUSE_RK, PROB>(m, ph, t, nod, accN, tl, erow, vol, ji, Un, dtp, rk_a, rk_b, acc);
-    else p1h_tet_half<3, 2, FUSE_RK, PROB>(m, ph, t, nod, accN, tl, erow, vol, ji, Un, dtp, rk_a, rk_b, acc);
-    if (WITH_DT && h == 0) dte = vol / sdelt[tl];
-  }
-  // rows out through LDS (row-major over the vertex states), as coalesced wave stores
-  __syncthreads();
-  if (valid) {
-    double2* row = reinterpret_cast<double2*>(nod + (size_t)tl * NPROP + (h == 0 ? 0 : 12));
-#pragma unroll
-    for (int j = 0; j < 4; ++j) row[j] = make_double2((&acc[0][0])[2 * j], (&acc[0][0])[2 * j + 1]);
-    if (h == 0) {
-#pragma unroll
-      for (int j = 4; j < 6; ++j) row[j] = make_double2((&acc[0][0])[2 * j], (&acc[0][0])[2 * j + 1]);
-    }
-  }
-  __syncthreads();
-  {
-    const double2* src = reinterpret_cast<const double2*>(nod);
-    double2* dst = reinterpret_cast<double2*>(R + (size_t)tile_e0 * NPROP);
-    const int nvalid = nloc * (NPROP / 2);
-#pragma unroll
-    for (int j = 0; j < (TILE * NPROP / 2 + BS - 1) / BS; ++j) {
-      const int i = j * BS + tid;
-      if (i < nvalid) dst[i] = src[i];
-    }
-  }
-
-  if (WITH_DT) {
-    for (int off = 32; off > 0; off >>= 1) dte = fmin(dte, __shfl_down(dte, off, 64));
-    __shared__ double wmin[BS / 64];
-    const int lane = tid & 63, wv = tid >> 6;
-    if (lane == 0) wmin[wv] = dte;
-    __syncthreads();
-    if (tid == 0) {
-      double mn = wmin[0];
-      for (int w = 1; w < BS / 64; ++w) mn = fmin(mn, wmin[w]);
       blockmin[tile] = mn;
     }
   }
@@ -1372,13 +1086,7 @@ void launch_rhs_p1t(const DevMesh& m0, const Phys& ph, double t, const double* U
   DevMesh m = m0;
   m.blk0 = first;
   const int nb = count < 0 ? m.ntile - first : count;
-  if (nb > 0 && !m.ndofel && m.p1_wide) {
-    if (with_dt) {
-      QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1h<true, false, P><<<nb, WIDE_BS, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr)));
-    } else {
-      QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1h<false, false, P><<<nb, WIDE_BS, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr)));
-    }
-  } else if (nb > 0 && !m.ndofel) {
+  if (nb > 0 && !m.ndofel) {
     if (with_dt) {
       QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1w<true, false, P><<<nb, TILE_BS, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr)));
     } else {
@@ -1404,10 +1112,6 @@ void launch_rhs_p1t_rk(const DevMesh& m0, const Phys& ph, double t, const double
   m.blk0 = first;
   const int nb = count < 0 ? m.ntile - first : count;
   if (nb <= 0) return;
-  if (!m.ndofel && m.p1_wide) {
-    QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1h<false, true, P><<<nb, WIDE_BS, 0, s>>>(m, ph, t, U, Uout, nullptr, a, b, dt, Un)));
-    return;
-  }
   if (!m.ndofel) {
     QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1w<false, true, P><<<nb, TILE_BS, 0, s>>>(m, ph, t, U, Uout, nullptr, a, b, dt, Un)));
     return;

@@ -284,18 +284,6 @@ def test_element_centric_rhs_kernel_passes_the_same_golden_runs(cases, monkeypat
     test_time_stepping_matches_reference_golden("vortical_flow_dgp1_lf", cases)
 
 
-def test_wide_tile_kernel_passes_the_same_golden_runs(cases, monkeypatch):
-    """Option p1_wide = 1 selects the 512-lane form of the DG-P1 tile kernel (two lanes per tet,
-    split by component; 4 waves per SIMD): same golden runs and operator checks as the default."""
-    from quinoa_amd import capi
-    monkeypatch.setattr(capi, "default_options", {"p1_wide": 1})
-    test_time_stepping_matches_reference_golden("sedov_dgp1", cases)
-    test_operators_match_oracle("sedov_dgp1", cases)
-    test_time_stepping_matches_reference_golden("vortical_flow_dgp1", cases)
-    test_operators_match_oracle("vortical_flow_dgp1", cases)
-    test_time_stepping_matches_reference_golden("vortical_flow_dgp1_lf", cases)
-
-
 def test_element_centric_rhs_kernel_is_bitwise_reproducible(cases):
     """two runs of the same steps with p1_rhs = 1 give identical bits"""
     from quinoa_amd import capi, dgmesh, meshgen
@@ -534,16 +522,15 @@ def test_p1_rhs_kernel_forms_agree():
         U0 = mesh.initialize(0.0)
         U0 = U0 + 1e-3 * rng.normal(size=U0.shape)
         out = {}
-        for tag, v, w in (("tile", 0, 0), ("element", 1, 0), ("wide", 0, 1)):
+        for tag, v in (("tile", 0), ("element", 1)):
             ctx.set_option("p1_rhs", v)
-            ctx.set_option("p1_wide", w)
             R = mesh.rhs(0.0, U0)
             mesh.state_upload(U0)
             t = 0.0
             for _ in range(3):
                 t += mesh.step(t)
             out[tag] = (R, mesh.state_download(), t)
-        for tag in ("element", "wide"):
+        for tag in ("element",):
             assert np.abs(out[tag][0] - out["tile"][0]).max() <= 1e-12 * max(1.0, np.abs(out["tile"][0]).max()), tag
             assert np.abs(out[tag][1] - out["tile"][1]).max() <= 1e-12 * max(1.0, np.abs(out["tile"][1]).max()), tag
             assert abs(out[tag][2] - out["tile"][2]) <= 1e-14 * out["tile"][2], tag

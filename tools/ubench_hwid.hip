@@ -13,10 +13,10 @@
 __global__ __launch_bounds__(256, 2) void k(unsigned* hw, unsigned long long* tm, int spin)
 {
   __shared__ double big[79360 / 8];
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();   // first instruction of the wave
   const int tid = threadIdx.x;
   big[tid] = tid;
   __syncthreads();
-  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
   double x = big[(tid * 7) & 255];
   for (int i = 0; i < spin; ++i) x = fma(x, 1.0000001, 1e-9);
   big[tid] = x;
@@ -24,8 +24,9 @@ __global__ __launch_bounds__(256, 2) void k(unsigned* hw, unsigned long long* tm
   const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
   if ((tid & 63) == 0) {
     const unsigned id = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID, all 32 bits
+    const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11));  // HW_REG_XCC_ID[3:0]
     const int w = blockIdx.x * 4 + (tid >> 6);
-    hw[w] = id;
+    hw[w] = (id & 0x0fffffffu) | (xcc << 28);
     tm[2 * w] = t0;
     tm[2 * w + 1] = t1 + (unsigned long long)(big[0] * 1e-300);
   }
@@ -76,7 +77,7 @@ int main()
   for (int b = 0; b < nb; ++b) {
     const unsigned id = hw[b * 4];
     // xcc id is not in HW_ID on gfx9; use (SE, SH, CU) + XCC_ID register is separate -- group by time overlap only within equal (se,sh,cu)
-    ws[b] = { (id >> 8) & 0xff, tm[8 * b], tm[8 * b + 1], (int)((id >> 4) & 3), (int)((id >> 16) & 15) };
+    ws[b] = { ((id >> 8) & 0xff) | ((id >> 28) << 8), tm[8 * b], tm[8 * b + 1], (int)((id >> 4) & 3), (int)((id >> 16) & 15) };
   }
   long long pairs = 0, same_s0 = 0, same_tgpar = 0;
   for (int a = 0; a < nb; ++a)
@@ -86,7 +87,22 @@ int main()
         if (ws[a].s0 == ws[b].s0) ++same_s0;
         if ((ws[a].tg & 1) == (ws[b].tg & 1)) ++same_tgpar;
       }
-  printf("time-overlapping pairs with equal (SE,SH,CU) bits (8 XCDs alias): %lld; wave 0 on the same SIMD: %lld; same TG_ID parity: %lld\n",
+  printf("time-overlapping pairs on one (XCC,SE,SH,CU): %lld; wave 0 on the same SIMD: %lld; same TG_ID parity: %lld\n",
          pairs, same_s0, same_tgpar);
+  // dispatch gap: on one (XCC, SE, SH, CU, workgroup slot), the time from the end of a workgroup (after its last
+  // barrier) to the first instruction of the next one; s_memrealtime ticks at 100 MHz
+  std::map<unsigned, std::vector<std::pair<unsigned long long, unsigned long long>>> slots;
+  for (int b = 0; b < nb; ++b) slots[(ws[b].cu << 4) | (unsigned)ws[b].tg].push_back({ ws[b].t0, ws[b].t1 });
+  std::vector<double> gaps, durs;
+  for (auto& kv : slots) {
+    auto& v = kv.second;
+    std::sort(v.begin(), v.end());
+    for (size_t i = 0; i + 1 < v.size(); ++i) gaps.push_back((double)((long long)v[i + 1].first - (long long)v[i].second) * 0.01);
+    for (auto& p : v) durs.push_back((double)(p.second - p.first) * 0.01);
+  }
+  std::sort(gaps.begin(), gaps.end()); std::sort(durs.begin(), durs.end());
+  if (!gaps.empty())
+    printf("slots %zu; workgroup duration median %.2f us; gap end -> next start on the same slot: min %.2f median %.2f p90 %.2f max %.2f us (%zu gaps)\n",
+           slots.size(), durs[durs.size() / 2], gaps.front(), gaps[gaps.size() / 2], gaps[gaps.size() * 9 / 10], gaps.back(), gaps.size());
   return 0;
 }
