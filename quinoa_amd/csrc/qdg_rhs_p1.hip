@@ -1050,266 +1050,6 @@ __global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1w(DevMesh m, Phys ph, doub
   }
 }
 
-// ------------------------------------------- DG-P1 RHS, tile / face-task form, the update folded into the accumulators
-// k_rhs_p1w with every global load at kernel entry and none in phase 2:
-//  * fused-RK launches (dt known): the tet's Un row is read WITH its U row in phase 0 and the whole
-//    linear part of the update goes into the accumulators as their INITIAL value -- with
-//    f_k = b dt imf_k / vol the new state is f_k (W_k + R_k), W_k = (a Un_k + b U_k) / f_k, so the
-//    per-vertex accumulators start at the nodal image of W instead of zero (the face sums reach them
-//    through the same ds_add_f64, the volume term is added in phase 2) and phase 2 multiplies by
-//    f_k.  Neither row is held across the face rounds (-40 registers) and phase 2 loads no row.
-//  * the node coordinates are gathered in phase 0 too and cross the face rounds as the inverse
-//    Jacobian (9 values) -- except for the problems with a source term, which need the points.
-// dt == 0 (nothing to divide by) takes the plain path: rows read in phase 2.
-template <int PROB>
-__device__ __forceinline__ void tet_volume_ji(const Phys& ph, double t, const double* __restrict__ nod, int tl,
-                                              double vol, const double (&ji)[3][3], const ElemGeom* gs,
-                                              double (&acc)[NCOMP][4])
-{
-  constexpr int NDOF = 4;
-  const Tables<4>& T = c_tab4;
-  double SV[NCOMP], Fs[NCOMP][3];
-#pragma unroll
-  for (int c = 0; c < NCOMP; ++c) {
-    SV[c] = (nod[LIDX(tl, 0, c)] + nod[LIDX(tl, 1, c)]) + (nod[LIDX(tl, 2, c)] + nod[LIDX(tl, 3, c)]);
-    Fs[c][0] = Fs[c][1] = Fs[c][2] = 0.0;
-  }
-#pragma unroll
-  for (int ig = 0; ig < 5; ++ig) {
-    double s[NCOMP];
-#pragma unroll
-    for (int c = 0; c < NCOMP; ++c)
-      s[c] = (ig == 0) ? 0.25 * SV[c] : fma(1.0 / 3.0, nod[LIDX(tl, (ig + 3) & 3, c)], SV[c] * (1.0 / 6.0));
-    const double ir = fast_rcp(s[0]);
-    const double uu = s[1] * ir, vv = s[2] * ir, ww = s[3] * ir;
-    const double p = eos_pressure(ph, s[0], uu, vv, ww, s[4]);
-    const double wg = T.vw[ig];
-    const double h = s[4] + p;
-    Fs[0][0] += wg * s[1];            Fs[0][1] += wg * s[2];            Fs[0][2] += wg * s[3];
-    Fs[1][0] += wg * (s[1] * uu + p); Fs[1][1] += wg * (s[2] * uu);     Fs[1][2] += wg * (s[3] * uu);
-    Fs[2][0] += wg * (s[1] * vv);     Fs[2][1] += wg * (s[2] * vv + p); Fs[2][2] += wg * (s[3] * vv);
-    Fs[3][0] += wg * (s[1] * ww);     Fs[3][1] += wg * (s[2] * ww);     Fs[3][2] += wg * (s[3] * ww + p);
-    Fs[4][0] += wg * (uu * h);        Fs[4][1] += wg * (vv * h);        Fs[4][2] += wg * (ww * h);
-  }
-#pragma unroll
-  for (int k = 1; k < NDOF; ++k) {
-    const double g0 = T.vdB[0][0][k], g1 = T.vdB[0][1][k], g2 = T.vdB[0][2][k];
-    const double dx = vol * (g0 * ji[0][0] + g1 * ji[1][0] + g2 * ji[2][0]);
-    const double dy = vol * (g0 * ji[0][1] + g1 * ji[1][1] + g2 * ji[2][1]);
-    const double dz = vol * (g0 * ji[0][2] + g1 * ji[1][2] + g2 * ji[2][2]);
-#pragma unroll
-    for (int c = 0; c < NCOMP; ++c) acc[c][k] += Fs[c][0] * dx + Fs[c][1] * dy + Fs[c][2] * dz;
-  }
-  if constexpr (prob_has_source<PROB>()) {
-    const ElemGeom& g = *gs;
-#pragma unroll 1
-    for (int ig = 0; ig < 5; ++ig) {
-      const double xi = T.vc[ig][0], eta = T.vc[ig][1], zeta = T.vc[ig][2];
-      const double w0 = 1.0 - xi - eta - zeta;
-      double P[3], sr[NCOMP];
-#pragma unroll
-      for (int d = 0; d < 3; ++d)
-        P[d] = g.p[0][d] * w0 + g.p[1][d] * xi + g.p[2][d] * eta + g.p[3][d] * zeta;
-      prob_src<PROB>(ph, P[0], P[1], P[2], t, sr);
-      const double wt = T.vw[ig] * vol;
-#pragma unroll
-      for (int c = 0; c < NCOMP; ++c) {
-        const double ws = wt * sr[c];
-        acc[c][0] += ws;
-#pragma unroll
-        for (int k = 1; k < NDOF; ++k) acc[c][k] += ws * T.vB[ig][k];
-      }
-    }
-  }
-}
-
-template <bool WITH_DT, bool FUSE_RK, int PROB>
-__global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1f(DevMesh m, Phys ph, double t,
-                                                        const double* __restrict__ U,
-                                                        double* __restrict__ R,
-                                                        double* __restrict__ blockmin,
-                                                        double rk_a, double rk_b,
-                                                        const double* __restrict__ dtp,
-                                                        const double* __restrict__ Un)
-{
-  constexpr int NDOF = 4, NPROP = NCOMP * NDOF, BS = TILE_BS;
-  constexpr int NR = 4;
-  constexpr bool SRC = prob_has_source<PROB>();
-  __shared__ __attribute__((aligned(16))) double nod[TILE * NPROP];
-  __shared__ double accN[TILE * NPROP];
-  __shared__ double sdelt[WITH_DT ? TILE : 1];
-  const int tid = threadIdx.x;
-  const int tile = m.blk0 + xcd_tile(blockIdx.x, gridDim.x);
-  const int tile_e0 = tile * TILE;
-  const int nloc = (m.nie - tile_e0 < TILE) ? m.nie - tile_e0 : TILE;
-  double dt = 0.0;
-  if constexpr (FUSE_RK) dt = dtp[0];
-  const bool fold = FUSE_RK && dt != 0.0;             // uniform
-
-  // kernel entry: every global load of the tile, the node ids first (the coordinates hang on them)
-  const size_t slot0 = (size_t)tile * (4 * TILE_BS) + tid;
-  const int erow = tile_e0 + ((tid < nloc) ? tid : 0);
-  int in4[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) in4[i] = m.inpoel[(size_t)i * m.stride + erow];
-  const double vol = m.vol[erow];
-  double r[NCOMP][NDOF];
-  load_row<NPROP>(U, erow, &r[0][0]);
-  [[maybe_unused]] double un[NCOMP][NDOF];
-  if constexpr (FUSE_RK) {
-    if (fold) load_row<NPROP>(Un, erow, &un[0][0]);
-  }
-  int ta[NR];
-#pragma unroll
-  for (int q = 0; q < NR; ++q) ta[q] = m.task_a[slot0 + BS * q];
-  double gnx[4];
-  load_row<4>(m.tgeo, slot0, gnx);
-  [[maybe_unused]] double ji[3][3];
-  if constexpr (!SRC) {
-    ElemGeom g;
-    double q[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      load_row<4>(m.xyz4, in4[i], q);
-      g.p[i][0] = q[0]; g.p[i][1] = q[1]; g.p[i][2] = q[2];
-    }
-    inverse_jacobian(g, ji);
-  }
-  const double fk = rk_b * dt / vol;                  // f_k = fk * imf_k
-
-  // ---- phase 0: modal row -> the 4 vertex states; accumulators = nodal image of W (or 0) ------
-  if (tid < TILE) {
-    if (tid >= nloc) {
-#pragma unroll
-      for (int c = 0; c < NCOMP; ++c) { r[c][0] = 1.0; r[c][1] = r[c][2] = r[c][3] = 0.0; }
-    }
-#pragma unroll
-    for (int c = 0; c < NCOMP; ++c) {
-      const double a = r[c][0] - r[c][3];
-      nod[LIDX(tid, 0, c)] = a - r[c][1] - r[c][2];
-      nod[LIDX(tid, 1, c)] = a + r[c][1] - r[c][2];
-      nod[LIDX(tid, 2, c)] = a + 2.0 * r[c][2];
-      nod[LIDX(tid, 3, c)] = r[c][0] + 3.0 * r[c][3];
-    }
-    if (fold) {
-      if constexpr (FUSE_RK) {
-        // W_k = (a Un_k + b U_k) / (fk imf_k); nodal image n: n0+n1+n2+n3 = W0, n1-n0 = W1,
-        // 2 n2 - n0 - n1 = W2, 3 n3 - n0 - n1 - n2 = W3 (the inverse of tet_face_sums)
-        const double ifk = 1.0 / fk;
-#pragma unroll
-        for (int c = 0; c < NCOMP; ++c) {
-          const double m0 = (rk_a * un[c][0] + rk_b * r[c][0]) * ifk;
-          const double m1 = (rk_a * un[c][1] + rk_b * r[c][1]) * (ifk * 0.1);
-          const double m2 = (rk_a * un[c][2] + rk_b * r[c][2]) * (ifk * 0.3);
-          const double m3 = (rk_a * un[c][3] + rk_b * r[c][3]) * (ifk * 0.6);
-          const double q = 0.25 * (3.0 * m0 - m3);
-          const double n3 = 0.25 * (m0 + m3);
-          const double n2 = (m2 + q) * (1.0 / 3.0);
-          const double s01 = q - n2;
-          accN[LIDX(tid, 0, c)] = 0.5 * (s01 - m1);
-          accN[LIDX(tid, 1, c)] = 0.5 * (s01 + m1);
-          accN[LIDX(tid, 2, c)] = n2;
-          accN[LIDX(tid, 3, c)] = n3;
-        }
-      }
-    } else {
-#pragma unroll
-      for (int c = 0; c < NCOMP; ++c)
-#pragma unroll
-        for (int vx = 0; vx < 4; ++vx) accN[LIDX(tid, vx, c)] = 0.0;
-    }
-    if (WITH_DT) sdelt[tid] = 0.0;
-  }
-  __syncthreads();
-
-  // ---- phase 1: one lane per face task ------------------------------------------
-#pragma unroll 1
-  for (int q = 0; q < NR; ++q) {
-    const int a = (q == 0) ? ta[0] : (q == 1) ? ta[1] : (q == 2) ? ta[2] : ta[3];
-    if (a < 0) break;
-    const double g4[4] = { gnx[0], gnx[1], gnx[2], gnx[3] };
-    const int an_ = (q == 0) ? ta[1] : (q == 1) ? ta[2] : (q == 2) ? ta[3] : -1;
-    if (an_ >= 0) load_row<4>(m.tgeo, slot0 + (size_t)BS * (q + 1), gnx);    // the next round's face record
-    face_task_lean<WITH_DT, PROB>(m, ph, t, U, nod, accN, sdelt, a, m.task_nb + slot0 + (size_t)BS * q, tile_e0, g4);
-  }
-
-  // phase-2 inputs of the paths that still have some (source problems: the points; dt == 0: the rows)
-  [[maybe_unused]] ElemGeom gs;
-  if constexpr (SRC) {
-    if (tid < nloc) {
-      double q[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        load_row<4>(m.xyz4, in4[i], q);
-        gs.p[i][0] = q[0]; gs.p[i][1] = q[1]; gs.p[i][2] = q[2];
-      }
-      inverse_jacobian(gs, ji);
-    }
-  }
-  __syncthreads();
-
-  // ---- phase 2: one lane per tet: face sums (+ W), volume (+source) term, scale, store --------
-  double dte = DBL_MAX;
-  double acc[NCOMP][NDOF];
-  if (tid < nloc) {
-    tet_face_sums(accN, tid, acc);
-    tet_volume_ji<PROB>(ph, t, nod, tid, vol, ji, SRC ? &gs : nullptr, acc);
-    if constexpr (FUSE_RK) {
-      constexpr double imf[4] = { 1.0, 10.0, 10.0 / 3.0, 5.0 / 3.0 };
-      if (fold) {
-#pragma unroll
-        for (int c = 0; c < NCOMP; ++c)
-#pragma unroll
-          for (int k = 0; k < NDOF; ++k) acc[c][k] *= fk * imf[k];
-      } else {
-        // dt == 0: Uout = a Un + b U, rows read here
-        double u2[NCOMP][NDOF], un2[NCOMP][NDOF];
-        load_row<NPROP>(U, tile_e0 + tid, &u2[0][0]);
-        load_row<NPROP>(Un, tile_e0 + tid, &un2[0][0]);
-#pragma unroll
-        for (int c = 0; c < NCOMP; ++c)
-#pragma unroll
-          for (int k = 0; k < NDOF; ++k) acc[c][k] = rk_a * un2[c][k] + rk_b * u2[c][k];
-      }
-    }
-    if (WITH_DT) dte = vol / sdelt[tid];
-  }
-  __syncthreads();
-  if (tid < nloc) {
-    double2* row = reinterpret_cast<double2*>(nod + (size_t)tid * NPROP);
-#pragma unroll
-    for (int j = 0; j < NPROP / 2; ++j) row[j] = make_double2((&acc[0][0])[2 * j], (&acc[0][0])[2 * j + 1]);
-  }
-  __syncthreads();
-  {
-    const double2* src = reinterpret_cast<const double2*>(nod);
-    double2* dst = reinterpret_cast<double2*>(R + (size_t)tile_e0 * NPROP);
-    const int nvalid = nloc * (NPROP / 2);
-#pragma unroll
-    for (int j = 0; j < NPROP / 2; ++j) {
-      const int i = j * BS + tid;
-      if (i < nvalid) dst[i] = src[i];
-    }
-  }
-
-  if (WITH_DT) {
-    for (int off = 32; off > 0; off >>= 1) dte = fmin(dte, __shfl_down(dte, off, 64));
-    __shared__ double wmin[(BS + 63) / 64];
-    const int lane = tid & 63, wv = tid >> 6;
-    if (lane == 0) wmin[wv] = dte;
-    __syncthreads();
-    if (tid == 0) {
-      double mn = wmin[0];
-      for (int w = 1; w < (BS + 63) / 64; ++w) mn = fmin(mn, wmin[w]);
-      blockmin[tile] = mn;
-    }
-  }
-}
-
-#if defined(QDG_X_FOLD)
-#define k_rhs_p1w k_rhs_p1f
-#endif
-
 // ================================================================ launchers
 
 
