@@ -78,17 +78,20 @@ enum { QDG_PROBLEM_USER_DEFINED = 0, QDG_PROBLEM_SOD_SHOCKTUBE = 1,
        /* more Transport policies (CylAdvect.cpp:28-129, GaussHump.cpp:28-125) */
        QDG_PROBLEM_CYL_ADVECT = 8, QDG_PROBLEM_GAUSS_HUMP = 9,
        /* CompFlow RayleighTaylor.cpp:28-175 (alpha, betax/y/z, p0, r0, kappa) */
-       QDG_PROBLEM_RAYLEIGH_TAYLOR = 10 };
+       QDG_PROBLEM_RAYLEIGH_TAYLOR = 10,
+       /* dg::Transport: TransportProblemShearDiff (src/PDE/Transport/Problem/ShearDiff.cpp:28-160) */
+       QDG_PROBLEM_SHEAR_DIFF = 11 };
+#define QDG_MAX_SCALARS 5   /* transported scalars of one dg::Transport system (diagnostics: 5 slots per kind) */
 /* BC state functions (src/PDE/CompFlow/DGCompFlow.hpp:649-701) */
 enum { QDG_BC_DIRICHLET = 1, QDG_BC_SYMMETRY = 2, QDG_BC_EXTRAPOLATE = 3,
        /* Transport only (src/PDE/Transport/DGTransport.hpp:163-168, 276-352) */
        QDG_BC_INLET = 4, QDG_BC_OUTLET = 5 };
 /* which DGPDE: dg::CompFlow (5 conserved variables, DGCompFlow.hpp) or dg::Transport
- * with one transported scalar (DGTransport.hpp:129-186; BASELINE config 1).
- * Transport: flux UPWIND, problems SLOT_CYL / CYL_ADVECT / GAUSS_HUMP, BCs Dirichlet/
+ * with ncomp transported scalars (DGTransport.hpp:78-186; BASELINE config 1 has one).
+ * Transport: flux UPWIND, problems SLOT_CYL / CYL_ADVECT / GAUSS_HUMP / SHEAR_DIFF, BCs Dirichlet/
  * Extrapolate/Inlet/Outlet, constant dt only (dg::Transport::dt returns max,
- * DGTransport.hpp:189-199), limiters and p-adaptive DG as for CompFlow;
- * rows of every field are ndof doubles. */
+ * DGTransport.hpp:189-199), limiters as for CompFlow, p-adaptive DG with one scalar;
+ * rows of every field are ncomp*ndof doubles, component-major (mark = c*rdof). */
 enum { QDG_PDE_COMPFLOW = 0, QDG_PDE_TRANSPORT = 1 };
 
 typedef struct qdg_config {
@@ -111,6 +114,13 @@ typedef struct qdg_config {
                                 Grammar.hpp:399-407): per-element ndof in {1,4} */
   double tolref;             /* pref::tolref (default 0.1, InputDeck.hpp:232) */
   double betax, betay, betaz, r0, ce, kappa;   /* nl_energy_growth parameters (with alpha) */
+  int32_t ncomp;             /* dg::Transport: component::transport, 1..QDG_MAX_SCALARS (0 = 1); CompFlow: 0 or 5 */
+  int32_t reserved0;
+  /* shear_diff parameters per scalar (param::transport::u0 | lambda | diffusivity,
+     ShearDiff.cpp:43-45): u0[ncomp], lambda[2*ncomp], diffusivity[3*ncomp]; null otherwise */
+  const double* tr_u0;
+  const double* tr_lambda;
+  const double* tr_diffusivity;
 } qdg_config;
 
 /* flattened std::map<int, std::vector<std::size_t>> FaceData::m_bface */
@@ -141,7 +151,8 @@ int qdg_ctx_set_option(qdg_ctx* ctx, const char* name, int value);
 int qdg_ctx_get_option(qdg_ctx* ctx, const char* name, int* value);
 /* Problem::solution at n points (DGPDE::analyticSolution, src/PDE/DGPDE.hpp:141-144;
  * also the Dirichlet state and the initial condition): out[i*ncomp + c], ncomp = 5
- * (CompFlow) or 1 (Transport); evaluated by the device functors of the context's problem */
+ * (CompFlow) or the number of scalars (Transport); evaluated by the device functors of the
+ * context's problem */
 int qdg_solution(qdg_ctx* ctx, size_t n, const double* x, const double* y, const double* z,
                  double t, double* out);
 

@@ -173,6 +173,10 @@ struct InputDeck {
   std::vector<std::string> bcinlet, bcoutlet;              // transport only (DGTransport.hpp:163-168)
   bool pref = false;                         // pref::pref (scheme pdg)
   real tolref = 0.1;                         // pref::tolref
+  // dg::Transport: component::transport (number of scalars of the system, DGTransport.hpp:84-85) and
+  // the shear_diff parameters param::transport::u0 | lambda | diffusivity (ShearDiff.cpp:43-45)
+  std::size_t ncomp = 1;
+  std::vector<real> u0, lambda, diffusivity;
   int device = 0;
 };
 
@@ -194,6 +198,7 @@ struct Advection { };
 struct SlotCyl        { static int type() noexcept { return QDG_PROBLEM_SLOT_CYL; } };
 struct CylAdvect      { static int type() noexcept { return QDG_PROBLEM_CYL_ADVECT; } };
 struct GaussHump      { static int type() noexcept { return QDG_PROBLEM_GAUSS_HUMP; } };
+struct ShearDiff      { static int type() noexcept { return QDG_PROBLEM_SHEAR_DIFF; } };
 
 namespace detail {
 
@@ -228,6 +233,16 @@ class DeviceDG {
     cfg.alpha = deck.alpha; cfg.beta = deck.beta; cfg.p0 = deck.p0; cfg.cfl = deck.cfl; cfg.dt = deck.dt;
     cfg.betax = deck.betax; cfg.betay = deck.betay; cfg.betaz = deck.betaz;
     cfg.r0 = deck.r0; cfg.ce = deck.ce; cfg.kappa = deck.kappa;
+    if (PDE == QDG_PDE_TRANSPORT) {
+      cfg.ncomp = (int32_t)deck.ncomp;
+      if (problem == QDG_PROBLEM_SHEAR_DIFF) {
+        // TransportProblemShearDiff::errchk (ShearDiff.cpp:92-113)
+        if (deck.u0.size() != deck.ncomp || deck.lambda.size() != 2 * deck.ncomp ||
+            deck.diffusivity.size() != 3 * deck.ncomp)
+          throw Exception("Wrong number of advection-diffusion PDE parameters u0 / lambda / diffusivity");
+        cfg.tr_u0 = deck.u0.data(); cfg.tr_lambda = deck.lambda.data(); cfg.tr_diffusivity = deck.diffusivity.data();
+      }
+    }
     check(qdg_ctx_create(&cfg, &m_state->ctx));
   }
 
@@ -247,7 +262,7 @@ class DeviceDG {
   //! only; before the chare's mesh is registered it is evaluated on the host.
   void lhs(const Fields& geoElem, Fields& l) const
   {
-    const std::size_t nd = m_deck.ndof, ncomp = PDE == QDG_PDE_TRANSPORT ? 1 : 5;
+    const std::size_t nd = m_deck.ndof, ncomp = PDE == QDG_PDE_TRANSPORT ? m_deck.ncomp : 5;
     for (std::size_t e = 0; e < geoElem.nunk(); ++e)
       for (std::size_t c = 0; c < ncomp; ++c) {
         const real vol = geoElem(e, 0, 0);
@@ -372,7 +387,7 @@ class DeviceDG {
   //! DGPDE::analyticSolution (src/PDE/DGPDE.hpp:141-144): the Problem's solution at a point
   std::vector<real> analyticSolution(real xi, real yi, real zi, real t) const
   {
-    std::vector<real> s(PDE == QDG_PDE_TRANSPORT ? 1 : 5);
+    std::vector<real> s(PDE == QDG_PDE_TRANSPORT ? m_deck.ncomp : 5);
     check(qdg_solution(m_state->ctx, 1, &xi, &yi, &zi, t, s.data()));
     return s;
   }

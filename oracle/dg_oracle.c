@@ -1474,13 +1474,36 @@ double orc_step_pdg(const orc_cfg* k, const orc_bc* bc, double t, double fixed_d
  * Upwind.hpp:35-55) and the Problem's prescribed velocity.
  * ===================================================================== */
 
-enum { ORC_TR_SLOT_CYL = 1, ORC_TR_CYL_ADVECT = 2, ORC_TR_GAUSS_HUMP = 3 };
+enum { ORC_TR_SLOT_CYL = 1, ORC_TR_CYL_ADVECT = 2, ORC_TR_GAUSS_HUMP = 3, ORC_TR_SHEAR_DIFF = 4 };
 enum { TR_BC_EXTRAPOLATE = 0, TR_BC_INLET = 1, TR_BC_OUTLET = 2, TR_BC_DIRICHLET = 3 };
 
-/* TransportProblemSlotCyl::solution, src/PDE/Transport/Problem/SlotCyl.cpp:30-110 (ncomp = 1) */
+/* Several transported scalars (DGTransport.hpp:84-85, m_ncomp): every integrator of the reference
+ * loops `for c < ncomp` over scalars that never couple (Surface.cpp:168-189 with Upwind.hpp:46-52,
+ * Volume.cpp:93-108 with the per-component flux of DGTransport.hpp:354-373, Limiter.cpp:187-312 per
+ * component), so the functions below compute ONE scalar -- component g_tr_c of g_tr_ncomp, selected
+ * with orc_tr_set_component; the driver (oracle.py) runs them per component on that component's
+ * slice of the rows.  The component enters through Problem::solution / prescribedVelocity only. */
+static int g_tr_c = 0, g_tr_ncomp = 1;
+/* shear_diff parameters of the selected component: u0, lambda[2], diffusivity[3] (ShearDiff.cpp:43-45) */
+static double g_sd_u0 = 0.0, g_sd_l[2] = { 0.0, 0.0 }, g_sd_d[3] = { 1.0, 1.0, 1.0 };
+
+void orc_tr_set_component(int c, int ncomp) { g_tr_c = c; g_tr_ncomp = ncomp > 0 ? ncomp : 1; }
+void orc_tr_set_shear_diff(double u0, const double* lambda2, const double* diff3)
+{
+  g_sd_u0 = u0; g_sd_l[0] = lambda2[0]; g_sd_l[1] = lambda2[1];
+  g_sd_d[0] = diff3[0]; g_sd_d[1] = diff3[1]; g_sd_d[2] = diff3[2];
+}
+
+/* TransportProblemSlotCyl::solution, src/PDE/Transport/Problem/SlotCyl.cpp:30-110, component g_tr_c */
 static double tr_solution(int problem, double x, double y, double z, double t)
 {
-  (void)z;
+  if (problem == ORC_TR_SHEAR_DIFF) {       /* ShearDiff.cpp:28-68 */
+    const double* l = g_sd_l; const double* d = g_sd_d;
+    const double phi3s = (l[0] * l[0] * d[1] / d[0] + l[1] * l[1] * d[2] / d[0]) / 12.0;
+    return 1.0 / (8.0 * pow(M_PI, 3.0 / 2.0) * sqrt(d[0] * d[1] * d[2]) * pow(t, 3.0 / 2.0) * sqrt(1.0 + phi3s * t * t)) *
+           exp(-pow(x - g_sd_u0 * t - 0.5 * (l[0] * y + l[1] * z) * t, 2.0) / (4.0 * d[0] * t * (1.0 + phi3s * t * t))
+               - y * y / (4.0 * d[1] * t) - z * z / (4.0 * d[2] * t));
+  }
   if (problem == ORC_TR_CYL_ADVECT) {       /* CylAdvect.cpp:28-60: square wave of radius 0.2 */
     const double x0 = 0.25 + 0.1 * t, y0 = 0.25 + 0.1 * t;
     const double r = sqrt((x - x0) * (x - x0) + (y - y0) * (y - y0));
@@ -1491,7 +1514,7 @@ static double tr_solution(int problem, double x, double y, double z, double t)
     return 1.0 * exp(-((x - x0) * (x - x0) + (y - y0) * (y - y0)) / (2.0 * 0.005));
   }
   {
-    const double T = t;          /* t + 2*pi/ncomp*c with c = 0 */
+    const double T = t + 2.0 * M_PI / g_tr_ncomp * g_tr_c;   /* SlotCyl.cpp:45 */
     const double R0 = 0.15;
     double s = 0.0;
     double x0 = 0.5, y0 = 0.25;
@@ -1531,7 +1554,10 @@ static double tr_solution(int problem, double x, double y, double z, double t)
 /* TransportProblemSlotCyl::prescribedVelocity, SlotCyl.cpp:152-170 */
 static void tr_velocity(int problem, double x, double y, double z, double* v)
 {
-  (void)z;
+  if (problem == ORC_TR_SHEAR_DIFF) {       /* ShearDiff.cpp:140-160 */
+    v[0] = g_sd_u0 + g_sd_l[0] * y + g_sd_l[1] * z; v[1] = 0.0; v[2] = 0.0;
+    return;
+  }
   if (problem == ORC_TR_CYL_ADVECT || problem == ORC_TR_GAUSS_HUMP) {
     v[0] = 0.1; v[1] = 0.1; v[2] = 0.0;    /* CylAdvect.cpp:114-129, GaussHump.cpp:110-125 */
     return;

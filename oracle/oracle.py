@@ -465,7 +465,39 @@ def run_case(case, fix, nstep=None, on_step=None):
 
 
 # ---------------------------------------------------------------- transport
-TR_PROBLEM = {"slot_cyl": 1, "cyl_advect": 2, "gauss_hump": 3}
+TR_PROBLEM = {"slot_cyl": 1, "cyl_advect": 2, "gauss_hump": 3, "shear_diff": 4}
+
+
+def tr_select_component(case, c):
+    """Select scalar c of case["ncomp"] for the orc_tr_* functions (the scalars of a dg::Transport
+    system never couple: DGTransport.hpp:129-186 loops over them inside every integrator), with
+    its shear_diff parameters u0[c], lambda[2c:2c+2], diffusivity[3c:3c+3] (ShearDiff.cpp:43-68)."""
+    L = lib()
+    L.orc_tr_set_component(C.c_int(c), C.c_int(int(case.get("ncomp", 1))))
+    if case.get("problem") == "shear_diff":
+        lam = np.ascontiguousarray(case["lambda"][2 * c:2 * c + 2], dtype=np.float64)
+        dif = np.ascontiguousarray(case["diffusivity"][3 * c:3 * c + 3], dtype=np.float64)
+        L.orc_tr_set_shear_diff(C.c_double(float(case["u0"][c])), _p(lam, c_f64p), _p(dif, c_f64p))
+
+
+def run_transport_multi(case, fix, nstep=None):
+    """dg::Transport with case["ncomp"] scalars: one run_transport_case per scalar (see
+    tr_select_component), rows assembled component-major, U[e, c*ndof + k] (mark = c*rdof).
+    case["t0"]: start time (shear_diff's solution is singular at t = 0)."""
+    nc, ndof = int(case.get("ncomp", 1)), case["ndof"]
+    runs = []
+    try:
+        for c in range(nc):
+            tr_select_component(case, c)
+            runs.append(run_transport_case(case, fix, nstep=nstep, t0=float(case.get("t0", 0.0))))
+    finally:
+        lib().orc_tr_set_component(C.c_int(0), C.c_int(1))
+    ne = runs[0]["mesh"].nelem
+    U = np.zeros((ne, nc * ndof))
+    for c, r in enumerate(runs):
+        U[:, c * ndof:(c + 1) * ndof] = r["U"].reshape(ne, ndof)
+    return {"mesh": runs[0]["mesh"], "U": U.reshape(-1), "t": runs[0]["t"], "runs": runs,
+            "diag": [r["diag"] for r in runs]}
 
 
 def run_transport_case(case, fix, nstep=None, U0=None, t0=0.0, it0=0):
@@ -499,7 +531,8 @@ def run_transport_case(case, fix, nstep=None, U0=None, t0=0.0, it0=0):
     L.orc_tr_mass(C.c_int64(ndof), _p(m.geoElem, c_f64p), C.c_int64(ne), _p(Lm, c_f64p))
     U = np.zeros(ne * ndof)
     L.orc_tr_initialize(prob, C.c_int64(ndof), _p(Lm, c_f64p), _p(inp, c_i64p), _p(m.x, c_f64p),
-                        _p(m.y, c_f64p), _p(m.z, c_f64p), _p(U, c_f64p), C.c_double(0.0), C.c_int64(ne))
+                        _p(m.y, c_f64p), _p(m.z, c_f64p), _p(U, c_f64p),
+                        C.c_double(0.0 if U0 is not None else float(t0)), C.c_int64(ne))
     if U0 is not None:
         U[:] = np.asarray(U0, dtype=np.float64).reshape(-1)
     ndofel = np.full(ne, ndof, dtype=np.int64)

@@ -18,7 +18,7 @@ LIMITER = {"nolimiter": 0, "wenop1": 1, "superbeep1": 2}
 PROBLEM = {"user_defined": 0, "sod_shocktube": 1, "sedov_blastwave": 2,
            "vortical_flow": 3, "taylor_green": 4, "slot_cyl": 5,
            "rotated_sod_shocktube": 6, "nl_energy_growth": 7, "cyl_advect": 8, "gauss_hump": 9,
-           "rayleigh_taylor": 10}
+           "rayleigh_taylor": 10, "shear_diff": 11}
 BC_DIRICHLET, BC_SYMMETRY, BC_EXTRAPOLATE, BC_INLET, BC_OUTLET = 1, 2, 3, 4, 5
 PDE = {"compflow": 0, "transport": 1}
 
@@ -41,7 +41,9 @@ class qdg_config(C.Structure):
                 ("p0", C.c_double), ("cfl", C.c_double), ("dt", C.c_double),
                 ("pde", C.c_int32), ("pref", C.c_int32), ("tolref", C.c_double),
                 ("betax", C.c_double), ("betay", C.c_double), ("betaz", C.c_double),
-                ("r0", C.c_double), ("ce", C.c_double), ("kappa", C.c_double)]
+                ("r0", C.c_double), ("ce", C.c_double), ("kappa", C.c_double),
+                ("ncomp", C.c_int32), ("reserved0", C.c_int32),
+                ("tr_u0", c_f64p), ("tr_lambda", c_f64p), ("tr_diffusivity", c_f64p)]
 
 
 class qdg_bface(C.Structure):
@@ -178,8 +180,19 @@ class Context:
                  gamma=1.4, pstiff=0.0, cv=717.5, cweight=1.0, alpha=0.0, beta=0.0, p0=0.0,
                  cfl=0.0, dt=0.0, bc_dirichlet=(), bc_sym=(), bc_extrapolate=(), device=0,
                  pde="compflow", bc_inlet=(), bc_outlet=(), pref=False, tolref=0.1,
-                 betax=0.0, betay=0.0, betaz=0.0, r0=0.0, ce=0.0, kappa=0.0, options=None):
+                 betax=0.0, betay=0.0, betaz=0.0, r0=0.0, ce=0.0, kappa=0.0, options=None,
+                 ncomp=None, u0=None, lam=None, diffusivity=None):
+        """ncomp: transported scalars of a dg::Transport system (default 1); u0 [ncomp], lam
+        [2*ncomp], diffusivity [3*ncomp]: the shear_diff parameters (param::transport::u0 |
+        lambda | diffusivity)."""
         L = lib()
+        nc = int(ncomp) if ncomp else (1 if pde == "transport" else 5)
+        self._sd = [np.ascontiguousarray(a, dtype=np.float64) if a is not None else None
+                    for a in (u0, lam, diffusivity)]
+        for a, n in zip(self._sd, (nc, 2 * nc, 3 * nc)):
+            if a is not None and a.size != n:
+                raise QdgError("shear_diff parameters: expected %d values, got %d" % (n, a.size))
+        psd = [a.ctypes.data_as(c_f64p) if a is not None else None for a in self._sd]
         ss = list(bc_dirichlet) + list(bc_sym) + list(bc_extrapolate) + list(bc_inlet) + list(bc_outlet)
         ty = [BC_DIRICHLET] * len(bc_dirichlet) + [BC_SYMMETRY] * len(bc_sym) + \
              [BC_EXTRAPOLATE] * len(bc_extrapolate) + [BC_INLET] * len(bc_inlet) + \
@@ -191,11 +204,14 @@ class Context:
                               problem=PROBLEM[problem], nbc=len(ss), bc_sideset=pss, bc_type=pty,
                               gamma=gamma, pstiff=pstiff, cv=cv, cweight=cweight, alpha=alpha,
                               beta=beta, p0=p0, cfl=cfl, dt=dt, pde=PDE[pde], pref=1 if pref else 0, tolref=tolref,
-                              betax=betax, betay=betay, betaz=betaz, r0=r0, ce=ce, kappa=kappa)
+                              betax=betax, betay=betay, betaz=betaz, r0=r0, ce=ce, kappa=kappa,
+                              ncomp=(nc if pde == "transport" else 0), tr_u0=psd[0], tr_lambda=psd[1],
+                              tr_diffusivity=psd[2])
         self.h = C.c_void_p()
         _chk(L.qdg_ctx_create(C.byref(self.cfg), C.byref(self.h)))
         self.ndof = ndof
-        self.nprop = (1 if pde == "transport" else 5) * ndof
+        self.ncomp = nc
+        self.nprop = nc * ndof
         for k, v in {**default_options, **(options or {})}.items():
             self.set_option(k, v)
 

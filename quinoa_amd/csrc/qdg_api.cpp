@@ -89,8 +89,19 @@ static int check_cfg(const qdg_config* c)
   if (c->pde == QDG_PDE_TRANSPORT) {
     if (c->flux != QDG_FLUX_UPWIND) return fail("qdg_ctx_create: transport needs the upwind flux");
     if (!(c->problem == QDG_PROBLEM_SLOT_CYL || c->problem == QDG_PROBLEM_CYL_ADVECT ||
-          c->problem == QDG_PROBLEM_GAUSS_HUMP))
+          c->problem == QDG_PROBLEM_GAUSS_HUMP || c->problem == QDG_PROBLEM_SHEAR_DIFF))
       return fail("qdg_ctx_create: unknown transport problem");
+    if (c->ncomp < 0 || c->ncomp > QDG_MAX_SCALARS)
+      return fail("qdg_ctx_create: transport ncomp must be 1.." + std::to_string(QDG_MAX_SCALARS));
+    if (c->problem == QDG_PROBLEM_SHEAR_DIFF) {
+      // TransportProblemShearDiff::errchk (ShearDiff.cpp:92-113): u0, lambda, diffusivity per scalar
+      if (!c->tr_u0 || !c->tr_lambda || !c->tr_diffusivity)
+        return fail("qdg_ctx_create: shear_diff needs u0[ncomp], lambda[2*ncomp], diffusivity[3*ncomp]");
+      for (int i = 0; i < 3 * (c->ncomp ? c->ncomp : 1); ++i)
+        if (!(c->tr_diffusivity[i] > 0.0)) return fail("qdg_ctx_create: shear_diff diffusivity must be > 0");
+    }
+    if (c->pref && c->ncomp > 1)
+      return fail("qdg_ctx_create: p-adaptive DG is supported for one transported scalar");
     if (!(c->dt > 0.0))
       return fail("qdg_ctx_create: transport needs a constant dt (dg::Transport::dt gives no CFL estimate)");
     if (c->pref) {
@@ -106,6 +117,7 @@ static int check_cfg(const qdg_config* c)
     return 0;
   }
   if (c->pde != QDG_PDE_COMPFLOW) return fail("qdg_ctx_create: unknown pde");
+  if (!(c->ncomp == 0 || c->ncomp == NCOMP)) return fail("qdg_ctx_create: CompFlow has 5 components");
   if (c->pref) {
     if (c->ndof != 4) return fail("qdg_ctx_create: p-adaptive DG needs ndof = rdof = 4");
     if (c->limiter == QDG_LIMITER_WENOP1) return fail("qdg_ctx_create: p-adaptive DG with WENO is not supported");
@@ -154,6 +166,16 @@ extern "C" int qdg_ctx_create(const qdg_config* cfg, qdg_ctx** out)
   c->ph.betax = cfg->betax; c->ph.betay = cfg->betay; c->ph.betaz = cfg->betaz;
   c->ph.r0 = cfg->r0; c->ph.ce = cfg->ce; c->ph.kappa = cfg->kappa;
   c->ph.flux = cfg->flux; c->ph.problem = cfg->problem; c->ph.limiter = cfg->limiter;
+  for (double& v : c->ph.sd_u0) v = 0.0;
+  for (double& v : c->ph.sd_lambda) v = 0.0;
+  for (double& v : c->ph.sd_diff) v = 1.0;
+  if (cfg->pde == QDG_PDE_TRANSPORT && cfg->problem == QDG_PROBLEM_SHEAR_DIFF) {
+    const int nc = cfg->ncomp ? cfg->ncomp : 1;
+    for (int i = 0; i < nc; ++i) c->ph.sd_u0[i] = cfg->tr_u0[i];
+    for (int i = 0; i < 2 * nc; ++i) c->ph.sd_lambda[i] = cfg->tr_lambda[i];
+    for (int i = 0; i < 3 * nc; ++i) c->ph.sd_diff[i] = cfg->tr_diffusivity[i];
+  }
+  c->cfg.tr_u0 = c->cfg.tr_lambda = c->cfg.tr_diffusivity = nullptr;   // copied into ph: no pointer into the caller kept
   HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   c->own_stream = true;
   // constant tables (one copy per device/module)
@@ -195,6 +217,12 @@ extern "C" int qdg_ctx_set_stream(qdg_ctx* ctx, void* s)
   ctx->own_stream = false;
   return 0;
   QDG_CATCH
+}
+
+// components of a row: 5 (CompFlow) or the transported scalars of the dg::Transport system
+static inline int ctx_ncomp(const qdg_ctx* ctx)
+{
+  return ctx->cfg.pde == QDG_PDE_TRANSPORT ? (ctx->cfg.ncomp > 0 ? ctx->cfg.ncomp : 1) : NCOMP;
 }
 
 // tuning / A-B switches by name (no behaviour is read from the process environment)
@@ -251,13 +279,13 @@ extern "C" int qdg_solution(qdg_ctx* ctx, size_t n, const double* x, const doubl
   if (n == 0) return 0;
   HIPCHK(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
-  const int ncomp = ctx->cfg.pde == QDG_PDE_TRANSPORT ? 1 : NCOMP;
+  const int ncomp = ctx_ncomp(ctx);
   DevBuf<double> d;
   HIPCHK(d.alloc((3 + (size_t)ncomp) * n));
   HIPCHK(hipMemcpyAsync(d.p, x, n * 8, hipMemcpyHostToDevice, s));
   HIPCHK(hipMemcpyAsync(d.p + n, y, n * 8, hipMemcpyHostToDevice, s));
   HIPCHK(hipMemcpyAsync(d.p + 2 * n, z, n * 8, hipMemcpyHostToDevice, s));
-  launch_solution(ncomp, ctx->ph, (int)n, d.p, d.p + n, d.p + 2 * n, t, d.p + 3 * n, s);
+  launch_solution(ctx->cfg.pde, ncomp, ctx->ph, (int)n, d.p, d.p + n, d.p + 2 * n, t, d.p + 3 * n, s);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(out, d.p + 3 * n, (size_t)ncomp * n * 8, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
@@ -279,7 +307,8 @@ int mesh_alloc_state(qdg_mesh* m, int ntile)
   HIPCHK(hipMemsetAsync(m->W.p, 0, fsz * sizeof(double), s));
   const size_t nblk = std::max((m->nie + 127) / 128, (size_t)ntile);   // k_rhs_p2s: 128 tets per workgroup
   HIPCHK(m->blockmin.alloc(nblk)); HIPCHK(m->dtraw.alloc(1)); HIPCHK(m->dtdev.alloc(1));
-  HIPCHK(m->diagpart.alloc(nblk * 15)); HIPCHK(m->diagout.alloc(15));
+  // (dg::Transport: one set of block results per scalar)
+  HIPCHK(m->diagpart.alloc(nblk * 15 * QDG_MAX_SCALARS)); HIPCHK(m->diagout.alloc(15));
   m->Ucur = m->U.p;
   m->dt_ptr = m->dtdev.p;
   return 0;
@@ -573,7 +602,7 @@ extern "C" int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t 
   std::unique_ptr<qdg_mesh> m(new qdg_mesh);
   m->ctx = ctx;
   m->ndof = ctx->cfg.ndof;
-  const int ncomp = ctx->cfg.pde == QDG_PDE_TRANSPORT ? 1 : NCOMP;
+  const int ncomp = ctx_ncomp(ctx);
   m->nprop = ncomp * m->ndof;
   m->nie = nie; m->ne = ne; m->stride = stride;
   hipStream_t s = ctx->stream;
@@ -617,7 +646,7 @@ extern "C" int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t 
     launch_task_geo(h_task_a.size(), m->task_a.p, m->task_f.p, m->fgeo.p, m->tgeo.p, s);
     dm.tgeo = m->tgeo.p;
   }
-  dm.blk0 = 0; dm.ninner = (int)ninner; dm.ncomp = ncomp;
+  dm.blk0 = 0; dm.ninner = (int)ninner; dm.ncomp = ncomp; dm.pde = ctx->cfg.pde;
   dm.ndofel = nullptr;
   if (ctx->cfg.pref) {
     HIPCHK(m->ndofel.alloc(ne)); HIPCHK(m->ndofel2.alloc(ne));
@@ -719,7 +748,7 @@ static int run_limiter(qdg_mesh* mesh, double*& Ucur, double* Ualt_in)
 // RHS dispatch: CompFlow DG-P1 has kernels of its own (qdg_rhs_p1.hip)
 static bool use_p1_fast(const qdg_mesh* mesh)
 {
-  return mesh->ndof == 4 && mesh->dm.ncomp == NCOMP;
+  return mesh->ndof == 4 && mesh->dm.pde == QDG_PDE_COMPFLOW;
 }
 
 // tile / face-task kernel (each in-tile face evaluated once, LDS accumulation with
@@ -790,7 +819,7 @@ extern "C" int qdg_dt(qdg_mesh* mesh, const double* U_aos, double* mindt)
   QDG_TRY
   MESH_ENTER("qdg_dt");
   if (!U_aos || !mindt) return fail("qdg_dt: null argument");
-  if (mesh->dm.ncomp == 1) {        // dg::Transport::dt: no estimate (DGTransport.hpp:189-199)
+  if (mesh->dm.pde == 1) {          // dg::Transport::dt: no estimate (DGTransport.hpp:189-199)
     *mindt = std::numeric_limits<double>::max();
     return 0;
   }
@@ -842,7 +871,7 @@ extern "C" int qdg_limit_from(qdg_ctx* ctx, size_t nielem, size_t nunk, const in
     }
   HIPCHK(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
-  const int ncomp = ctx->cfg.pde == QDG_PDE_TRANSPORT ? 1 : NCOMP;
+  const int ncomp = ctx_ncomp(ctx);
   const size_t np = (size_t)ncomp * ctx->cfg.ndof, fsz = np * stride;
   DevBuf<int> dn, dnd;
   DevBuf<double> d;
@@ -851,7 +880,7 @@ extern "C" int qdg_limit_from(qdg_ctx* ctx, size_t nielem, size_t nunk, const in
   HIPCHK(hipMemsetAsync(d.p, 0, 2 * fsz * 8, s));
   HIPCHK(hipMemcpyAsync(d.p, U_aos, np * nunk * 8, hipMemcpyHostToDevice, s));
   DevMesh dm{};
-  dm.nie = (int)nielem; dm.ne = (int)nunk; dm.stride = (int)stride; dm.ncomp = ncomp; dm.nbr = dn.p;
+  dm.nie = (int)nielem; dm.ne = (int)nunk; dm.stride = (int)stride; dm.ncomp = ncomp; dm.pde = ctx->cfg.pde; dm.nbr = dn.p;
   if (ctx->cfg.pref) {
     std::vector<int> nd(nunk);
     for (size_t e = 0; e < nunk; ++e) nd[e] = (int)ndofel[e];
@@ -931,11 +960,14 @@ static const char* problem_field_name(const qdg_ctx* ctx, size_t f)
                               "err(e)", "err(p)", "err(u)", "err(v)", "err(w)" };
   static const char* ud[] = { "density", "x-velocity", "y-velocity", "z-velocity",
                               "specific total energy", "pressure", "temperature" };
-  static const char* trn[] = { "c0_numerical", "c0_analytic", "c0_error" };
-  const int ncomp = ctx->cfg.pde == QDG_PDE_TRANSPORT ? 1 : NCOMP;
-  const size_t n = (size_t)field_count(ncomp, ctx->cfg.problem);
+  // depvar 'c' + component + suffix, the three blocks of DGTransport.hpp:211-228
+  static const char* trn[] = { "c0_numerical", "c1_numerical", "c2_numerical", "c3_numerical", "c4_numerical",
+                               "c0_analytic", "c1_analytic", "c2_analytic", "c3_analytic", "c4_analytic",
+                               "c0_error", "c1_error", "c2_error", "c3_error", "c4_error" };
+  const int ncomp = ctx_ncomp(ctx);
+  const size_t n = (size_t)field_count(ctx->cfg.pde, ncomp, ctx->cfg.problem);
   if (f >= n) return (f == n && ctx->cfg.pref) ? "ndof" : "";
-  if (ncomp == 1) return trn[f];
+  if (ctx->cfg.pde == QDG_PDE_TRANSPORT) return trn[5 * (f / ncomp) + f % ncomp];
   switch (ctx->cfg.problem) {
     case QDG_PROBLEM_VORTICAL_FLOW: return vort[f];
     case QDG_PROBLEM_TAYLOR_GREEN: return tg[f];
@@ -949,7 +981,7 @@ extern "C" int qdg_ctx_field_count(qdg_ctx* ctx, size_t* nfield)
 {
   QDG_TRY
   if (!ctx || !nfield) return fail("qdg_ctx_field_count: null argument");
-  *nfield = (size_t)field_count(ctx->cfg.pde == QDG_PDE_TRANSPORT ? 1 : NCOMP, ctx->cfg.problem) +
+  *nfield = (size_t)field_count(ctx->cfg.pde, ctx_ncomp(ctx), ctx->cfg.problem) +
             (ctx->cfg.pref ? 1 : 0);
   return 0;
   QDG_CATCH
@@ -1001,15 +1033,15 @@ extern "C" int qdg_field_output_from(qdg_ctx* ctx, double t, size_t nunk, const 
   if (nunk == 0) return 0;
   HIPCHK(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
-  const int ncomp = ctx->cfg.pde == QDG_PDE_TRANSPORT ? 1 : NCOMP;
-  const size_t np = (size_t)ncomp * ctx->cfg.rdof, nf = (size_t)field_count(ncomp, ctx->cfg.problem);
+  const int ncomp = ctx_ncomp(ctx);
+  const size_t np = (size_t)ncomp * ctx->cfg.rdof, nf = (size_t)field_count(ctx->cfg.pde, ncomp, ctx->cfg.problem);
   DevBuf<double> d;
   HIPCHK(d.alloc((np + 4 + nf) * nunk));
   double* dU = d.p; double* dG = d.p + np * nunk; double* dO = dG + 4 * nunk;
   HIPCHK(hipMemcpyAsync(dU, U_aos, np * nunk * 8, hipMemcpyHostToDevice, s));
   HIPCHK(hipMemcpyAsync(dG, geoElem, 4 * nunk * 8, hipMemcpyHostToDevice, s));
   DevMesh dm{};
-  dm.ncomp = ncomp;
+  dm.ncomp = ncomp; dm.pde = ctx->cfg.pde;
   launch_field_output(ctx->cfg.rdof, dm, ctx->ph, t, dU, dG, (int)nunk, dO, s);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(out, dO, nf * nunk * 8, hipMemcpyDeviceToHost, s));
@@ -1069,7 +1101,7 @@ extern "C" int qdg_initialize_from(qdg_ctx* ctx, size_t nielem, size_t nnode, co
     }
   HIPCHK(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
-  const int ncomp = ctx->cfg.pde == QDG_PDE_TRANSPORT ? 1 : NCOMP;
+  const int ncomp = ctx_ncomp(ctx);
   const size_t np = (size_t)ncomp * ctx->cfg.ndof;
   DevBuf<int> di;
   DevBuf<double> d;
@@ -1090,7 +1122,7 @@ extern "C" int qdg_initialize_from(qdg_ctx* ctx, size_t nielem, size_t nnode, co
     launch_tet_volumes((int)nielem, (int)stride, di.p, dx, dy, dz, dv, s);
   }
   DevMesh dm{};
-  dm.nie = dm.ne = (int)nielem; dm.stride = (int)stride; dm.nnode = (int)nnode; dm.ncomp = ncomp;
+  dm.nie = dm.ne = (int)nielem; dm.stride = (int)stride; dm.nnode = (int)nnode; dm.ncomp = ncomp; dm.pde = ctx->cfg.pde;
   dm.inpoel = di.p; dm.x = dx; dm.y = dy; dm.z = dz; dm.vol = dv;
   launch_init(ctx->cfg.ndof, dm, ctx->ph, t, dU, s);
   HIPCHK(hipGetLastError());
@@ -1246,7 +1278,7 @@ extern "C" int qdg_stage_rhs_dt(qdg_mesh* mesh, int stage, double t, double tlef
                        mesh->dt_ptr, mesh->Unp, s);
     if (ev) HIPCHK(hipEventRecord(ev->second, s));
     mesh->Upending = out;
-  } else if (fuse && mesh->dm.ncomp == NCOMP) {
+  } else if (fuse && mesh->dm.pde == QDG_PDE_COMPFLOW) {
     // P0 / P2 (and the generic P1 path): the same fusion in the generic kernel
     double* out = free_buf(mesh, mesh->Ucur, mesh->Unp);
     if (int rc = prof_begin(mesh, &ev)) return rc;
@@ -1265,7 +1297,7 @@ extern "C" int qdg_stage_rhs_dt(qdg_mesh* mesh, int stage, double t, double tlef
       launch_rhs_p1(mesh->dm, ctx->ph, t, mesh->Ucur, mesh->R.p, true, mesh->blockmin.p, scale,
                     tleft, mesh->dtraw.p, mesh->dt_ptr, s);
     if (ev) HIPCHK(hipEventRecord(ev->second, s));
-  } else if (cfl_dt && mesh->dm.ncomp == NCOMP) {
+  } else if (cfl_dt && mesh->dm.pde == QDG_PDE_COMPFLOW) {
     // P0 / P2 (and the generic P1 path): the CFL sum comes out of the same face loop
     const double p = (mesh->ndof == 4) ? 1.0 : (mesh->ndof == 10) ? 2.0 : 0.0;
     const double scale = ctx->cfg.cfl / (2.0 * p + 1.0);     // DG.cpp:1404-1418

@@ -79,7 +79,8 @@ struct DevMesh {
   // next to the halo, so a launch over the leading tiles never reads a ghost row.
   int blk0;
   int ninner;
-  int ncomp;        // 5: CompFlow, 1: scalar Transport (rows of ncomp*ndof doubles)
+  int ncomp;        // 5: CompFlow; dg::Transport: its number of scalars (rows of ncomp*ndof doubles)
+  int pde;          // 0: CompFlow, 1: dg::Transport (QDG_PDE_*)
   // p-adaptive DG (scheme pdg): DG::m_ndof per device row, 1 or 4; null otherwise
   const int* ndofel;
 };
@@ -114,6 +115,8 @@ struct Phys {
   double alpha, beta, p0;
   double betax, betay, betaz, r0, ce, kappa;   // nl_energy_growth
   int flux, problem, limiter;
+  // shear_diff (dg::Transport), per scalar: u0, lambda[2], diffusivity[3]
+  double sd_u0[5], sd_lambda[10], sd_diff[15];
 };
 
 // Quadrature / basis tables for one polynomial order, kept in constant memory

@@ -763,7 +763,7 @@ static int dev_build_layout(qdg_ctx* ctx, DevFD& fd, const std::vector<int>& bcf
   std::unique_ptr<qdg_mesh> m(new qdg_mesh);
   m->ctx = ctx;
   m->ndof = ctx->cfg.ndof;
-  const int ncomp = ctx->cfg.pde == QDG_PDE_TRANSPORT ? 1 : NCOMP;
+  const int ncomp = ctx->cfg.pde == QDG_PDE_TRANSPORT ? (ctx->cfg.ncomp > 0 ? ctx->cfg.ncomp : 1) : NCOMP;
   m->nprop = ncomp * m->ndof;
   m->nie = nie; m->ne = ne; m->stride = stride;
 
@@ -928,7 +928,7 @@ static int dev_build_layout(qdg_ctx* ctx, DevFD& fd, const std::vector<int>& bcf
     launch_task_geo(nslot, m->task_a.p, m->task_f.p, m->fgeo.p, m->tgeo.p, s);
     dm.tgeo = m->tgeo.p;
   }
-  dm.blk0 = 0; dm.ninner = (int)ninner; dm.ncomp = ncomp; dm.ndofel = nullptr;
+  dm.blk0 = 0; dm.ninner = (int)ninner; dm.ncomp = ncomp; dm.pde = ctx->cfg.pde; dm.ndofel = nullptr;
   if (ctx->cfg.pref) {
     HIPCHK(m->ndofel.alloc(ne)); HIPCHK(m->ndofel2.alloc(ne));
     k_fill_i32<<<nblk(ne), 256, 0, s>>>(m->ndofel.p, ne, 4);

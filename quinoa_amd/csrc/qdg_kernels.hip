@@ -1022,10 +1022,10 @@ __global__ void k_fill_int(int* __restrict__ p, int n, int v)
 // element-centric (every tet visits its 4 faces, R written once).
 namespace tr {
 
-// TransportProblemSlotCyl::solution (src/PDE/Transport/Problem/SlotCyl.cpp:30-110), c = 0
-__device__ double solution_slot_cyl(double x, double y, double t)
+// TransportProblemSlotCyl::solution (src/PDE/Transport/Problem/SlotCyl.cpp:30-110); T = t + 2 pi c / ncomp
+__device__ double solution_slot_cyl(double x, double y, double T)
 {
-  const double T = t, R0 = 0.15, PI = 3.14159265358979323846;
+  const double R0 = 0.15, PI = 3.14159265358979323846;
   double s = 0.0;
   double x0 = 0.5, y0 = 0.25;
   double r = sqrt((x0 - 0.5) * (x0 - 0.5) + (y0 - 0.5) * (y0 - 0.5));
@@ -1055,10 +1055,22 @@ __device__ double solution_slot_cyl(double x, double y, double t)
   return s;
 }
 
-// problem ids: 5 slot_cyl, 8 cyl_advect (CylAdvect.cpp:28-60), 9 gauss_hump (GaussHump.cpp:28-56)
-__device__ __forceinline__ double solution(int problem, double x, double y, double /*z*/, double t)
+// problem ids: 5 slot_cyl, 8 cyl_advect (CylAdvect.cpp:28-60), 9 gauss_hump (GaussHump.cpp:28-56),
+// 11 shear_diff (ShearDiff.cpp:28-68: the analytic solution of the advection-diffusion problem
+// with the per-component parameters u0, lambda, diffusivity).  Component c of ncomp.
+__device__ __forceinline__ double solution(const Phys& ph, int c, int ncomp, double x, double y, double z, double t)
 {
-  if (problem == 5) return solution_slot_cyl(x, y, t);
+  const int problem = ph.problem;
+  if (problem == 5) return solution_slot_cyl(x, y, t + 2.0 * 3.14159265358979323846 / ncomp * c);
+  if (problem == 11) {
+    const double PI = 3.14159265358979323846;
+    const double l0 = ph.sd_lambda[2 * c], l1 = ph.sd_lambda[2 * c + 1];
+    const double d0 = ph.sd_diff[3 * c], d1 = ph.sd_diff[3 * c + 1], d2 = ph.sd_diff[3 * c + 2];
+    const double phi3s = (l0 * l0 * d1 / d0 + l1 * l1 * d2 / d0) / 12.0;
+    const double xs = x - ph.sd_u0[c] * t - 0.5 * (l0 * y + l1 * z) * t;
+    return 1.0 / (8.0 * pow(PI, 3.0 / 2.0) * sqrt(d0 * d1 * d2) * pow(t, 3.0 / 2.0) * sqrt(1.0 + phi3s * t * t)) *
+           exp(-(xs * xs) / (4.0 * d0 * t * (1.0 + phi3s * t * t)) - y * y / (4.0 * d1 * t) - z * z / (4.0 * d2 * t));
+  }
   const double x0 = 0.25 + 0.1 * t, y0 = 0.25 + 0.1 * t;
   const double d2 = (x - x0) * (x - x0) + (y - y0) * (y - y0);
   if (problem == 8) return sqrt(d2) < 0.2 ? 1.0 : 0.0;
@@ -1067,10 +1079,12 @@ __device__ __forceinline__ double solution(int problem, double x, double y, doub
 }
 
 // Problem::prescribedVelocity: SlotCyl.cpp:152-170 solid-body rotation about (0.5, 0.5);
-// CylAdvect.cpp:114-129, GaussHump.cpp:110-125 constant (0.1, 0.1, 0)
-__device__ __forceinline__ void velocity(int problem, double x, double y, double /*z*/, double* v)
+// CylAdvect.cpp:114-129, GaussHump.cpp:110-125 constant (0.1, 0.1, 0); ShearDiff.cpp:140-160
+// (u0_c + lambda_2c y + lambda_2c+1 z, 0, 0)
+__device__ __forceinline__ void velocity(const Phys& ph, int c, double x, double y, double z, double* v)
 {
-  if (problem == 5) { v[0] = 0.5 - y; v[1] = x - 0.5; v[2] = 0.0; }
+  if (ph.problem == 5) { v[0] = 0.5 - y; v[1] = x - 0.5; v[2] = 0.0; }
+  else if (ph.problem == 11) { v[0] = ph.sd_u0[c] + ph.sd_lambda[2 * c] * y + ph.sd_lambda[2 * c + 1] * z; v[1] = 0.0; v[2] = 0.0; }
   else { v[0] = 0.1; v[1] = 0.1; v[2] = 0.0; }
 }
 
@@ -1083,10 +1097,15 @@ __device__ __forceinline__ double upwind(const double* fn, double ul, double ur,
   return splus * ul + sminus * ur;
 }
 
-template <int NDOF> __device__ __forceinline__ void load(const double* __restrict__ U, int e, double* u)
+// component c of a row: rows hold ncomp * NDOF doubles, component-major (mark = c * rdof)
+template <int NDOF> __device__ __forceinline__ size_t at(const DevMesh& m, int e, int c)
+{
+  return ((size_t)e * m.ncomp + c) * NDOF;
+}
+template <int NDOF> __device__ __forceinline__ void load(const double* __restrict__ U, size_t i0, double* u)
 {
 #pragma unroll
-  for (int k = 0; k < NDOF; ++k) u[k] = U[(size_t)e * NDOF + k];
+  for (int k = 0; k < NDOF; ++k) u[k] = U[i0 + k];
 }
 template <int NDOF> __device__ __forceinline__ double state(const double* u, const double* B)
 {
@@ -1108,6 +1127,7 @@ __global__ __launch_bounds__(256) void k_rhs(DevMesh m, Phys ph, double t,
 {
   const int e = xcd_tile(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   if (e >= m.nie) return;
+  const int c = blockIdx.y;                      // one transported scalar per grid row (the scalars do not couple)
   const Tables<NDOF>& T = tab<NDOF>();
   constexpr int NGF = Tables<NDOF>::NGF, NGV = Tables<NDOF>::NGV;
   const int stride = m.stride;
@@ -1116,7 +1136,7 @@ __global__ __launch_bounds__(256) void k_rhs(DevMesh m, Phys ph, double t,
   double acc[NDOF], u[NDOF];
 #pragma unroll
   for (int k = 0; k < NDOF; ++k) acc[k] = 0.0;
-  load<NDOF>(U, e, u);
+  load<NDOF>(U, at<NDOF>(m, e, c), u);
   if (p0) {
 #pragma unroll
     for (int k = 1; k < NDOF; ++k) u[k] = 0.0;
@@ -1135,7 +1155,7 @@ __global__ __launch_bounds__(256) void k_rhs(DevMesh m, Phys ph, double t,
     double un[NDOF];
     bool p0n = true;
     if (nb >= 0) {
-      load<NDOF>(U, nb, un);
+      load<NDOF>(U, at<NDOF>(m, nb, c), un);
       p0n = pdg && m.ndofel[nb] == 1;
       if (p0n) {
 #pragma unroll
@@ -1165,9 +1185,9 @@ __global__ __launch_bounds__(256) void k_rhs(DevMesh m, Phys ph, double t,
         sn = state<NDOF>(un, Bn);
       } else {
         const int bc = -nb - 1;
-        sn = (bc == 4) ? 0.0 : (bc == 1) ? solution(ph.problem, P[0], P[1], P[2], t) : so;
+        sn = (bc == 4) ? 0.0 : (bc == 1) ? solution(ph, c, m.ncomp, P[0], P[1], P[2], t) : so;
       }
-      velocity(ph.problem, P[0], P[1], P[2], v);
+      velocity(ph, c, P[0], P[1], P[2], v);
       const double fl = own_left ? upwind(fn, so, sn, v) : upwind(fn, sn, so, v);
       const double wt = (own_left ? -1.0 : 1.0) * (one ? 1.0 : T.fw[ig]) * area;
       acc[0] += wt * fl;
@@ -1191,7 +1211,7 @@ __global__ __launch_bounds__(256) void k_rhs(DevMesh m, Phys ph, double t,
         for (int d = 0; d < 3; ++d)
           P[d] = g.p[0][d] * w0 + g.p[1][d] * xi + g.p[2][d] * eta + g.p[3][d] * zeta;
         const double sc = state<NDOF>(u, T.vB[ig]);
-        velocity(ph.problem, P[0], P[1], P[2], v);
+        velocity(ph, c, P[0], P[1], P[2], v);
         const double wt = T.vw[ig] * vol;
 #pragma unroll
         for (int k = 1; k < NDOF; ++k) {
@@ -1205,7 +1225,7 @@ __global__ __launch_bounds__(256) void k_rhs(DevMesh m, Phys ph, double t,
     }
   }
 #pragma unroll
-  for (int k = 0; k < NDOF; ++k) R[(size_t)e * NDOF + k] = acc[k];
+  for (int k = 0; k < NDOF; ++k) R[at<NDOF>(m, e, c) + k] = acc[k];
 }
 
 // Superbee_P1 (src/PDE/Limiter.cpp:155-316) for one scalar; in place (only
@@ -1217,16 +1237,17 @@ __global__ __launch_bounds__(256) void k_superbee(DevMesh m, double* __restrict_
   if (e >= m.nie) return;
   if constexpr (NDOF > 1) {
     if (m.ndofel && m.ndofel[e] == 1) return;        // Limiter.cpp:179-180
+    const int c = blockIdx.y;
     const Tables<NDOF>& T = tab<NDOF>();
     constexpr int NGF = Tables<NDOF>::NGF;
     double u[NDOF];
-    load<NDOF>(U, e, u);
+    load<NDOF>(U, at<NDOF>(m, e, c), u);
     double uMin = u[0], uMax = u[0], phi = 1.0;
 #pragma unroll
     for (int lf = 0; lf < 4; ++lf) {
       const int nb = m.nbr[(size_t)lf * m.stride + e];
       if (nb < 0) continue;
-      const double v = U[(size_t)nb * NDOF];
+      const double v = U[at<NDOF>(m, nb, c)];
       uMin = fmin(uMin, v); uMax = fmax(uMax, v);
     }
 #pragma unroll 1
@@ -1242,7 +1263,7 @@ __global__ __launch_bounds__(256) void k_superbee(DevMesh m, double* __restrict_
         phi = fmin(phi, pg);
       }
 #pragma unroll
-    for (int k = 1; k < 4; ++k) U[(size_t)e * NDOF + k] = phi * u[k];
+    for (int k = 1; k < 4; ++k) U[at<NDOF>(m, e, c) + k] = phi * u[k];
   }
 }
 
@@ -1253,8 +1274,9 @@ __global__ __launch_bounds__(256) void k_weno(DevMesh m, double cweight, const d
 {
   const int e = xcd_tile(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   if (e >= m.ne) return;
+  const int c = blockIdx.y;
   double r[NDOF];
-  load<NDOF>(Uin, e, r);
+  load<NDOF>(Uin, at<NDOF>(m, e, c), r);
   if constexpr (NDOF > 1) {
     if (e < m.nie) {
       double g[5][3], wd[5], wtot = 0.0;
@@ -1267,7 +1289,7 @@ __global__ __launch_bounds__(256) void k_weno(DevMesh m, double cweight, const d
       for (int is = 1; is < 5; ++is)
 #pragma unroll
         for (int d = 0; d < 3; ++d)
-          g[is][d] = (nb[is - 1] >= 0) ? Uin[(size_t)nb[is - 1] * NDOF + 1 + d] : 0.0;
+          g[is][d] = (nb[is - 1] >= 0) ? Uin[at<NDOF>(m, nb[is - 1], c) + 1 + d] : 0.0;
 #pragma unroll
       for (int is = 0; is < 5; ++is) {
         const double wst = (is == 0) ? cweight : (nb[is - (is > 0)] >= 0 ? 1.0 : 0.0);
@@ -1286,7 +1308,7 @@ __global__ __launch_bounds__(256) void k_weno(DevMesh m, double cweight, const d
     }
   }
 #pragma unroll
-  for (int k = 0; k < NDOF; ++k) Uout[(size_t)e * NDOF + k] = r[k];
+  for (int k = 0; k < NDOF; ++k) Uout[at<NDOF>(m, e, c) + k] = r[k];
 }
 
 
@@ -1295,6 +1317,7 @@ __global__ __launch_bounds__(256) void k_init(DevMesh m, Phys ph, double t, doub
 {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= m.nie) return;
+  const int c = blockIdx.y;
   const QuadTet& Q = c_qinit[order_index<NDOF>()];
   ElemGeom g;
   load_geom(m, e, g);
@@ -1311,7 +1334,7 @@ __global__ __launch_bounds__(256) void k_init(DevMesh m, Phys ph, double t, doub
     for (int d = 0; d < 3; ++d)
       P[d] = g.p[0][d] * w0 + g.p[1][d] * xi + g.p[2][d] * eta + g.p[3][d] * zeta;
     eval_basis<NDOF>(xi, eta, zeta, B);
-    const double sv = solution(ph.problem, P[0], P[1], P[2], t);
+    const double sv = solution(ph, c, m.ncomp, P[0], P[1], P[2], t);
     const double wt = Q.w[ig] * vol;
     acc[0] += wt * sv;
 #pragma unroll
@@ -1320,7 +1343,7 @@ __global__ __launch_bounds__(256) void k_init(DevMesh m, Phys ph, double t, doub
   const double f[10] = { vol, vol / 10.0, vol * 3.0 / 10.0, vol * 3.0 / 5.0, vol / 35.0,
                          vol / 21.0, vol / 14.0, vol / 7.0, vol * 3.0 / 14.0, vol * 3.0 / 7.0 };
 #pragma unroll
-  for (int k = 0; k < NDOF; ++k) U[(size_t)e * NDOF + k] = acc[k] / f[k];
+  for (int k = 0; k < NDOF; ++k) U[at<NDOF>(m, e, c) + k] = acc[k] / f[k];
 }
 
 template <int NDOF>
@@ -1328,9 +1351,11 @@ __global__ __launch_bounds__(256) void k_diag(DevMesh m, Phys ph, double t_new,
                                               const double* __restrict__ U, double* __restrict__ part)
 {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.y;                      // <= 5 scalars: the diagnostics vector has 5 slots per kind
   double v[15];
 #pragma unroll
   for (int i = 0; i < 15; ++i) v[i] = 0.0;
+  double l2 = 0.0, l2e = 0.0, lie = 0.0;
   if (e < m.nie) {
     const bool p0 = NDOF > 1 && m.ndofel && m.ndofel[e] == 1;   // ElemDiagnostics.cpp:144
     const QuadTet& Q = p0 ? c_qdiag[0] : c_qdiag[order_index<NDOF>()];
@@ -1338,7 +1363,7 @@ __global__ __launch_bounds__(256) void k_diag(DevMesh m, Phys ph, double t_new,
     load_geom(m, e, g);
     const double vol = m.vol[e];
     double u[NDOF];
-    load<NDOF>(U, e, u);
+    load<NDOF>(U, at<NDOF>(m, e, c), u);
     if (p0) {
 #pragma unroll
       for (int k = 1; k < NDOF; ++k) u[k] = 0.0;
@@ -1353,14 +1378,18 @@ __global__ __launch_bounds__(256) void k_diag(DevMesh m, Phys ph, double t_new,
         P[d] = g.p[0][d] * w0 + g.p[1][d] * xi + g.p[2][d] * eta + g.p[3][d] * zeta;
       eval_basis<NDOF>(xi, eta, zeta, B);
       const double uu = state<NDOF>(u, B);
-      const double d = uu - solution(ph.problem, P[0], P[1], P[2], t_new);
+      const double d = uu - solution(ph, c, m.ncomp, P[0], P[1], P[2], t_new);
       const double wt = Q.w[ig] * vol;
-      v[0] += wt * uu * uu;
-      v[5] += wt * d * d;
-      v[10] = fmax(v[10], fabs(d));
+      l2 += wt * uu * uu;
+      l2e += wt * d * d;
+      lie = fmax(lie, fabs(d));
     }
   }
-  diag_block_reduce(v, part);
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    v[i] = (i == c) ? l2 : 0.0; v[5 + i] = (i == c) ? l2e : 0.0; v[10 + i] = (i == c) ? lie : 0.0;
+  }
+  diag_block_reduce(v, part + (size_t)blockIdx.y * gridDim.x * 15);
 }
 
 template <int NDOF>
@@ -1371,8 +1400,9 @@ __global__ void k_mass(DevMesh m, double* __restrict__ L)
   const double vol = m.vol[e];
   const double f[10] = { vol, vol / 10.0, vol * 3.0 / 10.0, vol * 3.0 / 5.0, vol / 35.0,
                          vol / 21.0, vol / 14.0, vol / 7.0, vol * 3.0 / 14.0, vol * 3.0 / 7.0 };
+  for (int c = 0; c < m.ncomp; ++c)
 #pragma unroll
-  for (int k = 0; k < NDOF; ++k) L[(size_t)e * NDOF + k] = f[k];
+    for (int k = 0; k < NDOF; ++k) L[at<NDOF>(m, e, c) + k] = f[k];
 }
 
 template <int NDOF>
@@ -1383,9 +1413,9 @@ __global__ __launch_bounds__(256) void k_rk(DevMesh m, double a, double b, const
   constexpr double imf[10] = { 1.0, 10.0, 10.0 / 3.0, 5.0 / 3.0, 35.0, 21.0, 14.0, 7.0,
                                14.0 / 3.0, 7.0 / 3.0 };
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (size_t)m.nie * NDOF) return;
-  const int e = (int)(i / NDOF);
-  const int k = (int)(i - (size_t)e * NDOF);
+  if (i >= (size_t)m.nie * m.ncomp * NDOF) return;
+  const int e = (int)(i / ((size_t)m.ncomp * NDOF));
+  const int k = (int)(i % NDOF);
   double f = imf[0];
 #pragma unroll
   for (int j = 1; j < NDOF; ++j) f = (k == j) ? imf[j] : f;
@@ -1552,8 +1582,8 @@ void launch_rhs(int ndof, const DevMesh& m, const Phys& ph, double t, const doub
                 hipStream_t s)
 {
   if (m.nie == 0) return;
-  if (m.ncomp == 1) {
-    QDG_DISPATCH_NDOF(ndof, (tr::k_rhs<N><<<nblk(m.nie, 256), 256, 0, s>>>(m, ph, t, U, R)));
+  if (m.pde == 1) {
+    QDG_DISPATCH_NDOF(ndof, (tr::k_rhs<N><<<dim3(nblk(m.nie, 256), m.ncomp), 256, 0, s>>>(m, ph, t, U, R)));
     return;
   }
   if (ndof == 10) { launch_rhs_p2(m, ph, t, U, R, 0, nullptr, 0.0, 0.0, nullptr, nullptr, s); return; }
@@ -1593,8 +1623,8 @@ void launch_rhs_rk(int ndof, const DevMesh& m, const Phys& ph, double t, const d
 void launch_superbee(int ndof, const DevMesh& m0, double* U, hipStream_t s, int first, int count)
 {
   if (m0.nie == 0 || ndof == 1) return;
-  if (m0.ncomp == 1) {
-    if (first == 0) QDG_DISPATCH_NDOF(ndof, (tr::k_superbee<N><<<nblk(m0.nie, 256), 256, 0, s>>>(m0, U)));
+  if (m0.pde == 1) {
+    if (first == 0) QDG_DISPATCH_NDOF(ndof, (tr::k_superbee<N><<<dim3(nblk(m0.nie, 256), m0.ncomp), 256, 0, s>>>(m0, U)));
     return;
   }
   DevMesh m = m0;
@@ -1623,8 +1653,8 @@ void launch_weno(int ndof, const DevMesh& m, double cweight, const double* Uin, 
                  hipStream_t s)
 {
   if (m.ne == 0 || ndof == 1) return;
-  if (m.ncomp == 1) {
-    QDG_DISPATCH_NDOF(ndof, (tr::k_weno<N><<<nblk(m.ne, 256), 256, 0, s>>>(m, cweight, Uin, Uout)));
+  if (m.pde == 1) {
+    QDG_DISPATCH_NDOF(ndof, (tr::k_weno<N><<<dim3(nblk(m.ne, 256), m.ncomp), 256, 0, s>>>(m, cweight, Uin, Uout)));
     return;
   }
   if (ndof == 10) k_weno<10, 128><<<nblk(m.ne, 128), 128, 0, s>>>(m, cweight, Uin, Uout);
@@ -1653,8 +1683,8 @@ void launch_rk(int ndof, const DevMesh& m, double a, double b, const double* dt,
                const double* R, const double* U, double* Uout, hipStream_t s)
 {
   if (m.nie == 0) return;
-  if (m.ncomp == 1) {
-    QDG_DISPATCH_NDOF(ndof, (tr::k_rk<N><<<(unsigned)(((size_t)m.nie * N + 255) / 256), 256, 0, s>>>(m, a, b, dt, Un, R, U, Uout)));
+  if (m.pde == 1) {
+    QDG_DISPATCH_NDOF(ndof, (tr::k_rk<N><<<(unsigned)(((size_t)m.nie * m.ncomp * N + 255) / 256), 256, 0, s>>>(m, a, b, dt, Un, R, U, Uout)));
     return;
   }
   QDG_DISPATCH_NDOF(ndof, (k_rk<N><<<(unsigned)(((size_t)m.nie * NCOMP * N + 255) / 256), 256, 0, s>>>(m, a, b, dt, Un, R, U, Uout)));
@@ -1663,7 +1693,7 @@ void launch_rk(int ndof, const DevMesh& m, double a, double b, const double* dt,
 void launch_mass(int ndof, const DevMesh& m, double* L, hipStream_t s)
 {
   if (m.ne == 0) return;
-  if (m.ncomp == 1) {
+  if (m.pde == 1) {
     QDG_DISPATCH_NDOF(ndof, (tr::k_mass<N><<<nblk(m.ne, 256), 256, 0, s>>>(m, L)));
     return;
   }
@@ -1673,8 +1703,8 @@ void launch_mass(int ndof, const DevMesh& m, double* L, hipStream_t s)
 void launch_init(int ndof, const DevMesh& m, const Phys& ph, double t, double* U, hipStream_t s)
 {
   if (m.nie == 0) return;
-  if (m.ncomp == 1) {
-    QDG_DISPATCH_NDOF(ndof, (tr::k_init<N><<<nblk(m.nie, 256), 256, 0, s>>>(m, ph, t, U)));
+  if (m.pde == 1) {
+    QDG_DISPATCH_NDOF(ndof, (tr::k_init<N><<<dim3(nblk(m.nie, 256), m.ncomp), 256, 0, s>>>(m, ph, t, U)));
     return;
   }
   QDG_DISPATCH_NDOF(ndof, QDG_DISPATCH_PROB(ph.problem, (k_init<N, P><<<nblk(m.nie, 256), 256, 0, s>>>(m, ph, t, U))));
@@ -1684,8 +1714,11 @@ void launch_diag(int ndof, const DevMesh& m, const Phys& ph, double t_new, const
                  double* part, double* out, hipStream_t s)
 {
   const int nb = nblk(m.nie, 256);
-  if (nb > 0 && m.ncomp == 1) {
-    QDG_DISPATCH_NDOF(ndof, (tr::k_diag<N><<<nb, 256, 0, s>>>(m, ph, t_new, U, part)));
+  if (nb > 0 && m.pde == 1) {
+    // one grid row per scalar; part holds nb * ncomp block results (qdg_api.cpp sizes it)
+    QDG_DISPATCH_NDOF(ndof, (tr::k_diag<N><<<dim3(nb, m.ncomp), 256, 0, s>>>(m, ph, t_new, U, part)));
+    k_diag_final<<<1, 64, 0, s>>>(part, nb * m.ncomp, out);
+    return;
   } else if (nb > 0)
     QDG_DISPATCH_NDOF(ndof, QDG_DISPATCH_PROB(ph.problem, (k_diag<N, P><<<nb, 256, 0, s>>>(m, ph, t_new, U, part))));
   k_diag_final<<<1, 64, 0, s>>>(part, nb, out);
@@ -1754,26 +1787,28 @@ void launch_halo_unpack(const double* slab, int nprop, int /*stride*/, int nie, 
   k_halo_unpack<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(slab, nprop, nie, nrecv, U, ndofel);
 }
 
-__global__ __launch_bounds__(256) void k_tr_solution(int problem, int n, const double* __restrict__ x,
+__global__ __launch_bounds__(256) void k_tr_solution(Phys ph, int ncomp, int n, const double* __restrict__ x,
                                                      const double* __restrict__ y,
                                                      const double* __restrict__ z, double t,
                                                      double* __restrict__ out)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = tr::solution(problem, x[i], y[i], z[i], t);
+  if (i >= n) return;
+  for (int c = 0; c < ncomp; ++c) out[(size_t)i * ncomp + c] = tr::solution(ph, c, ncomp, x[i], y[i], z[i], t);
 }
 
-void launch_solution(int ncomp, const Phys& ph, int n, const double* x, const double* y, const double* z,
+void launch_solution(int pde, int ncomp, const Phys& ph, int n, const double* x, const double* y, const double* z,
                      double t, double* out, hipStream_t s)
 {
   if (n == 0) return;
-  if (ncomp == 1) { k_tr_solution<<<nblk(n, 256), 256, 0, s>>>(ph.problem, n, x, y, z, t, out); return; }
+  if (pde == 1) { k_tr_solution<<<nblk(n, 256), 256, 0, s>>>(ph, ncomp, n, x, y, z, t, out); return; }
   QDG_DISPATCH_PROB(ph.problem, (k_solution<P><<<nblk(n, 256), 256, 0, s>>>(ph, n, x, y, z, t, out)));
 }
 
-// dg::Transport::fieldOutput, src/PDE/Transport/DGTransport.hpp:248-279 (one scalar):
-// mean, Problem::solution at the centroid, (analytic - numerical)^2 * vol
-__global__ __launch_bounds__(256) void k_tr_field_output(DevMesh m, int problem, int ndof, double t,
+// dg::Transport::fieldOutput, src/PDE/Transport/DGTransport.hpp:248-279: per scalar c the mean,
+// then per scalar Problem::solution at the centroid, then per scalar (analytic - numerical)^2 * vol
+// (three blocks of ncomp fields, the order of fieldNames, DGTransport.hpp:211-246)
+__global__ __launch_bounds__(256) void k_tr_field_output(DevMesh m, Phys ph, int ndof, double t,
                                                          const double* __restrict__ U,
                                                          const double* __restrict__ geoElem, int nrows,
                                                          double* __restrict__ out)
@@ -1798,13 +1833,18 @@ __global__ __launch_bounds__(256) void k_tr_field_output(DevMesh m, int problem,
     y = (q[0][1] + q[1][1] + q[2][1] + q[3][1]) / 4.0;
     z = (q[0][2] + q[1][2] + q[2][2] + q[3][2]) / 4.0;
   }
-  const double u = U[(size_t)e * ndof], sa = tr::solution(problem, x, y, z, t);
-  out[h] = u; out[(size_t)nrows + h] = sa; out[2 * (size_t)nrows + h] = (sa - u) * (sa - u) * vol;
+  const int nc = m.ncomp;
+  for (int c = 0; c < nc; ++c) {
+    const double u = U[((size_t)e * nc + c) * ndof], sa = tr::solution(ph, c, nc, x, y, z, t);
+    out[(size_t)c * nrows + h] = u;
+    out[(size_t)(nc + c) * nrows + h] = sa;
+    out[(size_t)(2 * nc + c) * nrows + h] = (sa - u) * (sa - u) * vol;
+  }
 }
 
-int field_count(int ncomp, int problem)
+int field_count(int pde, int ncomp, int problem)
 {
-  if (ncomp == 1) return 3;
+  if (pde == 1) return 3 * ncomp;
   return problem == 3 ? 12 : problem == 4 ? 15 : problem == 7 ? 14 : problem == 10 ? 18 : problem == 0 ? 7 : 6;
 }
 
@@ -1814,13 +1854,13 @@ void launch_field_output(int ndof, const DevMesh& m, const Phys& ph, double t, c
                          const double* geoElem, int nrows, double* out, hipStream_t s)
 {
   if (nrows == 0) return;
-  if (m.ncomp == 1) {
-    k_tr_field_output<<<nblk(nrows, 256), 256, 0, s>>>(m, ph.problem, ndof, t, U, geoElem, nrows, out);
+  if (m.pde == 1) {
+    k_tr_field_output<<<nblk(nrows, 256), 256, 0, s>>>(m, ph, ndof, t, U, geoElem, nrows, out);
   } else {
     QDG_DISPATCH_PROB(ph.problem, (k_field_output<P><<<nblk(nrows, 256), 256, 0, s>>>(m, ph, ndof, t, U, geoElem, nrows, out)));
   }
   if (!geoElem && m.ndofel)
-    k_field_ndof<<<nblk(nrows, 256), 256, 0, s>>>(m, nrows, out + (size_t)field_count(m.ncomp, ph.problem) * nrows);
+    k_field_ndof<<<nblk(nrows, 256), 256, 0, s>>>(m, nrows, out + (size_t)field_count(m.pde, m.ncomp, ph.problem) * nrows);
 }
 
 void launch_avg_elem_to_node(const Phys& ph, int rdof, int nelem, int nnode, const int* inpoel,

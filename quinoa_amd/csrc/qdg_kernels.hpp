@@ -71,10 +71,10 @@ void launch_state_transfer(int nrow, int nprop, const int* d2h_to, const int* pa
                            const double* Ufrom, double* Uto, hipStream_t s);
 void launch_rows_gather(size_t n, int nprop, const int* drow, const double* U, double* packed, hipStream_t s);
 void launch_rows_scatter(size_t n, int nprop, const int* drow, const double* packed, double* U, hipStream_t s);
-void launch_solution(int ncomp, const Phys& ph, int n, const double* x, const double* y, const double* z,
+void launch_solution(int pde, int ncomp, const Phys& ph, int n, const double* x, const double* y, const double* z,
                      double t, double* out, hipStream_t s);
 // number of element fields of Problem::fieldNames (without the ndof column of p-adaptive runs)
-int field_count(int ncomp, int problem);
+int field_count(int pde, int ncomp, int problem);
 void launch_field_output(int ndof, const DevMesh& m, const Phys& ph, double t, const double* U,
                          const double* geoElem, int nrows, double* out, hipStream_t s);
 void launch_avg_elem_to_node(const Phys& ph, int rdof, int nelem, int nnode, const int* inpoel,

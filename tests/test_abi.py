@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_config_struct_matches_header():
     # struct_size is checked by the library on every qdg_ctx_create
-    assert C.sizeof(capi.qdg_config) == 4 * 8 + 2 * 8 + 9 * 8 + 8 + 8 + 6 * 8   # + pde, pref, tolref, nleg parameters
+    assert C.sizeof(capi.qdg_config) == 4 * 8 + 2 * 8 + 9 * 8 + 8 + 8 + 6 * 8 + 8 + 3 * 8   # + pde, pref, tolref, nleg parameters, ncomp, shear_diff arrays
 
 
 def test_no_silent_cpu_fallback():
