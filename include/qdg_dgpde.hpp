@@ -407,7 +407,11 @@ class DeviceDG {
   //! DGPDE::names: labels of the integral variables in the diagnostics file
   std::vector<std::string> names() const
   {
-    if (PDE == QDG_PDE_TRANSPORT) return { "c0" };
+    if (PDE == QDG_PDE_TRANSPORT) {            // depvar + component (DGTransport.hpp:282-291)
+      std::vector<std::string> n;
+      for (std::size_t c = 0; c < m_deck.ncomp; ++c) n.push_back("c" + std::to_string(c));
+      return n;
+    }
     return { "r", "ru", "rv", "rw", "re" };
   }
 

@@ -117,13 +117,45 @@ int main(int argc, char** argv)
     for (int s = 0; s < 2; ++s) { qdg::check(qdg_step(tm, tt, 1e300, &tdts[s])); tt += tdts[s]; }
     qdg::check(qdg_state_download(tm, Ut2.data().data()));
 
+    // dg::Transport with two scalars, ShearDiff (component::transport 2; param::transport u0, lambda,
+    // diffusivity per scalar), DG-P1, started at t0 = 1
+    qdg::InputDeck sdeck;
+    sdeck.ndof = sdeck.rdof = 4;
+    sdeck.flux = QDG_FLUX_UPWIND;
+    sdeck.dt = 2.0e-3;
+    sdeck.bcdir = { "1", "2", "3", "4", "5", "6" };
+    sdeck.ncomp = 2;
+    sdeck.u0 = { 0.7, -0.3 }; sdeck.lambda = { 0.4, 0.1, -0.2, 0.3 };
+    sdeck.diffusivity = { 3.0, 2.0, 1.0, 1.5, 2.5, 0.8 };
+    qdg::dg::TransportHIP<qdg::dg::Advection, qdg::dg::ShearDiff> sq(0, sdeck);
+    qdg::Fields Ls(nelem, 8), Us(nelem, 8), Us2(nelem, 8);
+    sq.lhs(geoElem, Ls);
+    sq.initialize(Ls, inpoel, coord, Us, 1.0, nelem);
+    std::vector<std::size_t> ndofel4(nelem, 4);
+    (void)sq.dt(coord, inpoel, fd, geoFace, geoElem, ndofel4, Us);    // attaches the chare's mesh (as DG::dt does)
+    qdg_mesh* sm = sq.handle(inpoel);
+    qdg::check(qdg_state_upload(sm, Us.data().data()));
+    double st = 1.0, sdt = 0.0;
+    for (int s = 0; s < 2; ++s) { qdg::check(qdg_step(sm, st, 1e300, &sdt)); st += sdt; }
+    qdg::check(qdg_state_download(sm, Us2.data().data()));
+    const auto ssol = sq.analyticSolution(0.3, 0.2, 0.1, 1.5);
+    if (ssol.size() != 2 || sq.fieldNames().size() != 6) throw std::runtime_error("two-scalar Transport: wrong shapes");
+    bool sthrew = false;
+    try {
+      qdg::InputDeck bad = sdeck; bad.lambda.pop_back();
+      qdg::dg::TransportHIP<qdg::dg::Advection, qdg::dg::ShearDiff> b(0, bad);
+    } catch (const qdg::Exception&) { sthrew = true; }
+    if (!sthrew) throw std::runtime_error("ShearDiff errchk did not throw");
+
     FILE* o = fopen(argv[2], "wb");
     wr(o, L.data()); wr(o, U.data()); wr(o, R.data()); wr(o, Ulim.data()); wr(o, U2.data());
     wr(o, std::vector<double>{ dt, dts[0], dts[1], threw ? 1.0 : 0.0 });
     wr(o, Lt.data()); wr(o, Ut.data()); wr(o, Rt.data()); wr(o, Ut2.data());
     wr(o, std::vector<double>{ tdt, tdts[0], tdts[1] });
     wr(o, fout[0]); wr(o, fout[5]); wr(o, asol);
+    wr(o, Us.data()); wr(o, Us2.data()); wr(o, ssol);
     fclose(o);
+    sq.release(inpoel);
     tq.release(inpoel);
     eq.release(inpoel);
     printf("adapter ok: %zu tets, %zu faces, %zu boundary faces, dt=%.6e\n", nelem, fd.Nipfac(), nb, dt);

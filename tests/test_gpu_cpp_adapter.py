@@ -46,7 +46,7 @@ def test_cpp_adapter_matches_oracle(tmp_path):
     out = tmp_path / "out.bin"
     r = subprocess.run([EXE, str(mesh), str(out)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
-    L, U, R, Ulim, U2, sc, Lt, Ut, Rt, Ut2, tsc, f_rho, f_p, asol = _read_vecs(out)
+    L, U, R, Ulim, U2, sc, Lt, Ut, Rt, Ut2, tsc, f_rho, f_p, asol, Us, Us2, ssol = _read_vecs(out)
     kw = dict(flux="hllc", limiter="superbeep1", problem="sod_shocktube", gamma=1.4)
     om = O.OracleMesh(coord, inpoel, ch["sidesets"])
     orc = O.Oracle(om, O.make_cfg(4, **kw), bc_sym=[3, 4, 5, 6], bc_extrapolate=[1, 2])
@@ -79,6 +79,16 @@ def test_cpp_adapter_matches_oracle(tmp_path):
     r2 = O.run_transport_case(tcase, tfix, nstep=2)
     assert np.abs(Ut2 - r2["U"]).max() <= 1e-12
     assert np.isfinite(Rt).all() and np.abs(Rt).max() > 0.0
+
+    # TransportHIP with two scalars, ShearDiff (DG-P1, t0 = 1): initial condition and two steps vs the oracle
+    scase = dict(ndof=4, ncomp=2, problem="shear_diff", dt=2.0e-3, nstep=2, t0=1.0, u0=[0.7, -0.3],
+                 **{"lambda": [0.4, 0.1, -0.2, 0.3]}, diffusivity=[3.0, 2.0, 1.0, 1.5, 2.5, 0.8],
+                 bc_dirichlet=[1, 2, 3, 4, 5, 6], bc_extrapolate=[], bc_inlet=[], bc_outlet=[])
+    s0 = O.run_transport_multi(scase, tfix, nstep=0)
+    s2 = O.run_transport_multi(scase, tfix)
+    assert np.abs(Us - s0["U"]).max() <= 1e-13 * max(1.0, np.abs(s0["U"]).max())
+    assert np.abs(Us2 - s2["U"]).max() <= 1e-11 * max(1.0, np.abs(s2["U"]).max())
+    assert ssol.shape == (2,) and (ssol > 0.0).all()
 
     # output-side members: fieldOutput on the final state, analyticSolution (Sod left state)
     fo = orc.field_output(U2)
