@@ -136,6 +136,13 @@ const char* qdg_version(void);
 
 int qdg_ctx_create(const qdg_config* cfg, qdg_ctx** out);
 int qdg_ctx_destroy(qdg_ctx* ctx);
+/* Device buffers freed by the library (meshes closed, temporaries of a mesh build) are kept for the
+ * next allocation: on this platform hipMalloc of VRAM the process has used before costs ~34 ms per GiB,
+ * which a re-mesh (DG::resizePostAMR's new Discretization, src/Inciter/DG.cpp:1537-1612) would pay on
+ * every buffer.  The cache holds at most 40 % of the device's memory and is returned to the driver when an
+ * allocation fails or by this call (released_bytes may be NULL) -- not with the last context: the next one
+ * would pay the driver again. */
+int qdg_device_pool_trim(size_t* released_bytes);
 /* run all kernels of this context on an existing HIP stream (hipStream_t) */
 int qdg_ctx_set_stream(qdg_ctx* ctx, void* hip_stream);
 int qdg_ctx_synchronize(qdg_ctx* ctx);

@@ -71,6 +71,14 @@ def lib():
     return _lib
 
 
+def device_pool_trim():
+    """qdg_device_pool_trim: hand the library's cache of freed device buffers back to the driver;
+    returns the bytes released"""
+    n = C.c_size_t()
+    _chk(lib().qdg_device_pool_trim(C.byref(n)))
+    return n.value
+
+
 def _chk(rc):
     if rc != 0:
         raise QdgError(lib().qdg_last_error().decode())

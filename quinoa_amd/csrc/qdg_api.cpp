@@ -202,6 +202,15 @@ extern "C" int qdg_ctx_destroy(qdg_ctx* ctx)
   QDG_CATCH
 }
 
+extern "C" int qdg_device_pool_trim(size_t* released_bytes)
+{
+  QDG_TRY
+  const size_t n = qdg::DevicePool::get().trim();
+  if (released_bytes) *released_bytes = n;
+  return 0;
+  QDG_CATCH
+}
+
 extern "C" int qdg_ctx_set_stream(qdg_ctx* ctx, void* s)
 {
   QDG_TRY

@@ -55,8 +55,8 @@ namespace {
 
 template <class T> struct Buf {
   T* p = nullptr;
-  ~Buf() { if (p) (void)hipFree(p); }
-  hipError_t alloc(size_t n) { return hipMalloc((void**)&p, (n ? n : 1) * sizeof(T)); }
+  ~Buf() { if (p) qdg::dev_free(p); }
+  hipError_t alloc(size_t n) { return qdg::dev_alloc((void**)&p, (n ? n : 1) * sizeof(T)); }
 };
 
 __constant__ int c_lpofa[4][3] = { { 1, 2, 3 }, { 2, 0, 3 }, { 3, 0, 1 }, { 0, 2, 1 } };

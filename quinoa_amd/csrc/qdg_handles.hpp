@@ -12,6 +12,7 @@
 #include "../../include/qdg.h"
 #include "qdg_device.hpp"
 #include "qdg_host.hpp"
+#include "qdg_pool.hpp"
 
 namespace qdg {
 
@@ -22,13 +23,13 @@ template <class T> struct DevBuf {
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
-  ~DevBuf() { if (p) (void)hipFree(p); }
+  ~DevBuf() { if (p) dev_free(p); }
   hipError_t alloc(size_t count)
   {
-    if (p) { (void)hipFree(p); p = nullptr; }
+    if (p) { dev_free(p); p = nullptr; }
     n = count;
     if (count == 0) return hipSuccess;
-    return hipMalloc((void**)&p, count * sizeof(T));
+    return dev_alloc((void**)&p, count * sizeof(T));
   }
   hipError_t upload(const std::vector<T>& h, hipStream_t s)
   {
