@@ -295,7 +295,9 @@ def _amr_single(nx, steps, ne0, ne1, ms0, ms1, th, tr, tt, ok):
                     "refined mesh copied back to the host, where AMR bookkeeping stays; rebuild = "
                     "qdg_mesh_from_connectivity on the refined mesh, all on the device: boundary faces, "
                     "FaceData, geometry, Morton order, numbering, face tasks (only connectivity + "
-                    "coordinates cross PCIe); transfer = qdg_state_transfer (child <- parent, device)"}
+                    "coordinates cross PCIe); transfer = qdg_state_transfer (child <- parent, device). "
+                    "The rebuild includes hipMalloc of the new mesh's buffers: ~34 ms per GiB on VRAM that any "
+                    "process on the box has used before (driver scrubbing; DESIGN.md section 6)"}
 
 
 def config3_point(local_rank, nx=110, steps=20):
