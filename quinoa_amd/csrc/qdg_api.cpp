@@ -309,7 +309,8 @@ int mesh_alloc_state(qdg_mesh* m, int ntile)
   hipStream_t s = m->ctx->stream;
   const size_t fsz = (size_t)m->nprop * m->stride;
   HIPCHK(m->U.alloc(fsz)); HIPCHK(m->Un.alloc(fsz)); HIPCHK(m->R.alloc(fsz)); HIPCHK(m->W.alloc(fsz));
-  HIPCHK(m->aos.alloc(m->ne * (size_t)m->nprop));
+  // (m->aos, the staging buffer of rows in the caller's numbering, is allocated by its first user:
+  // a resident loop that never moves the state to the host does not pay for it)
   HIPCHK(hipMemsetAsync(m->U.p, 0, fsz * sizeof(double), s));
   HIPCHK(hipMemsetAsync(m->Un.p, 0, fsz * sizeof(double), s));
   HIPCHK(hipMemsetAsync(m->R.p, 0, fsz * sizeof(double), s));
@@ -690,10 +691,17 @@ extern "C" int qdg_mesh_destroy(qdg_mesh* mesh)
   (void)s
 
 // host AoS (all ne rows) -> SoA planes `dst`
+static int ensure_aos(qdg_mesh* mesh)
+{
+  if (!mesh->aos.p) HIPCHK(mesh->aos.alloc(mesh->ne * (size_t)mesh->nprop));
+  return 0;
+}
+
 static int host_to_planes(qdg_mesh* mesh, const double* aos_host, double* dst)
 {
   hipStream_t s = mesh->ctx->stream;
   const size_t n = mesh->ne * (size_t)mesh->nprop;
+  if (int rc = ensure_aos(mesh)) return rc;
   HIPCHK(hipMemcpyAsync(mesh->aos.p, aos_host, n * sizeof(double), hipMemcpyHostToDevice, s));
   launch_aos2soa(mesh->aos.p, mesh->nprop, mesh->d2h.p, 0, (int)mesh->ne, (int)mesh->stride, dst, s);
   HIPCHK(hipGetLastError());
@@ -707,6 +715,7 @@ static int planes_to_host(qdg_mesh* mesh, const double* src, size_t nrows, doubl
 {
   hipStream_t s = mesh->ctx->stream;
   const size_t n = mesh->ne * (size_t)mesh->nprop;
+  if (int rc = ensure_aos(mesh)) return rc;
   if (zero_rest && nrows < mesh->ne)
     HIPCHK(hipMemsetAsync(mesh->aos.p, 0, n * sizeof(double), s));
   launch_soa2aos(src, mesh->nprop, mesh->d2h.p, 0, (int)nrows, (int)mesh->stride, mesh->aos.p, s);
