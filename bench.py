@@ -480,6 +480,12 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_source,
                          "avg_launch_ms": w["avg_ms"], "launches": w["launches"],
                          "algorithmic_bytes_per_launch": w["alg"]},
+            # the three readings of "element update" -- `value` is the full-stage rate (limiter +
+            # dt + RHS + RK update + halo: every tet through every RK stage, over the wall time of the step);
+            # the RHS-only rate divides by the time of the RHS kernels alone; per time step = value / 3
+            "rates": {"full_stage_M_per_s": w["ntet"] * 3 * args.steps / w["el"] / 1e6,
+                      "rhs_only_M_per_s_rank0": w["ntet_local"] / (w["avg_ms"] * 1e-3) / 1e6,
+                      "per_time_step_M_per_s": w["ntet"] * args.steps / w["el"] / 1e6},
             "dt_last": w["dt_last"],
             "check": {"mass_drift": float(w["drift"][0]), "energy_drift": float(w["drift"][1]),
                       "note": "relative change of total mass / total energy over the whole run "
@@ -495,6 +501,9 @@ def main():
                 "steps": ns["steps"], "warmup": ns["warmup"],
                 "value": ns["ntet"] * 3 * ns["steps"] / ns["el"] / 1e6, "unit": "M element-updates/s",
                 "ms_per_step": ns["el"] / ns["steps"] * 1e3,
+                "rates": {"full_stage_M_per_s": ns["ntet"] * 3 * ns["steps"] / ns["el"] / 1e6,
+                          "rhs_only_M_per_s_rank0": ns["ntet_local"] / (ns["avg_ms"] * 1e-3) / 1e6,
+                          "per_time_step_M_per_s": ns["ntet"] * ns["steps"] / ns["el"] / 1e6},
                 "roofline": {"bound": "hbm", "kernel": "qdg::k_rhs_p1w on rank 0's chunk", "achieved": a2,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": f2, "avg_launch_ms": ns["avg_ms"],
                              "launches": ns["launches"], "algorithmic_bytes_per_launch": ns["alg"],
