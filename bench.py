@@ -40,6 +40,21 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+# Second reading beside the HBM roofline (the as-written algorithm sits at the fp64 ridge): the
+# kernels' vector-instruction counts against the chip's issue rate.  A wave64 fp64 instruction occupies its SIMD
+# for 4 cycles (tools/ubench_fp64.hip: 4.2 measured), so 1024 SIMDs at the 2.4 GHz peak clock issue at most
+# 614.4 G wave instructions per second.  Instructions per tet from the committed PMC passes (SQ_INSTS_VALU per
+# launch / tets: profiles/r03_nx119_pmc_per_launch.json, profiles/r03_cfg3_nx110_pmc_per_launch.json).
+VALU_ISSUE_PEAK_G = 1024 * 2.4 / 4.0
+VALU_WAVE_INSTR_PER_TET = {"p1": 40.9, "p2": 241.5}
+
+
+def valu_reading(kind, tets, avg_ms):
+    ach = VALU_WAVE_INSTR_PER_TET[kind] * tets / (avg_ms * 1e-3) / 1e9
+    return {"wave_instructions_per_tet": VALU_WAVE_INSTR_PER_TET[kind], "achieved_G_wave_instr_per_s": ach,
+            "issue_peak_G_wave_instr_per_s": VALU_ISSUE_PEAK_G, "frac_of_issue_peak": ach / VALU_ISSUE_PEAK_G,
+            "source": "SQ_INSTS_VALU of the committed rocprofv3 --pmc passes (profiles/r03_*_pmc_per_launch.json); "
+                      "a wave64 fp64 instruction holds its SIMD for 4 cycles"}
 
 
 def cpu_baseline(budget_s=10.0, budget_all_s=5.0):
@@ -336,7 +351,9 @@ def config3_point(local_rank, nx=110, steps=20):
                                                    "counted per launch)",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "avg_launch_ms": ms / nl, "launches": nl, "algorithmic_bytes_per_launch": alg,
-                         "traffic": None}}
+                         "traffic": None,
+                         # what bounds this kernel is the vector unit, not HBM
+                         "fp64_issue": valu_reading("p2", ne, ms / nl)}}
 
 
 def config4_point(local_rank, nx=110, steps=20):
@@ -479,7 +496,8 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac,
                          "traffic": traffic, "traffic_source": traffic_source,
                          "avg_launch_ms": w["avg_ms"], "launches": w["launches"],
-                         "algorithmic_bytes_per_launch": w["alg"]},
+                         "algorithmic_bytes_per_launch": w["alg"],
+                         "fp64_issue": valu_reading("p1", w["ntet_local"], w["avg_ms"])},
             # the three readings of "element update" -- `value` is the full-stage rate (limiter +
             # dt + RHS + RK update + halo: every tet through every RK stage, over the wall time of the step);
             # the RHS-only rate divides by the time of the RHS kernels alone; per time step = value / 3
@@ -507,7 +525,7 @@ def main():
                 "roofline": {"bound": "hbm", "kernel": "qdg::k_rhs_p1w on rank 0's chunk", "achieved": a2,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": f2, "avg_launch_ms": ns["avg_ms"],
                              "launches": ns["launches"], "algorithmic_bytes_per_launch": ns["alg"],
-                             "traffic": None},
+                             "traffic": None, "fp64_issue": valu_reading("p1", ns["ntet_local"], ns["avg_ms"])},
                 "check": {"mass_drift": float(ns["drift"][0]), "energy_drift": float(ns["drift"][1])},
             }
         if world == 1 and not args.no_amr and not args.self_halo:
