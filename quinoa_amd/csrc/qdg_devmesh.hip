@@ -178,7 +178,7 @@ __global__ void k_geoface(const uint64_t* __restrict__ inpofa, size_t nfac, cons
 // src/Mesh/DerivedData.cpp:1436-1491: volume triple(ba,ca,da)/6 and centroid
 __global__ void k_geoelem(const uint64_t* __restrict__ inpoel, size_t nelem, const double* __restrict__ x,
                           const double* __restrict__ y, const double* __restrict__ z,
-                          double* __restrict__ geoElem)
+                          double* __restrict__ geoElem, int* __restrict__ err)
 {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= nelem) return;
@@ -189,7 +189,9 @@ __global__ void k_geoelem(const uint64_t* __restrict__ inpoel, size_t nelem, con
   const double cx = ca[1] * da[2] - ca[2] * da[1];
   const double cy = ca[2] * da[0] - ca[0] * da[2];
   const double cz = ca[0] * da[1] - ca[1] * da[0];
-  geoElem[4*e]   = (ba[0] * cx + ba[1] * cy + ba[2] * cz) / 6.0;
+  const double vol = (ba[0] * cx + ba[1] * cy + ba[2] * cz) / 6.0;
+  if (!(vol > 0.0)) atomicMax(err, 3);          // the reference asserts a positive Jacobian (DerivedData.cpp:1478-1480)
+  geoElem[4*e]   = vol;
   geoElem[4*e+1] = (x[A] + x[B] + x[C] + x[D]) / 4.0;
   geoElem[4*e+2] = (y[A] + y[B] + y[C] + y[D]) / 4.0;
   geoElem[4*e+3] = (z[A] + z[B] + z[C] + z[D]) / 4.0;
@@ -206,6 +208,7 @@ struct DevFD {
   Buf<int> esuel, esuf;
   size_t nelem = 0, nnode = 0, nbfac = 0, nipfac = 0;
   size_t nie = 0;     // owned tets [0, nie); ghosts [nie, nelem) (nie == nelem: a chunk without ghosts)
+  bool nonpos_vol = false;   // some tet has a non-positive volume (an error for a mesh to compute on)
 };
 
 // connectivity and coordinates of a chunk to the device (validated on the host first)
@@ -414,10 +417,13 @@ static int dev_facedata_from(qdg_ctx* ctx, DevFD& fd)
                                                  fd.esuf.p, fd.belem.p, d_err.p);
   // ---- geometry ----------------------------------------------------------------------
   k_geoface<<<nblk(nipfac), 256, 0, s>>>(fd.inpofa.p, nipfac, fd.x.p, fd.y.p, fd.z.p, fd.geoFace.p);
-  k_geoelem<<<nblk(nelem), 256, 0, s>>>(fd.inpoel.p, nelem, fd.x.p, fd.y.p, fd.z.p, fd.geoElem.p);
+  k_geoelem<<<nblk(nelem), 256, 0, s>>>(fd.inpoel.p, nelem, fd.x.p, fd.y.p, fd.z.p, fd.geoElem.p, d_err.p);
   DHIP(hipGetLastError());
   DHIP(hipMemcpyAsync(&herr, d_err.p, sizeof(int), hipMemcpyDeviceToHost, s));
   DHIP(hipStreamSynchronize(s));
+  // (qdg_dev_facedata itself is a statement about connectivity: the reference's derived-data unit meshes
+  // are not all positively oriented; the mesh BUILD refuses such a tet)
+  fd.nonpos_vol = herr == 3;
   if (herr == 2) return fail("qdg_dev_facedata: a boundary face is not a face of any tet");
   return 0;
 }
@@ -1161,6 +1167,9 @@ extern "C" int qdg_mesh_from_chunk(qdg_ctx* ctx, size_t nielem, size_t nelem, si
     if (int rc = dev_bnd_faces(ctx, fd, ntri, tri, tri_set, fset)) return rc;
     lap("boundary faces (device)");
     if (int rc = dev_facedata_from(ctx, fd)) return rc;
+    if (fd.nonpos_vol)
+      return fail("qdg_mesh_from_connectivity: non-positive element volume (inverted or degenerate tet; the "
+                  "reference asserts a positive Jacobian, src/Mesh/DerivedData.cpp:1478-1480)");
     lap("FaceData + geometry (device)");
     // BC type per boundary face: bndSurfInt over the configured side sets of each type
     // (src/PDE/Integrate/Boundary.cpp:84-90); faces of unconfigured sets get no flux

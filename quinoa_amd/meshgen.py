@@ -53,6 +53,47 @@ for _perm in itertools.permutations(range(3)):
 _KUHN = np.array(_KUHN)            # [6 tets][4 nodes][3 ijk offsets]
 
 
+def _unit_jitter(i, j, k, nx, ny, nz, jitter, seed):
+    """jitter of global node (i, j, k) in units of the cell size, [.., 3]; zero on the boundary"""
+    g = (i + (nx + 1) * (j + (ny + 1) * k)).astype(np.uint64) + np.uint64(seed) * np.uint64(1000003)
+    inner = (i > 0) & (i < nx) & (j > 0) & (j < ny) & (k > 0) & (k < nz)
+    return np.stack([np.where(inner, (2 * _uniform(g, a) - 1) * jitter, 0.0) for a in range(3)], axis=-1)
+
+
+def _near_flat_hex_corner(ni, nj, nk, nx, ny, nz, jitter, seed, frac=0.02):
+    """True for the nodes (global indices ni, nj, nk) that are a corner of a hex with a Kuhn tet whose
+    volume, under the plain jitter, is below `frac` of the nominal h^3/6.  Evaluated on the index box of
+    the given nodes grown by one hex, from global ids only (cell-size units: a unit hex)."""
+    lo = [max(int(v.min()) - 1, 0) for v in (ni, nj, nk)]
+    hi = [min(int(v.max()) + 1, n) for v, n in zip((ni, nj, nk), (nx, ny, nz))]      # node index range
+    out = np.zeros(len(ni), dtype=bool)
+    nhx, nhy = hi[0] - lo[0], hi[1] - lo[1]
+    if nhx <= 0 or nhy <= 0 or hi[2] - lo[2] <= 0:
+        return out
+    bad_nodes = set()
+    for k in range(lo[2], hi[2]):                                                       # slab of hexes k
+        I, J = np.meshgrid(np.arange(lo[0], hi[0]), np.arange(lo[1], hi[1]), indexing="ij")
+        I, J = I.ravel(), J.ravel()
+        K = np.full_like(I, k)
+        # corner positions of the unit hexes: ijk offset + jitter
+        P = {}
+        for di, dj, dk in itertools.product((0, 1), repeat=3):
+            P[(di, dj, dk)] = np.array([di, dj, dk], dtype=float) + _unit_jitter(I + di, J + dj, K + dk, nx, ny, nz, jitter, seed)
+        flat = np.zeros(len(I), dtype=bool)
+        for t in _KUHN:
+            p0, p1, p2, p3 = (P[tuple(int(x) for x in v)] for v in t)
+            vol = np.einsum("ij,ij->i", p1 - p0, np.cross(p2 - p0, p3 - p0))          # 6 x volume, nominal 1
+            flat |= vol < frac
+        for h in np.nonzero(flat)[0]:
+            for di, dj, dk in itertools.product((0, 1), repeat=3):
+                bad_nodes.add((int(I[h]) + di, int(J[h]) + dj, k + dk))
+    if bad_nodes:
+        b = np.array(sorted(bad_nodes), dtype=np.int64)
+        key = lambda a, c, d: a + (nx + 1) * (c + (ny + 1) * d)
+        out = np.isin(key(ni, nj, nk), key(b[:, 0], b[:, 1], b[:, 2]))
+    return out
+
+
 def _block_ranges(n, p):
     edges = [(n * i) // p for i in range(p + 1)]
     return [(edges[i], edges[i + 1]) for i in range(p)]
@@ -175,9 +216,14 @@ def kuhn_box_chunk(nx, ny, nz, lengths=(1.0, 1.0, 1.0), parts=(1, 1, 1), rank=0,
     interior = (ni > 0) & (ni < nx) & (nj > 0) & (nj < ny) & (nk > 0) & (nk < nz)
     if jitter > 0:
         gid64 = g_used.astype(np.uint64) + np.uint64(seed) * np.uint64(1000003)
-        cx = cx + np.where(interior, (2 * _uniform(gid64, 0) - 1) * jitter * hx, 0.0)
-        cy = cy + np.where(interior, (2 * _uniform(gid64, 1) - 1) * jitter * hy, 0.0)
-        cz = cz + np.where(interior, (2 * _uniform(gid64, 2) - 1) * jitter * hz, 0.0)
+        # a node keeps its jitter unless one of the (up to 8) hexes around it would get a Kuhn tet of
+        # less than 2 % of the nominal volume -- one tet in 6.4e7 at 0.2 h comes out inverted (found at
+        # 220^3), and DerivedData.cpp:1478-1480 requires positive volumes.  The rule is a function of
+        # global ids alone (the jitter of any node can be evaluated anywhere), so all ranks agree.
+        keep = interior & ~_near_flat_hex_corner(ni, nj, nk, nx, ny, nz, jitter, seed)
+        cx = cx + np.where(keep, (2 * _uniform(gid64, 0) - 1) * jitter * hx, 0.0)
+        cy = cy + np.where(keep, (2 * _uniform(gid64, 1) - 1) * jitter * hy, 0.0)
+        cz = cz + np.where(keep, (2 * _uniform(gid64, 2) - 1) * jitter * hz, 0.0)
     coord = np.zeros((nn, 3))
     coord[nperm, 0], coord[nperm, 1], coord[nperm, 2] = cx, cy, cz
 

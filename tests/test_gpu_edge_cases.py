@@ -148,3 +148,19 @@ def test_device_buffer_cache_is_reused_and_can_be_trimmed():
     assert np.array_equal(states[0], states[1]) or np.abs(states[0] - states[1]).max() <= 1e-13
     assert capi.device_pool_trim() > 0          # the closed mesh's buffers were cached ...
     assert capi.device_pool_trim() == 0         # ... and are gone now
+
+
+def test_device_mesh_build_refuses_an_inverted_tet():
+    """A tet with non-positive volume (the reference asserts a positive Jacobian, DerivedData.cpp:1478-1480;
+    a CFL step over it is negative) is an input error of the device mesh build too, as it is of qdg_mesh_upload."""
+    from quinoa_amd import capi, meshgen
+    ch = meshgen.kuhn_box(3, 3, 3)
+    inp = ch["inpoel"].copy()
+    inp[5, [2, 3]] = inp[5, [3, 2]]                 # the same four nodes, orientation flipped
+    ctx = capi.Context(4, flux="hllc", problem="sod_shocktube", gamma=1.4, cfl=0.3,
+                       bc_extrapolate=[1, 2], bc_sym=[3, 4, 5, 6])
+    try:
+        with pytest.raises(capi.QdgError, match="non-positive element volume"):
+            capi.mesh_from_connectivity(ctx, inp, ch["coord"], ch["sidesets"])
+    finally:
+        ctx.close()

@@ -152,3 +152,33 @@ def test_synthetic_chunks_cover_mesh_and_halo_plans_agree():
             assert (ck.esuel >= c["nielem"]).sum() == ck.nfac - ck.nipfac
             vol += ck.meshvol
         assert abs(vol - 1.0) < 1e-12
+
+
+def test_synthetic_mesh_generator_has_no_inverted_tets_and_chunks_agree():
+    """meshgen.kuhn_box_chunk: a node whose jitter would give a hex a (nearly) inverted Kuhn tet keeps its
+    regular position (found at 220^3: one tet in 6.4e7 inverted at 0.2 h).  The rule is evaluated from global
+    ids, so every rank of a decomposition places every node exactly where the single-chunk mesh has it."""
+    from quinoa_amd import meshgen
+    dims = (6, 5, 4)
+
+    def vols(ch):
+        c, t = ch["coord"], ch["inpoel"]
+        a, b, d = c[t[:, 1]] - c[t[:, 0]], c[t[:, 2]] - c[t[:, 0]], c[t[:, 3]] - c[t[:, 0]]
+        return np.einsum("ij,ij->i", a, np.cross(b, d)) / 6.0
+
+    nominal = 1.0 / (6 * dims[0] * dims[1] * dims[2])
+    assert vols(meshgen.kuhn_box(*dims)).min() > 0.02 * nominal
+    for jit in (0.2, 0.45):                       # 0.45 h: the rule fires for many hexes
+        one = meshgen.kuhn_box_chunk(*dims, parts=(1, 1, 1), rank=0, jitter=jit)
+        cen = np.zeros((6 * dims[0] * dims[1] * dims[2], 3))
+        cen[one["gid"]] = one["coord"][one["inpoel"]].mean(axis=1)
+        for r in range(4):
+            ch = meshgen.kuhn_box_chunk(*dims, parts=(2, 2, 1), rank=r, jitter=jit)
+            got = ch["coord"][ch["inpoel"]].mean(axis=1)          # owned and ghost tets
+            assert np.abs(got - cen[ch["gid"]]).max() < 1e-15
+    # the rule changes something at 0.45 h and nothing at 0.2 h on this box
+    plain = meshgen._unit_jitter(*np.meshgrid(np.arange(7), np.arange(6), np.arange(5), indexing="ij"), 6, 5, 4, 0.45, 12345)
+    assert np.abs(plain).max() > 0.3
+    I, J, K = (a.ravel() for a in np.meshgrid(np.arange(7), np.arange(6), np.arange(5), indexing="ij"))
+    assert meshgen._near_flat_hex_corner(I, J, K, 6, 5, 4, 0.45, 12345).any()
+    assert not meshgen._near_flat_hex_corner(I, J, K, 6, 5, 4, 0.2, 12345).any()
