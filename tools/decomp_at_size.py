@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""The bench's block decomposition at its REAL size on one GPU: all px*py*pz chunks of the nx^3 Kuhn box
+(meshgen.kuhn_box_chunk, device-built chunk meshes with ghost halos, dg.LocalChunks: qdg_halo_copy as the
+transport) against the single-chunk run of the same global mesh -- states compared tet by tet through the
+global ids after a few CFL steps.  What the 8-GPU runs of the north-star box (119^3) and of config 4
+(220^3, Sedov) compute, minus RCCL.
+Usage: python tools/decomp_at_size.py NX PX PY PZ [sod|sedov] [steps]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+from quinoa_amd import capi, dg, meshgen  # noqa: E402
+
+nx = int(sys.argv[1]); parts = tuple(int(a) for a in sys.argv[2:5])
+work = sys.argv[5] if len(sys.argv) > 5 else "sod"
+steps = int(sys.argv[6]) if len(sys.argv) > 6 else 3
+kw = dict(flux="hllc", limiter="superbeep1", gamma=1.4, cfl=0.3)
+if work == "sedov":
+    kw.update(problem="sedov_blastwave", bc_extrapolate=[2, 4], bc_sym=[1, 3, 5, 6])
+else:
+    kw.update(problem="sod_shocktube", bc_extrapolate=[1, 2], bc_sym=[3, 4, 5, 6])
+nr = parts[0] * parts[1] * parts[2]
+ntet = 6 * nx ** 3
+t0 = time.perf_counter()
+ctx = capi.Context(4, **kw)
+chunks, meshes = [], []
+for r in range(nr):
+    c = meshgen.kuhn_box_chunk(nx, nx, nx, parts=parts, rank=r)
+    m = capi.mesh_from_connectivity(ctx, c["inpoel"], c["coord"], c["sidesets"], nielem=c["nielem"])
+    # keep only what the comparison and the halo plan need
+    chunks.append({k: c[k] for k in ("nielem", "gid", "nbr_rank", "send_lists", "recv_counts")})
+    meshes.append(m)
+    print("chunk %d: %d owned + %d ghost tets, %d neighbours  (%.0f s)" % (
+        r, c["nielem"], len(c["gid"]) - c["nielem"], len(c["nbr_rank"]), time.perf_counter() - t0), flush=True)
+    del c
+for m in meshes:
+    m.state_initialize(0.0)
+drv = dg.LocalChunks(ctx, meshes, chunks)
+t, dts = 0.0, []
+for _ in range(steps):
+    dt = drv.step(t); dts.append(dt); t += dt
+ctx.synchronize()
+ref = np.zeros((ntet, 20))
+seen = np.zeros(ntet, dtype=np.int8)
+for c, m in zip(chunks, meshes):
+    nie = c["nielem"]
+    ref[c["gid"][:nie]] = m.state_download().reshape(-1, 20)[:nie]
+    seen[c["gid"][:nie]] += 1
+    m.close()
+assert (seen == 1).all(), "every tet owned exactly once"
+print("decomposition ran: dt", dts, " (%.0f s)" % (time.perf_counter() - t0), flush=True)
+one = meshgen.kuhn_box_chunk(nx, nx, nx, parts=(1, 1, 1), rank=0)
+ctx1 = capi.Context(4, **kw)
+m1 = capi.mesh_from_connectivity(ctx1, one["inpoel"], one["coord"], one["sidesets"])
+gid1 = one["gid"].copy()
+cen1 = one["coord"][one["inpoel"]].mean(axis=1)
+del one
+m1.state_initialize(0.0)
+t1, dts1 = 0.0, []
+for _ in range(steps):
+    dt = m1.step(t1); dts1.append(dt); t1 += dt
+U1 = m1.state_download().reshape(-1, 20)
+err = np.abs(U1 - ref[gid1]).max() / max(1.0, np.abs(U1).max())
+print("single chunk: dt", dts1)
+d = np.abs(U1 - ref[gid1]).max(axis=1)
+bad = d > 1e-10 * max(1.0, np.abs(U1).max())
+if bad.any():
+    # where the two runs differ: HLLC's NaN fall-through (HLLC.hpp:93-124) takes the STORED right state, and which
+    # tet of a face is stored as left depends on the local numbering, i.e. on the decomposition
+    print("tets that differ by more than 1e-10: %d of %d, centroids within x [%.4f, %.4f] y [%.4f, %.4f] z [%.4f, %.4f]; "
+          "non-finite wave speeds possible where the P1 state has p < 0" % (
+              bad.sum(), len(bad), cen1[bad, 0].min(), cen1[bad, 0].max(), cen1[bad, 1].min(), cen1[bad, 1].max(),
+              cen1[bad, 2].min(), cen1[bad, 2].max()))
+print("nx %d (%d tets) %s in %dx%dx%d chunks vs single chunk after %d steps: max |dU| / max|U| = %.2e, |dt - dt1| / dt1 = %.1e  (%.0f s)"
+      % ((nx, ntet, work) + parts + (steps, err, max(abs(a - b) / b for a, b in zip(dts, dts1)), time.perf_counter() - t0)), flush=True)
+m1.close(); ctx.close(); ctx1.close()
+sys.exit(0 if err <= 1e-10 else 1)
