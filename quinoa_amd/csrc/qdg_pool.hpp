@@ -5,12 +5,13 @@
 // one out of dozens of temporaries, and paid that on every allocation: the device build of an 80.9 M-tet
 // mesh took 5.3 s in a process that had run other meshes before, 1.25 s in a fresh one.  Freed blocks
 // are therefore kept and handed out again (best fit within 25 % of the request), up to 40 % of the
-// device's memory; the cache is emptied when an allocation fails (then retried) or through
+// device's memory (and at most half of what was free at the process's first allocation); the cache is emptied when an allocation fails (then retried) or through
 // qdg_device_pool_trim -- not when the last context goes away: the next one would pay the driver again.  hipFree synchronises the device; a cached block that is handed out again does
 // the same (hipDeviceSynchronize), so a buffer freed while kernels of any stream may still use it is
 // never reused early.  Allocation never happens inside the time loop.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstddef>
 #include <map>
 #include <mutex>
@@ -54,7 +55,9 @@ class DevicePool {
     dev_[p] = dev;
     if (cap_.find(dev) == cap_.end()) {
       size_t fr = 0, tot = 0;
-      cap_[dev] = (hipMemGetInfo(&fr, &tot) == hipSuccess) ? tot / 5 * 2 : 0;
+      // 40 % of the device, and no more than half of what was free when this process first asked
+      // (several processes may share a GPU in tests)
+      cap_[dev] = (hipMemGetInfo(&fr, &tot) == hipSuccess) ? std::min(tot / 5 * 2, fr / 2) : 0;
     }
     *out = p;
     return hipSuccess;
