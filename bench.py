@@ -46,15 +46,35 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH
 # 614.4 G wave instructions per second.  Instructions per tet from the committed PMC passes (SQ_INSTS_VALU per
 # launch / tets: profiles/r03_nx119_pmc_per_launch.json, profiles/r03_cfg3_nx110_pmc_per_launch.json).
 VALU_ISSUE_PEAK_G = 1024 * 2.4 / 4.0
-VALU_WAVE_INSTR_PER_TET = {"p1": 40.9, "p2": 241.5}
+
+
+def valu_instr_per_tet(kind):
+    """Vector wave-instructions per tet of the RHS kernels of order `kind` ("p1" / "p2"), read at run time from
+    the committed counter file profiles/pmc_index.json points at (SQ_INSTS_VALU per launch, launch-weighted
+    over the kernel's instantiations, / the tets of the profiled mesh) -- so the figure follows the kernels
+    that were last profiled, not a constant in this file.  None when the files are missing."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_index.json")) as fh:
+            ent = json.load(fh)[kind]
+        with open(os.path.join(ROOT, "profiles", ent["file"])) as fh:
+            pmc = json.load(fh)
+        tot = w = 0.0
+        for k, wt in ent["kernels"].items():
+            tot += wt * pmc[k]["SQ_INSTS_VALU"]; w += wt
+        return tot / w / ent["tets"], "profiles/" + ent["file"]
+    except (OSError, KeyError, ValueError, ZeroDivisionError):
+        return None, None
 
 
 def valu_reading(kind, tets, avg_ms):
-    ach = VALU_WAVE_INSTR_PER_TET[kind] * tets / (avg_ms * 1e-3) / 1e9
-    return {"wave_instructions_per_tet": VALU_WAVE_INSTR_PER_TET[kind], "achieved_G_wave_instr_per_s": ach,
+    ipt, src = valu_instr_per_tet(kind)
+    if ipt is None:
+        return None
+    ach = ipt * tets / (avg_ms * 1e-3) / 1e9
+    return {"wave_instructions_per_tet": ipt, "achieved_G_wave_instr_per_s": ach,
             "issue_peak_G_wave_instr_per_s": VALU_ISSUE_PEAK_G, "frac_of_issue_peak": ach / VALU_ISSUE_PEAK_G,
-            "source": "SQ_INSTS_VALU of the committed rocprofv3 --pmc passes (profiles/r03_*_pmc_per_launch.json); "
-                      "a wave64 fp64 instruction holds its SIMD for 4 cycles"}
+            "source": "SQ_INSTS_VALU of the committed rocprofv3 --pmc pass %s (read at run time through "
+                      "profiles/pmc_index.json); a wave64 fp64 instruction holds its SIMD for 4 cycles" % src}
 
 
 def cpu_baseline(budget_s=10.0, budget_all_s=5.0):
@@ -134,7 +154,10 @@ def run_workload(args, rank, world, local_rank, dims, lengths, parts, steps, war
                            cfl=0.3, bc_extrapolate=[1, 2], bc_sym=[3, 4, 5, 6], device=local_rank)
     # FaceData, geometry and the device layout of the chunk (with its ghost layer) are built on
     # the GPU: only connectivity, coordinates and side-set triangles cross PCIe
-    mesh = capi.mesh_from_connectivity(ctx, ch["inpoel"], ch["coord"], ch["sidesets"], nielem=nielem)
+    # ... with the tets' global ids: faces oriented by global id, so the N-rank run takes the branches of the
+    # 1-rank run wherever HLLC falls through to the stored right state (qdg_mesh_from_chunk_gid)
+    mesh = capi.mesh_from_connectivity(ctx, ch["inpoel"], ch["coord"], ch["sidesets"], nielem=nielem,
+                                       elem_gid=None if self_halo else ch["gid"])
     comm = None
     if use_dist:
         if comm_kind == "rccl":
@@ -186,14 +209,25 @@ def run_workload(args, rank, world, local_rank, dims, lengths, parts, steps, war
     if not self_halo and not (drift.max() <= 1e-9):
         raise SystemExit("invalid run: mass / energy drift %r (halo or flux mismatch)" % (drift,))
     ntet = nielem
+    # what the transport itself reports: ranks in the RCCL communicator (ncclCommCount), this rank's device
+    seen = None
+    if isinstance(comm, dg.RcclComm):
+        seen = comm.comm.info()
+    per_rank = [{"rank": rank, "tets": nielem, "ghost_tets": int(len(ch["gid"]) - nielem),
+                 "neighbours": [int(r) for r in ch["nbr_rank"]], "device": local_rank,
+                 "rhs_avg_launch_ms": ms / max(nl, 1)}]
     if world > 1:
         tt = torch.tensor([el, float(ntet)], dtype=torch.float64, device="cuda")
         mx = tt.clone(); torch.distributed.all_reduce(mx, op=torch.distributed.ReduceOp.MAX)
         sm = tt.clone(); torch.distributed.all_reduce(sm, op=torch.distributed.ReduceOp.SUM)
         el, ntet = float(mx[0]), int(round(float(sm[1])))
+        gathered = [None] * world
+        torch.distributed.all_gather_object(gathered, per_rank[0])
+        per_rank = gathered
     res = {"el": el, "ntet": ntet, "ntet_local": nielem, "avg_ms": ms / max(nl, 1), "launches": nl,
            "alg": mesh.rhs_algorithmic_bytes(), "dt_last": dt_last, "drift": drift,
-           "backend": None if comm is None else comm.backend}
+           "backend": None if comm is None else comm.backend, "per_rank": per_rank,
+           "ranks_seen_by_rccl": None if seen is None else seen[0]}
     mesh.close()
     if isinstance(comm, dg.RcclComm):
         comm.close()
@@ -343,6 +377,13 @@ def config3_point(local_rank, nx=110, steps=20):
     ne = mesh.nielem
     mesh.close(); ctx.close()
     ach = alg / (ms / nl * 1e-3) / 1e9
+    vr = valu_reading("p2", ne, ms / nl)
+    # the roof that BINDS this kernel is the fp64 vector issue rate, not HBM (VALU ~80 % busy at
+    # 2 waves per SIMD, 2.3x the algorithmic bytes fetched at < 3 TB/s): report it as a roofline of its own
+    binding = None if vr is None else {
+        "bound": "fp64_valu", "achieved": vr["achieved_G_wave_instr_per_s"], "peak": VALU_ISSUE_PEAK_G,
+        "unit": "G wave64 fp64-instructions/s", "frac": vr["frac_of_issue_peak"],
+        "instructions_per_tet": vr["wave_instructions_per_tet"], "source": vr["source"]}
     return {"workload": "CompFlow vortical_flow DG-P2 + wenop1, Kuhn-tet box %d^3 hexes = %d tets, prescribed dt, "
                         "%d timed steps" % (nx, ne, steps),
             "tets_total": ne, "steps": steps, "value": ne * 3 / el / 1e6, "unit": "M element-updates/s",
@@ -351,9 +392,8 @@ def config3_point(local_rank, nx=110, steps=20):
                                                    "counted per launch)",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "avg_launch_ms": ms / nl, "launches": nl, "algorithmic_bytes_per_launch": alg,
-                         "traffic": None,
-                         # what bounds this kernel is the vector unit, not HBM
-                         "fp64_issue": valu_reading("p2", ne, ms / nl)}}
+                         "traffic": None, "fp64_issue": vr},
+            "roofline_binding": binding}
 
 
 def config4_point(local_rank, nx=110, steps=20):
@@ -391,6 +431,23 @@ def config4_point(local_rank, nx=110, steps=20):
                          "algorithmic_bytes_per_launch": alg, "traffic": None}}
 
 
+def self_launch(ngpus):
+    """Run this script on `ngpus` ranks of this node through torch.distributed.run, as child processes
+    sharing this process's stdout / stderr; returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:               # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    sys.stdout.flush()
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -425,12 +482,18 @@ def main():
                          "on a single GPU; not a physical set-up, prints the same JSON line")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` by itself: start the N ranks as CHILD processes (one per GPU, the
+        # launcher the driver would use) and relay rank 0's JSON line and the exit code -- the reference's
+        # analogue is one command too (charmrun +pN inciter ..., cmake/test_runner.cmake:88-113).  Nothing in
+        # this process has touched the GPU (torch is not even imported yet), and nothing is exec'ed.
+        sys.exit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: start one rank per GPU (python bench.py --gpus N does it "
+                         "itself when WORLD_SIZE is unset)" % (args.gpus, world))
     import __graft_entry__
     __graft_entry__.ensure_built()          # no-op when libqdg.so is there
     import torch
@@ -504,6 +567,9 @@ def main():
             "rates": {"full_stage_M_per_s": w["ntet"] * 3 * args.steps / w["el"] / 1e6,
                       "rhs_only_M_per_s_rank0": w["ntet_local"] / (w["avg_ms"] * 1e-3) / 1e6,
                       "per_time_step_M_per_s": w["ntet"] * args.steps / w["el"] / 1e6},
+            # who ran: ranks in the RCCL communicator as RCCL counts them (ncclCommCount; None without RCCL),
+            # and every rank's chunk, neighbours, device and own RHS launch time
+            "ranks_seen_by_rccl": w["ranks_seen_by_rccl"], "per_rank": w["per_rank"],
             "dt_last": w["dt_last"],
             "check": {"mass_drift": float(w["drift"][0]), "energy_drift": float(w["drift"][1]),
                       "note": "relative change of total mass / total energy over the whole run "
@@ -516,6 +582,7 @@ def main():
                             "the %d rank(s): BASELINE.json north_star (P1 RHS at ~10 M tets; strong scaling 1->8)"
                             % ((args.strong_nx, ns["ntet"]) + parts + (world,)),
                 "scaling": "strong", "tets_total": ns["ntet"], "tets_rank0": ns["ntet_local"],
+                "ranks_seen_by_rccl": ns["ranks_seen_by_rccl"], "per_rank": ns["per_rank"],
                 "steps": ns["steps"], "warmup": ns["warmup"],
                 "value": ns["ntet"] * 3 * ns["steps"] / ns["el"] / 1e6, "unit": "M element-updates/s",
                 "ms_per_step": ns["el"] / ns["steps"] * 1e3,

@@ -153,7 +153,11 @@ int qdg_ctx_synchronize(qdg_ctx* ctx);
  *                   reproducible run to run
  *   "fused_update"  1 (default) stage-0 RK update fused with the Superbee limiter of stage 1
  *   "renumber"      1 (default) Morton order of the device rows; 0 keeps the caller's order
- *   "host_layout"   1: qdg_mesh_from_connectivity runs qdg_mesh_upload's host layout code (A/B) */
+ *   "host_layout"   1: qdg_mesh_from_connectivity runs qdg_mesh_upload's host layout code (A/B)
+ *   "orient_by_gid" 1 (default): meshes built with global tet ids (qdg_mesh_upload_gid, qdg_mesh_from_chunk_gid)
+ *                   orient their faces by global id; 0: the chare-local rule of src/Inciter/DG.cpp:480-483
+ *   "keep_pool"     0 (default): qdg_ctx_destroy of the process's last context returns the device buffer
+ *                   cache to the driver; 1: keeps it for the next context */
 int qdg_ctx_set_option(qdg_ctx* ctx, const char* name, int value);
 int qdg_ctx_get_option(qdg_ctx* ctx, const char* name, int* value);
 /* Problem::solution at n points (DGPDE::analyticSolution, src/PDE/DGPDE.hpp:141-144;
@@ -175,6 +179,21 @@ int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t nnode,
                     const int* esuf, const int* esuel, const size_t* inpofa,
                     const double* geoFace, const double* geoElem,
                     const qdg_bface* bface, qdg_mesh** out);
+/* The same with the GLOBAL ids of the chunk's tets (elem_gid[nunk], the numbering of the whole mesh
+ * a serial run would see; NULL = qdg_mesh_upload).  With context option "orient_by_gid" (default 1) the
+ * device mesh stores every interior and chare-boundary face with the tet of LOWER GLOBAL id as its left
+ * tet -- the serial run's rule (src/Mesh/DerivedData.cpp:1127-1139: a face is kept by its lower-numbered
+ * tet) -- instead of the chare-local one (left = the owned tet, src/Inciter/DG.cpp:480-483).  HLLC falls
+ * through to the STORED right state where a wave speed is NaN (src/PDE/Integrate/Riemann/HLLC.hpp:93-124:
+ * negative pressure at a face point next to a strong shock), so only then does a partitioned run take
+ * the serial run's branches at such faces and equal it on every tet.  The caller's esuf / geoFace stay
+ * as they are (left = owned); the flip happens in the device copy. */
+int qdg_mesh_upload_gid(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t nnode,
+                        const size_t* inpoel, const double* x, const double* y,
+                        const double* z, size_t nbfac, size_t nfac,
+                        const int* esuf, const int* esuel, const size_t* inpofa,
+                        const double* geoFace, const double* geoElem,
+                        const qdg_bface* bface, const size_t* elem_gid, qdg_mesh** out);
 int qdg_mesh_destroy(qdg_mesh* mesh);
 
 /* -- stateless operators on host fields (the DGPDE-shaped calls) ---------- */
@@ -304,6 +323,10 @@ typedef struct qdg_comm qdg_comm;
 int qdg_comm_unique_id(void* id128);
 int qdg_comm_create(qdg_ctx* ctx, int nranks, int rank, const void* id128, qdg_comm** out);
 int qdg_comm_destroy(qdg_comm* comm);
+/* what RCCL itself reports for the communicator (ncclCommCount, ncclCommUserRank, ncclCommCuDevice):
+ * the number of ranks that joined, this rank, its HIP device -- so that a run can state which ranks
+ * its halo really crossed (any pointer may be NULL) */
+int qdg_comm_info(qdg_comm* comm, int* nranks, int* rank, int* device);
 int qdg_halo_exchange(qdg_mesh* mesh, qdg_comm* comm);   /* pack, send / recv into ghost rows */
 int qdg_stage_dt_allreduce(qdg_mesh* mesh, qdg_comm* comm);
 /* whole SSP-RK3 step of one chunk of a partitioned mesh:
@@ -486,6 +509,13 @@ int qdg_mesh_from_connectivity(qdg_ctx* ctx, size_t nelem, size_t nnode, const s
 int qdg_mesh_from_chunk(qdg_ctx* ctx, size_t nielem, size_t nelem, size_t nnode, const size_t* inpoel,
                         const double* x, const double* y, const double* z, size_t ntri,
                         const size_t* tri, const int32_t* tri_set, qdg_mesh** out);
+/* ... with the tets' global ids (elem_gid[nelem], e.g. qdg_chunk_get's elem_gid; NULL = the call above):
+ * faces oriented by global id as described at qdg_mesh_upload_gid, the face's nodes taken in the new
+ * left tet's local face order and the geometry computed from them, as the serial run stores the face. */
+int qdg_mesh_from_chunk_gid(qdg_ctx* ctx, size_t nielem, size_t nelem, size_t nnode, const size_t* inpoel,
+                            const double* x, const double* y, const double* z, size_t ntri,
+                            const size_t* tri, const int32_t* tri_set, const size_t* elem_gid,
+                            qdg_mesh** out);
 
 #ifdef __cplusplus
 }

@@ -306,7 +306,7 @@ class Mesh:
     geoFace[7*nfac], geoElem[4*nunk], bface."""
 
     def __init__(self, ctx, nielem, inpoel, coord, esuf, esuel, inpofa, geoFace, geoElem,
-                 bface, nbfac):
+                 bface, nbfac, elem_gid=None):
         L = lib()
         self.ctx = ctx
         inp, pinp = _sz(np.asarray(inpoel).reshape(-1))
@@ -331,10 +331,15 @@ class Mesh:
         off, poff = _sz(off)
         bf = qdg_bface(nset=len(ids), set_id=pid, set_off=poff, face=pface)
         self.h = C.c_void_p()
-        _chk(L.qdg_mesh_upload(ctx.h, C.c_size_t(self.nielem), C.c_size_t(self.nunk),
-                               C.c_size_t(coord.shape[0]), pinp, px, py, pz, C.c_size_t(nbfac),
-                               C.c_size_t(len(esuf) // 2), pesuf, pesuel, pinpofa, pgf, pge,
-                               C.byref(bf), C.byref(self.h)))
+        pgid = None                 # global tet ids: faces oriented as in the serial run (qdg_mesh_upload_gid)
+        if elem_gid is not None:
+            gid, pgid = _sz(np.asarray(elem_gid))
+            if len(gid) != self.nunk:
+                raise QdgError("Mesh: elem_gid needs one entry per tet (ghosts included)")
+        _chk(L.qdg_mesh_upload_gid(ctx.h, C.c_size_t(self.nielem), C.c_size_t(self.nunk),
+                                   C.c_size_t(coord.shape[0]), pinp, px, py, pz, C.c_size_t(nbfac),
+                                   C.c_size_t(len(esuf) // 2), pesuf, pesuel, pinpofa, pgf, pge,
+                                   C.byref(bf), pgid, C.byref(self.h)))
         self.nprop = ctx.nprop
 
     # stateless DGPDE-shaped calls
@@ -535,10 +540,11 @@ class Mesh:
             self.h = C.c_void_p()
 
 
-def mesh_from_connectivity(ctx, inpoel, coord, sidesets, nielem=None):
-    """qdg_mesh_from_connectivity / qdg_mesh_from_chunk: a Mesh handle straight from
+def mesh_from_connectivity(ctx, inpoel, coord, sidesets, nielem=None, elem_gid=None):
+    """qdg_mesh_from_connectivity / qdg_mesh_from_chunk[_gid]: a Mesh handle straight from
     (inpoel, coord, {side set id: triangles}); FaceData, geometry and the device layout are
-    made on the GPU.  nielem < number of tets: the trailing tets are the chunk's ghost layer."""
+    made on the GPU.  nielem < number of tets: the trailing tets are the chunk's ghost layer.
+    elem_gid: global tet ids -- faces oriented by global id (a partitioned run = the serial run)."""
     inpoel = np.ascontiguousarray(inpoel, dtype=np.uint64).reshape(-1)
     coord = np.ascontiguousarray(coord, dtype=np.float64)
     ids = sorted(sidesets)
@@ -554,11 +560,17 @@ def mesh_from_connectivity(ctx, inpoel, coord, sidesets, nielem=None):
     m.nielem = m.nunk if nielem is None else int(nielem)
     m.h = C.c_void_p()
     ntri = sum(len(sidesets[s_]) for s_ in ids)
-    _chk(lib().qdg_mesh_from_chunk(ctx.h, C.c_size_t(m.nielem), C.c_size_t(m.nunk), C.c_size_t(coord.shape[0]),
-                                   inpoel.ctypes.data_as(c_szp), x.ctypes.data_as(c_f64p),
-                                   y.ctypes.data_as(c_f64p), z.ctypes.data_as(c_f64p),
-                                   C.c_size_t(ntri), tri.ctypes.data_as(c_szp),
-                                   tset.ctypes.data_as(c_i32p), C.byref(m.h)))
+    pgid = None
+    if elem_gid is not None:
+        gid = np.ascontiguousarray(elem_gid, dtype=np.uint64)
+        if gid.size != m.nunk:
+            raise QdgError("mesh_from_connectivity: elem_gid needs one entry per tet (ghosts included)")
+        pgid = gid.ctypes.data_as(c_szp)
+    _chk(lib().qdg_mesh_from_chunk_gid(ctx.h, C.c_size_t(m.nielem), C.c_size_t(m.nunk), C.c_size_t(coord.shape[0]),
+                                       inpoel.ctypes.data_as(c_szp), x.ctypes.data_as(c_f64p),
+                                       y.ctypes.data_as(c_f64p), z.ctypes.data_as(c_f64p),
+                                       C.c_size_t(ntri), tri.ctypes.data_as(c_szp),
+                                       tset.ctypes.data_as(c_i32p), pgid, C.byref(m.h)))
     return m
 
 
@@ -605,6 +617,12 @@ class Comm:
         self.nranks, self.rank = nranks, rank
         buf = (C.c_ubyte * 128).from_buffer_copy(unique_id)
         _chk(lib().qdg_comm_create(ctx.h, C.c_int(nranks), C.c_int(rank), buf, C.byref(self.h)))
+
+    def info(self):
+        """(ranks, rank, device) as RCCL reports them (ncclCommCount / UserRank / CuDevice)"""
+        n, r, d = C.c_int(), C.c_int(), C.c_int()
+        _chk(lib().qdg_comm_info(self.h, C.byref(n), C.byref(r), C.byref(d)))
+        return n.value, r.value, d.value
 
     def close(self):
         if self.h:

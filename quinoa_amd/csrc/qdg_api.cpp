@@ -189,6 +189,7 @@ extern "C" int qdg_ctx_create(const qdg_config* cfg, qdg_ctx** out)
     for (int i = 0; i < 3; ++i) { fill_quadtet(qi[i], nginit(nd[i])); fill_quadtet(qd[i], ngdiag(nd[i])); }
     HIPCHK(upload_tables(*t1, *t4, *t10, qi, qd));
   }
+  qdg::DevicePool::get().ctx_opened();
   *out = c.release();
   return 0;
   QDG_CATCH
@@ -197,7 +198,12 @@ extern "C" int qdg_ctx_create(const qdg_config* cfg, qdg_ctx** out)
 extern "C" int qdg_ctx_destroy(qdg_ctx* ctx)
 {
   QDG_TRY
+  if (!ctx) return 0;
+  const bool keep = ctx->opt.keep_pool != 0;
   delete ctx;      // ~qdg_ctx drains and destroys the stream it owns
+  // the process's last context returns the device buffer cache (an embedding application shares the GPU
+  // with other allocators that never see this cache); option keep_pool = 1 keeps it
+  if (qdg::DevicePool::get().ctx_closed() == 0 && !keep) (void)qdg::DevicePool::get().trim();
   return 0;
   QDG_CATCH
 }
@@ -241,6 +247,7 @@ static int* option_slot(qdg_ctx* ctx, const char* name)
     { "p1_rhs", &qdg::Options::p1_rhs },
     { "fused_update", &qdg::Options::fused_update },
     { "renumber", &qdg::Options::renumber },       { "host_layout", &qdg::Options::host_layout },
+    { "orient_by_gid", &qdg::Options::orient_by_gid }, { "keep_pool", &qdg::Options::keep_pool },
   };
   for (const auto& t : tab)
     if (std::strcmp(name, t.n) == 0) return &(ctx->opt.*(t.p));
@@ -343,6 +350,17 @@ extern "C" int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t 
                                const double* z, size_t nbfac, size_t nfac, const int* esuf,
                                const int* esuel, const size_t* inpofa, const double* geoFace,
                                const double* geoElem, const qdg_bface* bface, qdg_mesh** out)
+{
+  return qdg_mesh_upload_gid(ctx, nielem, nunk, nnode, inpoel, x, y, z, nbfac, nfac, esuf, esuel, inpofa, geoFace,
+                             geoElem, bface, nullptr, out);
+}
+
+extern "C" int qdg_mesh_upload_gid(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t nnode,
+                                   const size_t* inpoel, const double* x, const double* y,
+                                   const double* z, size_t nbfac, size_t nfac, const int* esuf,
+                                   const int* esuel, const size_t* inpofa, const double* geoFace,
+                                   const double* geoElem, const qdg_bface* bface, const size_t* elem_gid,
+                                   qdg_mesh** out)
 {
   QDG_TRY
   if (!ctx || !out) return fail("qdg_mesh_upload: null ctx/out");
@@ -463,6 +481,18 @@ extern "C" int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t 
     if (rface[i] < 0) return fail("qdg_mesh_upload: element face without an entry in esuf "
                                   "(every boundary face must be listed in [0,nbfac))");
 
+  // ---- orientation by global tet id (option orient_by_gid; see k_orient_gid in qdg_devmesh.hip) ----
+  // flip[f]: the face's stored left tet (the caller's esuf[2f], an owned tet) has the HIGHER global id:
+  // the device mesh takes the other tet as left and the negated normal, as the serial run of the whole
+  // mesh stores the face (src/Mesh/DerivedData.cpp:1127-1139)
+  std::vector<char> flip;
+  if (elem_gid && ctx->opt.orient_by_gid) {
+    flip.assign(nfac, 0);
+    for (size_t f = nbfac; f < nfac; ++f)
+      if (esuf[2 * f + 1] >= 0 && elem_gid[esuf[2 * f]] > elem_gid[esuf[2 * f + 1]]) flip[f] = 1;
+  }
+  auto left_of = [&](int f) { return (!flip.empty() && flip[f]) ? esuf[2 * f + 1] : esuf[2 * f]; };
+
   lap("face ids per (tet, local face)");
   // ---- BC type of every boundary face -------------------------------------
   // reference: bndSurfInt over the configured side sets of each BC type
@@ -513,7 +543,7 @@ extern "C" int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t 
         const int f = rface[4 * h + lf];
         h_fid[lf * stride + d] = fmap[f];
         const int nb = esuel[4 * h + lf];
-        int info = ((size_t)esuf[2 * f] == h) ? (1 << 6) : 0;
+        int info = ((size_t)left_of(f) == h) ? (1 << 6) : 0;
         if (nb < 0) {
           h_nbr[lf * stride + d] = -(1 + bcface[f]);
         } else {
@@ -534,10 +564,11 @@ extern "C" int qdg_mesh_upload(qdg_ctx* ctx, size_t nielem, size_t nunk, size_t 
   std::vector<double> h_area(std::max(nfd, 1)), h_nx(std::max(nfd, 1)), h_ny(std::max(nfd, 1)), h_nz(std::max(nfd, 1));
   for (size_t f = 0; f < nfac; ++f)
     if (fmap[f] >= 0) {
+      const double sgn = (!flip.empty() && flip[f]) ? -1.0 : 1.0;   // the stored normal points out of the left tet
       h_area[fmap[f]] = geoFace[7 * f];
-      h_nx[fmap[f]] = geoFace[7 * f + 1];
-      h_ny[fmap[f]] = geoFace[7 * f + 2];
-      h_nz[fmap[f]] = geoFace[7 * f + 3];
+      h_nx[fmap[f]] = sgn * geoFace[7 * f + 1];
+      h_ny[fmap[f]] = sgn * geoFace[7 * f + 2];
+      h_nz[fmap[f]] = sgn * geoFace[7 * f + 3];
     }
 
   lap("device arrays (host side)");
@@ -1348,6 +1379,8 @@ extern "C" int qdg_stage_update(qdg_mesh* mesh, int stage)
                             mesh->Ucur + mesh->nie * (size_t)mesh->nprop,
                             (mesh->ne - mesh->nie) * (size_t)mesh->nprop * sizeof(double),
                             hipMemcpyDeviceToDevice, s));
+    else if (mesh->ne > mesh->nie)
+      mesh->carry_src = mesh->Ucur;           // where the ghost rows still are, should the receive not happen
     mesh->Ucur = mesh->Upending;
     mesh->Upending = nullptr;
   } else {
@@ -1748,6 +1781,9 @@ struct RcclApi {
   decltype(&ncclSend) Send = nullptr;
   decltype(&ncclRecv) Recv = nullptr;
   decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclCommCount) CommCount = nullptr;
+  decltype(&ncclCommUserRank) CommUserRank = nullptr;
+  decltype(&ncclCommCuDevice) CommCuDevice = nullptr;
   std::string error;
 };
 
@@ -1768,6 +1804,7 @@ RcclApi* rccl_api()
     QDG_RCCL_SYM(GetUniqueId) QDG_RCCL_SYM(CommInitRank) QDG_RCCL_SYM(CommDestroy)
     QDG_RCCL_SYM(GetErrorString) QDG_RCCL_SYM(GroupStart) QDG_RCCL_SYM(GroupEnd)
     QDG_RCCL_SYM(Send) QDG_RCCL_SYM(Recv) QDG_RCCL_SYM(AllReduce)
+    QDG_RCCL_SYM(CommCount) QDG_RCCL_SYM(CommUserRank) QDG_RCCL_SYM(CommCuDevice)
 #undef QDG_RCCL_SYM
     return &api;
   }();
@@ -1822,8 +1859,26 @@ extern "C" int qdg_comm_create(qdg_ctx* ctx, int nranks, int rank, const void* i
   std::memcpy(&id, id128, sizeof id);
   std::unique_ptr<qdg_comm> c(new qdg_comm);
   c->nranks = nranks; c->rank = rank; c->device = ctx->device;
+  // RCCL allocates from the driver and never sees this library's cache of freed blocks: hand it back first
+  (void)qdg::DevicePool::get().trim();
   RCCLCHK(a->CommInitRank(&c->comm, nranks, id, rank));
   *out = c.release();
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_comm_info(qdg_comm* comm, int* nranks, int* rank, int* device)
+{
+  QDG_TRY
+  if (!comm || !comm->comm) return fail("qdg_comm_info: null communicator");
+  RcclApi* a = rccl_api();
+  int n = 0, r = 0, d = 0;
+  RCCLCHK(a->CommCount(comm->comm, &n));
+  RCCLCHK(a->CommUserRank(comm->comm, &r));
+  RCCLCHK(a->CommCuDevice(comm->comm, &d));
+  if (nranks) *nranks = n;
+  if (rank) *rank = r;
+  if (device) *device = d;
   return 0;
   QDG_CATCH
 }
@@ -1878,6 +1933,7 @@ static int exchange_on(qdg_mesh* mesh, qdg_comm* comm, hipStream_t s)
                        (int)mesh->nrecv, mesh->Ucur, s, mesh->ndofel.p);
     HIPCHK(hipGetLastError());
   }
+  mesh->carry_src = nullptr;         // the ghost rows of the current state have been received
   return 0;
 }
 
@@ -1926,11 +1982,37 @@ extern "C" int qdg_stage_dt_allreduce(qdg_mesh* mesh, qdg_comm* comm)
   QDG_CATCH
 }
 
+static int step_comm_stages(qdg_mesh* mesh, qdg_comm* comm, double t, double tleft);
+
 extern "C" int qdg_step_comm(qdg_mesh* mesh, qdg_comm* comm, double t, double tleft, double* dt_taken)
 {
   QDG_TRY
   MESH_ENTER("qdg_step_comm");
   if (!comm) return fail("qdg_step_comm: null communicator");
+  // the skipped ghost-row carries below rely on every ghost row being received by the next exchange
+  if (mesh->nnbr > 0 && mesh->nrecv != mesh->ne - mesh->nie)
+    return fail("qdg_step_comm: the halo plan does not cover every ghost row");
+  const int rc = step_comm_stages(mesh, comm, t, tleft);
+  if (rc && mesh->carry_src && mesh->carry_src != mesh->Ucur) {
+    // an exchange failed after an update whose ghost-row carry was skipped: do the carry now, so that
+    // the state the caller is left with has the last received ghost rows, not a buffer's older content
+    const std::string msg = qdg_last_error();
+    (void)hipMemcpyAsync(mesh->Ucur + mesh->nie * (size_t)mesh->nprop, mesh->carry_src + mesh->nie * (size_t)mesh->nprop,
+                         (mesh->ne - mesh->nie) * (size_t)mesh->nprop * sizeof(double), hipMemcpyDeviceToDevice, s);
+    mesh->carry_src = nullptr;
+    return fail(msg);
+  }
+  mesh->carry_src = nullptr;
+  if (rc) return rc;
+  if (dt_taken) return qdg_stage_dt_get(mesh, dt_taken);
+  return 0;
+  QDG_CATCH
+}
+
+static int step_comm_stages(qdg_mesh* mesh, qdg_comm* comm, double t, double tleft)
+{
+  qdg_ctx* ctx = mesh->ctx;
+  hipStream_t s = ctx->stream;
   const bool limited = ctx->cfg.limiter != QDG_LIMITER_NONE && mesh->ndof > 1;
   const bool fuse = can_fuse_update_limit(mesh);
   for (int stage = 0; stage < 3; ++stage) {
@@ -1956,9 +2038,7 @@ extern "C" int qdg_step_comm(qdg_mesh* mesh, qdg_comm* comm, double t, double tl
       if (rc) return rc;
     }
   }
-  if (dt_taken) return qdg_stage_dt_get(mesh, dt_taken);
   return 0;
-  QDG_CATCH
 }
 
 // ---------------------------------------------------------------- measurement

@@ -92,7 +92,7 @@ __global__ void k_match(const uint32_t* __restrict__ sa, const uint32_t* __restr
   if (i >= n) return;
   const bool eq_next = i + 1 < n && sa[i] == sa[i + 1] && sb[i] == sb[i + 1] && sc[i] == sc[i + 1];
   const bool eq_prev = i > 0 && sa[i] == sa[i - 1] && sb[i] == sb[i - 1] && sc[i] == sc[i - 1];
-  if (eq_next && eq_prev) *err = 1;                 // a face shared by more than two tets
+  if (eq_next && eq_prev) atomicOr(err, 1);         // a face shared by more than two tets (error bits: 1, 2, 4)
   int v = -1;
   if (eq_next) v = (int)(perm[i + 1] >> 2);
   else if (eq_prev) v = (int)(perm[i - 1] >> 2);
@@ -123,6 +123,31 @@ __global__ void k_interior_faces(const uint64_t* __restrict__ inpoel, const int*
   esuf[2 * fid + 1] = esuel[i];
 }
 
+// Orientation by GLOBAL tet id (context option "orient_by_gid", default on, when the chunk comes with
+// its tets' global ids): the stored left tet of an interior or chare-boundary face is the one with
+// the lower global id -- the rule of the serial run of the whole mesh (src/Mesh/DerivedData.cpp:
+// 1127-1139: a face is kept by its lower-numbered tet) instead of the chare-local one (left = the
+// owned tet, src/Inciter/DG.cpp:480-483).  HLLC's ladder falls through to the STORED right state
+// when a wave speed is NaN (src/PDE/Integrate/Riemann/HLLC.hpp:93-124), so only with a
+// partition-independent orientation is a partitioned run equal to the serial one at such faces.
+// The face's nodes are taken in the new left tet's local face order, as the serial run would store them.
+__global__ void k_orient_gid(const uint64_t* __restrict__ inpoel, const uint64_t* __restrict__ gid, size_t nbfac,
+                             size_t nipfac, uint64_t* __restrict__ inpofa, int* __restrict__ esuf)
+{
+  const size_t f = nbfac + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= nipfac) return;
+  const int el = esuf[2 * f], er = esuf[2 * f + 1];
+  if (er < 0 || gid[el] < gid[er]) return;
+  const uint64_t a = inpofa[3 * f], b = inpofa[3 * f + 1], c = inpofa[3 * f + 2];
+  int q = 0;                                         // local face of er = its node that is not on the face
+  for (int k = 0; k < 4; ++k) {
+    const uint64_t g = inpoel[4 * (size_t)er + k];
+    if (g != a && g != b && g != c) q = k;
+  }
+  for (int j = 0; j < 3; ++j) inpofa[3 * f + j] = inpoel[4 * (size_t)er + c_lpofa[q][j]];
+  esuf[2 * f] = er; esuf[2 * f + 1] = el;
+}
+
 // boundary faces: inpofa = triinpoel; host element by binary search in the sorted keys
 __global__ void k_boundary_faces(const uint64_t* __restrict__ tri, size_t nbfac,
                                  const uint32_t* __restrict__ sa, const uint32_t* __restrict__ sb,
@@ -143,7 +168,7 @@ __global__ void k_boundary_faces(const uint64_t* __restrict__ tri, size_t nbfac,
     const bool less = sa[mid] < k0 || (sa[mid] == k0 && (sb[mid] < k1 || (sb[mid] == k1 && sc[mid] < k2)));
     if (less) lo = mid + 1; else hi = mid;
   }
-  if (lo >= n || sa[lo] != k0 || sb[lo] != k1 || sc[lo] != k2) { *err = 2; return; }
+  if (lo >= n || sa[lo] != k0 || sb[lo] != k1 || sc[lo] != k2) { atomicOr(err, 2); return; }
   const uint64_t e = perm[lo] >> 2;
   belem[f] = e;
   esuf[2 * f] = (int)e;
@@ -190,7 +215,7 @@ __global__ void k_geoelem(const uint64_t* __restrict__ inpoel, size_t nelem, con
   const double cy = ca[2] * da[0] - ca[0] * da[2];
   const double cz = ca[0] * da[1] - ca[1] * da[0];
   const double vol = (ba[0] * cx + ba[1] * cy + ba[2] * cz) / 6.0;
-  if (!(vol > 0.0)) atomicMax(err, 3);          // the reference asserts a positive Jacobian (DerivedData.cpp:1478-1480)
+  if (!(vol > 0.0)) atomicOr(err, 4);           // the reference asserts a positive Jacobian (DerivedData.cpp:1478-1480)
   geoElem[4*e]   = vol;
   geoElem[4*e+1] = (x[A] + x[B] + x[C] + x[D]) / 4.0;
   geoElem[4*e+2] = (y[A] + y[B] + y[C] + y[D]) / 4.0;
@@ -204,6 +229,7 @@ inline unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
 // the FaceData arrays and the geometry of a chunk, resident on the device
 struct DevFD {
   Buf<uint64_t> inpoel, tri, inpofa, belem;
+  Buf<uint64_t> gid;         // global tet ids (null: faces keep the chunk-local orientation)
   Buf<double> x, y, z, geoFace, geoElem;
   Buf<int> esuel, esuf;
   size_t nelem = 0, nnode = 0, nbfac = 0, nipfac = 0;
@@ -404,7 +430,7 @@ static int dev_facedata_from(qdg_ctx* ctx, DevFD& fd)
   DHIP(hipMemcpyAsync(&last_flag, d_flag.p + (n4 - 1), sizeof(int), hipMemcpyDeviceToHost, s));
   DHIP(hipMemcpyAsync(&herr, d_err.p, sizeof(int), hipMemcpyDeviceToHost, s));
   DHIP(hipStreamSynchronize(s));
-  if (herr == 1) return fail("qdg_dev_facedata: face shared by more than two tets (non-manifold mesh)");
+  if (herr & 1) return fail("qdg_dev_facedata: face shared by more than two tets (non-manifold mesh)");
   const size_t nint = (size_t)last_pos + (size_t)last_flag, nipfac = nbfac + nint;
   if (nipfac > nfmax) return fail("qdg_dev_facedata: inconsistent face count");
   fd.nipfac = nipfac;
@@ -412,6 +438,8 @@ static int dev_facedata_from(qdg_ctx* ctx, DevFD& fd)
   DHIP(fd.geoFace.alloc(7 * nipfac)); DHIP(fd.geoElem.alloc(4 * nelem));
   k_interior_faces<<<nblk(n4), 256, 0, s>>>(fd.inpoel.p, fd.esuel.p, d_flag.p, d_pos.p, n4, nbfac,
                                            fd.inpofa.p, fd.esuf.p);
+  if (fd.gid.p && nint)
+    k_orient_gid<<<nblk(nint), 256, 0, s>>>(fd.inpoel.p, fd.gid.p, nbfac, nipfac, fd.inpofa.p, fd.esuf.p);
   if (nbfac)
     k_boundary_faces<<<nblk(nbfac), 256, 0, s>>>(fd.tri.p, nbfac, sa.p, sb.p, sc.p, sperm, n4, fd.inpofa.p,
                                                  fd.esuf.p, fd.belem.p, d_err.p);
@@ -423,8 +451,8 @@ static int dev_facedata_from(qdg_ctx* ctx, DevFD& fd)
   DHIP(hipStreamSynchronize(s));
   // (qdg_dev_facedata itself is a statement about connectivity: the reference's derived-data unit meshes
   // are not all positively oriented; the mesh BUILD refuses such a tet)
-  fd.nonpos_vol = herr == 3;
-  if (herr == 2) return fail("qdg_dev_facedata: a boundary face is not a face of any tet");
+  fd.nonpos_vol = (herr & 4) != 0;      // its own bit: an inverted tet must not hide an unmatched boundary face
+  if (herr & 2) return fail("qdg_dev_facedata: a boundary face is not a face of any tet");
   return 0;
 }
 
@@ -1147,6 +1175,14 @@ extern "C" int qdg_mesh_from_chunk(qdg_ctx* ctx, size_t nielem, size_t nelem, si
                                    const double* x, const double* y, const double* z,
                                    size_t ntri, const size_t* tri, const int32_t* tri_set, qdg_mesh** out)
 {
+  return qdg_mesh_from_chunk_gid(ctx, nielem, nelem, nnode, inpoel, x, y, z, ntri, tri, tri_set, nullptr, out);
+}
+
+extern "C" int qdg_mesh_from_chunk_gid(qdg_ctx* ctx, size_t nielem, size_t nelem, size_t nnode, const size_t* inpoel,
+                                       const double* x, const double* y, const double* z,
+                                       size_t ntri, const size_t* tri, const int32_t* tri_set,
+                                       const size_t* elem_gid, qdg_mesh** out)
+{
   QDG_TRY
   if (!ctx || !out || !inpoel || !x || !y || !z) return fail("qdg_mesh_from_connectivity: null argument");
   if (ntri > 0 && (!tri || !tri_set)) return fail("qdg_mesh_from_connectivity: null side-set arrays");
@@ -1162,6 +1198,10 @@ extern "C" int qdg_mesh_from_chunk(qdg_ctx* ctx, size_t nielem, size_t nelem, si
     DevFD fd;
     if (int rc = dev_upload_mesh(ctx, nelem, nnode, inpoel, x, y, z, fd)) return rc;
     fd.nie = nielem;
+    if (elem_gid && ctx->opt.orient_by_gid) {
+      DHIP(fd.gid.alloc(nelem));
+      DHIP(hipMemcpyAsync(fd.gid.p, elem_gid, nelem * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
     lap("validation + upload of inpoel, coord");
     std::vector<int32_t> fset;
     if (int rc = dev_bnd_faces(ctx, fd, ntri, tri, tri_set, fset)) return rc;
@@ -1212,7 +1252,7 @@ extern "C" int qdg_mesh_from_chunk(qdg_ctx* ctx, size_t nielem, size_t nelem, si
   off.push_back(nbfac);
   if (ids.empty()) { ids.push_back(0); off.assign({ 0, 0 }); }
   qdg_bface bf{ nbfac ? ids.size() : 0, ids.data(), off.data(), faces.data() };
-  return qdg_mesh_upload(ctx, nelem, nelem, nnode, inpoel, x, y, z, nbfac, nipfac, esuf.data(),
-                         esuel.data(), inpofa.data(), geoFace.data(), geoElem.data(), &bf, out);
+  return qdg_mesh_upload_gid(ctx, nelem, nelem, nnode, inpoel, x, y, z, nbfac, nipfac, esuf.data(),
+                             esuel.data(), inpofa.data(), geoFace.data(), geoElem.data(), &bf, elem_gid, out);
   QDG_CATCH
 }

@@ -51,6 +51,9 @@ struct Options {
   int fused_update = 1;  // stage-0 RK update fused with the Superbee limiter of stage 1
   int renumber = 1;      // Morton order of the interior tets (0: caller's order; layout experiments)
   int host_layout = 0;   // qdg_mesh_from_connectivity: 1 routes through qdg_mesh_upload's host code (A/B)
+  int orient_by_gid = 1; // meshes built WITH global tet ids (qdg_mesh_*_gid): left tet of a face = lower global id
+                         // (a partitioned run takes the serial run's HLLC branches); 0: chunk-local rule
+  int keep_pool = 0;     // 1: qdg_ctx_destroy of the last context keeps the device buffer cache
 };
 }  // namespace qdg
 
@@ -93,6 +96,7 @@ struct qdg_mesh {
   double* Unp = nullptr;
   double* Upending = nullptr;     // output of a fused RHS+RK launch, adopted by qdg_stage_update
   bool skip_ghost_carry = false;  // set by qdg_step_comm around an update whose ghost rows are received next
+  double* carry_src = nullptr;    // buffer that still holds the ghost rows of a skipped carry (qdg_step_comm's error path)
   qdg::DevBuf<double> S1, S2;          // scratch of the stateless operators (allocated on first use)
   qdg::DevBuf<int> ndofel, ndofel2;    // p-adaptive DG: DG::m_ndof per device row (+ Jacobi copy)
   qdg::DevBuf<double> fout;            // field output staging (allocated on first use)

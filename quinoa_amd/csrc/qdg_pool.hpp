@@ -5,8 +5,10 @@
 // one out of dozens of temporaries, and paid that on every allocation: the device build of an 80.9 M-tet
 // mesh took 5.3 s in a process that had run other meshes before, 1.25 s in a fresh one.  Freed blocks
 // are therefore kept and handed out again (best fit within 25 % of the request), up to 40 % of the
-// device's memory (and at most half of what was free at the process's first allocation); the cache is emptied when an allocation fails (then retried) or through
-// qdg_device_pool_trim -- not when the last context goes away: the next one would pay the driver again.  hipFree synchronises the device; a cached block that is handed out again does
+// device's memory (and at most half of what was free at the process's first allocation); the cache is emptied when an allocation fails (then retried), through
+// qdg_device_pool_trim, before the library lets a third party allocate (qdg_comm_create: RCCL) and when the
+// process's last context is destroyed (context option "keep_pool" = 1 keeps it: the next context would pay
+// the driver again).  Cached bytes are counted per device.  hipFree synchronises the device; a cached block that is handed out again does
 // the same (hipDeviceSynchronize), so a buffer freed while kernels of any stream may still use it is
 // never reused early.  Allocation never happens inside the time loop.
 #pragma once
@@ -36,7 +38,7 @@ class DevicePool {
       if (it != fl.end() && it->first <= want + want / 4) {
         void* p = it->second;
         size_[p] = it->first;
-        cached_ -= it->first;
+        cached_[dev] -= it->first;
         fl.erase(it);
         *out = p;
       }
@@ -71,13 +73,13 @@ class DevicePool {
     const int dev = dev_[p];
     const size_t sz = it->second;
     size_.erase(it);
-    if (cached_ + sz > cap_[dev]) {                             // cache full: back to the driver
+    if (cached_[dev] + sz > cap_[dev]) {                        // this device's cache is full: back to the driver
       dev_.erase(p);
       (void)hipFree(p);
       return;
     }
     free_[dev].emplace(sz, p);
-    cached_ += sz;
+    cached_[dev] += sz;
   }
   // hands every cached block back to the driver; returns the bytes released
   size_t trim()
@@ -87,13 +89,22 @@ class DevicePool {
       std::lock_guard<std::mutex> g(mu_);
       for (auto& d : free_) { all.insert(d.second.begin(), d.second.end()); d.second.clear(); }
       for (auto& b : all) dev_.erase(b.second);
-      cached_ = 0;
+      cached_.clear();
     }
     size_t n = 0;
     for (auto& b : all) { (void)hipFree(b.second); n += b.first; }
     return n;
   }
-  size_t cached_bytes() { std::lock_guard<std::mutex> g(mu_); return cached_; }
+  size_t cached_bytes()
+  {
+    std::lock_guard<std::mutex> g(mu_);
+    size_t n = 0;
+    for (auto& c : cached_) n += c.second;
+    return n;
+  }
+  // contexts alive in this process: the last one to go returns the cache (qdg_ctx_destroy)
+  int ctx_opened() { std::lock_guard<std::mutex> g(mu_); return ++nctx_; }
+  int ctx_closed() { std::lock_guard<std::mutex> g(mu_); return nctx_ > 0 ? --nctx_ : 0; }
 
  private:
   static size_t round(size_t b)
@@ -106,7 +117,8 @@ class DevicePool {
   std::map<void*, size_t> size_;                        // live blocks handed out
   std::map<void*, int> dev_;                            // device of every block we own
   std::map<int, size_t> cap_;                           // per device: most bytes kept in the cache
-  size_t cached_ = 0;
+  std::map<int, size_t> cached_;                        // per device: bytes held in free_
+  int nctx_ = 0;
 };
 
 inline hipError_t dev_alloc(void** p, size_t bytes) { return DevicePool::get().alloc(p, bytes); }

@@ -93,7 +93,7 @@ def _match_rows(a, b):
     return oa[ok], ob[pos[ok]]
 
 
-def upload(ctx, chunk):
-    """qdg_mesh_upload of a chunk (capi.Mesh)."""
+def upload(ctx, chunk, elem_gid=None):
+    """qdg_mesh_upload[_gid] of a chunk (capi.Mesh); elem_gid: global tet ids, faces oriented by them."""
     return capi.Mesh(ctx, chunk.nielem, chunk.inpoel, chunk.coord, chunk.esuf, chunk.esuel,
-                     chunk.inpofa, chunk.geoFace, chunk.geoElem, chunk.bface, chunk.nbfac)
+                     chunk.inpofa, chunk.geoFace, chunk.geoElem, chunk.bface, chunk.nbfac, elem_gid=elem_gid)

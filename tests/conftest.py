@@ -39,3 +39,17 @@ def load_fixture(name):
 @pytest.fixture(scope="session")
 def fixture_loader():
     return load_fixture
+
+
+def compflow_err(Ug, U, ndof):
+    """max over tets, components and DOFs of |Ug - U| relative to the COMPONENT's own magnitude (not to the
+    global max |U|, which for Sedov is the blast's rho*E ~ 2e3 and would allow 2e-7 absolute on density):
+    density by max |rho|, total energy by max |rho*E|, the three momenta together by the largest momentum
+    mean (floored by 1e-3 sqrt(max rho * max rho*E), a thousandth of rho * sound speed, so that a flow at rest,
+    whose momenta are zero but for rounding, does not turn rounding into a relative error)."""
+    A = np.asarray(Ug).reshape(-1, 5, ndof)
+    B = np.asarray(U).reshape(-1, 5, ndof)
+    mean = np.abs(B[:, :, 0]).max(axis=0)
+    mom = max(mean[1:4].max(), 1e-3 * np.sqrt(mean[0] * mean[4]))
+    scale = np.array([mean[0], mom, mom, mom, mean[4]])
+    return float((np.abs(A - B).max(axis=(0, 2)) / scale).max())

@@ -6,7 +6,7 @@ config's CompFlow DG-P1 physics, against the oracle on the refined mesh."""
 import numpy as np
 import pytest
 
-from conftest import load_fixture
+from conftest import compflow_err, load_fixture
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -92,7 +92,7 @@ def test_config5_physics_refine_once_matches_oracle(ndof, limiter):
             dto = orc2.step(t, U, L2, cfl=0.3)
             assert abs(dtg - dto) <= 1e-11 * dto
             t += dto
-        assert np.abs(run.mesh.state_download() - U).max() <= 1e-10 * max(1.0, np.abs(U).max())
+        assert compflow_err(run.mesh.state_download(), U, ndof) <= 1e-10
     finally:
         run.mesh.close(); ctx.close()
 

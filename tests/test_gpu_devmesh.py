@@ -72,6 +72,32 @@ def test_device_facedata_known_answers_and_tiny_meshes():
         ctx.close()
 
 
+def test_inverted_tet_does_not_hide_an_unmatched_boundary_face():
+    """qdg_dev_facedata tolerates inverted tets (the reference's derived-data unit meshes are not all
+    positively oriented) but must still refuse a boundary triangle that is a face of no tet -- the two
+    conditions have separate error bits on the device (round 3's build lost the second behind the first)."""
+    from quinoa_amd import capi, meshgen
+    ch = meshgen.kuhn_box(2, 2, 2)
+    inp = ch["inpoel"].copy()
+    inp[5, [0, 1]] = inp[5, [1, 0]]                     # one inverted tet
+    _, tri = capi.bnd_faces(inp, ch["sidesets"])
+    ctx = capi.Context(1, cfl=0.3)
+    try:
+        g = capi.dev_facedata(ctx, inp, ch["coord"], tri)      # inverted tet alone: accepted here
+        assert g["geoElem"][4 * 5] < 0.0
+        # a triangle of three nodes that no tet has as a face
+        n = ch["coord"].shape[0]
+        bogus = np.array([[0, n // 2, n - 1]], dtype=np.uint64)
+        faces = {tuple(sorted(inp[e][list(f)])) for e in range(len(inp)) for f in ([1, 2, 3], [2, 0, 3], [3, 0, 1], [0, 2, 1])}
+        assert tuple(sorted(int(v) for v in bogus[0])) not in faces
+        with pytest.raises(capi.QdgError, match="not a face of any tet"):
+            capi.dev_facedata(ctx, inp, ch["coord"], np.concatenate([tri.astype(np.uint64), bogus]))
+        with pytest.raises(capi.QdgError, match="non-positive element volume"):
+            capi.mesh_from_connectivity(ctx, inp, ch["coord"], ch["sidesets"])
+    finally:
+        ctx.close()
+
+
 def test_device_facedata_full_size_and_timing():
     """998 250 tets: identical to the host mirror; the timing is printed for DESIGN.md"""
     from quinoa_amd import capi, meshgen

@@ -190,6 +190,7 @@ def _run_rccl(rank, world, port, parts, out):
         ctx = capi.Context(4, cfl=0.3, device=rank, **KW, **BC)
         mesh = dgmesh.upload(ctx, ck)
         comm = dg.RcclComm(ctx)
+        assert comm.comm.info() == (world, rank, rank)     # ncclCommCount / UserRank / CuDevice
         drv = dg.DGDriver(ctx, mesh, ch["nbr_rank"], ch["send_lists"], ch["recv_counts"], comm)
         mesh.state_initialize(0.0)
         t = 0.0
@@ -197,17 +198,18 @@ def _run_rccl(rank, world, port, parts, out):
             drv.step(t)
             t += drv.dt_taken()
         U = mesh.state_download().reshape(-1, 20)[:ck.nielem]
-        np.savez(out % rank, gid=ch["gid"][:ck.nielem], U=U, t=t)
+        np.savez(out % rank, gid=ch["gid"][:ck.nielem], U=U, t=t, nnbr=len(ch["nbr_rank"]))
         mesh.close(); comm.close(); ctx.close()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("parts", [(2, 1, 1)])
+@pytest.mark.parametrize("parts", [(2, 1, 1), (2, 2, 1), (2, 2, 2)])
 def test_rccl_between_two_gpus_equals_single_chunk(tmp_path, parts):
-    """RcclComm / qdg_step_comm -- what `bench.py --gpus N` runs -- across two DIFFERENT devices
-    vs the single-chunk run.  Needs a lease with >= 2 GPUs: skipped on the one-GPU test box
-    (torch.cuda.device_count() does not initialise the GPU)."""
+    """RcclComm / qdg_step_comm -- what `bench.py --gpus N` runs -- across DIFFERENT devices vs the
+    single-chunk run, for every cut the visible device count allows: (2,1,1) one neighbour per rank,
+    (2,2,1) two, (2,2,2) three (the 8-GPU bench's decomposition).  Needs a lease with that many GPUs:
+    skipped on the one-GPU test box (torch.cuda.device_count() does not initialise the GPU)."""
     import torch
     import torch.multiprocessing as mp
     world = parts[0] * parts[1] * parts[2]
@@ -222,5 +224,6 @@ def test_rccl_between_two_gpus_equals_single_chunk(tmp_path, parts):
     ref[s["gid"]] = s["U"]
     for r in range(world):
         d = np.load(out2 % r)
+        assert int(d["nnbr"]) == sum(1 for p in parts if p > 1)
         assert abs(float(d["t"]) - float(s["t"])) <= 1e-12 * float(s["t"])
         assert np.abs(d["U"] - ref[d["gid"]]).max() / np.abs(ref).max() <= 1e-10, r

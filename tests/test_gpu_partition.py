@@ -6,7 +6,7 @@ of the test box (quinoa_amd.dg.LocalChunks: halo slabs moved by device copies)."
 import numpy as np
 import pytest
 
-from conftest import load_fixture
+from conftest import compflow_err, load_fixture
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -165,6 +165,143 @@ def test_bench_block_decomposition_on_the_gpu_equals_single_chunk(parts, dims):
             seen[g] += 1
             assert np.abs(U - ref[g]).max() <= TOL * max(1.0, np.abs(ref).max())
         assert (seen == 1).all()
+    finally:
+        for m in meshes:
+            m.close()
+        m1.close(); ctx.close(); ctx1.close()
+
+
+def _negative_pressure_face_points(U, gamma=1.4):
+    """number of face Gauss points (4 faces x 3 points per tet) at which the DG-P1 state U[ne, 20] has a
+    non-positive density or pressure -- where HLLC's wave speeds are NaN and its ladder falls through to the
+    stored right state (src/PDE/Integrate/Riemann/HLLC.hpp:93-124).  A P1 state is affine: its value at a
+    face point is the barycentric mix of its vertex values; Dubiner basis of src/PDE/Integrate/Basis.cpp:267-307."""
+    vert = np.array([[0., 0., 0.], [1., 0., 0.], [0., 1., 0.], [0., 0., 1.]])
+    B = np.stack([np.ones(4), 2 * vert[:, 0] + vert[:, 1] + vert[:, 2] - 1, 3 * vert[:, 1] + vert[:, 2] - 1,
+                  4 * vert[:, 2] - 1], axis=1)                       # [vertex, mode]
+    V = np.einsum("eck,vk->ecv", U.reshape(-1, 5, 4), B)              # vertex values
+    lpofa = [[1, 2, 3], [2, 0, 3], [3, 0, 1], [0, 2, 1]]
+    n = 0
+    for f in lpofa:
+        for h in range(3):
+            w = np.full(3, 1.0 / 6.0); w[h] = 2.0 / 3.0
+            s = sum(w[j] * V[:, :, f[j]] for j in range(3))
+            with np.errstate(divide="ignore", invalid="ignore"):
+                p = (gamma - 1.0) * (s[:, 4] - 0.5 * (s[:, 1] ** 2 + s[:, 2] ** 2 + s[:, 3] ** 2) / s[:, 0])
+            n += int(((p <= 0.0) | (s[:, 0] <= 0.0) | ~np.isfinite(p)).sum())
+    return n
+
+
+def test_config4_sedov_block_decomposition_equals_single_chunk_on_every_tet():
+    """BASELINE config 4's scheme (Sedov DG-P1 + Superbee, CFL 0.3) on the bench's 2 x 2 x 2 block
+    decomposition of a 48^3 box (663 552 tets), 3 CFL steps, all chunks on this GPU: EVERY tet, every
+    component, <= 1e-10 of the single-chunk run (tolerance per component, relative to that component's
+    largest mean).  The P1 projection of the 10^9 : 1 pressure jump has negative pressure at face points of
+    the blast column; HLLC then falls through to the STORED right state (HLLC.hpp:93-124), so the two runs
+    agree only because both orient their faces by GLOBAL tet id (qdg_mesh_from_chunk_gid, option
+    orient_by_gid).  The test asserts that such face points exist in the limited state the first RHS sees,
+    and that with the chare-local orientation (DG.cpp:480-483; option off) the same decomposition does
+    differ -- so it keeps testing the fall-through."""
+    from quinoa_amd import capi, dg, meshgen
+    parts, nx, nsteps = (2, 2, 2), 48, 3
+    kw = dict(flux="hllc", limiter="superbeep1", problem="sedov_blastwave", gamma=1.4, cfl=0.3,
+              bc_extrapolate=[2, 4], bc_sym=[1, 3, 5, 6])
+    ntet = 6 * nx ** 3
+    one = meshgen.kuhn_box_chunk(nx, nx, nx, parts=(1, 1, 1), rank=0)
+    chunks = [meshgen.kuhn_box_chunk(nx, nx, nx, parts=parts, rank=r) for r in range(8)]
+
+    def single():
+        ctx = capi.Context(4, **kw)
+        m = capi.mesh_from_connectivity(ctx, one["inpoel"], one["coord"], one["sidesets"], elem_gid=one["gid"])
+        try:
+            m.state_initialize(0.0)
+            nneg = _negative_pressure_face_points(m.limit(m.state_download()).reshape(-1, 20))
+            t = 0.0
+            for _ in range(nsteps):
+                t += m.step(t)
+            ref = np.zeros((ntet, 20))
+            ref[one["gid"]] = m.state_download().reshape(-1, 20)
+            return ref, t, nneg
+        finally:
+            m.close(); ctx.close()
+
+    def decomposed(orient_by_gid):
+        ctx = capi.Context(4, **kw)
+        ctx.set_option("orient_by_gid", int(orient_by_gid))
+        meshes = [capi.mesh_from_connectivity(ctx, c["inpoel"], c["coord"], c["sidesets"], nielem=c["nielem"],
+                                              elem_gid=c["gid"]) for c in chunks]
+        try:
+            for m in meshes:
+                m.state_initialize(0.0)
+            drv = dg.LocalChunks(ctx, meshes, chunks)
+            t = 0.0
+            for _ in range(nsteps):
+                t += drv.step(t)
+            out = np.zeros((ntet, 20))
+            seen = np.zeros(ntet, dtype=int)
+            for c, m in zip(chunks, meshes):
+                nie = c["nielem"]
+                out[c["gid"][:nie]] = m.state_download().reshape(-1, 20)[:nie]
+                seen[c["gid"][:nie]] += 1
+            assert (seen == 1).all()
+            return out, t
+        finally:
+            for m in meshes:
+                m.close()
+            ctx.close()
+
+    ref, t1, nneg = single()
+    assert nneg > 0, "no face point with p <= 0: the test no longer exercises HLLC's fall-through"
+    got, t = decomposed(True)
+    assert abs(t - t1) <= 1e-13 * t1
+    err = compflow_err(got, ref, 4)               # per component, max over ALL tets and DOFs
+    assert err <= TOL, "worst tet %d: %.2e" % (int(np.abs(got - ref).max(axis=1).argmax()), err)
+    loc, _ = decomposed(False)
+    assert compflow_err(loc, ref, 4) > 10 * TOL, \
+        "chare-local orientation no longer differs: is the fall-through still reached?"
+
+
+@pytest.mark.parametrize("device_build", [True, False])
+def test_general_partition_with_global_ids_equals_the_serial_run(device_build):
+    """The serial run of a mesh (one chunk, NO global ids: left tet of a face = lower tet id, the
+    reference's own rule, DerivedData.cpp:1127-1139) against the same mesh cut into 5 RCB chunks by
+    qdg_partition / qdg_chunk_build whose meshes are built with the chunks' elem_gid -- through the device
+    build (qdg_mesh_from_chunk_gid) and through the host-array upload (qdg_mesh_upload_gid, the caller's
+    FaceData keeps left = owned tet).  Sedov on a 20^3 box, 3 CFL steps, every tet <= 1e-10."""
+    from quinoa_amd import capi, dg, dgmesh, meshgen, partition
+    kw = dict(flux="hllc", limiter="superbeep1", problem="sedov_blastwave", gamma=1.4, cfl=0.3,
+              bc_extrapolate=[2, 4], bc_sym=[1, 3, 5, 6])
+    g = meshgen.kuhn_box(20, 20, 20)
+    coord, inpoel, ss = g["coord"], g["inpoel"], g["sidesets"]
+    ctx1 = capi.Context(4, **kw)
+    m1 = capi.mesh_from_connectivity(ctx1, inpoel, coord, ss)
+    ctx = capi.Context(4, **kw)
+    nparts = 5
+    part = partition.partition(coord, inpoel, nparts, "rcb")
+    chunks = [partition.build_chunk(coord, inpoel, ss, part, nparts, r) for r in range(nparts)]
+    if device_build:
+        meshes = [capi.mesh_from_connectivity(ctx, c["inpoel"], c["coord"], c["sidesets"], nielem=c["nielem"],
+                                              elem_gid=c["gid"]) for c in chunks]
+    else:
+        meshes = [dgmesh.upload(ctx, dgmesh.build_chunk(c["coord"], c["inpoel"], c["nielem"], c["sidesets"]),
+                                elem_gid=c["gid"]) for c in chunks]
+    try:
+        m1.state_initialize(0.0)
+        assert _negative_pressure_face_points(m1.limit(m1.state_download()).reshape(-1, 20)) > 0
+        for m in meshes:
+            m.state_initialize(0.0)
+        drv = dg.LocalChunks(ctx, meshes, chunks)
+        t = t1 = 0.0
+        for _ in range(3):
+            t += drv.step(t)
+            t1 += m1.step(t1)
+        assert abs(t - t1) <= 1e-13 * t1
+        ref = m1.state_download().reshape(-1, 20)
+        got = np.zeros_like(ref)
+        for c, m in zip(chunks, meshes):
+            nie = c["nielem"]
+            got[c["gid"][:nie]] = m.state_download().reshape(-1, 20)[:nie]
+        assert compflow_err(got, ref, 4) <= TOL
     finally:
         for m in meshes:
             m.close()

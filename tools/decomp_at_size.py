@@ -4,7 +4,10 @@
 transport) against the single-chunk run of the same global mesh -- states compared tet by tet through the
 global ids after a few CFL steps.  What the 8-GPU runs of the north-star box (119^3) and of config 4
 (220^3, Sedov) compute, minus RCCL.
-Usage: python tools/decomp_at_size.py NX PX PY PZ [sod|sedov] [steps]"""
+Faces are oriented by global tet id in both runs (qdg_mesh_from_chunk_gid, context option orient_by_gid;
+round 4) unless the last argument is "local" (the chare-local rule, src/Inciter/DG.cpp:480-483: the runs
+then differ where HLLC falls through to the stored right state).
+Usage: python tools/decomp_at_size.py NX PX PY PZ [sod|sedov] [steps] [gid|local]"""
 import os
 import sys
 import time
@@ -16,6 +19,7 @@ from quinoa_amd import capi, dg, meshgen  # noqa: E402
 nx = int(sys.argv[1]); parts = tuple(int(a) for a in sys.argv[2:5])
 work = sys.argv[5] if len(sys.argv) > 5 else "sod"
 steps = int(sys.argv[6]) if len(sys.argv) > 6 else 3
+orient = sys.argv[7] if len(sys.argv) > 7 else "gid"
 kw = dict(flux="hllc", limiter="superbeep1", gamma=1.4, cfl=0.3)
 if work == "sedov":
     kw.update(problem="sedov_blastwave", bc_extrapolate=[2, 4], bc_sym=[1, 3, 5, 6])
@@ -28,7 +32,8 @@ ctx = capi.Context(4, **kw)
 chunks, meshes = [], []
 for r in range(nr):
     c = meshgen.kuhn_box_chunk(nx, nx, nx, parts=parts, rank=r)
-    m = capi.mesh_from_connectivity(ctx, c["inpoel"], c["coord"], c["sidesets"], nielem=c["nielem"])
+    m = capi.mesh_from_connectivity(ctx, c["inpoel"], c["coord"], c["sidesets"], nielem=c["nielem"],
+                                    elem_gid=c["gid"] if orient == "gid" else None)
     # keep only what the comparison and the halo plan need
     chunks.append({k: c[k] for k in ("nielem", "gid", "nbr_rank", "send_lists", "recv_counts")})
     meshes.append(m)
@@ -53,7 +58,8 @@ assert (seen == 1).all(), "every tet owned exactly once"
 print("decomposition ran: dt", dts, " (%.0f s)" % (time.perf_counter() - t0), flush=True)
 one = meshgen.kuhn_box_chunk(nx, nx, nx, parts=(1, 1, 1), rank=0)
 ctx1 = capi.Context(4, **kw)
-m1 = capi.mesh_from_connectivity(ctx1, one["inpoel"], one["coord"], one["sidesets"])
+m1 = capi.mesh_from_connectivity(ctx1, one["inpoel"], one["coord"], one["sidesets"],
+                                 elem_gid=one["gid"] if orient == "gid" else None)
 gid1 = one["gid"].copy()
 cen1 = one["coord"][one["inpoel"]].mean(axis=1)
 del one
@@ -73,7 +79,13 @@ if bad.any():
           "non-finite wave speeds possible where the P1 state has p < 0" % (
               bad.sum(), len(bad), cen1[bad, 0].min(), cen1[bad, 0].max(), cen1[bad, 1].min(), cen1[bad, 1].max(),
               cen1[bad, 2].min(), cen1[bad, 2].max()))
-print("nx %d (%d tets) %s in %dx%dx%d chunks vs single chunk after %d steps: max |dU| / max|U| = %.2e, |dt - dt1| / dt1 = %.1e  (%.0f s)"
-      % ((nx, ntet, work) + parts + (steps, err, max(abs(a - b) / b for a, b in zip(dts, dts1)), time.perf_counter() - t0)), flush=True)
+# per component: the largest difference over all tets and DOFs relative to that component's own magnitude
+comp = [float(np.abs(U1[:, 4 * c:4 * c + 4] - ref[gid1][:, 4 * c:4 * c + 4]).max() / max(1e-300, np.abs(U1[:, 4 * c]).max()))
+        for c in range(5)]
+print("nx %d (%d tets) %s in %dx%dx%d chunks vs single chunk after %d steps, faces oriented by %s: max |dU| / max|U| = %.2e, "
+      "per component (rho, rho*u, rho*v, rho*w, rho*E) %s, tets off by > 1e-10: %d, |dt - dt1| / dt1 = %.1e  (%.0f s)"
+      % ((nx, ntet, work) + parts + (steps, "global id" if orient == "gid" else "chunk-local id", err,
+                                     " ".join("%.1e" % v for v in comp), int(bad.sum()),
+                                     max(abs(a - b) / b for a, b in zip(dts, dts1)), time.perf_counter() - t0)), flush=True)
 m1.close(); ctx.close(); ctx1.close()
 sys.exit(0 if err <= 1e-10 else 1)
