@@ -13,7 +13,7 @@ Control-file parameters of each case (scheme, dt/cfl, nstep, flux, limiter,
 BC side sets, material gamma, problem constants) are transcribed in
 tests/golden/cases.json from the `.q` files named there.
 
-Usage:  python tests/golden/make_fixtures.py
+Usage:  python tests/golden/make_fixtures.py [case ...]     (no argument: every case of cases.json)
 """
 import json
 import os
@@ -108,13 +108,25 @@ def read_diag(path):
 def main():
     with open(os.path.join(HERE, "cases.json")) as fh:
         cases = json.load(fh)
+    only = set(sys.argv[1:])
     for name, c in cases.items():
+        if only and name not in only:
+            continue
         d = os.path.join(REF, c["dir"])
+        # (mesh_is_golden_output: a run with initial mesh refinement computes on the mesh the reference's
+        # Refiner produced; that mesh -- coordinates, tets, side sets -- is stored in the golden output file)
         coord, inpoel, ss = read_mesh(os.path.join(d, c["mesh"]))
         out = {"coord": coord, "inpoel": inpoel.astype(np.int64),
                "ss_ids": np.array(sorted(ss), dtype=np.int64)}
         for sid in ss:
             out["ss_tri_%d" % sid] = ss[sid].astype(np.int64)
+        if c.get("input_mesh"):
+            # the unrefined input mesh of that run, to check this repository's uniform refinement against
+            ic, ii, iss = read_mesh(os.path.join(d, c["input_mesh"]))
+            out["in_coord"], out["in_inpoel"] = ic, ii.astype(np.int64)
+            out["in_ss_ids"] = np.array(sorted(iss), dtype=np.int64)
+            for sid in iss:
+                out["in_ss_tri_%d" % sid] = iss[sid].astype(np.int64)
         if c.get("golden_exo"):
             t, names, vals, conn, gcoord = read_golden_exo(
                 os.path.join(d, c["golden_exo"]), inpoel.shape[0])

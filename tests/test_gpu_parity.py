@@ -41,7 +41,9 @@ def _setup(case, fix, dt=None, cfl=None):
 
 CASES = ["sod_dg", "rotated_sod_dg", "nleg_dgp2", "sedov_dgp1", "sedov_pdg", "vortical_flow_dg", "vortical_flow_dg_lf",
          "vortical_flow_dgp1", "vortical_flow_dgp1_lf", "taylor_green_dgp2",
-         "taylor_green_dgp2_cfl"]
+         "taylor_green_dgp2_cfl",
+         # the reference Refiner's own t0-refined mesh as caller-supplied connectivity (mesh_refinement/t0ref)
+         "t0ref_vortical_flow_dg"]
 
 
 @pytest.mark.parametrize("name", CASES)

@@ -96,7 +96,9 @@ def test_transport_config_errors():
 
 
 MORE = ["cyl_advect_dg", "cyl_advect_dgp1", "cyl_advect_dgp1_weno", "gauss_hump_dgp1",
-        "gauss_hump_dgp2", "gauss_hump_pdg"]
+        "gauss_hump_dgp2", "gauss_hump_pdg",
+        # round 4: GaussHump DG-P0, the cube case (diag table only) and the reference Refiner's t0-refined mesh
+        "gauss_hump_dg", "gauss_hump_cube", "t0ref_gauss_hump_dg"]
 
 
 @pytest.mark.parametrize("name", MORE)
