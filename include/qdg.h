@@ -156,6 +156,8 @@ int qdg_ctx_synchronize(qdg_ctx* ctx);
  *   "host_layout"   1: qdg_mesh_from_connectivity runs qdg_mesh_upload's host layout code (A/B)
  *   "orient_by_gid" 1 (default): meshes built with global tet ids (qdg_mesh_upload_gid, qdg_mesh_from_chunk_gid)
  *                   orient their faces by global id; 0: the chare-local rule of src/Inciter/DG.cpp:480-483
+ *   "keep_connectivity" 1: meshes built on the device without ghosts keep their connectivity, coordinates, esuel
+ *                   and boundary faces resident (~ 60 B per tet) for qdg_mesh_refine_uniform; default 0
  *   "keep_pool"     0 (default): qdg_ctx_destroy of the process's last context returns the device buffer
  *                   cache to the driver; 1: keeps it for the next context */
 int qdg_ctx_set_option(qdg_ctx* ctx, const char* name, int value);
@@ -441,6 +443,22 @@ int qdg_chunk_refined_get(const qdg_chunk_refined* c, size_t* inpoel, size_t* gi
                           size_t* send_off, size_t* send_list, size_t* recv_counts);
 int qdg_chunk_refined_destroy(qdg_chunk_refined* c);
 int qdg_state_transfer(qdg_mesh* from, qdg_mesh* to, const size_t* parent_of_child);
+/* The whole re-mesh of a resident chunk WITHOUT ghosts in one call, with nothing but the host's copy of the
+ * refined mesh crossing PCIe (DG::resizePostAMR, src/Inciter/DG.cpp:1536-1612; BASELINE config 5): uniform
+ * 1:8 refinement from the connectivity `mesh` kept on the device (build it with context option
+ * "keep_connectivity" = 1; a mesh made by this call always keeps its own), esuel of the children derived from
+ * the parents' by the 1:8 template (src/Inciter/AMR/refinement.hpp:425-536) instead of a sort over all child
+ * faces, boundary faces from the children of the parent's boundary faces, the same device layout as every
+ * other build (the new handle is array for array the one qdg_mesh_from_connectivity makes from the refined
+ * connectivity), and the state handed over child <- parent.  `mesh` stays valid (destroy it when done).
+ * host_copy (may be NULL): the refined mesh for the host's book-keeping -- children 8 e + k of tet e, old
+ * nodes followed by edge midpoints as qdg_refine_uniform numbers them, triangles = the children 4 b + k of
+ * the parent's boundary faces b in the library's order (side set: qdg_refined_tri_sets) -- filled by a second
+ * host thread on a second stream while this call builds the mesh; qdg_refined_sizes / _get / _tri_sets wait
+ * for it. */
+int qdg_mesh_refine_uniform(qdg_mesh* mesh, qdg_mesh** refined_mesh, qdg_refined** host_copy);
+int qdg_refined_sizes(const qdg_refined* r, size_t* nelem, size_t* nnode, size_t* ntri);
+int qdg_refined_tri_sets(const qdg_refined* r, int32_t* tri_set);
 /* The child mesh need not come from qdg_refine_*: ANY conforming tetrahedron mesh with a parent
  * per tet is accepted -- what Refiner hands DG::resizePostAMR (src/Inciter/DG.cpp:1537-1612), e.g. a
  * region refined 1:8 and closed with the 1:2 / 1:4 templates of src/Inciter/AMR/refinement.hpp:78-424;

@@ -67,17 +67,36 @@ class RefinedRun:
     """One chunk without ghosts that is refined uniformly while it runs: holds the host mesh
     (what Discretization holds), the device mesh handle and the resident state."""
 
-    def __init__(self, ctx, coord, inpoel, sidesets, device_refine=True):
+    def __init__(self, ctx, coord, inpoel, sidesets, device_refine=True, resident=False):
+        """resident: the re-mesh never leaves the device (qdg_mesh_refine_uniform; the mesh handle keeps its
+        connectivity resident, the host gets its copy of the refined mesh from a second thread)"""
         self.ctx = ctx
         self.device_refine = device_refine
+        self.resident = resident
+        if resident:
+            ctx.set_option("keep_connectivity", 1)
         self.coord, self.inpoel, self.sidesets = np.asarray(coord, dtype=np.float64), np.asarray(inpoel), sidesets
         self.mesh = capi.mesh_from_connectivity(ctx, self.inpoel, self.coord, self.sidesets)
         self.timings = []
+        self.host_copy_s = None
 
     def refine(self):
         """uniform 1:8 refinement (on the device by default, copied back for the host's book-keeping)
         + rebuild on the device + state transfer; returns the seconds spent in (refinement, device
-        mesh rebuild incl. upload, state transfer)"""
+        mesh rebuild incl. upload, state transfer).  resident: (0, the one call that does all three, 0);
+        self.host_copy_s = seconds from the start of that call until the host holds the refined mesh."""
+        if self.resident:
+            t0 = time.perf_counter()
+            new, ref = self.mesh.refine_uniform(host_copy=True)
+            self.ctx.synchronize()
+            t1 = time.perf_counter()
+            self.mesh.close()
+            self.mesh = new
+            self.coord, self.inpoel, self.sidesets, _ = ref.get()       # waits for the copying thread
+            self.host_copy_s = time.perf_counter() - t0
+            ref.close()
+            self.timings.append((0.0, t1 - t0, 0.0))
+            return self.timings[-1]
         t0 = time.perf_counter()
         c2, i2, s2, par = refine_uniform(self.coord, self.inpoel, self.sidesets,
                                          ctx=self.ctx if self.device_refine else None)

@@ -498,6 +498,17 @@ class Mesh:
         r, pr = _sz(np.asarray(rows))
         _chk(lib().qdg_state_rows_put(self.h, C.c_size_t(len(r)), pr, C.c_void_p(int(packed_dev))))
 
+    def refine_uniform(self, host_copy=True):
+        """qdg_mesh_refine_uniform: the re-mesh of this resident chunk on the device (needs context option
+        keep_connectivity = 1 at build time).  Returns (new Mesh with the state handed over, Refined or None);
+        this mesh stays valid until closed."""
+        new = Mesh.__new__(Mesh)
+        new.ctx, new.nprop, new.h = self.ctx, self.nprop, C.c_void_p()
+        r = C.c_void_p()
+        _chk(lib().qdg_mesh_refine_uniform(self.h, C.byref(new.h), C.byref(r) if host_copy else None))
+        new.nielem = new.nunk = 8 * self.nielem
+        return new, (Refined(r) if host_copy else None)
+
     def profile_enable(self, on=True):
         _chk(lib().qdg_profile_enable(self.h, C.c_int(1 if on else 0)))
 
@@ -572,6 +583,37 @@ def mesh_from_connectivity(ctx, inpoel, coord, sidesets, nielem=None, elem_gid=N
                                        C.c_size_t(ntri), tri.ctypes.data_as(c_szp),
                                        tset.ctypes.data_as(c_i32p), pgid, C.byref(m.h)))
     return m
+
+
+class Refined:
+    """qdg_refined handle of qdg_mesh_refine_uniform: the refined mesh on the host, copied from the device by a
+    second thread; get() waits for it.  -> coord[nnode, 3], inpoel[ne, 4], {side set: triangles}, parent[ne]"""
+
+    def __init__(self, h):
+        self.h = h
+
+    def get(self):
+        L = lib()
+        ne, nn, nt = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        _chk(L.qdg_refined_sizes(self.h, C.byref(ne), C.byref(nn), C.byref(nt)))
+        ne, nn, nt = ne.value, nn.value, nt.value
+        inp = np.empty(4 * ne, dtype=np.uint64); par = np.empty(ne, dtype=np.uint64)
+        c = np.empty((3, nn)); tri = np.zeros(max(1, 3 * nt), dtype=np.uint64)
+        tset = np.zeros(max(1, nt), dtype=np.int32)
+        _chk(L.qdg_refined_get(self.h, None, inp.ctypes.data_as(c_szp), par.ctypes.data_as(c_szp),
+                               c[0].ctypes.data_as(c_f64p), c[1].ctypes.data_as(c_f64p),
+                               c[2].ctypes.data_as(c_f64p), tri.ctypes.data_as(c_szp)))
+        if nt:
+            _chk(L.qdg_refined_tri_sets(self.h, tset.ctypes.data_as(c_i32p)))
+        tri = tri[:3 * nt].view(np.int64).reshape(-1, 3)
+        tset = tset[:nt]
+        ss = {int(s_): tri[tset == s_] for s_ in np.unique(tset)}
+        return np.ascontiguousarray(c.T), inp.view(np.int64).reshape(-1, 4), ss, par.view(np.int64)
+
+    def close(self):
+        if self.h:
+            lib().qdg_refined_destroy(self.h)
+            self.h = C.c_void_p()
 
 
 def dev_facedata(ctx, inpoel, coord, triinpoel):

@@ -248,6 +248,7 @@ static int* option_slot(qdg_ctx* ctx, const char* name)
     { "fused_update", &qdg::Options::fused_update },
     { "renumber", &qdg::Options::renumber },       { "host_layout", &qdg::Options::host_layout },
     { "orient_by_gid", &qdg::Options::orient_by_gid }, { "keep_pool", &qdg::Options::keep_pool },
+    { "keep_connectivity", &qdg::Options::keep_connectivity },
   };
   for (const auto& t : tab)
     if (std::strcmp(name, t.n) == 0) return &(ctx->opt.*(t.p));
@@ -372,6 +373,7 @@ extern "C" int qdg_mesh_upload_gid(qdg_ctx* ctx, size_t nielem, size_t nunk, siz
     return fail("qdg_mesh_upload: chunk too large for 32-bit device indices");
   if (nbfac > nfac) return fail("qdg_mesh_upload: nbfac > nfac");
   HIPCHK(hipSetDevice(ctx->device));
+  qdg::StreamScope scope(ctx->stream);
   const size_t nie = nielem, ne = nunk;
 
   // QDG_UPLOAD_STATS=1: wall time of the host sections below, on stderr
@@ -707,6 +709,7 @@ extern "C" int qdg_mesh_destroy(qdg_mesh* mesh)
   if (!mesh) return 0;
   (void)hipSetDevice(mesh->ctx->device);
   (void)hipStreamSynchronize(mesh->ctx->stream);
+  qdg::StreamScope scope(mesh->ctx->stream);
   delete mesh;
   return 0;
   QDG_CATCH
@@ -719,6 +722,7 @@ extern "C" int qdg_mesh_destroy(qdg_mesh* mesh)
   qdg_ctx* ctx = mesh->ctx;                                      \
   HIPCHK(hipSetDevice(ctx->device));                             \
   hipStream_t s = ctx->stream;                                   \
+  qdg::StreamScope stream_scope_(s);                             \
   (void)s
 
 // host AoS (all ne rows) -> SoA planes `dst`

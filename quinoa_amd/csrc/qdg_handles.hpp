@@ -54,6 +54,8 @@ struct Options {
   int orient_by_gid = 1; // meshes built WITH global tet ids (qdg_mesh_*_gid): left tet of a face = lower global id
                          // (a partitioned run takes the serial run's HLLC branches); 0: chunk-local rule
   int keep_pool = 0;     // 1: qdg_ctx_destroy of the last context keeps the device buffer cache
+  int keep_connectivity = 0;  // 1: device-built meshes without ghosts keep connectivity, coordinates, esuel and
+                              // boundary faces (caller's numbering) resident: qdg_mesh_refine_uniform needs them
 };
 }  // namespace qdg
 
@@ -110,6 +112,10 @@ struct qdg_mesh {
   double* recv_ptr = nullptr;
   double* dt_ptr = nullptr;       // dt scalar in use
   size_t nnode_used = 0;
+  // connectivity kept on the device for a re-mesh that does not go through the host (qdg_devmesh.hip)
+  struct Keep;
+  Keep* keep = nullptr;
+  void (*keep_free)(Keep*) = nullptr;
   // measurement: event pairs around the RHS kernel (cont: second part of a split launch)
   bool prof = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
@@ -118,6 +124,7 @@ struct qdg_mesh {
   ~qdg_mesh()
   {
     for (auto& e : ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    if (keep && keep_free) keep_free(keep);
   }
 };
 

@@ -4,6 +4,8 @@
 #include <cstdint>
 #include <exception>
 #include <memory>
+#include <mutex>
+#include <thread>
 #include <utility>
 #include <string>
 #include <vector>
@@ -43,9 +45,22 @@ template <class T> struct raw_alloc : std::allocator<T> {
 };
 template <class T> using rawvec = std::vector<T, raw_alloc<T>>;
 
+// a host thread that is still filling a qdg_refined from device buffers (qdg_mesh_refine_uniform): joined by
+// whoever needs the data or wants to free the buffers it reads
+struct qdg_host_copy {
+  std::thread th;
+  std::mutex mu;
+  std::string error;
+  void join() { std::lock_guard<std::mutex> g(mu); if (th.joinable()) th.join(); }
+  ~qdg_host_copy() { join(); }
+};
+
 struct qdg_refined {
   size_t nnode = 0;
   rawvec<size_t> inpoel, parent, tri;
   rawvec<double> x, y, z;
+  std::vector<int32_t> tri_set;                 // side set of every refined triangle (qdg_mesh_refine_uniform)
+  std::shared_ptr<qdg_host_copy> pending;       // the arrays above are complete once this has been joined
+  void wait() const { if (pending) pending->join(); }
 };
 

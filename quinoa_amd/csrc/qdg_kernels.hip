@@ -1469,7 +1469,8 @@ __global__ __launch_bounds__(256) void k_state_transfer(int nrow, int nchunk, co
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)nrow * nchunk) return;
   const int d = (int)(i / nchunk), p = (int)(i - (size_t)d * nchunk);
-  const int par = parent[d2h_to[d]];
+  const int c = d2h_to[d];
+  const int par = parent ? parent[c] : (c >> 3);     // (no list: uniform 1:8 refinement, child 8 e + k of tet e)
   if (par < 0) return;                         // row not served by this source (state migration)
   Uto[i] = Ufrom[(size_t)h2d_from[par] * nchunk + p];
 }
@@ -1482,7 +1483,8 @@ __global__ __launch_bounds__(256) void k_state_transfer1(int nrow, int nprop, co
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)nrow * nprop) return;
   const int d = (int)(i / nprop), p = (int)(i - (size_t)d * nprop);
-  const int par = parent[d2h_to[d]];
+  const int c = d2h_to[d];
+  const int par = parent ? parent[c] : (c >> 3);
   if (par < 0) return;
   Uto[i] = Ufrom[(size_t)h2d_from[par] * nprop + p];
 }

@@ -649,6 +649,8 @@ extern "C" int qdg_refined_get(const qdg_refined* r, size_t* nnode, size_t* inpo
 {
   QDG_TRY
   if (!r) return fail("qdg_refined_get: null handle");
+  r->wait();                                   // (a copy from the device may still be in flight)
+  if (r->pending && !r->pending->error.empty()) return fail("qdg_refined_get: " + r->pending->error);
   if (nnode) *nnode = r->nnode;
   auto cp = [](auto* dst, const auto& v) { if (dst && !v.empty()) std::memcpy(dst, v.data(), v.size() * sizeof(v[0])); };
   cp(inpoel, r->inpoel); cp(parent, r->parent); cp(x, r->x); cp(y, r->y); cp(z, r->z); cp(tri, r->tri);
@@ -656,9 +658,34 @@ extern "C" int qdg_refined_get(const qdg_refined* r, size_t* nnode, size_t* inpo
   QDG_CATCH
 }
 
+extern "C" int qdg_refined_sizes(const qdg_refined* r, size_t* nelem, size_t* nnode, size_t* ntri)
+{
+  QDG_TRY
+  if (!r) return fail("qdg_refined_sizes: null handle");
+  r->wait();
+  if (nelem) *nelem = r->inpoel.size() / 4;
+  if (nnode) *nnode = r->nnode;
+  if (ntri) *ntri = r->tri.size() / 3;
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_refined_tri_sets(const qdg_refined* r, int32_t* tri_set)
+{
+  QDG_TRY
+  if (!r || !tri_set) return fail("qdg_refined_tri_sets: null argument");
+  r->wait();
+  if (r->tri_set.size() != r->tri.size() / 3)
+    return fail("qdg_refined_tri_sets: this handle carries no side-set ids (it was made from the caller's own triangle list)");
+  std::memcpy(tri_set, r->tri_set.data(), r->tri_set.size() * sizeof(int32_t));
+  return 0;
+  QDG_CATCH
+}
+
 extern "C" int qdg_refined_destroy(qdg_refined* r)
 {
   QDG_TRY
+  if (r) r->wait();
   delete r;
   return 0;
   QDG_CATCH

@@ -9,8 +9,8 @@
 // qdg_device_pool_trim, before the library lets a third party allocate (qdg_comm_create: RCCL) and when the
 // process's last context is destroyed (context option "keep_pool" = 1 keeps it: the next context would pay
 // the driver again).  Cached bytes are counted per device.  hipFree synchronises the device; a cached block that is handed out again does
-// the same (hipDeviceSynchronize), so a buffer freed while kernels of any stream may still use it is
-// never reused early.  Allocation never happens inside the time loop.
+// the same (hipDeviceSynchronize) unless it stays on the stream it was freed under (StreamTag below), so a
+// buffer freed while kernels may still use it is never reused early.  Allocation never happens inside the time loop.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -19,6 +19,25 @@
 #include <mutex>
 
 namespace qdg {
+
+// The stream the calling thread's library call enqueues its work on (set by every entry point that
+// allocates or frees device buffers).  A block that was freed under stream S and is handed out again to
+// a caller working on S needs no synchronisation: everything the block's previous life enqueued on S runs
+// before anything its next life enqueues there.  Any other pairing waits for the device, as hipFree would.
+struct StreamTag {
+  static hipStream_t& cur() { static thread_local hipStream_t s = nullptr; return s; }
+  static bool& known() { static thread_local bool k = false; return k; }
+};
+struct StreamScope {
+  hipStream_t prev; bool prev_known;
+  explicit StreamScope(hipStream_t s) : prev(StreamTag::cur()), prev_known(StreamTag::known())
+  {
+    StreamTag::cur() = s; StreamTag::known() = true;
+  }
+  ~StreamScope() { StreamTag::cur() = prev; StreamTag::known() = prev_known; }
+  StreamScope(const StreamScope&) = delete;
+  StreamScope& operator=(const StreamScope&) = delete;
+};
 
 class DevicePool {
  public:
@@ -31,6 +50,7 @@ class DevicePool {
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     const size_t want = round(bytes);
+    bool same_stream = false;
     {
       std::lock_guard<std::mutex> g(mu_);
       auto& fl = free_[dev];
@@ -40,10 +60,13 @@ class DevicePool {
         size_[p] = it->first;
         cached_[dev] -= it->first;
         fl.erase(it);
+        auto st = freed_on_.find(p);
+        same_stream = st != freed_on_.end() && StreamTag::known() && st->second == StreamTag::cur();
+        if (st != freed_on_.end()) freed_on_.erase(st);
         *out = p;
       }
     }
-    if (*out) return hipDeviceSynchronize();      // what hipFree would have waited for
+    if (*out) return same_stream ? hipSuccess : hipDeviceSynchronize();   // (what hipFree would have waited for)
     void* p = nullptr;
     e = hipMalloc(&p, want);
     if (e != hipSuccess) {
@@ -80,6 +103,7 @@ class DevicePool {
     }
     free_[dev].emplace(sz, p);
     cached_[dev] += sz;
+    if (StreamTag::known()) freed_on_[p] = StreamTag::cur();
   }
   // hands every cached block back to the driver; returns the bytes released
   size_t trim()
@@ -88,7 +112,7 @@ class DevicePool {
     {
       std::lock_guard<std::mutex> g(mu_);
       for (auto& d : free_) { all.insert(d.second.begin(), d.second.end()); d.second.clear(); }
-      for (auto& b : all) dev_.erase(b.second);
+      for (auto& b : all) { dev_.erase(b.second); freed_on_.erase(b.second); }
       cached_.clear();
     }
     size_t n = 0;
@@ -118,6 +142,7 @@ class DevicePool {
   std::map<void*, int> dev_;                            // device of every block we own
   std::map<int, size_t> cap_;                           // per device: most bytes kept in the cache
   std::map<int, size_t> cached_;                        // per device: bytes held in free_
+  std::map<void*, hipStream_t> freed_on_;               // cached blocks: the stream their last user worked on
   int nctx_ = 0;
 };
 
