@@ -143,6 +143,13 @@ int qdg_ctx_destroy(qdg_ctx* ctx);
  * allocation fails or by this call (released_bytes may be NULL) -- not with the last context: the next one
  * would pay the driver again. */
 int qdg_device_pool_trim(size_t* released_bytes);
+/* Allocate `nblocks` device blocks of `bytes_each` now and keep them in that cache: a run that knows it
+ * will re-mesh (amr: dtref, src/Inciter/Refiner.cpp:403-408) pays the driver for the refined mesh's state
+ * buffers here, at start-up or beside the time stepping, instead of inside the re-mesh -- at 80.9 M tets the
+ * four state buffers are 52 GB, 0.5 s of hipMalloc on this platform.  qdg_mesh_state_bytes tells how many
+ * blocks of what size the state of `mesh` refined uniformly `refine_levels` times will ask for. */
+int qdg_device_pool_reserve(qdg_ctx* ctx, size_t nblocks, size_t bytes_each);
+int qdg_mesh_state_bytes(qdg_mesh* mesh, size_t refine_levels, size_t* nblocks, size_t* bytes_each);
 /* run all kernels of this context on an existing HIP stream (hipStream_t) */
 int qdg_ctx_set_stream(qdg_ctx* ctx, void* hip_stream);
 int qdg_ctx_synchronize(qdg_ctx* ctx);

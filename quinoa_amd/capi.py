@@ -498,6 +498,14 @@ class Mesh:
         r, pr = _sz(np.asarray(rows))
         _chk(lib().qdg_state_rows_put(self.h, C.c_size_t(len(r)), pr, C.c_void_p(int(packed_dev))))
 
+    def reserve_refined_state(self, levels=1):
+        """qdg_device_pool_reserve of the state buffers this mesh will ask for after `levels` uniform
+        refinements: the driver's allocation cost is paid here, not inside the re-mesh"""
+        n, b = C.c_size_t(), C.c_size_t()
+        _chk(lib().qdg_mesh_state_bytes(self.h, C.c_size_t(levels), C.byref(n), C.byref(b)))
+        _chk(lib().qdg_device_pool_reserve(self.ctx.h, n, b))
+        return n.value * b.value
+
     def refine_uniform(self, host_copy=True):
         """qdg_mesh_refine_uniform: the re-mesh of this resident chunk on the device (needs context option
         keep_connectivity = 1 at build time).  Returns (new Mesh with the state handed over, Refined or None);

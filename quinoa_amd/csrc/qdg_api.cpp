@@ -217,6 +217,29 @@ extern "C" int qdg_device_pool_trim(size_t* released_bytes)
   QDG_CATCH
 }
 
+extern "C" int qdg_device_pool_reserve(qdg_ctx* ctx, size_t nblocks, size_t bytes_each)
+{
+  QDG_TRY
+  if (!ctx) return fail("qdg_device_pool_reserve: null ctx");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(qdg::DevicePool::get().reserve(nblocks, bytes_each));
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_mesh_state_bytes(qdg_mesh* mesh, size_t refine_levels, size_t* nblocks, size_t* bytes_each)
+{
+  QDG_TRY
+  if (!mesh || !nblocks || !bytes_each) return fail("qdg_mesh_state_bytes: null argument");
+  size_t ne = mesh->ne;
+  for (size_t l = 0; l < refine_levels; ++l) ne *= 8;
+  const size_t stride = (ne + 63) / 64 * 64;
+  *nblocks = 4;                                          // U, Un, R, W (mesh_alloc_state)
+  *bytes_each = (size_t)mesh->nprop * stride * sizeof(double);
+  return 0;
+  QDG_CATCH
+}
+
 extern "C" int qdg_ctx_set_stream(qdg_ctx* ctx, void* s)
 {
   QDG_TRY
@@ -680,6 +703,7 @@ extern "C" int qdg_mesh_upload_gid(qdg_ctx* ctx, size_t nielem, size_t nunk, siz
   HIPCHK(m->task_nb.upload(h_task_nb, s)); HIPCHK(m->task_f.upload(h_task_f, s));
   dm.ntile = ntile; dm.ntile_inner = ntile_inner; dm.tile_row = m->tile_row.p; dm.task_stride = task_stride;
   dm.tile_rows = TILE;
+  dm.persistent = ctx->opt.p1_rhs >= 2 ? ctx->opt.p1_rhs : 0;
   dm.tile_off = m->tile_off.p; dm.task_a = m->task_a.p;
   dm.task_nb = m->task_nb.p; dm.task_f = m->task_f.p;
   dm.tgeo = nullptr;
@@ -808,7 +832,10 @@ static bool use_p1_fast(const qdg_mesh* mesh)
 // ds_add_f64) unless bitwise run-to-run reproducibility is requested (option "p1_rhs" = 1)
 static bool use_tile(const qdg_mesh* mesh)
 {
-  return mesh->ctx->opt.p1_rhs == 0 || mesh->dm.ndofel;      // p-adaptive DG exists in the tile kernel only
+  // (read at launch time: 2 = role-specialised persistent workgroups where a launch has at least two tiles
+  // per CU, 3 = always; DevMesh is passed to the kernels by value)
+  const_cast<qdg_mesh*>(mesh)->dm.persistent = mesh->ctx->opt.p1_rhs >= 2 ? mesh->ctx->opt.p1_rhs : 0;
+  return mesh->ctx->opt.p1_rhs != 1 || mesh->dm.ndofel;      // p-adaptive DG exists in the tile kernel only
 }
 
 static void run_rhs(qdg_mesh* mesh, double t, const double* U, double* R)

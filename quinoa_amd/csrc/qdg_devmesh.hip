@@ -1092,6 +1092,7 @@ static int dev_build_layout(qdg_ctx* ctx, DevFD& fd, const std::vector<int>& bcf
   while (ntile_inner < ntile && std::min((size_t)(ntile_inner + 1) * TILE, nie) <= ninner) ++ntile_inner;
   dm.ntile = ntile; dm.ntile_inner = ntile_inner; dm.tile_row = m->tile_row.p; dm.task_stride = task_stride;
   dm.tile_rows = TILE;
+  dm.persistent = ctx->opt.p1_rhs >= 2 ? ctx->opt.p1_rhs : 0;
   dm.tile_off = m->tile_off.p; dm.task_a = m->task_a.p; dm.task_nb = m->task_nb.p; dm.task_f = m->task_f.p;
   dm.tgeo = nullptr;
   if (task_stride > 0 && ctx->cfg.ndof == 4) {

@@ -105,6 +105,30 @@ class DevicePool {
     cached_[dev] += sz;
     if (StreamTag::known()) freed_on_[p] = StreamTag::cur();
   }
+  // `nblocks` blocks of `bytes` each, allocated now and put into the cache (the cap grows by as much): what
+  // a later allocation of that size is then served from, without the driver (qdg_device_pool_reserve)
+  hipError_t reserve(size_t nblocks, size_t bytes)
+  {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const size_t want = round(bytes);
+    for (size_t i = 0; i < nblocks; ++i) {
+      void* p = nullptr;
+      e = hipMalloc(&p, want);
+      if (e != hipSuccess) { (void)hipGetLastError(); return e; }
+      std::lock_guard<std::mutex> g(mu_);
+      if (cap_.find(dev) == cap_.end()) {
+        size_t fr = 0, tot = 0;
+        cap_[dev] = (hipMemGetInfo(&fr, &tot) == hipSuccess) ? std::min(tot / 5 * 2, fr / 2) : 0;
+      }
+      cap_[dev] += want;
+      dev_[p] = dev;
+      free_[dev].emplace(want, p);
+      cached_[dev] += want;
+    }
+    return hipSuccess;
+  }
   // hands every cached block back to the driver; returns the bytes released
   size_t trim()
   {

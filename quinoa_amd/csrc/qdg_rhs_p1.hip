@@ -674,7 +674,20 @@ __global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1t(DevMesh m, Phys ph, doub
 // evaluation (Sl' = -Sr, Sm' = -Sm, Sr' = -Sl), so HLLC's ladder (HLLC.hpp:93-124) is applied in
 // its mirrored form (flux_hllc_own) -- same four fluxes, same fall-through of a NaN wave speed to
 // the STORED right state -- and the own tet always loses what the neighbour gains.
-template <bool WITH_DT, int PROB>
+// LDS layouts of a tile's vertex states / accumulators: idx(tet, vertex) is the word of component 0,
+// components are CS words apart
+struct LyTile {            // planes [vertex][component][tet] over the whole tile (k_rhs_p1w)
+  static constexpr int CS = TILE;
+  __device__ static __forceinline__ int idx(int e, int v) { return v * NCOMP * TILE + e; }
+};
+struct LyBlk {             // the same planes per BLOCK of 62 tets, 4 blocks per tile: a wave of the role-specialised
+  static constexpr int BLK = 62, CS = BLK, VS = NCOMP * BLK, BSZ = 4 * VS;   // kernel owns its block's words
+  static_assert(4 * BLK == TILE || TILE != 248, "4 blocks of 62 tets = the 248-row tile");
+  __device__ static __forceinline__ int blk(int e) { return (e * 1057) >> 16; }          // e / 62 for e < 1024
+  __device__ static __forceinline__ int idx(int e, int v) { const int b = blk(e); return b * BSZ + v * VS + (e - b * BLK); }
+};
+
+template <bool WITH_DT, int PROB, class LY = LyTile>
 __device__ __forceinline__ void face_task_lean(const DevMesh& m, const Phys& ph, double t,
                                                const double* __restrict__ U, double* __restrict__ nod,
                                                double* __restrict__ accN, double* __restrict__ sdelt,
@@ -695,8 +708,8 @@ __device__ __forceinline__ void face_task_lean(const DevMesh& m, const Phys& ph,
   int ao[3], an[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
-    ao[j] = LIDX(el, lpofa(lf, j), 0);
-    an[j] = LIDX(pl, (code >> (2 * j)) & 3, 0);
+    ao[j] = LY::idx(el, lpofa(lf, j));
+    an[j] = LY::idx(pl, (code >> (2 * j)) & 3);
   }
   // X[g]: the neighbour's state at point g -- in-tile face: from its three vertex states in LDS,
   // read ONCE (the partner tets of a wave's lanes are scattered over the tile, so these are the
@@ -705,14 +718,14 @@ __device__ __forceinline__ void face_task_lean(const DevMesh& m, const Phys& ph,
   double Y[3][NCOMP], X[3][NCOMP];
 #pragma unroll
   for (int c = 0; c < NCOMP; ++c) {
-    const double v0 = nod[ao[0] + c * TILE], v1 = nod[ao[1] + c * TILE], v2 = nod[ao[2] + c * TILE];
+    const double v0 = nod[ao[0] + c * LY::CS], v1 = nod[ao[1] + c * LY::CS], v2 = nod[ao[2] + c * LY::CS];
     const double bo = (v0 + v1 + v2) * (1.0 / 6.0);
     Y[0][c] = fma(0.5, v1, bo); Y[1][c] = fma(0.5, v2, bo); Y[2][c] = fma(0.5, v0, bo);
   }
   if (kind == TASK_INT) {
 #pragma unroll
     for (int c = 0; c < NCOMP; ++c) {
-      const double v0 = nod[an[0] + c * TILE], v1 = nod[an[1] + c * TILE], v2 = nod[an[2] + c * TILE];
+      const double v0 = nod[an[0] + c * LY::CS], v1 = nod[an[1] + c * LY::CS], v2 = nod[an[2] + c * LY::CS];
       const double bn = (v0 + v1 + v2) * (1.0 / 6.0);
       X[0][c] = fma(0.5, v1, bn); X[1][c] = fma(0.5, v2, bn); X[2][c] = fma(0.5, v0, bn);
     }
@@ -785,13 +798,13 @@ __device__ __forceinline__ void face_task_lean(const DevMesh& m, const Phys& ph,
   for (int c = 0; c < NCOMP; ++c) {
     const double Ssum = k1 * ((Fg[0][c] + Fg[1][c]) + Fg[2][c]);
     const double w0 = fma(k2, Fg[2][c], Ssum), w1 = fma(k2, Fg[0][c], Ssum), w2 = fma(k2, Fg[1][c], Ssum);
-    __hip_atomic_fetch_add(accN + ao[0] + c * TILE, -w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    __hip_atomic_fetch_add(accN + ao[1] + c * TILE, -w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    __hip_atomic_fetch_add(accN + ao[2] + c * TILE, -w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(accN + ao[0] + c * LY::CS, -w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(accN + ao[1] + c * LY::CS, -w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(accN + ao[2] + c * LY::CS, -w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (kind == TASK_INT) {
-      __hip_atomic_fetch_add(accN + an[0] + c * TILE, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      __hip_atomic_fetch_add(accN + an[1] + c * TILE, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      __hip_atomic_fetch_add(accN + an[2] + c * TILE, w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(accN + an[0] + c * LY::CS, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(accN + an[1] + c * LY::CS, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(accN + an[2] + c * LY::CS, w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   }
   if (WITH_DT) {
@@ -1050,6 +1063,314 @@ __global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1w(DevMesh m, Phys ph, doub
   }
 }
 
+// ------------------------------------------- DG-P1 RHS, role-specialised persistent workgroups
+// (round 4; option p1_rhs = 2).  ONE workgroup of 8 waves per CU walks over its share of the tiles.
+// Waves 0-3 are FACE waves: they run the face tasks of tile i (face_task_lean, the task lists of
+// k_rhs_p1w) back to back.  Waves 4-7 are STREAM waves, one block of 62 tets each: while the face
+// waves work on tile i they FINISH tile i-1 (accumulators -> modal row, scale, coalesced store of
+// the block's 62 rows through the block's own LDS words) and LOAD tile i+1 (rows of U [and Un], node
+// ids, volume, coordinates; vertex states to LDS; the volume term [+ source] and, for the fused RK
+// stages, the image of a*Un + b*U are computed from the row in registers and become the INITIAL
+// accumulators -- finishing a tile then needs no row: Uout = f_k * (face sums + G_k),
+// G_k = (a*Un + b*U)/f_k + volume term, f_k = b*dt*imf_k/vol).  LDS holds two tiles (2 x (vertex states
+// + accumulators) = 155 KB), hand-off by ONE workgroup barrier per tile.  Every SIMD hosts one face
+// wave (fp64 issue) and one stream wave (loads in flight for the whole face phase).
+// Reference work per face: src/PDE/Integrate/Surface.cpp:73-189; volume term Volume.cpp:54-111.
+constexpr int RBS = 512;                 // lanes of a role-specialised workgroup
+
+// volume term (+ source) of one tet from its four vertex states in registers: the arithmetic of
+// tet_volume_lean (which reads the same vertex states from LDS)
+template <int PROB>
+__device__ __forceinline__ void tet_volume_regs(const Phys& ph, double t, const double (&V)[4][NCOMP], double vol,
+                                                const ElemGeom& g, double (&acc)[NCOMP][4])
+{
+  constexpr int NDOF = 4;
+  const Tables<4>& T = c_tab4;
+  double ji[3][3];
+  inverse_jacobian(g, ji);
+  double SV[NCOMP], Fs[NCOMP][3];
+#pragma unroll
+  for (int c = 0; c < NCOMP; ++c) {
+    SV[c] = (V[0][c] + V[1][c]) + (V[2][c] + V[3][c]);
+    Fs[c][0] = Fs[c][1] = Fs[c][2] = 0.0;
+  }
+#pragma unroll
+  for (int ig = 0; ig < 5; ++ig) {
+    double s[NCOMP];
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c)
+      s[c] = (ig == 0) ? 0.25 * SV[c] : fma(1.0 / 3.0, V[(ig + 3) & 3][c], SV[c] * (1.0 / 6.0));
+    const double ir = fast_rcp(s[0]);
+    const double uu = s[1] * ir, vv = s[2] * ir, ww = s[3] * ir;
+    const double p = eos_pressure(ph, s[0], uu, vv, ww, s[4]);
+    const double wg = T.vw[ig];
+    const double h = s[4] + p;
+    Fs[0][0] += wg * s[1];            Fs[0][1] += wg * s[2];            Fs[0][2] += wg * s[3];
+    Fs[1][0] += wg * (s[1] * uu + p); Fs[1][1] += wg * (s[2] * uu);     Fs[1][2] += wg * (s[3] * uu);
+    Fs[2][0] += wg * (s[1] * vv);     Fs[2][1] += wg * (s[2] * vv + p); Fs[2][2] += wg * (s[3] * vv);
+    Fs[3][0] += wg * (s[1] * ww);     Fs[3][1] += wg * (s[2] * ww);     Fs[3][2] += wg * (s[3] * ww + p);
+    Fs[4][0] += wg * (uu * h);        Fs[4][1] += wg * (vv * h);        Fs[4][2] += wg * (ww * h);
+  }
+#pragma unroll
+  for (int c = 0; c < NCOMP; ++c) acc[c][0] = 0.0;
+#pragma unroll
+  for (int k = 1; k < NDOF; ++k) {
+    const double g0 = T.vdB[0][0][k], g1 = T.vdB[0][1][k], g2 = T.vdB[0][2][k];
+    const double dx = vol * (g0 * ji[0][0] + g1 * ji[1][0] + g2 * ji[2][0]);
+    const double dy = vol * (g0 * ji[0][1] + g1 * ji[1][1] + g2 * ji[2][1]);
+    const double dz = vol * (g0 * ji[0][2] + g1 * ji[1][2] + g2 * ji[2][2]);
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c) acc[c][k] = Fs[c][0] * dx + Fs[c][1] * dy + Fs[c][2] * dz;
+  }
+  if constexpr (prob_has_source<PROB>()) {
+#pragma unroll 1
+    for (int ig = 0; ig < 5; ++ig) {
+      const double xi = T.vc[ig][0], eta = T.vc[ig][1], zeta = T.vc[ig][2];
+      const double w0 = 1.0 - xi - eta - zeta;
+      double P[3], s[NCOMP];
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+        P[d] = g.p[0][d] * w0 + g.p[1][d] * xi + g.p[2][d] * eta + g.p[3][d] * zeta;
+      prob_src<PROB>(ph, P[0], P[1], P[2], t, s);
+      const double wt = T.vw[ig] * vol;
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) {
+        const double ws = wt * s[c];
+        acc[c][0] += ws;
+#pragma unroll
+        for (int k = 1; k < NDOF; ++k) acc[c][k] += ws * T.vB[ig][k];
+      }
+    }
+  }
+}
+
+template <bool WITH_DT, bool FUSE_RK, int PROB>
+__global__ __launch_bounds__(RBS, 1) void k_rhs_p1r(DevMesh m, Phys ph, double t,
+                                                    const double* __restrict__ U, double* __restrict__ R,
+                                                    double* __restrict__ blockmin, double rk_a, double rk_b,
+                                                    const double* __restrict__ dtp,
+                                                    const double* __restrict__ Un, int ntile_run)
+{
+  constexpr int NDOF = 4, NPROP = NCOMP * NDOF, NR = 4, FBS = TILE_BS;
+  static_assert(TILE == 248 && TILE_BS == 256, "k_rhs_p1r: 4 blocks of 62 tets, 4 rounds of 256 task slots");
+  constexpr double imf[4] = { 1.0, 10.0, 10.0 / 3.0, 5.0 / 3.0 };
+  __shared__ __attribute__((aligned(16))) double nodS[2][TILE * NPROP];
+  __shared__ __attribute__((aligned(16))) double accS[2][TILE * NPROP];
+  __shared__ double sdeltS[WITH_DT ? 2 * TILE : 1];
+  __shared__ double wminS[WITH_DT ? 8 : 1];
+  const int tid = threadIdx.x;
+  const bool face = tid < FBS;
+  // this workgroup's tiles: XCD x owns the contiguous range of tiles xcd_tile() would give it; its
+  // workgroups stride through that range, so that the tiles in flight on an XCD are neighbours
+  constexpr int NXCD = 8;
+  const int nwg = gridDim.x, xcd = blockIdx.x % NXCD, jw = blockIdx.x / NXCD;
+  const int wgx = nwg / NXCD + (xcd < nwg % NXCD ? 1 : 0);             // workgroups on this XCD
+  const int per = ntile_run / NXCD, rem = ntile_run - per * NXCD;
+  const int x0 = m.blk0 + xcd * per + (xcd < rem ? xcd : rem), cnt = per + (xcd < rem ? 1 : 0);
+  const int ntl = (jw < cnt) ? (cnt - jw + wgx - 1) / wgx : 0;          // tiles of this workgroup
+  auto tile_of = [&](int i) { return x0 + jw + i * wgx; };
+
+  // ---- stream lanes: tet tl of block w ----
+  const int stid = tid - FBS, sw = stid >> 6, sl = stid & 63;
+  const int tl = LyBlk::BLK * sw + sl;
+  const bool slot = !face && sl < LyBlk::BLK;          // lane owns a tet slot of the tile
+
+  // load tile `tile` into buffer `b`: vertex states, initial accumulators
+  auto load_tile = [&](int tile, int b) {
+    if (!slot) return;
+    const int tile_e0 = tile * TILE;
+    const int nloc = (m.nie - tile_e0 < TILE) ? m.nie - tile_e0 : TILE;
+    const bool act = tl < nloc;
+    const int erow = tile_e0 + (act ? tl : 0);
+    double r[NCOMP][NDOF];
+    load_row<NPROP>(U, erow, &r[0][0]);
+    [[maybe_unused]] double un[NCOMP][NDOF];
+    if constexpr (FUSE_RK) load_row<NPROP>(Un, erow, &un[0][0]);
+    int in4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) in4[i] = m.inpoel[(size_t)i * m.stride + erow];
+    const double vol = m.vol[erow];
+    ElemGeom g;
+    {
+      double q[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        load_row<4>(m.xyz4, in4[i], q);
+        g.p[i][0] = q[0]; g.p[i][1] = q[1]; g.p[i][2] = q[2];
+      }
+    }
+    double* nod = nodS[b];
+    double* accN = accS[b];
+    if (!act) {
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) { r[c][0] = 1.0; r[c][1] = r[c][2] = r[c][3] = 0.0; }
+    }
+    double V[4][NCOMP];
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c) {
+      const double a = r[c][0] - r[c][3];
+      V[0][c] = a - r[c][1] - r[c][2];
+      V[1][c] = a + r[c][1] - r[c][2];
+      V[2][c] = a + 2.0 * r[c][2];
+      V[3][c] = r[c][0] + 3.0 * r[c][3];
+#pragma unroll
+      for (int vx = 0; vx < 4; ++vx) nod[LyBlk::idx(tl, vx) + c * LyBlk::CS] = V[vx][c];
+    }
+    double G[NCOMP][NDOF];
+    if (act) {
+      tet_volume_regs<PROB>(ph, t, V, vol, g, G);
+      if constexpr (FUSE_RK) {
+        const double bdtv = rk_b * dtp[0] / vol;
+#pragma unroll
+        for (int k = 0; k < NDOF; ++k) {
+          const double ifk = 1.0 / (bdtv * imf[k]);
+#pragma unroll
+          for (int c = 0; c < NCOMP; ++c) G[c][k] += (rk_a * un[c][k] + rk_b * r[c][k]) * ifk;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) G[c][0] = G[c][1] = G[c][2] = G[c][3] = 0.0;
+    }
+    // the accumulators start at the vertex image of G: tet_face_sums maps (n0..n3) to
+    // (n0+n1+n2+n3, n1-n0, 2 n2-n0-n1, 3 n3-n0-n1-n2)
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c) {
+      const double n3 = 0.25 * (G[c][0] + G[c][3]);
+      const double T3 = G[c][0] - n3;
+      const double n2 = (G[c][2] + T3) * (1.0 / 3.0);
+      const double Q = T3 - n2;
+      const double n1 = 0.5 * (Q + G[c][1]), n0 = 0.5 * (Q - G[c][1]);
+      accN[LyBlk::idx(tl, 0) + c * LyBlk::CS] = n0;
+      accN[LyBlk::idx(tl, 1) + c * LyBlk::CS] = n1;
+      accN[LyBlk::idx(tl, 2) + c * LyBlk::CS] = n2;
+      accN[LyBlk::idx(tl, 3) + c * LyBlk::CS] = n3;
+    }
+    if (WITH_DT) sdeltS[b * TILE + tl] = 0.0;
+  };
+
+  // finish tile `tile` from buffer `b`: rows out; the block's minimum of vol / delt into wminS
+  auto finish_tile = [&](int tile, int b) {
+    if (face) return;
+    const int tile_e0 = tile * TILE;
+    const int nloc = (m.nie - tile_e0 < TILE) ? m.nie - tile_e0 : TILE;
+    const bool act = slot && tl < nloc;
+    double* nod = nodS[b];
+    const double* accN = accS[b];
+    double dte = DBL_MAX;
+    if (act) {
+      const double vol = m.vol[tile_e0 + tl];
+      double out[NCOMP][NDOF];
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) {
+        const double n0 = accN[LyBlk::idx(tl, 0) + c * LyBlk::CS], n1 = accN[LyBlk::idx(tl, 1) + c * LyBlk::CS],
+                     n2 = accN[LyBlk::idx(tl, 2) + c * LyBlk::CS], n3 = accN[LyBlk::idx(tl, 3) + c * LyBlk::CS];
+        out[c][0] = (n0 + n1) + (n2 + n3);
+        out[c][1] = n1 - n0;
+        out[c][2] = 2.0 * n2 - n0 - n1;
+        out[c][3] = 3.0 * n3 - n0 - n1 - n2;
+      }
+      if constexpr (FUSE_RK) {
+        const double bdtv = rk_b * dtp[0] / vol;
+#pragma unroll
+        for (int k = 0; k < NDOF; ++k) {
+          const double fk = bdtv * imf[k];
+#pragma unroll
+          for (int c = 0; c < NCOMP; ++c) out[c][k] *= fk;
+        }
+      }
+      if (WITH_DT) dte = vol / sdeltS[b * TILE + tl];
+      // the block's rows, row-major, over the block's own vertex-state words (nobody reads them any more)
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      double2* row = reinterpret_cast<double2*>(nod + (size_t)sw * LyBlk::BSZ + (size_t)sl * NPROP);
+#pragma unroll
+      for (int j = 0; j < NPROP / 2; ++j) row[j] = make_double2((&out[0][0])[2 * j], (&out[0][0])[2 * j + 1]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    {
+      const int nrows = nloc - LyBlk::BLK * sw;                       // rows of this block that exist
+      const int nvalid = (nrows < 0 ? 0 : nrows > LyBlk::BLK ? LyBlk::BLK : nrows) * (NPROP / 2);
+      const double2* src = reinterpret_cast<const double2*>(nod + (size_t)sw * LyBlk::BSZ);
+      double2* dst = reinterpret_cast<double2*>(R + ((size_t)tile_e0 + (size_t)LyBlk::BLK * sw) * NPROP);
+#pragma unroll
+      for (int j = 0; j < NPROP / 2; ++j) {
+        const int i = j * 64 + sl;
+        if (i < nvalid) dst[i] = src[i];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (WITH_DT) {
+      for (int off = 32; off > 0; off >>= 1) dte = fmin(dte, __shfl_down(dte, off, 64));
+      if (sl == 0) wminS[(b & 1) * 4 + sw] = dte;
+    }
+  };
+
+  // ---- prologue ----
+  if (ntl > 0) load_tile(tile_of(0), 0);
+  // the face lanes' task words of tile 0
+  int ta[NR];
+  double gnx[4];
+  size_t slot0 = 0;
+  if (face && ntl > 0) {
+    slot0 = (size_t)tile_of(0) * (4 * FBS) + tid;
+#pragma unroll
+    for (int q = 0; q < NR; ++q) ta[q] = m.task_a[slot0 + FBS * q];
+    load_row<4>(m.tgeo, slot0, gnx);
+  }
+  __syncthreads();
+
+#pragma unroll 1
+  for (int i = 0; i <= ntl; ++i) {
+    const int b = i & 1;
+    if (face) {
+      if (i < ntl) {
+        const int tile = tile_of(i);
+        const int tile_e0 = tile * TILE;
+        // the next tile's task words are requested now and used one step later
+        int tn[NR] = { -1, -1, -1, -1 };
+        size_t slotn = 0;
+        if (i + 1 < ntl) {
+          slotn = (size_t)tile_of(i + 1) * (4 * FBS) + tid;
+#pragma unroll
+          for (int q = 0; q < NR; ++q) tn[q] = m.task_a[slotn + FBS * q];
+        }
+#pragma unroll 1
+        for (int q = 0; q < NR; ++q) {
+          const int a = (q == 0) ? ta[0] : (q == 1) ? ta[1] : (q == 2) ? ta[2] : ta[3];
+          if (a < 0) break;
+          const double g4[4] = { gnx[0], gnx[1], gnx[2], gnx[3] };
+          const int an_ = (q == 0) ? ta[1] : (q == 1) ? ta[2] : (q == 2) ? ta[3] : -1;
+          if (an_ >= 0) load_row<4>(m.tgeo, slot0 + (size_t)FBS * (q + 1), gnx);
+          face_task_lean<WITH_DT, PROB, LyBlk>(m, ph, t, U, nodS[b], accS[b], sdeltS + (WITH_DT ? b * TILE : 0), a,
+                                               m.task_nb + slot0 + (size_t)FBS * q, tile_e0, g4);
+        }
+        if (i + 1 < ntl) {
+#pragma unroll
+          for (int q = 0; q < NR; ++q) ta[q] = tn[q];
+          slot0 = slotn;
+          load_row<4>(m.tgeo, slot0, gnx);
+        }
+      }
+      // the minimum of the tile finished one step ago (its four block minima are in LDS since the last barrier)
+      if (WITH_DT && tid == 0 && i >= 2) {
+        const double* w = wminS + ((i - 2) & 1) * 4;
+        blockmin[tile_of(i - 2)] = fmin(fmin(w[0], w[1]), fmin(w[2], w[3]));
+      }
+    } else {
+      if (i >= 1) finish_tile(tile_of(i - 1), 1 - b);
+      if (i + 1 < ntl) load_tile(tile_of(i + 1), 1 - b);
+    }
+    __syncthreads();
+  }
+  if (WITH_DT && tid == 0 && ntl >= 1) {
+    const double* w = wminS + ((ntl - 1) & 1) * 4;
+    blockmin[tile_of(ntl - 1)] = fmin(fmin(w[0], w[1]), fmin(w[2], w[3]));
+  }
+}
+
 // ================================================================ launchers
 
 
@@ -1075,6 +1396,23 @@ void launch_rhs_p1(const DevMesh& m, const Phys& ph, double t, const double* U, 
   }
 }
 
+// one role-specialised workgroup per CU
+static int persistent_grid()
+{
+  static const int ncu = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    return n / 8 * 8;                    // a multiple of the XCD count
+  }();
+  return ncu;
+}
+// (launches of fewer than two tiles per workgroup keep the one-tile-per-workgroup kernel)
+static bool use_persistent(const DevMesh& m, int ntile_run)
+{
+  return m.persistent == 3 || (m.persistent == 2 && ntile_run >= 2 * persistent_grid());
+}
+
 // tile / face-task form of the P1 RHS; tiles [first, first+count) (count < 0: all).
 // Uniform order runs k_rhs_p1w, p-adaptive meshes (m.ndofel) k_rhs_p1t.  With with_dt the
 // launch that ends at the last tile also reduces the per-tile minima to the time step.
@@ -1086,7 +1424,14 @@ void launch_rhs_p1t(const DevMesh& m0, const Phys& ph, double t, const double* U
   DevMesh m = m0;
   m.blk0 = first;
   const int nb = count < 0 ? m.ntile - first : count;
-  if (nb > 0 && !m.ndofel) {
+  if (nb > 0 && !m.ndofel && use_persistent(m, nb)) {
+    const int nwg = persistent_grid();
+    if (with_dt) {
+      QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1r<true, false, P><<<nwg, RBS, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr, nb)));
+    } else {
+      QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1r<false, false, P><<<nwg, RBS, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr, nb)));
+    }
+  } else if (nb > 0 && !m.ndofel) {
     if (with_dt) {
       QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1w<true, false, P><<<nb, TILE_BS, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr)));
     } else {
@@ -1112,6 +1457,10 @@ void launch_rhs_p1t_rk(const DevMesh& m0, const Phys& ph, double t, const double
   m.blk0 = first;
   const int nb = count < 0 ? m.ntile - first : count;
   if (nb <= 0) return;
+  if (!m.ndofel && use_persistent(m, nb)) {
+    QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1r<false, true, P><<<persistent_grid(), RBS, 0, s>>>(m, ph, t, U, Uout, nullptr, a, b, dt, Un, nb)));
+    return;
+  }
   if (!m.ndofel) {
     QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1w<false, true, P><<<nb, TILE_BS, 0, s>>>(m, ph, t, U, Uout, nullptr, a, b, dt, Un)));
     return;
