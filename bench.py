@@ -244,7 +244,7 @@ def _tet_volumes(coord, inpoel):
     return np.einsum("ij,ij->i", a, np.cross(b, d)) / 6.0
 
 
-def amr_point(local_rank, nx=32, steps=20, with_partition=True, resident=True):
+def amr_point(local_rank, nx=32, steps=20, with_partition=True, resident=True, reserve=False):
     """BASELINE config 5's loop once, on one GPU: Sod DG-P1 on an nx^3 Kuhn box, `steps` time
     steps, uniform 1:8 refinement (the refinement the reference's DG scheme performs during
     time stepping), mesh-derived data of the new mesh on the device, state handed over on the
@@ -257,6 +257,14 @@ def amr_point(local_rank, nx=32, steps=20, with_partition=True, resident=True):
     run = amr.RefinedRun(ctx, ch["coord"], ch["inpoel"], ch["sidesets"], resident=resident)
     run.mesh.state_initialize(0.0)
     ne0 = run.mesh.nielem
+    reserved = 0
+    if reserve:
+        # a run that knows it will re-mesh takes its memory budget from the driver ONCE, at start-up
+        # (qdg_device_pool_reserve; here 60 % of what is free): the re-mesh then allocates from that region
+        t0 = time.perf_counter()
+        reserved = int(0.6 * ctx.device_memory()[0])
+        ctx.reserve_device_memory(reserved)
+        t_reserve = time.perf_counter() - t0
 
     def advance(n):
         run.mesh.step(0.0, want_dt=False)
@@ -279,6 +287,9 @@ def amr_point(local_rank, nx=32, steps=20, with_partition=True, resident=True):
         out["remesh_total_ms"] = (th + tr + tt) * 1e3
         out["steps_of_new_mesh_per_remesh"] = (th + tr + tt) * 1e3 / ms1
         out["host_copy_complete_ms"] = run.host_copy_s * 1e3
+        out["state_buffers_reserved_ahead"] = bool(reserve)
+        if reserve:
+            out["reserve_bytes"], out["reserve_ms_outside_the_remesh"] = reserved, t_reserve * 1e3
         out["note"] = ("qdg_mesh_refine_uniform: the whole re-mesh in ONE call on the device (key rebuild_upload_ms = "
                        "remesh_total_ms): refinement from the connectivity the handle keeps resident (edge sort, midpoints, "
                        "children), esuel of the children by the 1:8 template, boundary faces from the parents', faces + "
@@ -608,8 +619,12 @@ def main():
         if world == 1 and not args.no_amr and not args.self_halo:
             out["amr_point"] = amr_point(local_rank)
             # config 5 at the north-star box: 119^3 x 6 = 10.1 M -> 80.9 M tets on one GPU
+            # (two runs: cold, where the re-mesh pays the driver for every buffer itself, and with the
+            # run's memory budget reserved from the driver at start-up -- what a run that knows it refines does)
+            out["amr_point"]["at_north_star_size_cold"] = amr_point(local_rank, nx=args.strong_nx, steps=5,
+                                                                    with_partition=False, reserve=False)
             out["amr_point"]["at_north_star_size"] = amr_point(local_rank, nx=args.strong_nx, steps=5,
-                                                               with_partition=False)
+                                                               with_partition=False, reserve=True)
         if world == 1 and not args.no_config3 and not args.self_halo:
             out["config3_point"] = config3_point(local_rank, args.config3_nx)
         if world == 1 and not args.no_config4 and not args.self_halo:

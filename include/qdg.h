@@ -143,13 +143,14 @@ int qdg_ctx_destroy(qdg_ctx* ctx);
  * allocation fails or by this call (released_bytes may be NULL) -- not with the last context: the next one
  * would pay the driver again. */
 int qdg_device_pool_trim(size_t* released_bytes);
-/* Allocate `nblocks` device blocks of `bytes_each` now and keep them in that cache: a run that knows it
- * will re-mesh (amr: dtref, src/Inciter/Refiner.cpp:403-408) pays the driver for the refined mesh's state
- * buffers here, at start-up or beside the time stepping, instead of inside the re-mesh -- at 80.9 M tets the
- * four state buffers are 52 GB, 0.5 s of hipMalloc on this platform.  qdg_mesh_state_bytes tells how many
- * blocks of what size the state of `mesh` refined uniformly `refine_levels` times will ask for. */
-int qdg_device_pool_reserve(qdg_ctx* ctx, size_t nblocks, size_t bytes_each);
-int qdg_mesh_state_bytes(qdg_mesh* mesh, size_t refine_levels, size_t* nblocks, size_t* bytes_each);
+/* Take one region of `bytes` from the driver now; every later device allocation of the library that fits is
+ * carved out of it (and goes back into it) without reaching the driver.  A run that will re-mesh (amr: dtref,
+ * src/Inciter/Refiner.cpp:403-408) calls this once at start-up, sized by its memory budget: on this platform
+ * hipMalloc of memory that has been used before costs ~34 ms per GiB, and a re-mesh at 80.9 M tets allocates
+ * ~100 GB in dozens of pieces.  The region is returned by qdg_device_pool_trim / the last context once nothing
+ * lives in it.  qdg_device_memory: free and total bytes of the context's device, bytes reserved this way. */
+int qdg_device_pool_reserve(qdg_ctx* ctx, size_t bytes);
+int qdg_device_memory(qdg_ctx* ctx, size_t* free_bytes, size_t* total_bytes, size_t* reserved_bytes);
 /* run all kernels of this context on an existing HIP stream (hipStream_t) */
 int qdg_ctx_set_stream(qdg_ctx* ctx, void* hip_stream);
 int qdg_ctx_synchronize(qdg_ctx* ctx);

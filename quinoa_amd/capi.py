@@ -278,6 +278,16 @@ class Context:
                                        pL, C.c_double(t), U.ctypes.data_as(c_f64p)))
         return U
 
+    def device_memory(self):
+        """(free, total, reserved by qdg_device_pool_reserve) bytes of this context's device"""
+        f, t, r = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        _chk(lib().qdg_device_memory(self.h, C.byref(f), C.byref(t), C.byref(r)))
+        return f.value, t.value, r.value
+
+    def reserve_device_memory(self, nbytes):
+        """qdg_device_pool_reserve: one region from the driver now, the library's later allocations out of it"""
+        _chk(lib().qdg_device_pool_reserve(self.h, C.c_size_t(int(nbytes))))
+
     def set_stream(self, stream_ptr):
         _chk(lib().qdg_ctx_set_stream(self.h, C.c_void_p(stream_ptr)))
 
@@ -497,14 +507,6 @@ class Mesh:
     def state_rows_put(self, rows, packed_dev):
         r, pr = _sz(np.asarray(rows))
         _chk(lib().qdg_state_rows_put(self.h, C.c_size_t(len(r)), pr, C.c_void_p(int(packed_dev))))
-
-    def reserve_refined_state(self, levels=1):
-        """qdg_device_pool_reserve of the state buffers this mesh will ask for after `levels` uniform
-        refinements: the driver's allocation cost is paid here, not inside the re-mesh"""
-        n, b = C.c_size_t(), C.c_size_t()
-        _chk(lib().qdg_mesh_state_bytes(self.h, C.c_size_t(levels), C.byref(n), C.byref(b)))
-        _chk(lib().qdg_device_pool_reserve(self.ctx.h, n, b))
-        return n.value * b.value
 
     def refine_uniform(self, host_copy=True):
         """qdg_mesh_refine_uniform: the re-mesh of this resident chunk on the device (needs context option

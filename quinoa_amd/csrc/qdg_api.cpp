@@ -217,25 +217,26 @@ extern "C" int qdg_device_pool_trim(size_t* released_bytes)
   QDG_CATCH
 }
 
-extern "C" int qdg_device_pool_reserve(qdg_ctx* ctx, size_t nblocks, size_t bytes_each)
+extern "C" int qdg_device_pool_reserve(qdg_ctx* ctx, size_t bytes)
 {
   QDG_TRY
   if (!ctx) return fail("qdg_device_pool_reserve: null ctx");
   HIPCHK(hipSetDevice(ctx->device));
-  HIPCHK(qdg::DevicePool::get().reserve(nblocks, bytes_each));
+  HIPCHK(qdg::DevicePool::get().reserve(bytes));
   return 0;
   QDG_CATCH
 }
 
-extern "C" int qdg_mesh_state_bytes(qdg_mesh* mesh, size_t refine_levels, size_t* nblocks, size_t* bytes_each)
+extern "C" int qdg_device_memory(qdg_ctx* ctx, size_t* free_bytes, size_t* total_bytes, size_t* reserved_bytes)
 {
   QDG_TRY
-  if (!mesh || !nblocks || !bytes_each) return fail("qdg_mesh_state_bytes: null argument");
-  size_t ne = mesh->ne;
-  for (size_t l = 0; l < refine_levels; ++l) ne *= 8;
-  const size_t stride = (ne + 63) / 64 * 64;
-  *nblocks = 4;                                          // U, Un, R, W (mesh_alloc_state)
-  *bytes_each = (size_t)mesh->nprop * stride * sizeof(double);
+  if (!ctx) return fail("qdg_device_memory: null ctx");
+  HIPCHK(hipSetDevice(ctx->device));
+  size_t fr = 0, tot = 0;
+  HIPCHK(hipMemGetInfo(&fr, &tot));
+  if (free_bytes) *free_bytes = fr;
+  if (total_bytes) *total_bytes = tot;
+  if (reserved_bytes) *reserved_bytes = qdg::DevicePool::get().reserved_bytes();
   return 0;
   QDG_CATCH
 }

@@ -861,6 +861,61 @@ __global__ void k_task_fill(size_t ntask, size_t ne, int stride, int tile_rows, 
   task_a[pos] = a; task_nb[pos] = nbid; task_f[pos] = f;
 }
 
+// Padded task lists without a global sort: one workgroup per tile.  Within a tile the order is (kind rank,
+// local face), then device row -- the key of the sort path (k_task_keys + stable radix sort); a row has at
+// most one task per (rank, local face), so a task's position is the number of tasks in lower bins plus the
+// number of lower rows in its own bin: 12 wave ballots per wave, popcounts, no sort.  The kernel writes all
+// task_stride slots of its tile (unused: -1 / 0 / 0) and the tile's task count.
+__global__ __launch_bounds__(256) void k_tile_tasks(size_t ne, int stride, int tile_rows, int task_stride,
+                                                    const int* __restrict__ nbr, const int* __restrict__ finfo,
+                                                    const int* __restrict__ fid, int* __restrict__ task_a,
+                                                    int* __restrict__ task_nb, int* __restrict__ task_f,
+                                                    int* __restrict__ tile_cnt)
+{
+  __shared__ unsigned long long mask[12][4];
+  __shared__ int base[13];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const size_t tile = blockIdx.x, d = tile * (size_t)tile_rows + tid;
+  const bool row = tid < tile_rows && d < ne;
+  int a[4], nbid[4], f[4], bin[4];
+#pragma unroll
+  for (int lf = 0; lf < 4; ++lf) {
+    uint32_t k = 0;
+    bin[lf] = -1;
+    if (row && task_of(d, lf, stride, tile_rows, ne, nbr, finfo, fid, a[lf], nbid[lf], f[lf], k)) bin[lf] = (int)(k & 15);
+  }
+#pragma unroll
+  for (int b = 0; b < 12; ++b) {
+    const int lf = b & 3;
+    const unsigned long long m = __ballot(bin[lf] == b);
+    if (lane == 0) mask[b][wave] = m;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int b = 0; b < 12; ++b) {
+      base[b] = acc;
+      acc += __popcll(mask[b][0]) + __popcll(mask[b][1]) + __popcll(mask[b][2]) + __popcll(mask[b][3]);
+    }
+    base[12] = acc;
+    tile_cnt[tile] = acc;
+  }
+  __syncthreads();
+  const size_t slot0 = tile * (size_t)task_stride;
+#pragma unroll
+  for (int lf = 0; lf < 4; ++lf) {
+    const int b = bin[lf];
+    if (b < 0) continue;
+    int pos = base[b];
+    for (int w = 0; w < wave; ++w) pos += __popcll(mask[b][w]);
+    pos += __popcll(mask[b][wave] & ((1ull << lane) - 1ull));
+    task_a[slot0 + pos] = a[lf]; task_nb[slot0 + pos] = nbid[lf]; task_f[slot0 + pos] = f[lf];
+  }
+  for (int p = base[12] + tid; p < task_stride; p += 256) {
+    task_a[slot0 + p] = -1; task_nb[slot0 + p] = 0; task_f[slot0 + p] = 0;
+  }
+}
+
 __global__ void k_fill_i32(int* p, size_t n, int v)
 {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1046,31 +1101,51 @@ static int dev_build_layout(qdg_ctx* ctx, DevFD& fd, const std::vector<int>& bcf
   const int tile_rows = TILE;
   const int ntile = (int)((nie + TILE - 1) / TILE);
   const size_t nt4 = 4 * nie;
-  Buf<uint32_t> tk, tk2, tv, tv2;
-  DHIP(tk.alloc(nt4)); DHIP(tk2.alloc(nt4)); DHIP(tv.alloc(nt4)); DHIP(tv2.alloc(nt4));
-  Buf<int> d_nt;
-  DHIP(d_nt.alloc(1));
-  DHIP(hipMemsetAsync(d_nt.p, 0, sizeof(int), s));
-  k_task_keys<<<nblk(nt4), 256, 0, s>>>(nie, (int)stride, tile_rows, m->nbr.p, m->finfo.p, m->fid.p, tk.p, tv.p, d_nt.p);
-  if (int rc = sort32(tk.p, tk2.p, tv.p, tv2.p, nt4, s)) return rc;
-  int ntask = 0, herr = 0;
-  DHIP(hipMemcpyAsync(&ntask, d_nt.p, sizeof(int), hipMemcpyDeviceToHost, s));
-  DHIP(hipMemcpyAsync(&herr, d_err.p, sizeof(int), hipMemcpyDeviceToHost, s));
-  DHIP(hipStreamSynchronize(s));
-  if (herr == 6) return fail("qdg_mesh_from_connectivity: a free face of an owned tet is in no side set");
-  if (herr) return fail("qdg_mesh_from_connectivity: neighbour does not share the face nodes (bad connectivity)");
   const int task_stride = !ctx->cfg.pref ? 4 * TILE_BS : 0;
-  const size_t nslot = task_stride ? (size_t)ntile * task_stride : (size_t)ntask;
   HIPCHK(m->tile_off.alloc(ntile + 1)); HIPCHK(m->tile_row.alloc(ntile + 1));
-  HIPCHK(m->task_a.alloc(std::max<size_t>(nslot, 1))); HIPCHK(m->task_nb.alloc(std::max<size_t>(nslot, 1)));
-  HIPCHK(m->task_f.alloc(std::max<size_t>(nslot, 1)));
-  k_fill_i32<<<nblk(nslot), 256, 0, s>>>(m->task_a.p, nslot, -1);
-  k_fill_i32<<<nblk(nslot), 256, 0, s>>>(m->task_nb.p, nslot, 0);
-  k_fill_i32<<<nblk(nslot), 256, 0, s>>>(m->task_f.p, nslot, 0);
-  k_tile_off<<<nblk((size_t)ntask + 1), 256, 0, s>>>((size_t)ntask, ntile, tk2.p, m->tile_off.p);
-  k_task_fill<<<nblk((size_t)ntask), 256, 0, s>>>((size_t)ntask, nie, (int)stride, tile_rows, task_stride, m->nbr.p,
-                                                  m->finfo.p, m->fid.p, tv2.p, m->tile_off.p, m->task_a.p,
-                                                  m->task_nb.p, m->task_f.p);
+  size_t nslot = 0;
+  if (task_stride) {
+    // padded lists (every run but the p-adaptive ones): built tile by tile, no sort over 4 * nie keys
+    nslot = (size_t)ntile * task_stride;
+    HIPCHK(m->task_a.alloc(std::max<size_t>(nslot, 1))); HIPCHK(m->task_nb.alloc(std::max<size_t>(nslot, 1)));
+    HIPCHK(m->task_f.alloc(std::max<size_t>(nslot, 1)));
+    Buf<int> cnt;
+    DHIP(cnt.alloc(ntile + 1));
+    DHIP(hipMemsetAsync(cnt.p, 0, (ntile + 1) * sizeof(int), s));
+    k_tile_tasks<<<ntile, 256, 0, s>>>(nie, (int)stride, tile_rows, task_stride, m->nbr.p, m->finfo.p, m->fid.p,
+                                       m->task_a.p, m->task_nb.p, m->task_f.p, cnt.p);
+    size_t bytes = 0;
+    DHIP(rocprim::exclusive_scan(nullptr, bytes, cnt.p, m->tile_off.p, 0, (size_t)ntile + 1, rocprim::plus<int>(), s));
+    Buf<char> tmp;
+    DHIP(tmp.alloc(bytes));
+    DHIP(rocprim::exclusive_scan(tmp.p, bytes, cnt.p, m->tile_off.p, 0, (size_t)ntile + 1, rocprim::plus<int>(), s));
+    int herr = 0;
+    DHIP(hipMemcpyAsync(&herr, d_err.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    DHIP(hipStreamSynchronize(s));
+    if (herr == 6) return fail("qdg_mesh_from_connectivity: a free face of an owned tet is in no side set");
+    if (herr) return fail("qdg_mesh_from_connectivity: neighbour does not share the face nodes (bad connectivity)");
+  } else {
+    Buf<uint32_t> tk, tk2, tv, tv2;
+    DHIP(tk.alloc(nt4)); DHIP(tk2.alloc(nt4)); DHIP(tv.alloc(nt4)); DHIP(tv2.alloc(nt4));
+    Buf<int> d_nt;
+    DHIP(d_nt.alloc(1));
+    DHIP(hipMemsetAsync(d_nt.p, 0, sizeof(int), s));
+    k_task_keys<<<nblk(nt4), 256, 0, s>>>(nie, (int)stride, tile_rows, m->nbr.p, m->finfo.p, m->fid.p, tk.p, tv.p, d_nt.p);
+    if (int rc = sort32(tk.p, tk2.p, tv.p, tv2.p, nt4, s)) return rc;
+    int ntask = 0, herr = 0;
+    DHIP(hipMemcpyAsync(&ntask, d_nt.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    DHIP(hipMemcpyAsync(&herr, d_err.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    DHIP(hipStreamSynchronize(s));
+    if (herr == 6) return fail("qdg_mesh_from_connectivity: a free face of an owned tet is in no side set");
+    if (herr) return fail("qdg_mesh_from_connectivity: neighbour does not share the face nodes (bad connectivity)");
+    nslot = (size_t)ntask;
+    HIPCHK(m->task_a.alloc(std::max<size_t>(nslot, 1))); HIPCHK(m->task_nb.alloc(std::max<size_t>(nslot, 1)));
+    HIPCHK(m->task_f.alloc(std::max<size_t>(nslot, 1)));
+    k_tile_off<<<nblk((size_t)ntask + 1), 256, 0, s>>>((size_t)ntask, ntile, tk2.p, m->tile_off.p);
+    k_task_fill<<<nblk((size_t)ntask), 256, 0, s>>>((size_t)ntask, nie, (int)stride, tile_rows, task_stride, m->nbr.p,
+                                                    m->finfo.p, m->fid.p, tv2.p, m->tile_off.p, m->task_a.p,
+                                                    m->task_nb.p, m->task_f.p);
+  }
   {
     std::vector<int> rows(ntile + 1);
     for (int t = 0; t <= ntile; ++t) rows[t] = (int)std::min((size_t)t * TILE, nie);

@@ -17,6 +17,7 @@
 #include <cstddef>
 #include <map>
 #include <mutex>
+#include <vector>
 
 namespace qdg {
 
@@ -51,6 +52,28 @@ class DevicePool {
     if (e != hipSuccess) return e;
     const size_t want = round(bytes);
     bool same_stream = false;
+    {
+      // a reserved region first
+      std::lock_guard<std::mutex> g(mu_);
+      for (auto& a : arenas_) {
+        if (a.dev != dev) continue;
+        auto best = a.free.end();
+        for (auto it = a.free.begin(); it != a.free.end(); ++it)
+          if (it->second.size >= want && (best == a.free.end() || it->second.size < best->second.size)) best = it;
+        if (best == a.free.end()) continue;
+        const size_t off = best->first;
+        const Range r = best->second;
+        a.free.erase(best);
+        if (r.size > want) { Range rest = r; rest.size = r.size - want; a.free[off + want] = rest; }
+        a.live[a.base + off] = want;
+        *out = a.base + off;
+        same_stream = r.known && StreamTag::known() && r.stream == StreamTag::cur();
+        // (a range nobody has used yet needs no synchronisation either)
+        if (r.fresh) same_stream = true;
+        break;
+      }
+    }
+    if (*out) return same_stream ? hipSuccess : hipDeviceSynchronize();
     {
       std::lock_guard<std::mutex> g(mu_);
       auto& fl = free_[dev];
@@ -91,6 +114,32 @@ class DevicePool {
   {
     if (!p) return;
     std::lock_guard<std::mutex> g(mu_);
+    for (auto& a : arenas_) {
+      auto lv = a.live.find(p);
+      if (lv == a.live.end()) continue;
+      size_t off = (size_t)(static_cast<char*>(p) - a.base), sz = lv->second;
+      a.live.erase(lv);
+      Range r{ sz, StreamTag::cur(), StreamTag::known(), false };
+      // merge with the free neighbours; a merged range is safe to reuse without a device synchronisation
+      // only if all its parts were freed under one stream
+      auto nx = a.free.find(off + sz);
+      if (nx != a.free.end()) {
+        if (!(nx->second.fresh) && !(nx->second.known && r.known && nx->second.stream == r.stream)) r.known = false;
+        r.size += nx->second.size;
+        a.free.erase(nx);
+      }
+      auto pv = a.free.lower_bound(off);
+      if (pv != a.free.begin()) {
+        --pv;
+        if (pv->first + pv->second.size == off) {
+          if (!(pv->second.fresh) && !(pv->second.known && r.known && pv->second.stream == r.stream)) r.known = false;
+          off = pv->first; r.size += pv->second.size;
+          a.free.erase(pv);
+        }
+      }
+      a.free[off] = r;
+      return;
+    }
     auto it = size_.find(p);
     if (it == size_.end()) { (void)hipFree(p); return; }      // not ours
     const int dev = dev_[p];
@@ -105,29 +154,32 @@ class DevicePool {
     cached_[dev] += sz;
     if (StreamTag::known()) freed_on_[p] = StreamTag::cur();
   }
-  // `nblocks` blocks of `bytes` each, allocated now and put into the cache (the cap grows by as much): what
-  // a later allocation of that size is then served from, without the driver (qdg_device_pool_reserve)
-  hipError_t reserve(size_t nblocks, size_t bytes)
+  // One region of `bytes` taken from the driver NOW; every later allocation that fits is carved out of it
+  // (best fit over its free ranges, neighbours merged on free) and never reaches the driver again -- what
+  // a long run needs on this platform, where hipMalloc of memory the process (or an earlier one on the box)
+  // has used before costs ~34 ms per GiB: a re-mesh at 80.9 M tets allocates ~100 GB in dozens of pieces.
+  hipError_t reserve(size_t bytes)
   {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    const size_t want = round(bytes);
-    for (size_t i = 0; i < nblocks; ++i) {
-      void* p = nullptr;
-      e = hipMalloc(&p, want);
-      if (e != hipSuccess) { (void)hipGetLastError(); return e; }
-      std::lock_guard<std::mutex> g(mu_);
-      if (cap_.find(dev) == cap_.end()) {
-        size_t fr = 0, tot = 0;
-        cap_[dev] = (hipMemGetInfo(&fr, &tot) == hipSuccess) ? std::min(tot / 5 * 2, fr / 2) : 0;
-      }
-      cap_[dev] += want;
-      dev_[p] = dev;
-      free_[dev].emplace(want, p);
-      cached_[dev] += want;
-    }
+    const size_t want = (bytes + GRAN - 1) / GRAN * GRAN;
+    void* p = nullptr;
+    e = hipMalloc(&p, want);
+    if (e != hipSuccess) { (void)hipGetLastError(); return e; }
+    std::lock_guard<std::mutex> g(mu_);
+    Arena a;
+    a.base = static_cast<char*>(p); a.size = want; a.dev = dev;
+    a.free[0] = Range{ want, nullptr, false, true };
+    arenas_.push_back(std::move(a));
     return hipSuccess;
+  }
+  size_t reserved_bytes()
+  {
+    std::lock_guard<std::mutex> g(mu_);
+    size_t n = 0;
+    for (auto& a : arenas_) n += a.size;
+    return n;
   }
   // hands every cached block back to the driver; returns the bytes released
   size_t trim()
@@ -141,6 +193,16 @@ class DevicePool {
     }
     size_t n = 0;
     for (auto& b : all) { (void)hipFree(b.second); n += b.first; }
+    // reserved regions nothing lives in any more
+    std::vector<void*> gone;
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      for (auto it = arenas_.begin(); it != arenas_.end();) {
+        if (it->live.empty()) { gone.push_back(it->base); n += it->size; it = arenas_.erase(it); }
+        else ++it;
+      }
+    }
+    for (void* p : gone) (void)hipFree(p);
     return n;
   }
   size_t cached_bytes()
@@ -160,6 +222,14 @@ class DevicePool {
     const size_t q = b >= ((size_t)1 << 21) ? ((size_t)1 << 21) : 4096;   // 2 MiB / 4 KiB granules
     return b == 0 ? q : (b + q - 1) / q * q;
   }
+  static constexpr size_t GRAN = (size_t)1 << 21;
+  struct Range { size_t size; hipStream_t stream; bool known; bool fresh = true; };
+  struct Arena {
+    char* base = nullptr; size_t size = 0; int dev = 0;
+    std::map<size_t, Range> free;                       // offset -> free range
+    std::map<void*, size_t> live;                       // blocks handed out
+  };
+  std::vector<Arena> arenas_;
   std::mutex mu_;
   std::map<int, std::multimap<size_t, void*>> free_;   // per device: size -> block
   std::map<void*, size_t> size_;                        // live blocks handed out

@@ -683,7 +683,7 @@ struct LyTile {            // planes [vertex][component][tet] over the whole til
 struct LyBlk {             // the same planes per BLOCK of 62 tets, 4 blocks per tile: a wave of the role-specialised
   static constexpr int BLK = 62, CS = BLK, VS = NCOMP * BLK, BSZ = 4 * VS;   // kernel owns its block's words
   static_assert(4 * BLK == TILE || TILE != 248, "4 blocks of 62 tets = the 248-row tile");
-  __device__ static __forceinline__ int blk(int e) { return (e * 1057) >> 16; }          // e / 62 for e < 1024
+  __device__ static __forceinline__ int blk(int e) { return (e * 1058) >> 16; }          // e / 62 for e < 256
   __device__ static __forceinline__ int idx(int e, int v) { const int b = blk(e); return b * BSZ + v * VS + (e - b * BLK); }
 };
 
@@ -1175,35 +1175,57 @@ __global__ __launch_bounds__(RBS, 1) void k_rhs_p1r(DevMesh m, Phys ph, double t
   const int tl = LyBlk::BLK * sw + sl;
   const bool slot = !face && sl < LyBlk::BLK;          // lane owns a tet slot of the tile
 
-  // load tile `tile` into buffer `b`: vertex states, initial accumulators
-  auto load_tile = [&](int tile, int b) {
+  // the loads of a tile are REQUESTED at the top of a step and CONSUMED after the previous tile has been
+  // finished, so that their latency runs under that work; the node ids come one step earlier still (four
+  // loop-carried registers), so that the coordinate gathers go out with the rows
+  struct StreamRegs { double r[NCOMP][NDOF]; double un[NCOMP][NDOF]; double vol; ElemGeom g; };
+  auto tile_row = [&](int tile) {
+    const int tile_e0 = tile * TILE;
+    const int nloc = (m.nie - tile_e0 < TILE) ? m.nie - tile_e0 : TILE;
+    return tile_e0 + ((tl < nloc) ? tl : 0);
+  };
+  auto load_ids = [&](int tile, int (&in4)[4]) {
+    if (!slot) return;
+    const int erow = tile_row(tile);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) in4[i] = m.inpoel[(size_t)i * m.stride + erow];
+  };
+  auto load_issue = [&](int tile, const int (&in4)[4], StreamRegs& sr) {
+    if (!slot) return;
+    const int erow = tile_row(tile);
+    load_row<NPROP>(U, erow, &sr.r[0][0]);
+    if constexpr (FUSE_RK) load_row<NPROP>(Un, erow, &sr.un[0][0]);
+    sr.vol = m.vol[erow];
+    double q[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      load_row<4>(m.xyz4, in4[i], q);
+      sr.g.p[i][0] = q[0]; sr.g.p[i][1] = q[1]; sr.g.p[i][2] = q[2];
+    }
+  };
+  // vertex states and initial accumulators of tile `tile` into buffer `b`
+  auto load_consume = [&](int tile, int b, StreamRegs& sr) {
     if (!slot) return;
     const int tile_e0 = tile * TILE;
     const int nloc = (m.nie - tile_e0 < TILE) ? m.nie - tile_e0 : TILE;
     const bool act = tl < nloc;
-    const int erow = tile_e0 + (act ? tl : 0);
-    double r[NCOMP][NDOF];
-    load_row<NPROP>(U, erow, &r[0][0]);
-    [[maybe_unused]] double un[NCOMP][NDOF];
-    if constexpr (FUSE_RK) load_row<NPROP>(Un, erow, &un[0][0]);
-    int in4[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) in4[i] = m.inpoel[(size_t)i * m.stride + erow];
-    const double vol = m.vol[erow];
-    ElemGeom g;
-    {
-      double q[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        load_row<4>(m.xyz4, in4[i], q);
-        g.p[i][0] = q[0]; g.p[i][1] = q[1]; g.p[i][2] = q[2];
-      }
-    }
+    double (&r)[NCOMP][NDOF] = sr.r;
+    const double vol = sr.vol;
     double* nod = nodS[b];
     double* accN = accS[b];
     if (!act) {
 #pragma unroll
       for (int c = 0; c < NCOMP; ++c) { r[c][0] = 1.0; r[c][1] = r[c][2] = r[c][3] = 0.0; }
+    }
+    // the image of the RK combination first: un <- (a*Un + b*U) / f_k (the two rows are dead after this)
+    if constexpr (FUSE_RK) {
+      const double bdtv = rk_b * dtp[0] / vol;
+#pragma unroll
+      for (int k = 0; k < NDOF; ++k) {
+        const double ifk = 1.0 / (bdtv * imf[k]);
+#pragma unroll
+        for (int c = 0; c < NCOMP; ++c) sr.un[c][k] = (rk_a * sr.un[c][k] + rk_b * r[c][k]) * ifk;
+      }
     }
     double V[4][NCOMP];
 #pragma unroll
@@ -1218,15 +1240,17 @@ __global__ __launch_bounds__(RBS, 1) void k_rhs_p1r(DevMesh m, Phys ph, double t
     }
     double G[NCOMP][NDOF];
     if (act) {
-      tet_volume_regs<PROB>(ph, t, V, vol, g, G);
+#ifndef QDG_P1R_KO_VOL
+      tet_volume_regs<PROB>(ph, t, V, vol, sr.g, G);
+#else
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) G[c][0] = G[c][1] = G[c][2] = G[c][3] = sr.g.p[c & 3][c % 3];
+#endif
       if constexpr (FUSE_RK) {
-        const double bdtv = rk_b * dtp[0] / vol;
 #pragma unroll
-        for (int k = 0; k < NDOF; ++k) {
-          const double ifk = 1.0 / (bdtv * imf[k]);
+        for (int c = 0; c < NCOMP; ++c)
 #pragma unroll
-          for (int c = 0; c < NCOMP; ++c) G[c][k] += (rk_a * un[c][k] + rk_b * r[c][k]) * ifk;
-        }
+          for (int k = 0; k < NDOF; ++k) G[c][k] += sr.un[c][k];
       }
     } else {
 #pragma unroll
@@ -1260,32 +1284,29 @@ __global__ __launch_bounds__(RBS, 1) void k_rhs_p1r(DevMesh m, Phys ph, double t
     double dte = DBL_MAX;
     if (act) {
       const double vol = m.vol[tile_e0 + tl];
-      double out[NCOMP][NDOF];
-#pragma unroll
-      for (int c = 0; c < NCOMP; ++c) {
-        const double n0 = accN[LyBlk::idx(tl, 0) + c * LyBlk::CS], n1 = accN[LyBlk::idx(tl, 1) + c * LyBlk::CS],
-                     n2 = accN[LyBlk::idx(tl, 2) + c * LyBlk::CS], n3 = accN[LyBlk::idx(tl, 3) + c * LyBlk::CS];
-        out[c][0] = (n0 + n1) + (n2 + n3);
-        out[c][1] = n1 - n0;
-        out[c][2] = 2.0 * n2 - n0 - n1;
-        out[c][3] = 3.0 * n3 - n0 - n1 - n2;
-      }
+      [[maybe_unused]] double fk[NDOF] = { 1.0, 1.0, 1.0, 1.0 };
       if constexpr (FUSE_RK) {
         const double bdtv = rk_b * dtp[0] / vol;
 #pragma unroll
-        for (int k = 0; k < NDOF; ++k) {
-          const double fk = bdtv * imf[k];
-#pragma unroll
-          for (int c = 0; c < NCOMP; ++c) out[c][k] *= fk;
-        }
+        for (int k = 0; k < NDOF; ++k) fk[k] = bdtv * imf[k];
       }
       if (WITH_DT) dte = vol / sdeltS[b * TILE + tl];
-      // the block's rows, row-major, over the block's own vertex-state words (nobody reads them any more)
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      __builtin_amdgcn_wave_barrier();
+      // all accumulators are read before the first staging store: the block's rows, row-major, go over the
+      // block's own vertex-state words (nobody reads those any more), component by component
+      double n[NCOMP][4];
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) n[c][v] = accN[LyBlk::idx(tl, v) + c * LyBlk::CS];
       double2* row = reinterpret_cast<double2*>(nod + (size_t)sw * LyBlk::BSZ + (size_t)sl * NPROP);
 #pragma unroll
-      for (int j = 0; j < NPROP / 2; ++j) row[j] = make_double2((&out[0][0])[2 * j], (&out[0][0])[2 * j + 1]);
+      for (int c = 0; c < NCOMP; ++c) {
+        const double n0 = n[c][0], n1 = n[c][1], n2 = n[c][2], n3 = n[c][3];
+        double o0 = (n0 + n1) + (n2 + n3), o1 = n1 - n0, o2 = 2.0 * n2 - n0 - n1, o3 = 3.0 * n3 - n0 - n1 - n2;
+        if constexpr (FUSE_RK) { o0 *= fk[0]; o1 *= fk[1]; o2 *= fk[2]; o3 *= fk[3]; }
+        row[2 * c] = make_double2(o0, o1);
+        row[2 * c + 1] = make_double2(o2, o3);
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -1309,47 +1330,60 @@ __global__ __launch_bounds__(RBS, 1) void k_rhs_p1r(DevMesh m, Phys ph, double t
   };
 
   // ---- prologue ----
-  if (ntl > 0) load_tile(tile_of(0), 0);
-  // the face lanes' task words of tile 0
-  int ta[NR];
+  int in4n[4] = { 0, 0, 0, 0 };                 // node ids of the tile the stream lanes load next
+  if (!face && ntl > 0) {
+    StreamRegs sr;
+    load_ids(tile_of(0), in4n);
+    load_issue(tile_of(0), in4n, sr);
+    if (ntl > 1) load_ids(tile_of(1), in4n);
+    load_consume(tile_of(0), 0, sr);
+  }
+  // the face lanes' task words, neighbour rows and first face record of tile 0
+  int ta[NR], tb[NR];
   double gnx[4];
   size_t slot0 = 0;
   if (face && ntl > 0) {
     slot0 = (size_t)tile_of(0) * (4 * FBS) + tid;
 #pragma unroll
-    for (int q = 0; q < NR; ++q) ta[q] = m.task_a[slot0 + FBS * q];
+    for (int q = 0; q < NR; ++q) { ta[q] = m.task_a[slot0 + FBS * q]; tb[q] = m.task_nb[slot0 + FBS * q]; }
     load_row<4>(m.tgeo, slot0, gnx);
   }
   __syncthreads();
 
+  // The two roles run their own loops (one workgroup barrier per step in each: s_barrier counts waves, and a
+  // wave is in one role for good) -- written as ONE loop with a role branch inside, the register allocator
+  // merges the live ranges of both bodies and spills (256 registers + 96 B of scratch against 200 / 228).
+  if (face) {
 #pragma unroll 1
-  for (int i = 0; i <= ntl; ++i) {
-    const int b = i & 1;
-    if (face) {
+    for (int i = 0; i <= ntl; ++i) {
+      const int b = i & 1;
       if (i < ntl) {
         const int tile = tile_of(i);
         const int tile_e0 = tile * TILE;
-        // the next tile's task words are requested now and used one step later
-        int tn[NR] = { -1, -1, -1, -1 };
+        // the next tile's task words and neighbour rows are requested now and used one step later
+        int tn[NR] = { -1, -1, -1, -1 }, tnb[NR] = { 0, 0, 0, 0 };
         size_t slotn = 0;
         if (i + 1 < ntl) {
           slotn = (size_t)tile_of(i + 1) * (4 * FBS) + tid;
 #pragma unroll
-          for (int q = 0; q < NR; ++q) tn[q] = m.task_a[slotn + FBS * q];
+          for (int q = 0; q < NR; ++q) { tn[q] = m.task_a[slotn + FBS * q]; tnb[q] = m.task_nb[slotn + FBS * q]; }
         }
+#ifndef QDG_P1R_KO_FACE
 #pragma unroll 1
         for (int q = 0; q < NR; ++q) {
           const int a = (q == 0) ? ta[0] : (q == 1) ? ta[1] : (q == 2) ? ta[2] : ta[3];
           if (a < 0) break;
+          const int nbr_row = (q == 0) ? tb[0] : (q == 1) ? tb[1] : (q == 2) ? tb[2] : tb[3];
           const double g4[4] = { gnx[0], gnx[1], gnx[2], gnx[3] };
           const int an_ = (q == 0) ? ta[1] : (q == 1) ? ta[2] : (q == 2) ? ta[3] : -1;
           if (an_ >= 0) load_row<4>(m.tgeo, slot0 + (size_t)FBS * (q + 1), gnx);
           face_task_lean<WITH_DT, PROB, LyBlk>(m, ph, t, U, nodS[b], accS[b], sdeltS + (WITH_DT ? b * TILE : 0), a,
-                                               m.task_nb + slot0 + (size_t)FBS * q, tile_e0, g4);
+                                               &nbr_row, tile_e0, g4);
         }
+#endif
         if (i + 1 < ntl) {
 #pragma unroll
-          for (int q = 0; q < NR; ++q) ta[q] = tn[q];
+          for (int q = 0; q < NR; ++q) { ta[q] = tn[q]; tb[q] = tnb[q]; }
           slot0 = slotn;
           load_row<4>(m.tgeo, slot0, gnx);
         }
@@ -1359,11 +1393,24 @@ __global__ __launch_bounds__(RBS, 1) void k_rhs_p1r(DevMesh m, Phys ph, double t
         const double* w = wminS + ((i - 2) & 1) * 4;
         blockmin[tile_of(i - 2)] = fmin(fmin(w[0], w[1]), fmin(w[2], w[3]));
       }
-    } else {
-      if (i >= 1) finish_tile(tile_of(i - 1), 1 - b);
-      if (i + 1 < ntl) load_tile(tile_of(i + 1), 1 - b);
+      __syncthreads();
     }
-    __syncthreads();
+  } else {
+#pragma unroll 1
+    for (int i = 0; i <= ntl; ++i) {
+      const int b = i & 1;
+#ifndef QDG_P1R_KO_STREAM
+      StreamRegs sr;
+      const bool more = i + 1 < ntl;
+      if (more) {
+        load_issue(tile_of(i + 1), in4n, sr);
+        if (i + 2 < ntl) load_ids(tile_of(i + 2), in4n);
+      }
+      if (i >= 1) finish_tile(tile_of(i - 1), 1 - b);
+      if (more) load_consume(tile_of(i + 1), 1 - b, sr);
+#endif
+      __syncthreads();
+    }
   }
   if (WITH_DT && tid == 0 && ntl >= 1) {
     const double* w = wminS + ((ntl - 1) & 1) * 4;
