@@ -312,11 +312,12 @@ class DeviceDG {
     m_state->meshes[inpoel.data()] = Cached{ m, nunk, coord[0].size(), fd.Esuf().size() / 2, sig };
   }
 
-  //! Content signature of a chare's mesh: FNV-1a over the sizes and up to 4096 evenly spaced
-  //! entries each of inpoel, the three coordinate arrays (bit patterns) and esuf -- O(1) per call,
-  //! so it can guard every rhs()/dt().  Two different meshes of equal sizes in the same storage
-  //! that also agree on all sampled entries are not told apart: call release() when a chare's
-  //! mesh changes (DG::resizePostAMR, migration), as INTEGRATION.md asks.
+  //! Content signature of a chare's mesh: ALL of inpoel (integer data: four interleaved multiply-xor
+  //! lanes, ~1 ms per million tets -- a different chunk of the same size or a locally swapped
+  //! connectivity in the same storage is always told apart), and FNV-1a over the sizes and up to 4096
+  //! evenly spaced entries each of the three coordinate arrays (bit patterns) and esuf.  Nodes moved
+  //! between the sampled entries with the connectivity unchanged are the one change it can miss: call
+  //! release() when a chare's mesh changes (DG::resizePostAMR, migration), as INTEGRATION.md asks.
   static std::uint64_t signature(const std::vector<std::size_t>& inpoel, const Coords& coord, const FaceData& fd)
   {
     std::uint64_t h = 1469598103934665603ull;
@@ -331,7 +332,15 @@ class DeviceDG {
       }
       if (n) { std::uint64_t v = 0; std::memcpy(&v, &a[n - 1], sizeof(a[n - 1]) < 8 ? sizeof(a[n - 1]) : 8); mix(v); }
     };
-    sample(inpoel); sample(coord[0]); sample(coord[1]); sample(coord[2]); sample(fd.Esuf());
+    {
+      std::uint64_t l[4] = { 0x9e3779b97f4a7c15ull, 0xbf58476d1ce4e5b9ull, 0x94d049bb133111ebull, 0x2545f4914f6cdd1dull };
+      const std::size_t n = inpoel.size(), n4 = n / 4 * 4;
+      for (std::size_t i = 0; i < n4; i += 4)
+        for (int j = 0; j < 4; ++j) l[j] = (l[j] ^ (std::uint64_t)inpoel[i + j]) * 0x100000001b3ull + 0x632be59bd9b4e019ull;
+      for (std::size_t i = n4; i < n; ++i) l[0] = (l[0] ^ (std::uint64_t)inpoel[i]) * 0x100000001b3ull + 0x632be59bd9b4e019ull;
+      mix(n); mix(l[0]); mix(l[1]); mix(l[2]); mix(l[3]);
+    }
+    sample(coord[0]); sample(coord[1]); sample(coord[2]); sample(fd.Esuf());
     return h;
   }
 

@@ -687,7 +687,7 @@ struct LyBlk {             // the same planes per BLOCK of 62 tets, 4 blocks per
   __device__ static __forceinline__ int idx(int e, int v) { const int b = blk(e); return b * BSZ + v * VS + (e - b * BLK); }
 };
 
-template <bool WITH_DT, int PROB, class LY = LyTile>
+template <bool WITH_DT, int PROB, class LY = LyTile, bool ILP3 = false>
 __device__ __forceinline__ void face_task_lean(const DevMesh& m, const Phys& ph, double t,
                                                const double* __restrict__ U, double* __restrict__ nod,
                                                double* __restrict__ accN, double* __restrict__ sdelt,
@@ -755,6 +755,46 @@ __device__ __forceinline__ void face_task_lean(const DevMesh& m, const Phys& ph,
   // 3-point rule: state at point g = B + V_h(g)/2, h(g) = (g+1)%3; vertex-weighted flux sums
   // W_j = A/18 (F_0+F_1+F_2) + A/6 F_g(j), g(j) = (j+2)%3   (Quadrature.cpp:261-339)
   double Fg[3][NCOMP], dsum = 0.0;
+  if constexpr (ILP3) {
+    // the three points side by side (see flux_hllc_own3): the same arithmetic per point
+    if (kind == TASK_BND) {
+#pragma unroll
+      for (int ig = 0; ig < NGF; ++ig) {
+        const double* so = Y[ig];
+        const double vn2 = refl * (so[1] * fn[0] + so[2] * fn[1] + so[3] * fn[2]);
+        X[ig][0] = so[0]; X[ig][1] = so[1] - vn2 * fn[0]; X[ig][2] = so[2] - vn2 * fn[1];
+        X[ig][3] = so[3] - vn2 * fn[2]; X[ig][4] = so[4];
+        if constexpr (HAS_DIRICHLET) {
+          if (bc == 1) {
+            double P[3];
+            face_point(gdir, lf, T.fs[ig][0], T.fs[ig][1], T.fs[ig][2], P);
+            prob_solution<PROB>(ph, P[0], P[1], P[2], t, X[ig]);
+          }
+        }
+      }
+    }
+    Prim3 qo, qn;
+    primitives3(ph, fn, Y, qo);
+    primitives3(ph, fn, X, qn);
+    if (WITH_DT) {
+#pragma unroll
+      for (int ig = 0; ig < NGF; ++ig) {
+        const double d_o = fabs(qo.vn[ig]) + qo.a[ig];
+        const double d_n = bnd ? 0.0 : fabs(qn.vn[ig]) + qn.a[ig];
+        const bool take_n = own_left ? (d_o < d_n) : !(d_n < d_o);
+        dsum += take_n ? d_n : d_o;
+      }
+    }
+    if (ph.flux == 1) {
+#pragma unroll
+      for (int ig = 0; ig < NGF; ++ig) {
+        const Prim a1{ qo.ir[ig], qo.p[ig], qo.a[ig], qo.vn[ig] }, a2{ qn.ir[ig], qn.p[ig], qn.a[ig], qn.vn[ig] };
+        flux_lf_q(fn, Y[ig], X[ig], a1, a2, Fg[ig]);
+      }
+    } else {
+      flux_hllc_own3(fn, Y, X, qo, qn, own_left, Fg);
+    }
+  } else {
 #pragma unroll
   for (int ig = 0; ig < NGF; ++ig) {
     double so[NCOMP], sn[NCOMP];
@@ -789,7 +829,10 @@ __device__ __forceinline__ void face_task_lean(const DevMesh& m, const Phys& ph,
     }
     if (ph.flux == 1) flux_lf_q(fn, so, sn, qo, qn, Fg[ig]);   // symmetric under the mirror image
     else flux_hllc_own(fn, so, sn, qo, qn, own_left, Fg[ig]);
+#ifndef QDG_FACE_ILP
     __builtin_amdgcn_sched_barrier(0);     // keep the three points in sequence (register pressure)
+#endif
+  }
   }
 
   // scatter the vertex-weighted flux sums: the own tet loses, the neighbour gains
@@ -1077,6 +1120,9 @@ __global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1w(DevMesh m, Phys ph, doub
 // wave (fp64 issue) and one stream wave (loads in flight for the whole face phase).
 // Reference work per face: src/PDE/Integrate/Surface.cpp:73-189; volume term Volume.cpp:54-111.
 constexpr int RBS = 512;                 // lanes of a role-specialised workgroup
+#ifndef QDG_P1R_ILP3
+#define QDG_P1R_ILP3 true
+#endif
 
 // volume term (+ source) of one tet from its four vertex states in registers: the arithmetic of
 // tet_volume_lean (which reads the same vertex states from LDS)
@@ -1377,7 +1423,7 @@ __global__ __launch_bounds__(RBS, 1) void k_rhs_p1r(DevMesh m, Phys ph, double t
           const double g4[4] = { gnx[0], gnx[1], gnx[2], gnx[3] };
           const int an_ = (q == 0) ? ta[1] : (q == 1) ? ta[2] : (q == 2) ? ta[3] : -1;
           if (an_ >= 0) load_row<4>(m.tgeo, slot0 + (size_t)FBS * (q + 1), gnx);
-          face_task_lean<WITH_DT, PROB, LyBlk>(m, ph, t, U, nodS[b], accS[b], sdeltS + (WITH_DT ? b * TILE : 0), a,
+          face_task_lean<WITH_DT, PROB, LyBlk, QDG_P1R_ILP3>(m, ph, t, U, nodS[b], accS[b], sdeltS + (WITH_DT ? b * TILE : 0), a,
                                                &nbr_row, tile_e0, g4);
         }
 #endif
