@@ -748,6 +748,7 @@ extern "C" int qdg_mesh_destroy(qdg_mesh* mesh)
   HIPCHK(hipSetDevice(ctx->device));                             \
   hipStream_t s = ctx->stream;                                   \
   qdg::StreamScope stream_scope_(s);                             \
+  mesh->slab_ready_for = nullptr;                                \
   (void)s
 
 // host AoS (all ne rows) -> SoA planes `dst`
@@ -1707,6 +1708,26 @@ extern "C" int qdg_halo_setup(qdg_mesh* mesh, size_t nnbr, const int32_t* nbr_ra
     se[i] = h2d[send_elem[i]];
   }
   HIPCHK(mesh->send_elem.upload(se, s));
+  // inverse of the send list for the packs folded into the producing kernels (qdg_step_comm): the slab rows
+  // of every halo-adjacent device row.  Only where the plan has the shape the device order was built for --
+  // every send row among the trailing rows [ninner, nie), at most four slab rows per tet -- and not for
+  // p-adaptive runs (their slab rows carry the ndof column)
+  (void)mesh->fold_slot.alloc(0);
+  mesh->slab_ready_for = nullptr;
+  if (!mesh->dm.ndofel && mesh->nsend > 0) {
+    const size_t ninner = (size_t)mesh->dm.ninner, nh = mesh->nie - ninner;
+    std::vector<int> slot(4 * std::max<size_t>(nh, 1), -1);
+    bool ok = true;
+    for (size_t j = 0; j < mesh->nsend && ok; ++j) {
+      const size_t d = (size_t)se[j];
+      if (d < ninner) { ok = false; break; }
+      int* sl = &slot[4 * (d - ninner)];
+      int q = 0;
+      while (q < 4 && sl[q] >= 0) ++q;
+      if (q == 4) ok = false; else sl[q] = (int)j;
+    }
+    if (ok) HIPCHK(mesh->fold_slot.upload(slot, s));
+  }
   HIPCHK(mesh->send_slab.alloc(std::max<size_t>(1, mesh->nsend * slab_w(mesh))));
   HIPCHK(mesh->recv_slab.alloc(std::max<size_t>(1, mesh->nrecv * slab_w(mesh))));
   mesh->send_ptr = mesh->send_slab.p;
@@ -1932,7 +1953,7 @@ extern "C" int qdg_comm_destroy(qdg_comm* comm)
 }
 
 // pack, grouped send / receive into the ghost rows -- all enqueued on stream `s`
-static int exchange_on(qdg_mesh* mesh, qdg_comm* comm, hipStream_t s)
+static int exchange_on(qdg_mesh* mesh, qdg_comm* comm, hipStream_t s, bool packed = false)
 {
   if (mesh->nnbr == 0) return 0;
   if (!comm) return fail("qdg_halo_exchange: null communicator");
@@ -1942,9 +1963,11 @@ static int exchange_on(qdg_mesh* mesh, qdg_comm* comm, hipStream_t s)
   RcclApi* a = rccl_api();
   const size_t np = (size_t)mesh->nprop, w = slab_w(mesh);
   const bool direct = w == np;       // ghost rows are contiguous per neighbour: received in place
-  launch_halo_pack(mesh->Ucur, mesh->nprop, (int)mesh->stride, mesh->send_elem.p, (int)mesh->nsend,
-                   mesh->send_ptr, s, mesh->dm.ndofel);
-  HIPCHK(hipGetLastError());
+  if (!packed) {                     // (packed: the kernel that produced the state has filled the slab)
+    launch_halo_pack(mesh->Ucur, mesh->nprop, (int)mesh->stride, mesh->send_elem.p, (int)mesh->nsend,
+                     mesh->send_ptr, s, mesh->dm.ndofel);
+    HIPCHK(hipGetLastError());
+  }
   RCCLCHK(a->GroupStart());
   // an error inside the group must not leave it open: remember the first one, always
   // close the group, then report
@@ -2000,7 +2023,7 @@ extern "C" int qdg_halo_exchange(qdg_mesh* mesh, qdg_comm* comm)
 {
   QDG_TRY
   MESH_ENTER("qdg_halo_exchange");
-  return exchange_on(mesh, comm, s);
+  return exchange_on(mesh, comm, s, false);
   QDG_CATCH
 }
 
@@ -2014,17 +2037,21 @@ extern "C" int qdg_stage_dt_allreduce(qdg_mesh* mesh, qdg_comm* comm)
   QDG_CATCH
 }
 
-static int step_comm_stages(qdg_mesh* mesh, qdg_comm* comm, double t, double tleft);
+static int step_comm_stages(qdg_mesh* mesh, qdg_comm* comm, double t, double tleft, bool slab_ready);
 
 extern "C" int qdg_step_comm(qdg_mesh* mesh, qdg_comm* comm, double t, double tleft, double* dt_taken)
 {
   QDG_TRY
+  // (read before MESH_ENTER clears it: the slab still holds this state's send rows if the previous call on
+  // this mesh was a qdg_step_comm whose last kernel packed them)
+  const bool slab_ready = mesh && mesh->slab_ready_for && mesh->slab_ready_for == mesh->Ucur;
   MESH_ENTER("qdg_step_comm");
   if (!comm) return fail("qdg_step_comm: null communicator");
   // the skipped ghost-row carries below rely on every ghost row being received by the next exchange
   if (mesh->nnbr > 0 && mesh->nrecv != mesh->ne - mesh->nie)
     return fail("qdg_step_comm: the halo plan does not cover every ghost row");
-  const int rc = step_comm_stages(mesh, comm, t, tleft);
+  const int rc = step_comm_stages(mesh, comm, t, tleft, slab_ready);
+  const double* ready_after = mesh->slab_ready_for;
   if (rc && mesh->carry_src && mesh->carry_src != mesh->Ucur) {
     // an exchange failed after an update whose ghost-row carry was skipped: do the carry now, so that
     // the state the caller is left with has the last received ghost rows, not a buffer's older content
@@ -2036,25 +2063,42 @@ extern "C" int qdg_step_comm(qdg_mesh* mesh, qdg_comm* comm, double t, double tl
   }
   mesh->carry_src = nullptr;
   if (rc) return rc;
-  if (dt_taken) return qdg_stage_dt_get(mesh, dt_taken);
+  if (dt_taken) {
+    const int rc2 = qdg_stage_dt_get(mesh, dt_taken);      // (its MESH_ENTER clears the mark)
+    mesh->slab_ready_for = ready_after;
+    return rc2;
+  }
   return 0;
   QDG_CATCH
 }
 
-static int step_comm_stages(qdg_mesh* mesh, qdg_comm* comm, double t, double tleft)
+static int step_comm_stages(qdg_mesh* mesh, qdg_comm* comm, double t, double tleft, bool slab_ready)
 {
   qdg_ctx* ctx = mesh->ctx;
   hipStream_t s = ctx->stream;
   const bool limited = ctx->cfg.limiter != QDG_LIMITER_NONE && mesh->ndof > 1;
   const bool fuse = can_fuse_update_limit(mesh);
+  // Packs folded into the kernels that produce the rows (halo_fold_row): the Superbee kernels write the
+  // limited send rows to the slab themselves, the DG-P1 tile kernel with the fused RK update the rows of the
+  // new state.  Enabled for THIS call's launches only (DevMesh goes to the kernels by value).
+  const bool can_fold = mesh->fold_slot.p && mesh->nnbr > 0;
+  const bool lim_folds = can_fold && ctx->cfg.limiter == QDG_LIMITER_SUPERBEEP1 && mesh->ndof > 1;
+  const bool rhs_folds = can_fold && use_p1_fast(mesh) && use_tile(mesh) && ctx->opt.p1_rhs < 2 && !mesh->dm.ndofel;
+  struct FoldScope {
+    qdg_mesh* m;
+    FoldScope(qdg_mesh* mm, bool on) : m(mm) { if (on) { m->dm.fold_slot = m->fold_slot.p; m->dm.fold_slab = m->send_ptr; } }
+    ~FoldScope() { m->dm.fold_slot = nullptr; m->dm.fold_slab = nullptr; }
+  } fold_scope(mesh, can_fold);
+  bool packed = slab_ready && rhs_folds;       // the previous step's last kernel packed this state's send rows
   for (int stage = 0; stage < 3; ++stage) {
     const bool pdg0 = stage == 0 && mesh->dm.ndofel;
     const bool fused1 = fuse && stage == 1;        // comsol + limiter of stage 1 ran with the update
     if (pdg0) if (int rc = qdg_stage_pdg_eval(mesh)) return rc;          // DG::next: eval_ndof
-    if (!fused1) if (int rc = exchange_on(mesh, comm, s)) return rc;    // DG::next -> comsol
+    if (!fused1) if (int rc = exchange_on(mesh, comm, s, packed && !pdg0)) return rc;    // DG::next -> comsol
+    packed = false;
     if (pdg0) if (int rc = qdg_stage_pdg_propagate(mesh)) return rc;     // DG::lim: propagate_ndof
     if (!fused1) if (int rc = qdg_stage_limit(mesh)) return rc;          // DG::lim
-    if (limited || pdg0) if (int rc = exchange_on(mesh, comm, s)) return rc;   // -> comlim
+    if (limited || pdg0) if (int rc = exchange_on(mesh, comm, s, lim_folds && !pdg0)) return rc;   // -> comlim
     if (int rc = qdg_stage_rhs_dt(mesh, stage, t, tleft)) return rc;     // DG::dt, DG::solve
     if (stage == 0) if (int rc = qdg_stage_dt_allreduce(mesh, comm)) return rc;
     if (fuse && stage == 0) {
@@ -2065,11 +2109,15 @@ static int step_comm_stages(qdg_mesh* mesh, qdg_comm* comm, double t, double tle
     } else {
       // stages 0, 1: the next stage starts by receiving the ghost rows of the new state
       mesh->skip_ghost_carry = stage < 2 && mesh->nnbr > 0;
+      const bool by_kernel = mesh->Upending != nullptr;      // the fused RHS + RK kernel wrote the new state
       const int rc = qdg_stage_update(mesh, stage);
       mesh->skip_ghost_carry = false;
       if (rc) return rc;
+      packed = by_kernel && rhs_folds;                       // ... and with it the next comsol's send rows
     }
   }
+  // (qdg_step_comm hands this to the next call if nothing else touches the mesh in between)
+  mesh->slab_ready_for = packed ? mesh->Ucur : nullptr;
   return 0;
 }
 

@@ -580,6 +580,21 @@ __device__ __forceinline__ double fast_sqrt(double x)
   return (x == 0.0) ? 0.0 : g;
 }
 
+// halo pack folded into a producing kernel's epilogue: device row d of the new state also goes to the
+// send slab rows that carry it (DG::next / DG::lim pack m_u[tet] per neighbour, DG.cpp:1023-1031, 1262-1279)
+template <int NPROP>
+__device__ __forceinline__ void halo_fold_row(const DevMesh& m, int d, const double* row)
+{
+  if (!m.fold_slot || d < m.ninner || d >= m.nie) return;
+  const int* sl = m.fold_slot + 4 * (size_t)(d - m.ninner);
+#pragma unroll 1
+  for (int q = 0; q < 4; ++q) {
+    const int j = sl[q];
+    if (j < 0) break;
+    store_row<NPROP>(m.fold_slab, j, row);
+  }
+}
+
 // primitive quantities of one side of a face
 struct Prim {
   double ir, p, a, vn;

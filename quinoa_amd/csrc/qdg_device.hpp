@@ -79,6 +79,11 @@ struct DevMesh {
   // next to the halo, so a launch over the leading tiles never reads a ghost row.
   int blk0;
   int ninner;
+  // halo pack folded into the producing kernels (set by qdg_step_comm for its own launches only): a row
+  // d >= ninner that neighbours need is ALSO written to the send slab, at up to 4 slab rows
+  // fold_slot[4 * (d - ninner) ...] (-1 = none); null: no folding
+  const int* fold_slot;
+  double* fold_slab;
   int persistent;   // DG-P1 tile RHS: option p1_rhs when 2 (role-specialised persistent workgroups, k_rhs_p1r,
                     // for launches of >= 2 tiles per CU) or 3 (always), else 0
   int ncomp;        // 5: CompFlow; dg::Transport: its number of scalars (rows of ncomp*ndof doubles)

@@ -107,6 +107,8 @@ struct qdg_mesh {
   std::vector<int32_t> nbr_rank;
   std::vector<size_t> send_off, recv_off;
   qdg::DevBuf<int> send_elem;
+  qdg::DevBuf<int> fold_slot;     // [4 * (nie - ninner)] slab rows of every halo-adjacent row (-1 = none); empty: no folding
+  const double* slab_ready_for = nullptr;   // the state whose send rows the slab already holds (qdg_step_comm)
   qdg::DevBuf<double> send_slab, recv_slab;
   double* send_ptr = nullptr;     // slabs in use (own or caller-provided)
   double* recv_ptr = nullptr;

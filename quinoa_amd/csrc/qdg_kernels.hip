@@ -302,6 +302,7 @@ __global__ __launch_bounds__(256) void k_superbee(DevMesh m, double* __restrict_
     for (int c = 0; c < NCOMP; ++c)
 #pragma unroll
       for (int k = 1; k < 4; ++k) u[c][k] = phi[c] * u[c][k];
+    if (active) halo_fold_row<NPROP>(m, e, &u[0][0]);      // (qdg_step_comm: the comlim pack, folded in)
     // Out-of-tile neighbours may be read from U while another tile has already
     // stored its limited rows: safe, Superbee never changes a mean.
     tile_store_rows<NPROP>(U, tile_e0, m.nie, lds, &u[0][0]);
@@ -391,6 +392,7 @@ __global__ __launch_bounds__(256) void k_upd_superbee(DevMesh m, const double* _
   for (int c = 0; c < NCOMP; ++c)
 #pragma unroll
     for (int k = 1; k < 4; ++k) u[c][k] = phi[c] * u[c][k];
+  if (active) halo_fold_row<NPROP>(m, e, &u[0][0]);        // (qdg_step_comm: the comlim pack of stage 1, folded in)
   tile_store_rows<NPROP>(Uout, tile_e0, m.nie, lds, &u[0][0]);
 }
 

@@ -1067,7 +1067,10 @@ __global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1w(DevMesh m, Phys ph, doub
   if (tid < nloc) {
     tet_face_sums(accN, tid, acc);
     tet_volume_lean<PROB>(ph, t, nod, tid, vol, g, acc);
-    if constexpr (FUSE_RK) rk_epilogue_rows(r, un, dtp[0] / vol, rk_a, rk_b, acc);
+    if constexpr (FUSE_RK) {
+      rk_epilogue_rows(r, un, dtp[0] / vol, rk_a, rk_b, acc);
+      halo_fold_row<NPROP>(m, tile_e0 + tid, &acc[0][0]);      // (qdg_step_comm: the next comsol pack, folded in)
+    }
     if (WITH_DT) dte = vol / sdelt[tid];
   }
   // rows out, coalesced: a lane storing its own 160-B row issues 64 separate 16-B write
@@ -1121,7 +1124,7 @@ __global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1w(DevMesh m, Phys ph, doub
 // Reference work per face: src/PDE/Integrate/Surface.cpp:73-189; volume term Volume.cpp:54-111.
 constexpr int RBS = 512;                 // lanes of a role-specialised workgroup
 #ifndef QDG_P1R_ILP3
-#define QDG_P1R_ILP3 true
+#define QDG_P1R_ILP3 false      // the three Gauss points side by side: measured, no gain (profiles/r04_p1_experiments.log)
 #endif
 
 // volume term (+ source) of one tet from its four vertex states in registers: the arithmetic of

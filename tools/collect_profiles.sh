@@ -41,7 +41,7 @@ if rhs:
         nl = cnt[(k, "FETCH_SIZE")]
         ker[k] = {"hbm_bytes_per_launch": b, "launches_counted": nl}
         tot += b * nl; n += nl
-    json.dump({"nx": $nx, "n_gpus": 1, "round": 3,
+    json.dump({"nx": $nx, "n_gpus": 1, "round": 4,
                "note": "x2 on FETCH_SIZE is the guide's calibration for 16-B-per-lane reads (what the RHS kernels issue); "
                        "other widths are uncalibrated, so for the gather-heavy kernels read this as an upper bound",
                "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes), per-launch means; "
