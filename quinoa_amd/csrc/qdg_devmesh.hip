@@ -608,12 +608,28 @@ __host__ inline double dord_inv(unsigned long long k)
 
 __global__ void k_bbox(const double* __restrict__ geoElem, size_t ne, unsigned long long* __restrict__ mm)
 {
-  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= ne) return;
+  // wave reduction first, one atomic per wave and bound: every thread hitting the same six words cost 10.7 ms at
+  // 10.1 M tets (86 ms of the 106 ms "Morton order" stage at 80.9 M, profiles/r04_nx119_kernel_stats.csv)
+  // (a fixed grid striding over the tets: a few thousand atomics in all)
+  unsigned long long lo[3] = { ~0ull, ~0ull, ~0ull }, hi[3] = { 0ull, 0ull, 0ull };
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += (size_t)gridDim.x * blockDim.x) {
 #pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    const unsigned long long k = dord(geoElem[4 * e + 1 + d]);
-    atomicMin(mm + d, k); atomicMax(mm + 3 + d, k);
+    for (int d = 0; d < 3; ++d) {
+      const unsigned long long k = dord(geoElem[4 * e + 1 + d]);
+      lo[d] = k < lo[d] ? k : lo[d];
+      hi[d] = k > hi[d] ? k : hi[d];
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+    for (int off = 32; off > 0; off >>= 1) {
+      const unsigned long long a = __shfl_down(lo[d], off, 64), b = __shfl_down(hi[d], off, 64);
+      lo[d] = a < lo[d] ? a : lo[d];
+      hi[d] = b > hi[d] ? b : hi[d];
+    }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { atomicMin(mm + d, lo[d]); atomicMax(mm + 3 + d, hi[d]); }
   }
 }
 
@@ -635,19 +651,24 @@ __global__ void k_morton(const double* __restrict__ geoElem, size_t ne, const in
                          int* __restrict__ ninner)
 {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= ne) return;
-  bool halo = false;
-  for (int lf = 0; lf < 4; ++lf) halo = halo || esuel[4 * e + lf] >= (int)ne;
-  const double lo[3] = { lx, ly, lz };
-  uint64_t k = 0;
+  bool inner = false;
+  if (e < ne) {
+    bool halo = false;
+    for (int lf = 0; lf < 4; ++lf) halo = halo || esuel[4 * e + lf] >= (int)ne;
+    const double lo[3] = { lx, ly, lz };
+    uint64_t k = 0;
 #pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    const double t = (geoElem[4 * e + 1 + d] - lo[d]) / ext;
-    const uint64_t q = (uint64_t)fmin(2097151.0, fmax(0.0, t * 2097152.0));
-    k |= spread21d(q) << d;
+    for (int d = 0; d < 3; ++d) {
+      const double t = (geoElem[4 * e + 1 + d] - lo[d]) / ext;
+      const uint64_t q = (uint64_t)fmin(2097151.0, fmax(0.0, t * 2097152.0));
+      k |= spread21d(q) << d;
+    }
+    key[e] = k | (halo ? 0x8000000000000000ull : 0ull); val[e] = (uint32_t)e;
+    inner = !halo;
   }
-  key[e] = k | (halo ? 0x8000000000000000ull : 0ull); val[e] = (uint32_t)e;
-  if (!halo) atomicAdd(ninner, 1);
+  // one atomic per wave (every tet of a chunk without ghosts used to add 1 to the same word)
+  const unsigned long long b = __ballot(inner);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(ninner, (int)__popcll(b));
 }
 
 __global__ void k_ghost_ids(uint32_t* __restrict__ val, size_t nie, size_t ne)
@@ -1004,7 +1025,7 @@ static int dev_build_layout(qdg_ctx* ctx, DevFD& fd, const std::vector<int>& bcf
     const unsigned long long init[6] = { ~0ull, ~0ull, ~0ull, 0ull, 0ull, 0ull };
     DHIP(hipMemcpyAsync(d_mm.p, init, sizeof init, hipMemcpyHostToDevice, s));
   }
-  k_bbox<<<nblk(nie), 256, 0, s>>>(fd.geoElem.p, nie, d_mm.p);
+  k_bbox<<<std::min(nblk(nie), 1024u), 256, 0, s>>>(fd.geoElem.p, nie, d_mm.p);
   unsigned long long hmm[6];
   DHIP(hipMemcpyAsync(hmm, d_mm.p, sizeof hmm, hipMemcpyDeviceToHost, s));
   DHIP(hipStreamSynchronize(s));

@@ -298,11 +298,19 @@ __global__ __launch_bounds__(256) void k_superbee(DevMesh m, double* __restrict_
 #pragma unroll
       for (int c = 0; c < NCOMP; ++c) phi[c] = 1.0;
     }
+    bool changed = false;
 #pragma unroll
     for (int c = 0; c < NCOMP; ++c)
 #pragma unroll
-      for (int k = 1; k < 4; ++k) u[c][k] = phi[c] * u[c][k];
+      for (int k = 1; k < 4; ++k) {
+        const double v = phi[c] * u[c][k];
+        changed = changed || (v != u[c][k]);
+        u[c][k] = v;
+      }
     if (active) halo_fold_row<NPROP>(m, e, &u[0][0]);      // (qdg_step_comm: the comlim pack, folded in)
+    // A tile in which the limiter changed no value (phi = 1 or zero slopes on every row: uniform and smooth
+    // regions) has nothing to write back -- the limiter works in place -- which halves this pass's traffic there.
+    if (!__syncthreads_or(changed && active)) return;
     // Out-of-tile neighbours may be read from U while another tile has already
     // stored its limited rows: safe, Superbee never changes a mean.
     tile_store_rows<NPROP>(U, tile_e0, m.nie, lds, &u[0][0]);
