@@ -48,3 +48,32 @@ def test_product_does_not_reference_the_oracle():
             if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "oracle" not in txt.lower() or f == "__init__.py" and False, os.path.join(dp, f)
+
+
+def test_bench_gpus_n_starts_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` with WORLD_SIZE unset starts N ranks as a CHILD process
+    (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same
+    arguments>) before anything touches the GPU, and relays the launcher's exit code -- the shape of the
+    reference's `charmrun +pN inciter ...` (cmake/test_runner.cmake:88-113).  No GPU needed: the child is
+    intercepted."""
+    import subprocess
+    import sys
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = list(cmd), dict(env or {})
+        return 7
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    with pytest.raises(SystemExit) as ex:
+        bench.main()
+    assert ex.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert seen["env"].get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"

@@ -170,3 +170,37 @@ def test_device_mesh_build_refuses_an_inverted_tet():
             capi.mesh_from_connectivity(ctx, inp, ch["coord"], ch["sidesets"])
     finally:
         ctx.close()
+
+
+def test_reserved_device_region_serves_the_librarys_allocations():
+    """qdg_device_pool_reserve: one region from the driver; later allocations of the library are carved out of
+    it (mesh builds, re-mesh), results are the same, the region goes back with the last context."""
+    from quinoa_amd import capi, meshgen
+    ch = meshgen.kuhn_box(7, 6, 5)
+    kw = dict(flux="hllc", limiter="superbeep1", problem="sod_shocktube", gamma=1.4, cfl=0.3,
+              bc_extrapolate=[1, 2], bc_sym=[3, 4, 5, 6])
+    capi.device_pool_trim()
+    out = []
+    for reserve in (0, 256 << 20):
+        ctx = capi.Context(4, options={"keep_connectivity": 1}, **kw)
+        free0 = ctx.device_memory()[0]
+        if reserve:
+            ctx.reserve_device_memory(reserve)
+            f, t, r = ctx.device_memory()
+            assert r == reserve and f <= free0 - reserve + (64 << 20)
+        mesh = capi.mesh_from_connectivity(ctx, ch["inpoel"], ch["coord"], ch["sidesets"])
+        mesh.state_initialize(0.0)
+        t = 0.0
+        for _ in range(2):
+            t += mesh.step(t)
+        free1 = ctx.device_memory()[0]
+        new, _ = mesh.refine_uniform(host_copy=False)
+        t += new.step(t)
+        if reserve:
+            # the build, the state buffers and the re-mesh all came out of the region: the driver saw nothing
+            assert abs(ctx.device_memory()[0] - free1) <= (8 << 20)
+        out.append((t, new.state_download()))
+        new.close(); mesh.close(); ctx.close()
+        assert capi.device_pool_trim() == 0          # the last context returned region and cache
+    assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1]) or \
+        np.abs(out[0][1] - out[1][1]).max() <= 1e-13
