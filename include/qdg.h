@@ -465,6 +465,16 @@ int qdg_state_transfer(qdg_mesh* from, qdg_mesh* to, const size_t* parent_of_chi
  * host thread on a second stream while this call builds the mesh; qdg_refined_sizes / _get / _tri_sets wait
  * for it. */
 int qdg_mesh_refine_uniform(qdg_mesh* mesh, qdg_mesh** refined_mesh, qdg_refined** host_copy);
+/* ... and of ONE RANK's chunk WITH its ghost layer (config 5 on a decomposition; the device form of
+ * qdg_refine_chunk): the handle was built by qdg_mesh_from_chunk_gid (the tets' global ids order the new ghosts)
+ * under "keep_connectivity" = 1 and has had its qdg_halo_setup.  Children of the owned tets, the new ghost layer
+ * (children of old ghosts that share a face with an owned child, grouped by owner, by global child id
+ * 8 * gid(parent) + k), the new halo plan and the renumbered nodes are derived on the device exactly as
+ * qdg_refine_chunk derives them on the host -- without communication: both ranks of a pair get the same sets --
+ * then the chunk build, qdg_halo_setup of the new handle and the state of the owned tets (child <- parent).
+ * host_copy (may be NULL): gid[nunk], parent[nunk] (old local id), send lists, receive counts -- and with
+ * copy_mesh != 0 connectivity, coordinates and side-set triangles too -- through qdg_chunk_refined_sizes / _get. */
+int qdg_mesh_refine_chunk(qdg_mesh* mesh, qdg_mesh** refined_mesh, qdg_chunk_refined** host_copy, int copy_mesh);
 int qdg_refined_sizes(const qdg_refined* r, size_t* nelem, size_t* nnode, size_t* ntri);
 int qdg_refined_tri_sets(const qdg_refined* r, int32_t* tri_set);
 /* The child mesh need not come from qdg_refine_*: ANY conforming tetrahedron mesh with a parent

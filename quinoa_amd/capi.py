@@ -519,6 +519,49 @@ class Mesh:
         new.nielem = new.nunk = 8 * self.nielem
         return new, (Refined(r) if host_copy else None)
 
+    def refine_chunk(self, nbr_rank, copy_mesh=False):
+        """qdg_mesh_refine_chunk: the re-mesh of this rank's chunk WITH its ghost layer on the device (built by
+        mesh_from_connectivity(..., nielem, elem_gid) under keep_connectivity = 1, halo_setup done).  Returns
+        (new Mesh -- halo plan set up, owned state handed over --, chunk dict: nielem, gid, parent, nbr_rank,
+        send_lists, recv_counts [+ inpoel, coord, sidesets with copy_mesh])."""
+        L = lib()
+        new = Mesh.__new__(Mesh)
+        new.ctx, new.nprop, new.h = self.ctx, self.nprop, C.c_void_p()
+        h = C.c_void_p()
+        _chk(L.qdg_mesh_refine_chunk(self.h, C.byref(new.h), C.byref(h), C.c_int(1 if copy_mesh else 0)))
+        try:
+            n = [C.c_size_t() for _ in range(5)]
+            _chk(L.qdg_chunk_refined_sizes(h, *[C.byref(v) for v in n]))
+            nie2, nunk2, nn2, ntri2, nsend = (int(v.value) for v in n)
+            nnbr = len(nbr_rank)
+            gid = np.empty(nunk2, dtype=np.uint64); par = np.empty(nunk2, dtype=np.uint64)
+            soff = np.zeros(nnbr + 1, dtype=np.uint64); slist = np.zeros(max(1, nsend), dtype=np.uint64)
+            rc = np.zeros(max(1, nnbr), dtype=np.uint64)
+            inp = np.empty(4 * nunk2 if copy_mesh else 1, dtype=np.uint64)
+            c = np.empty((3, nn2 if copy_mesh else 1))
+            tri = np.zeros(max(1, 3 * ntri2), dtype=np.uint64); tset = np.zeros(max(1, ntri2), dtype=np.int32)
+            _chk(L.qdg_chunk_refined_get(h, inp.ctypes.data_as(c_szp) if copy_mesh else None, gid.ctypes.data_as(c_szp),
+                                         par.ctypes.data_as(c_szp),
+                                         c[0].ctypes.data_as(c_f64p) if copy_mesh else None,
+                                         c[1].ctypes.data_as(c_f64p) if copy_mesh else None,
+                                         c[2].ctypes.data_as(c_f64p) if copy_mesh else None,
+                                         tri.ctypes.data_as(c_szp) if copy_mesh else None,
+                                         tset.ctypes.data_as(c_i32p) if copy_mesh else None,
+                                         soff.ctypes.data_as(c_szp), slist.ctypes.data_as(c_szp),
+                                         rc.ctypes.data_as(c_szp)))
+        finally:
+            L.qdg_chunk_refined_destroy(h)
+        new.nielem, new.nunk = nie2, nunk2
+        soff = soff.astype(np.int64)
+        ch = {"nielem": nie2, "gid": gid.view(np.int64), "parent": par.view(np.int64), "nbr_rank": list(nbr_rank),
+              "send_lists": [slist[soff[i]:soff[i + 1]].astype(np.int64) for i in range(nnbr)],
+              "recv_counts": [int(v) for v in rc[:nnbr]]}
+        if copy_mesh:
+            tri = tri[:3 * ntri2].view(np.int64).reshape(-1, 3); tset = tset[:ntri2]
+            ch.update(inpoel=inp.view(np.int64).reshape(-1, 4), coord=np.ascontiguousarray(c.T),
+                      sidesets={int(s_): tri[tset == s_] for s_ in np.unique(tset)})
+        return new, ch
+
     def profile_enable(self, on=True):
         _chk(lib().qdg_profile_enable(self.h, C.c_int(1 if on else 0)))
 

@@ -1698,6 +1698,7 @@ extern "C" int qdg_halo_setup(qdg_mesh* mesh, size_t nnbr, const int32_t* nbr_ra
   mesh->recv_off.assign(recv_off, recv_off + nnbr + 1);
   mesh->nsend = send_off[nnbr];
   mesh->nrecv = recv_off[nnbr];
+  qdg::keep_set_plan(mesh, nnbr, nbr_rank, recv_off);      // (a handle that keeps its connectivity: for its re-mesh)
   // host tet id -> device row of the send list
   std::vector<int> d2h(mesh->ne), h2d(mesh->ne);
   HIPCHK(hipMemcpy(d2h.data(), mesh->d2h.p, mesh->ne * sizeof(int), hipMemcpyDeviceToHost));

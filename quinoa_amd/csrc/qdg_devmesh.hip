@@ -249,7 +249,8 @@ inline unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
 // the FaceData arrays and the geometry of a chunk, resident on the device
 struct DevFD {
   Buf<uint64_t> inpoel, tri, inpofa, belem;
-  Buf<uint64_t> gid;         // global tet ids (null: faces keep the chunk-local orientation)
+  Buf<uint64_t> gid;         // global tet ids of the chunk's tets (when the caller gave them)
+  bool orient = false;       // ... and faces are oriented by them (option orient_by_gid)
   Buf<double> x, y, z, geoFace, geoElem;
   Buf<int> esuel, esuf;
   size_t nelem = 0, nnode = 0, nbfac = 0, nipfac = 0;
@@ -516,7 +517,7 @@ static int dev_faces_geometry(qdg_ctx* ctx, DevFD& fd, const SortedFaces* sf)
   DHIP(fd.geoFace.alloc(7 * nipfac)); DHIP(fd.geoElem.alloc(4 * nelem));
   k_interior_faces<<<nblk(n4), 256, 0, s>>>(fd.inpoel.p, fd.esuel.p, d_flag.p, d_pos.p, n4, nbfac,
                                            fd.inpofa.p, fd.esuf.p);
-  if (fd.gid.p && nint)
+  if (fd.gid.p && fd.orient && nint)
     k_orient_gid<<<nblk(nint), 256, 0, s>>>(fd.inpoel.p, fd.gid.p, nbfac, nipfac, fd.inpofa.p, fd.esuf.p);
   if (nbfac) {
     if (fd.belem_known)
@@ -942,6 +943,11 @@ __global__ void k_fill_i32(int* p, size_t n, int v)
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
 }
+__global__ void k_iota_i32(int* p, size_t n)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = (int)i;
+}
 __global__ void k_fill_f64(double* p, size_t n, double v)
 {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1204,7 +1210,8 @@ static int dev_build_layout(qdg_ctx* ctx, DevFD& fd, const std::vector<int>& bcf
   }
   DHIP(hipStreamSynchronize(s));
   lap("state allocation");
-  if (ctx->opt.keep_connectivity && fd.nie == fd.nelem)
+  // (a chunk with ghosts is kept only with its tets' global ids: its re-mesh orders the new ghosts by them)
+  if (ctx->opt.keep_connectivity && (fd.nie == fd.nelem || fd.gid.p))
     if (int rc = keep_connectivity(m.get(), fd)) return rc;
   *out = m.release();
   return 0;
@@ -1437,8 +1444,13 @@ struct qdg_mesh::Keep {
   Buf<uint64_t> inpoel, tri;        // caller's numbering; tri = the boundary faces in their order
   Buf<double> x, y, z;
   Buf<int> esuel;
+  Buf<uint64_t> gid;                // global tet ids (chunks with ghosts)
+  bool orient = false;
   std::vector<int32_t> fset;        // side set of every boundary face
-  size_t nelem = 0, nnode = 0, nbfac = 0;
+  size_t nelem = 0, nie = 0, nnode = 0, nbfac = 0;
+  // halo plan of a chunk with ghosts (qdg_halo_setup): neighbour ranks, ghosts received from each
+  std::vector<int32_t> nbr_rank;
+  std::vector<size_t> recv_counts;
   std::shared_ptr<qdg_host_copy> pending;   // a host copy still reading these buffers
   ~Keep() { if (pending) pending->join(); }
 };
@@ -1549,14 +1561,25 @@ void launch_state_transfer(int nrow, int nprop, const int* d2h_to, const int* pa
                            const double* Ufrom, double* Uto, hipStream_t s);
 }
 
+namespace qdg {
+void keep_set_plan(qdg_mesh* m, size_t nnbr, const int32_t* nbr_rank, const size_t* recv_off)
+{
+  if (!m || !m->keep) return;
+  m->keep->nbr_rank.assign(nbr_rank, nbr_rank + nnbr);
+  m->keep->recv_counts.resize(nnbr);
+  for (size_t i = 0; i < nnbr; ++i) m->keep->recv_counts[i] = recv_off[i + 1] - recv_off[i];
+}
+}  // namespace qdg
+
 // after a build: the chunk's connectivity stays resident with the mesh handle
 static int keep_connectivity(qdg_mesh* m, DevFD& fd)
 {
   std::unique_ptr<qdg_mesh::Keep> k(new qdg_mesh::Keep);
   k->inpoel.take(fd.inpoel); k->tri.take(fd.tri); k->x.take(fd.x); k->y.take(fd.y); k->z.take(fd.z);
   k->esuel.take(fd.esuel);
+  k->gid.take(fd.gid); k->orient = fd.orient;
   k->fset = fd.fset;
-  k->nelem = fd.nelem; k->nnode = fd.nnode; k->nbfac = fd.nbfac;
+  k->nelem = fd.nelem; k->nie = fd.nie; k->nnode = fd.nnode; k->nbfac = fd.nbfac;
   m->keep = k.release();
   m->keep_free = keep_free_fn;
   return 0;
@@ -1712,6 +1735,345 @@ extern "C" int qdg_mesh_refine_uniform(qdg_mesh* mesh, qdg_mesh** out, qdg_refin
   QDG_CATCH
 }
 
+// ======================================================================================
+// The same for ONE RANK's chunk with its ghost layer (config 5 on a decomposition): what qdg_refine_chunk
+// derives on the host -- the children of the owned tets, the new ghost layer (children of old ghosts that
+// share a face with an owned child, grouped by owner, ordered by global child id 8 * gid(parent) + k), the
+// new halo plan (per neighbour the owned children next to its ghosts, ordered by global child id), nodes
+// renumbered in ascending order of their ids in the refined chunk -- computed on the device from the
+// connectivity, esuel, global ids and plan the handle keeps, without communication: both ranks of a pair
+// derive the same sets.  Then the common chunk build, the halo set-up and the state of the owned tets.
+namespace {
+__global__ void k_ghost_child_flag(const int* __restrict__ esuel2, size_t nown, size_t nall, int* __restrict__ flag)
+{
+  const size_t c = nown + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nall) return;
+  int f = 0;
+  for (int q = 0; q < 4; ++q) { const int nb = esuel2[4 * c + q]; f |= (nb >= 0 && (size_t)nb < nown) ? 1 : 0; }
+  flag[c - nown] = f;
+}
+// keys of the new ghosts: (owner index << 48) | global child id; value = child index
+__global__ void k_ghost_keys(const int* __restrict__ flag, const int* __restrict__ pos, size_t nown, size_t nall,
+                             size_t nie_p, const uint64_t* __restrict__ gid_p, const size_t* __restrict__ recv_off,
+                             int nnbr, uint64_t* __restrict__ key, uint32_t* __restrict__ val)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nall - nown || !flag[i]) return;
+  const size_t c = nown + i, p = c >> 3, g = p - nie_p;         // g: index of the old ghost
+  int ow = 0;
+  while (ow + 1 < nnbr && g >= recv_off[ow + 1]) ++ow;
+  key[pos[i]] = ((uint64_t)ow << 48) | (8 * gid_p[p] + (c & 7));
+  val[pos[i]] = (uint32_t)c;
+}
+// (owner << 48 | global id of the owned child) for every (new ghost, face to an owned child); ~0 elsewhere
+__global__ void k_send_keys(const uint64_t* __restrict__ gkey, const uint32_t* __restrict__ gchild, size_t ng,
+                            const int* __restrict__ esuel2, size_t nown, const uint64_t* __restrict__ gid_p,
+                            uint64_t* __restrict__ skey, uint32_t* __restrict__ sval)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 4 * ng) return;
+  const size_t j = i >> 2; const int q = (int)(i & 3);
+  const uint32_t c = gchild[j];
+  const int nb = esuel2[4 * (size_t)c + q];
+  uint64_t k = ~0ull; uint32_t v = 0;
+  if (nb >= 0 && (size_t)nb < nown) {
+    k = (gkey[j] & 0xffff000000000000ull) | (8 * gid_p[(size_t)nb >> 3] + ((uint32_t)nb & 7));
+    v = (uint32_t)nb;
+  }
+  skey[i] = k; sval[i] = v;
+}
+__global__ void k_mark_unique(const uint64_t* __restrict__ skey, size_t n, int* __restrict__ flag)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  flag[i] = (skey[i] != ~0ull && (i == 0 || skey[i] != skey[i - 1])) ? 1 : 0;
+}
+__global__ void k_compact_pairs(const uint64_t* __restrict__ skey, const uint32_t* __restrict__ sval,
+                                const int* __restrict__ flag, const int* __restrict__ pos, size_t n,
+                                uint64_t* __restrict__ okey, uint32_t* __restrict__ oval)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !flag[i]) return;
+  okey[pos[i]] = skey[i]; oval[pos[i]] = sval[i];
+}
+// kept tets: owned children [0, nown) in order, then the new ghosts in their sorted order
+__global__ void k_kept_pos(const uint32_t* __restrict__ gchild, size_t ng, size_t nown, int* __restrict__ pos_of_child)
+{
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < ng) pos_of_child[gchild[j]] = (int)(nown + j);
+}
+__global__ void k_mark_nodes(const uint64_t* __restrict__ inpoel2, const uint32_t* __restrict__ gchild, size_t nown,
+                             size_t nkept, int* __restrict__ used)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 4 * nkept) return;
+  const size_t k = i >> 2, c = k < nown ? k : gchild[k - nown];
+  used[inpoel2[4 * c + (i & 3)]] = 1;
+}
+__global__ void k_kept_tets(const uint64_t* __restrict__ inpoel2, const int* __restrict__ esuel2,
+                            const uint32_t* __restrict__ gchild, const int* __restrict__ pos_of_child,
+                            const int* __restrict__ used, const int* __restrict__ nodepos, size_t nown, size_t nkept,
+                            const uint64_t* __restrict__ gid_p, uint64_t* __restrict__ inp_out,
+                            int* __restrict__ esuel_out, uint64_t* __restrict__ gid_out, uint64_t* __restrict__ par_out)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 4 * nkept) return;
+  const size_t k = i >> 2, c = k < nown ? k : gchild[k - nown];
+  const int q = (int)(i & 3);
+  inp_out[i] = (uint64_t)nodepos[inpoel2[4 * c + q]];
+  const int nb = esuel2[4 * c + q];
+  esuel_out[i] = nb < 0 ? -1 : pos_of_child[nb];
+  if (q == 0) { gid_out[k] = 8 * gid_p[c >> 3] + (c & 7); par_out[k] = c >> 3; }
+}
+__global__ void k_compact_nodes(const int* __restrict__ used, const int* __restrict__ nodepos, size_t nn,
+                                const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ z,
+                                double* __restrict__ ox, double* __restrict__ oy, double* __restrict__ oz)
+{
+  const size_t n = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= nn || !used[n]) return;
+  ox[nodepos[n]] = x[n]; oy[nodepos[n]] = y[n]; oz[nodepos[n]] = z[n];
+}
+__global__ void k_remap_u64(uint64_t* __restrict__ a, size_t n, const int* __restrict__ nodepos)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] = (uint64_t)nodepos[a[i]];
+}
+
+static int dev_scan_int(const int* in, int* out, size_t n, hipStream_t s)
+{
+  size_t bytes = 0;
+  DHIP(rocprim::exclusive_scan(nullptr, bytes, in, out, 0, n, rocprim::plus<int>(), s));
+  Buf<char> tmp;
+  DHIP(tmp.alloc(bytes));
+  DHIP(rocprim::exclusive_scan(tmp.p, bytes, in, out, 0, n, rocprim::plus<int>(), s));
+  DHIP(hipStreamSynchronize(s));
+  return 0;
+}
+static int dev_sort_pairs64(uint64_t* ki, uint64_t* ko, uint32_t* vi, uint32_t* vo, size_t n, hipStream_t s)
+{
+  size_t bytes = 0;
+  DHIP(rocprim::radix_sort_pairs(nullptr, bytes, ki, ko, vi, vo, n, 0, 64, s));
+  Buf<char> tmp;
+  DHIP(tmp.alloc(bytes));
+  DHIP(rocprim::radix_sort_pairs(tmp.p, bytes, ki, ko, vi, vo, n, 0, 64, s));
+  DHIP(hipStreamSynchronize(s));
+  return 0;
+}
+}  // namespace
+
+extern "C" int qdg_mesh_refine_chunk(qdg_mesh* mesh, qdg_mesh** out, qdg_chunk_refined** host_copy, int copy_mesh)
+{
+  QDG_TRY
+  if (!mesh || !out) return fail("qdg_mesh_refine_chunk: null argument");
+  *out = nullptr;
+  if (host_copy) *host_copy = nullptr;
+  qdg_ctx* ctx = mesh->ctx;
+  if (!mesh->keep || !mesh->keep->gid.p)
+    return fail("qdg_mesh_refine_chunk: the mesh keeps no connectivity / global ids on the device (context option "
+                "keep_connectivity = 1, built by qdg_mesh_from_chunk_gid)");
+  if (mesh->dm.ndofel) return fail("qdg_mesh_refine_chunk: p-adaptive runs are not combined with mesh refinement");
+  qdg_mesh::Keep& kp = *mesh->keep;
+  if (kp.pending) kp.pending->join();
+  const size_t nunk = kp.nelem, nie = kp.nie, nnode = kp.nnode, nb = kp.nbfac, nnbr = kp.nbr_rank.size();
+  if (nunk > nie && (nnbr == 0 || mesh->nnbr != nnbr))
+    return fail("qdg_mesh_refine_chunk: the chunk has ghosts: call qdg_halo_setup before the re-mesh");
+  if (8 * nunk > (size_t)(INT32_MAX - 64) / 4) return fail("qdg_mesh_refine_chunk: refined chunk too large for 32-bit ids");
+  DHIP(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  qdg::StreamScope scope(s);
+  Lap lap(s);
+  // ---- refinement of ALL tets of the chunk (owned and ghosts: the midpoints are numbered over both) ----
+  RefineOut o;
+  if (int rc = dev_refine_core(ctx, kp.inpoel.p, kp.x.p, kp.y.p, kp.z.p, nunk, nnode, kp.tri.p, nb, false, o)) return rc;
+  const size_t nown = 8 * nie, nall = 8 * nunk, n4 = 4 * nall;
+  Buf<int> esuel2, d_err;
+  DHIP(esuel2.alloc(n4)); DHIP(d_err.alloc(1));
+  {
+    const ChildTables& t = child_tables();
+    DHIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_child), &t, sizeof t, 0, hipMemcpyHostToDevice, s));
+    DHIP(hipMemsetAsync(d_err.p, 0, sizeof(int), s));
+    k_child_esuel<<<nblk(n4), 256, 0, s>>>(o.inpoel2.p, kp.esuel.p, n4, esuel2.p, d_err.p);
+    int herr = 0;
+    DHIP(hipMemcpyAsync(&herr, d_err.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    DHIP(hipStreamSynchronize(s));
+    if (herr) return fail("qdg_mesh_refine_chunk: a child face finds no partner across its parent's face");
+  }
+  lap("refinement + esuel of the children");
+  // ---- the new ghost layer ----
+  const size_t ngc = nall - nown;                       // ghost children
+  std::vector<size_t> recv_off(nnbr + 1, 0);
+  for (size_t i = 0; i < nnbr; ++i) recv_off[i + 1] = recv_off[i] + kp.recv_counts[i];
+  if (recv_off[nnbr] != nunk - nie) return fail("qdg_mesh_refine_chunk: the kept halo plan does not match the ghost count");
+  Buf<size_t> d_roff;
+  DHIP(d_roff.alloc(nnbr + 1));
+  DHIP(hipMemcpyAsync(d_roff.p, recv_off.data(), (nnbr + 1) * sizeof(size_t), hipMemcpyHostToDevice, s));
+  Buf<int> gflag, gpos;
+  Buf<uint64_t> gkey, gkey2;
+  Buf<uint32_t> gval, gval2;
+  size_t ng = 0;
+  if (ngc) {
+    DHIP(gflag.alloc(ngc + 1)); DHIP(gpos.alloc(ngc + 1));
+    DHIP(hipMemsetAsync(gflag.p + ngc, 0, sizeof(int), s));
+    k_ghost_child_flag<<<nblk(ngc), 256, 0, s>>>(esuel2.p, nown, nall, gflag.p);
+    if (int rc = dev_scan_int(gflag.p, gpos.p, ngc + 1, s)) return rc;
+    int cnt = 0;
+    DHIP(hipMemcpyAsync(&cnt, gpos.p + ngc, sizeof(int), hipMemcpyDeviceToHost, s));
+    DHIP(hipStreamSynchronize(s));
+    ng = (size_t)cnt;
+  }
+  DHIP(gkey.alloc(ng)); DHIP(gkey2.alloc(ng)); DHIP(gval.alloc(ng)); DHIP(gval2.alloc(ng));
+  std::vector<size_t> new_recv(nnbr, 0), send_off(nnbr + 1, 0), send_list;
+  if (ng) {
+    k_ghost_keys<<<nblk(ngc), 256, 0, s>>>(gflag.p, gpos.p, nown, nall, nie, kp.gid.p, d_roff.p, (int)nnbr, gkey.p, gval.p);
+    if (int rc = dev_sort_pairs64(gkey.p, gkey2.p, gval.p, gval2.p, ng, s)) return rc;
+    std::vector<uint64_t> hk(ng);
+    DHIP(hipMemcpyAsync(hk.data(), gkey2.p, ng * 8, hipMemcpyDeviceToHost, s));
+    DHIP(hipStreamSynchronize(s));
+    for (uint64_t k : hk) ++new_recv[(size_t)(k >> 48)];
+    // send lists: owned children next to the new ghosts, per owner by global child id, each once
+    const size_t ns4 = 4 * ng;
+    Buf<uint64_t> sk, sk2, sk3;
+    Buf<uint32_t> sv, sv2, sv3;
+    Buf<int> uf, up;
+    DHIP(sk.alloc(ns4)); DHIP(sk2.alloc(ns4)); DHIP(sv.alloc(ns4)); DHIP(sv2.alloc(ns4));
+    DHIP(uf.alloc(ns4 + 1)); DHIP(up.alloc(ns4 + 1));
+    k_send_keys<<<nblk(ns4), 256, 0, s>>>(gkey2.p, gval2.p, ng, esuel2.p, nown, kp.gid.p, sk.p, sv.p);
+    if (int rc = dev_sort_pairs64(sk.p, sk2.p, sv.p, sv2.p, ns4, s)) return rc;
+    DHIP(hipMemsetAsync(uf.p + ns4, 0, sizeof(int), s));
+    k_mark_unique<<<nblk(ns4), 256, 0, s>>>(sk2.p, ns4, uf.p);
+    if (int rc = dev_scan_int(uf.p, up.p, ns4 + 1, s)) return rc;
+    int nsend = 0;
+    DHIP(hipMemcpyAsync(&nsend, up.p + ns4, sizeof(int), hipMemcpyDeviceToHost, s));
+    DHIP(hipStreamSynchronize(s));
+    DHIP(sk3.alloc((size_t)nsend)); DHIP(sv3.alloc((size_t)nsend));
+    k_compact_pairs<<<nblk(ns4), 256, 0, s>>>(sk2.p, sv2.p, uf.p, up.p, ns4, sk3.p, sv3.p);
+    std::vector<uint64_t> hsk((size_t)nsend); std::vector<uint32_t> hsv((size_t)nsend);
+    DHIP(hipMemcpyAsync(hsk.data(), sk3.p, (size_t)nsend * 8, hipMemcpyDeviceToHost, s));
+    DHIP(hipMemcpyAsync(hsv.data(), sv3.p, (size_t)nsend * 4, hipMemcpyDeviceToHost, s));
+    DHIP(hipStreamSynchronize(s));
+    send_list.resize((size_t)nsend);
+    for (size_t i = 0; i < (size_t)nsend; ++i) { ++send_off[(size_t)(hsk[i] >> 48) + 1]; send_list[i] = hsv[i]; }
+    for (size_t q = 0; q < nnbr; ++q) send_off[q + 1] += send_off[q];
+  }
+  lap("new ghost layer and halo plan");
+  // ---- the kept tets, nodes renumbered in ascending order of their ids in the refined chunk ----
+  const size_t nkept = nown + ng, nn_all = o.nn;
+  Buf<int> pos_of_child, used, nodepos;
+  DHIP(pos_of_child.alloc(nall)); DHIP(used.alloc(nn_all + 1)); DHIP(nodepos.alloc(nn_all + 1));
+  k_fill_i32<<<nblk(nall), 256, 0, s>>>(pos_of_child.p, nall, -1);
+  k_iota_i32<<<nblk(nown), 256, 0, s>>>(pos_of_child.p, nown);            // owned children keep their index
+  if (ng) k_kept_pos<<<nblk(ng), 256, 0, s>>>(gval2.p, ng, nown, pos_of_child.p);
+  DHIP(hipMemsetAsync(used.p, 0, (nn_all + 1) * sizeof(int), s));
+  k_mark_nodes<<<nblk(4 * nkept), 256, 0, s>>>(o.inpoel2.p, gval2.p, nown, nkept, used.p);
+  if (int rc = dev_scan_int(used.p, nodepos.p, nn_all + 1, s)) return rc;
+  int nn2 = 0;
+  DHIP(hipMemcpyAsync(&nn2, nodepos.p + nn_all, sizeof(int), hipMemcpyDeviceToHost, s));
+  DHIP(hipStreamSynchronize(s));
+  DevFD fd;
+  fd.nelem = nkept; fd.nie = nown; fd.nnode = (size_t)nn2;
+  Buf<uint64_t> par_out;
+  DHIP(fd.inpoel.alloc(4 * nkept)); DHIP(fd.esuel.alloc(4 * nkept)); DHIP(fd.gid.alloc(nkept)); DHIP(par_out.alloc(nkept));
+  DHIP(fd.x.alloc((size_t)nn2)); DHIP(fd.y.alloc((size_t)nn2)); DHIP(fd.z.alloc((size_t)nn2));
+  fd.orient = kp.orient;
+  k_kept_tets<<<nblk(4 * nkept), 256, 0, s>>>(o.inpoel2.p, esuel2.p, gval2.p, pos_of_child.p, used.p, nodepos.p, nown, nkept,
+                                             kp.gid.p, fd.inpoel.p, fd.esuel.p, fd.gid.p, par_out.p);
+  k_compact_nodes<<<nblk(nn_all), 256, 0, s>>>(used.p, nodepos.p, nn_all, o.x2.p, o.y2.p, o.z2.p, fd.x.p, fd.y.p, fd.z.p);
+  const size_t ntri2 = 4 * nb;
+  if (ntri2) k_remap_u64<<<nblk(3 * ntri2), 256, 0, s>>>(o.tri2.p, 3 * ntri2, nodepos.p);   // (all on owned children: kept)
+  lap("kept tets, node renumbering");
+  // ---- boundary faces of the owned children ----
+  std::vector<int32_t> sets(kp.fset);
+  std::sort(sets.begin(), sets.end());
+  sets.erase(std::unique(sets.begin(), sets.end()), sets.end());
+  if (ntri2 == 0) {
+    DHIP(fd.tri.alloc(1)); DHIP(fd.belem.alloc(1));
+    fd.nbfac = 0; fd.belem_known = true;
+  } else {
+    std::vector<uint32_t> hrank(nb);
+    for (size_t b = 0; b < nb; ++b) hrank[b] = (uint32_t)(std::lower_bound(sets.begin(), sets.end(), kp.fset[b]) - sets.begin());
+    Buf<uint32_t> prank, ka, kb, kc, key, key2, perm, perm2, ta, tb, tc, tr;
+    DHIP(prank.alloc(nb)); DHIP(ka.alloc(ntri2)); DHIP(kb.alloc(ntri2)); DHIP(kc.alloc(ntri2)); DHIP(key.alloc(ntri2));
+    DHIP(key2.alloc(ntri2)); DHIP(perm.alloc(ntri2)); DHIP(perm2.alloc(ntri2));
+    DHIP(ta.alloc(ntri2)); DHIP(tb.alloc(ntri2)); DHIP(tc.alloc(ntri2)); DHIP(tr.alloc(ntri2));
+    DHIP(hipMemcpyAsync(prank.p, hrank.data(), nb * 4, hipMemcpyHostToDevice, s));
+    k_tri_keys<<<nblk(ntri2), 256, 0, s>>>(o.tri2.p, ntri2, ka.p, kb.p, kc.p, perm.p);
+    unsigned bits = 1;
+    while (bits < 32 && ((size_t)1 << bits) < fd.nnode) ++bits;
+    size_t bytes = 0;
+    DHIP(rocprim::radix_sort_pairs(nullptr, bytes, key.p, key2.p, perm.p, perm2.p, ntri2, 0, bits, s));
+    Buf<char> tmp;
+    DHIP(tmp.alloc(bytes));
+    const uint32_t* pass[3] = { kc.p, kb.p, ka.p };
+    uint32_t *pin = perm.p, *pout = perm2.p;
+    for (int ps = 0; ps < 3; ++ps) {
+      k_gather<<<nblk(ntri2), 256, 0, s>>>(pass[ps], pin, ntri2, key.p);
+      DHIP(rocprim::radix_sort_pairs(tmp.p, bytes, key.p, key2.p, pin, pout, ntri2, 0, bits, s));
+      std::swap(pin, pout);
+    }
+    k_gather<<<nblk(ntri2), 256, 0, s>>>(ka.p, pin, ntri2, ta.p);
+    k_gather<<<nblk(ntri2), 256, 0, s>>>(kb.p, pin, ntri2, tb.p);
+    k_gather<<<nblk(ntri2), 256, 0, s>>>(kc.p, pin, ntri2, tc.p);
+    k_rank_of_child<<<nblk(ntri2), 256, 0, s>>>(prank.p, pin, ntri2, tr.p);
+    if (int rc = dev_bnd_faces_core(ctx, fd, ntri2, ta.p, tb.p, tc.p, tr.p, sets)) return rc;
+    if (fd.nbfac != ntri2) return fail("qdg_mesh_refine_chunk: the refined boundary faces do not match the parents'");
+  }
+  if (int rc = dev_faces_geometry(ctx, fd, nullptr)) return rc;
+  if (fd.nonpos_vol) return fail("qdg_mesh_refine_chunk: non-positive child volume");
+  lap("boundary faces, faces + geometry");
+  std::vector<int> bcface;
+  if (int rc = bc_of_faces(ctx, fd, bcface)) return rc;
+  // the host's copy of what it needs for its book-keeping, taken before the layout build consumes fd
+  std::unique_ptr<qdg_chunk_refined> hc;
+  if (host_copy) {
+    hc.reset(new qdg_chunk_refined);
+    hc->nielem = nown; hc->nunk = nkept; hc->nnode = (size_t)nn2;
+    hc->gid.resize(nkept); hc->parent.resize(nkept);
+    DHIP(hipMemcpyAsync(hc->gid.data(), fd.gid.p, nkept * 8, hipMemcpyDeviceToHost, s));
+    DHIP(hipMemcpyAsync(hc->parent.data(), par_out.p, nkept * 8, hipMemcpyDeviceToHost, s));
+    hc->send_off = send_off; hc->send_list = send_list; hc->recv_counts = new_recv;
+    if (copy_mesh) {
+      hc->inpoel.resize(4 * nkept); hc->x.resize((size_t)nn2); hc->y.resize((size_t)nn2); hc->z.resize((size_t)nn2);
+      hc->tri.resize(3 * ntri2); hc->tri_set.resize(ntri2);
+      DHIP(hipMemcpyAsync(hc->inpoel.data(), fd.inpoel.p, 4 * nkept * 8, hipMemcpyDeviceToHost, s));
+      DHIP(hipMemcpyAsync(hc->x.data(), fd.x.p, (size_t)nn2 * 8, hipMemcpyDeviceToHost, s));
+      DHIP(hipMemcpyAsync(hc->y.data(), fd.y.p, (size_t)nn2 * 8, hipMemcpyDeviceToHost, s));
+      DHIP(hipMemcpyAsync(hc->z.data(), fd.z.p, (size_t)nn2 * 8, hipMemcpyDeviceToHost, s));
+      if (ntri2) DHIP(hipMemcpyAsync(hc->tri.data(), o.tri2.p, 3 * ntri2 * 8, hipMemcpyDeviceToHost, s));
+      for (size_t b = 0; b < nb; ++b) for (int k = 0; k < 4; ++k) hc->tri_set[4 * b + k] = kp.fset[b];
+    }
+    DHIP(hipStreamSynchronize(s));
+  }
+  qdg_mesh* nm = nullptr;
+  const int keep_opt = ctx->opt.keep_connectivity;
+  ctx->opt.keep_connectivity = 1;
+  const int rc = dev_build_layout(ctx, fd, bcface, &nm);
+  ctx->opt.keep_connectivity = keep_opt;
+  if (rc) return rc;
+  std::unique_ptr<qdg_mesh, int (*)(qdg_mesh*)> guard(nm, qdg_mesh_destroy);
+  lap("layout");
+  // ---- halo plan of the new chunk ----
+  {
+    std::vector<size_t> roff(nnbr + 1, 0);
+    for (size_t q = 0; q < nnbr; ++q) roff[q + 1] = roff[q] + new_recv[q];
+    if (int rc2 = qdg_halo_setup(nm, nnbr, kp.nbr_rank.data(), send_off.data(), send_list.data(), roff.data())) return rc2;
+  }
+  // ---- state of the owned tets: child <- parent (ghost rows arrive with the next exchange) ----
+  {
+    Buf<int> h2d_from;
+    DHIP(h2d_from.alloc(mesh->ne));
+    k_invert_perm<<<nblk(mesh->ne), 256, 0, s>>>(mesh->d2h.p, mesh->ne, h2d_from.p);
+    launch_state_transfer((int)nm->nie, nm->nprop, nm->d2h.p, nullptr, h2d_from.p, mesh->Ucur, nm->Ucur, s);
+    DHIP(hipGetLastError());
+    DHIP(hipStreamSynchronize(s));
+    nm->Unp = nullptr; nm->Upending = nullptr;
+  }
+  lap("halo set-up + state transfer");
+  if (host_copy) *host_copy = hc.release();
+  *out = guard.release();
+  return 0;
+  QDG_CATCH
+}
+
 extern "C" int qdg_mesh_from_connectivity(qdg_ctx* ctx, size_t nelem, size_t nnode, const size_t* inpoel,
                                           const double* x, const double* y, const double* z,
                                           size_t ntri, const size_t* tri, const int32_t* tri_set,
@@ -1747,9 +2109,10 @@ extern "C" int qdg_mesh_from_chunk_gid(qdg_ctx* ctx, size_t nielem, size_t nelem
     DevFD fd;
     if (int rc = dev_upload_mesh(ctx, nelem, nnode, inpoel, x, y, z, fd)) return rc;
     fd.nie = nielem;
-    if (elem_gid && ctx->opt.orient_by_gid) {
+    if (elem_gid) {
       DHIP(fd.gid.alloc(nelem));
       DHIP(hipMemcpyAsync(fd.gid.p, elem_gid, nelem * 8, hipMemcpyHostToDevice, ctx->stream));
+      fd.orient = ctx->opt.orient_by_gid != 0;
     }
     lap("validation + upload of inpoel, coord");
     {

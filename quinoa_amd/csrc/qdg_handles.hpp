@@ -134,4 +134,6 @@ struct qdg_mesh {
 namespace qdg {
 // qdg_api.cpp
 int mesh_alloc_state(qdg_mesh* m, int ntile);
+// qdg_devmesh.hip: the halo plan of a chunk whose handle keeps its connectivity (for its re-mesh)
+void keep_set_plan(qdg_mesh* m, size_t nnbr, const int32_t* nbr_rank, const size_t* recv_off);
 }  // namespace qdg

@@ -64,3 +64,12 @@ struct qdg_refined {
   void wait() const { if (pending) pending->join(); }
 };
 
+
+// one rank's uniformly refined chunk (qdg_refine_chunk on the host, qdg_mesh_refine_chunk from the device)
+struct qdg_chunk_refined {
+  size_t nielem = 0, nunk = 0, nnode = 0;
+  rawvec<size_t> inpoel, gid, parent;
+  std::vector<size_t> tri, send_off, send_list, recv_counts;
+  std::vector<int32_t> tri_set;
+  rawvec<double> x, y, z;
+};

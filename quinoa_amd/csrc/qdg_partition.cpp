@@ -421,13 +421,7 @@ extern "C" int qdg_refine_uniform(size_t nelem, size_t nnode, const size_t* inpo
 // tet B only where A and B touched, i.e. only where both ranks already hold the other's tet -- so
 // my send list to q and q's new ghosts from me are the same set, and both sides order it by the
 // global id of the child (8 * parent's global id + child number).
-struct qdg_chunk_refined {
-  size_t nielem = 0, nunk = 0, nnode = 0;
-  rawvec<size_t> inpoel, gid, parent;
-  std::vector<size_t> tri, send_off, send_list, recv_counts;
-  std::vector<int32_t> tri_set;
-  rawvec<double> x, y, z;
-};
+// (struct qdg_chunk_refined: qdg_host.hpp -- qdg_mesh_refine_chunk fills one from the device)
 
 namespace {
 struct FK { uint32_t a, b, c, idx; };      // sorted node triple of a face, index of (tet, local face)

@@ -381,3 +381,85 @@ def test_device_resident_remesh_equals_the_sort_path(ndof, limiter, problem):
             if m:
                 m.close()
         ctx.close(); plain.close()
+
+
+def test_device_resident_chunk_remesh_equals_the_host_path():
+    """qdg_mesh_refine_chunk: config 5's re-mesh of ONE RANK's chunk WITH its ghost layer, on the device.
+    3 RCB chunks of a box (all on this GPU), Sod DG-P1 + Superbee: 3 steps, then every chunk is refined twice
+    over -- by the host path (qdg_refine_chunk -> qdg_mesh_from_chunk_gid -> qdg_state_transfer) and by the
+    one device call.  (a) The device call's plan and numbering = the host's: global ids, parents, send lists,
+    receive counts, and with copy_mesh connectivity, coordinates and side-set triangles; (b) the owned state =
+    the parents' rows; (c) after 3 more steps (halos between the chunks) the two decompositions hold BITWISE the
+    same states (reproducible DG-P1 kernel), and (d) equal the single chunk refined by its own path to 1e-10;
+    (e) a second re-mesh works from the new handles' kept connectivity and plan."""
+    from quinoa_amd import amr, capi, dg, meshgen, partition
+    g = meshgen.kuhn_box(6, 5, 4)
+    kw = dict(flux="hllc", limiter="superbeep1", problem="sod_shocktube", gamma=1.4, cfl=0.3,
+              bc_sym=[3, 4, 5, 6], bc_extrapolate=[1, 2])
+    opt = {"keep_connectivity": 1, "p1_rhs": 1}
+    ctxa, ctxb, ctx1 = capi.Context(4, options=opt, **kw), capi.Context(4, options=opt, **kw), capi.Context(4, options=opt, **kw)
+    one = amr.RefinedRun(ctx1, g["coord"], g["inpoel"], g["sidesets"], resident=True)
+    part = partition.partition(g["coord"], g["inpoel"], 3, "rcb")
+    chunks = [partition.build_chunk(g["coord"], g["inpoel"], g["sidesets"], part, 3, r) for r in range(3)]
+
+    def build(ctx, ch):
+        return capi.mesh_from_connectivity(ctx, ch["inpoel"], ch["coord"], ch["sidesets"], nielem=ch["nielem"],
+                                           elem_gid=ch["gid"])
+
+    A = [build(ctxa, ch) for ch in chunks]          # host-path decomposition
+    B = [build(ctxb, ch) for ch in chunks]          # device-path decomposition
+    allm = []
+    try:
+        for m in A + B:
+            m.state_initialize(0.0)
+        one.mesh.state_initialize(0.0)
+        da, db = dg.LocalChunks(ctxa, A, chunks), dg.LocalChunks(ctxb, B, chunks)
+        t = tb = t1 = 0.0
+        for _ in range(3):
+            t += da.step(t); tb += db.step(tb); t1 += one.mesh.step(t1)
+        assert t == tb
+        A2, B2, chA, chB = [], [], [], []
+        for ch, ma, mb in zip(chunks, A, B):
+            ch2, par = amr.refine_chunk(ch)                                       # host path
+            m2 = build(ctxa, ch2)
+            amr.state_transfer(ma, m2, par)
+            n2, plan = mb.refine_chunk(ch["nbr_rank"], copy_mesh=True)          # device path
+            nie2 = ch2["nielem"]
+            assert plan["nielem"] == nie2 and np.array_equal(plan["gid"], ch2["gid"])             # (a)
+            assert np.array_equal(plan["parent"], par) and plan["recv_counts"] == list(ch2["recv_counts"])
+            assert all(np.array_equal(p, q) for p, q in zip(plan["send_lists"], ch2["send_lists"]))
+            assert np.array_equal(plan["inpoel"], ch2["inpoel"]) and np.array_equal(plan["coord"], ch2["coord"])
+            key = lambda tri: set(map(tuple, np.sort(np.asarray(tri).reshape(-1, 3), axis=1).tolist()))
+            assert sorted(plan["sidesets"]) == sorted(ch2["sidesets"])
+            assert all(key(plan["sidesets"][k]) == key(ch2["sidesets"][k]) for k in ch2["sidesets"])
+            Ub = mb.state_download().reshape(mb.nunk, -1)
+            assert np.array_equal(n2.state_download().reshape(n2.nunk, -1)[:nie2], Ub[par[:nie2]])   # (b)
+            A2.append(m2); B2.append(n2); chA.append(ch2); chB.append(plan)
+        allm = A2 + B2
+        for m in A + B:
+            m.close()
+        A, B = [], []
+        one.refine()
+        da, db = dg.LocalChunks(ctxa, A2, chA), dg.LocalChunks(ctxb, B2, chB)
+        for _ in range(3):
+            t += da.step(t); tb += db.step(tb); t1 += one.mesh.step(t1)
+        assert t == tb and abs(t - t1) <= 1e-12 * t1
+        ref = one.mesh.state_download().reshape(-1, 20)
+        for ch, ma, mb in zip(chA, A2, B2):
+            nie = ch["nielem"]
+            Ua, Ub = ma.state_download().reshape(-1, 20)[:nie], mb.state_download().reshape(-1, 20)[:nie]
+            assert np.array_equal(Ua, Ub)                                                            # (c)
+            assert np.abs(Ub - ref[ch["gid"][:nie]]).max() <= 1e-10 * np.abs(ref).max()              # (d)
+        B3 = []
+        for plan, mb in zip(chB, B2):                                                                # (e)
+            n3, plan3 = mb.refine_chunk(plan["nbr_rank"])
+            assert plan3["nielem"] == 8 * plan["nielem"] and len(plan3["gid"]) == n3.nunk
+            B3.append((n3, plan3))
+        allm += [m for m, _ in B3]
+        d3 = dg.LocalChunks(ctxb, [m for m, _ in B3], [p for _, p in B3])
+        d3.step(tb)
+        assert all(np.isfinite(m.state_download()).all() for m, _ in B3)
+    finally:
+        for m in A + B + allm:
+            m.close()
+        one.mesh.close(); ctxa.close(); ctxb.close(); ctx1.close()
