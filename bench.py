@@ -301,21 +301,27 @@ def amr_point(local_rank, nx=32, steps=20, with_partition=True, resident=True, r
     return out
 
 
-def amr_partitioned(local_rank, g, nparts, steps):
+def amr_partitioned(local_rank, g, nparts, steps, host_path=True, reserve=False):
     """The same re-mesh on a decomposition: `nparts` chunks with ghost halos (all on this one GPU,
-    quinoa_amd.dg.LocalChunks), every chunk refined by its own rank's logic (qdg_refine_chunk: new
-    owned tets, new ghost layer and halo plan without communication), rebuilt on the device WITH
-    its ghosts (qdg_mesh_from_chunk) and handed its state (qdg_state_transfer).  Times are the
-    maximum over the chunks, i.e. what a rank of a one-process-per-GPU run spends."""
+    quinoa_amd.dg.LocalChunks), every chunk refined by its own rank's logic, without communication.
+    Device path (round 4): qdg_mesh_refine_chunk -- children, new ghost layer, halo plan, chunk build with its
+    ghosts, halo set-up and the owned state in ONE call from the connectivity / global ids / plan the handle
+    keeps.  Host path (rounds 2-3, timed beside it when host_path): qdg_refine_chunk on the host's cores,
+    qdg_mesh_from_chunk on the device, qdg_state_transfer.  Times are the maximum over the chunks, i.e. what a
+    rank of a one-process-per-GPU run spends."""
     import numpy as np
     from quinoa_amd import amr, capi, dg, partition
     ctx = capi.Context(4, flux="hllc", limiter="superbeep1", problem="sod_shocktube", gamma=1.4,
-                       cfl=0.3, bc_extrapolate=[1, 2], bc_sym=[3, 4, 5, 6], device=local_rank)
+                       cfl=0.3, bc_extrapolate=[1, 2], bc_sym=[3, 4, 5, 6], device=local_rank,
+                       options={"keep_connectivity": 1})
+    if reserve:       # the run's memory budget from the driver, once (see amr_point)
+        ctx.reserve_device_memory(int(0.6 * ctx.device_memory()[0]))
     pt = partition.partition(g["coord"], g["inpoel"], nparts, "rcb")
     chunks = [partition.build_chunk(g["coord"], g["inpoel"], g["sidesets"], pt, nparts, r) for r in range(nparts)]
 
     def build(ch):
-        return capi.mesh_from_connectivity(ctx, ch["inpoel"], ch["coord"], ch["sidesets"], nielem=ch["nielem"])
+        return capi.mesh_from_connectivity(ctx, ch["inpoel"], ch["coord"], ch["sidesets"], nielem=ch["nielem"],
+                                           elem_gid=ch["gid"])
 
     meshes = [build(ch) for ch in chunks]
     for m in meshes:
@@ -325,30 +331,47 @@ def amr_partitioned(local_rank, g, nparts, steps):
         drv.step(0.0)
     ctx.synchronize()
     t_ref = t_reb = t_tr = 0.0
+    if host_path:
+        for ch, m in zip(chunks, meshes):
+            t0 = time.perf_counter()
+            ch2, par = amr.refine_chunk(ch)
+            t1 = time.perf_counter()
+            m2 = build(ch2)
+            ctx.synchronize()
+            t2 = time.perf_counter()
+            amr.state_transfer(m, m2, par)
+            ctx.synchronize()
+            t3 = time.perf_counter()
+            m2.close()
+            t_ref, t_reb, t_tr = max(t_ref, t1 - t0), max(t_reb, t2 - t1), max(t_tr, t3 - t2)
+    t_dev = 0.0
     new_chunks, new_meshes = [], []
     for ch, m in zip(chunks, meshes):
         t0 = time.perf_counter()
-        ch2, par = amr.refine_chunk(ch)
-        t1 = time.perf_counter()
-        m2 = build(ch2)
+        m2, plan = m.refine_chunk(ch["nbr_rank"])
         ctx.synchronize()
-        t2 = time.perf_counter()
-        amr.state_transfer(m, m2, par)
-        ctx.synchronize()
-        t3 = time.perf_counter()
+        t_dev = max(t_dev, time.perf_counter() - t0)
         m.close()
-        t_ref, t_reb, t_tr = max(t_ref, t1 - t0), max(t_reb, t2 - t1), max(t_tr, t3 - t2)
-        new_chunks.append(ch2); new_meshes.append(m2)
+        new_chunks.append(plan); new_meshes.append(m2)
     drv = dg.LocalChunks(ctx, new_meshes, new_chunks)
+    ctx.synchronize()
+    t0 = time.perf_counter()
     for _ in range(steps):
         drv.step(0.0)
     ctx.synchronize()
+    ms_step = (time.perf_counter() - t0) / steps * 1e3
     ok = all(bool(np.isfinite(m.state_download()).all()) for m in new_meshes)
     out = {"chunks": nparts, "owned_tets_per_chunk_before": [int(c["nielem"]) for c in chunks],
            "owned_tets_per_chunk_after": [int(c["nielem"]) for c in new_chunks],
-           "ghost_tets_per_chunk_after": [int(c["inpoel"].shape[0] - c["nielem"]) for c in new_chunks],
-           "refine_chunk_host_ms": t_ref * 1e3, "rebuild_with_ghosts_device_ms": t_reb * 1e3,
-           "state_transfer_ms": t_tr * 1e3, "finite": ok}
+           "ghost_tets_per_chunk_after": [int(len(c["gid"]) - c["nielem"]) for c in new_chunks],
+           "remesh_device_ms": t_dev * 1e3, "ms_per_step_after_all_chunks_on_this_gpu": ms_step, "finite": ok,
+           "memory_reserved_ahead": bool(reserve),
+           "note": "remesh_device_ms = qdg_mesh_refine_chunk per rank (maximum over the chunks): refinement, new "
+                   "ghost layer and halo plan, chunk build with ghosts, halo set-up, owned state -- one call, nothing "
+                   "uploaded; the host gets global ids, parents and the plan back"}
+    if host_path:
+        out.update({"refine_chunk_host_ms": t_ref * 1e3, "rebuild_with_ghosts_device_ms": t_reb * 1e3,
+                    "state_transfer_ms": t_tr * 1e3})
     for m in new_meshes:
         m.close()
     ctx.close()
@@ -625,6 +648,11 @@ def main():
                                                                     with_partition=False, reserve=False)
             out["amr_point"]["at_north_star_size"] = amr_point(local_rank, nx=args.strong_nx, steps=5,
                                                                with_partition=False, reserve=True)
+            # ... and on a decomposition of that box: 2 chunks of 5.06 M owned tets -> 40.4 M each (device path)
+            from quinoa_amd import meshgen as _mg
+            out["amr_point"]["on_a_decomposition_at_north_star_size"] = amr_partitioned(
+                local_rank, _mg.kuhn_box(args.strong_nx, args.strong_nx, args.strong_nx), nparts=2, steps=2,
+                host_path=False, reserve=True)
         if world == 1 and not args.no_config3 and not args.self_halo:
             out["config3_point"] = config3_point(local_rank, args.config3_nx)
         if world == 1 and not args.no_config4 and not args.self_halo:
