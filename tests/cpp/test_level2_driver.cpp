@@ -53,10 +53,13 @@ struct Chunk {
   qdg_mesh* mesh = nullptr;
 };
 
+static bool g_device_remesh = false;    // 7th argument "device": the re-mesh by qdg_mesh_refine_chunk
+
 static void to_device(qdg_ctx* ctx, Chunk& c)
 {
-  CHECK(qdg_mesh_from_chunk(ctx, c.nielem, c.nunk, c.nnode, c.inpoel.data(), c.x.data(), c.y.data(), c.z.data(),
-                            c.tri_set.size(), c.tri.data(), c.tri_set.data(), &c.mesh));
+  // (with the tets' global ids: faces oriented as in the serial run, and what the device re-mesh orders by)
+  CHECK(qdg_mesh_from_chunk_gid(ctx, c.nielem, c.nunk, c.nnode, c.inpoel.data(), c.x.data(), c.y.data(), c.z.data(),
+                                c.tri_set.size(), c.tri.data(), c.tri_set.data(), c.gid.data(), &c.mesh));
   CHECK(qdg_halo_setup(c.mesh, c.nbr_rank.size(), c.nbr_rank.data(), c.send_off.data(), c.send_elem.data(),
                        c.recv_off.data()));
 }
@@ -97,7 +100,8 @@ static double step(std::vector<Chunk>& ch, double t)
 
 int main(int argc, char** argv)
 {
-  if (argc != 6) { fprintf(stderr, "usage: %s mesh.bin out.bin nparts nsteps_before nsteps_after\n", argv[0]); return 2; }
+  if (argc != 6 && argc != 7) { fprintf(stderr, "usage: %s mesh.bin out.bin nparts nsteps_before nsteps_after [device]\n", argv[0]); return 2; }
+  g_device_remesh = argc == 7 && std::string(argv[6]) == "device";
   const int nparts = atoi(argv[3]), n0 = atoi(argv[4]), n1 = atoi(argv[5]);
   FILE* f = fopen(argv[1], "rb");
   if (!f) { perror("mesh"); return 2; }
@@ -122,6 +126,7 @@ int main(int argc, char** argv)
   cfg.gamma = 1.4; cfg.cv = 717.5; cfg.cweight = 1.0; cfg.cfl = 0.3; cfg.pde = QDG_PDE_COMPFLOW; cfg.tolref = 0.1;
   qdg_ctx* ctx = nullptr;
   CHECK(qdg_ctx_create(&cfg, &ctx));
+  if (g_device_remesh) CHECK(qdg_ctx_set_option(ctx, "keep_connectivity", 1));
 
   // ---- decomposition (Partitioner + the DG chare's ghost set-up) ---------------------------
   std::vector<int32_t> part(nelem);
@@ -167,6 +172,26 @@ int main(int argc, char** argv)
   for (auto& c : ch) {
     std::vector<size_t> recv_counts(c.nbr_rank.size());
     for (size_t i = 0; i < recv_counts.size(); ++i) recv_counts[i] = c.recv_off[i + 1] - c.recv_off[i];
+    if (g_device_remesh) {
+      // the whole re-mesh of the rank's chunk on the device; the host keeps global ids and the new plan
+      qdg_mesh* nm = nullptr; qdg_chunk_refined* h = nullptr;
+      CHECK(qdg_mesh_refine_chunk(c.mesh, &nm, &h, 0));
+      Chunk n;
+      size_t ntri2 = 0, nsend = 0;
+      CHECK(qdg_chunk_refined_sizes(h, &n.nielem, &n.nunk, &n.nnode, &ntri2, &nsend));
+      n.gid.resize(n.nunk);
+      n.nbr_rank = c.nbr_rank;
+      n.send_off.resize(n.nbr_rank.size() + 1); n.send_elem.resize(nsend);
+      CHECK(qdg_chunk_refined_get(h, nullptr, n.gid.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                  n.send_off.data(), n.send_elem.data(), recv_counts.data()));
+      CHECK(qdg_chunk_refined_destroy(h));
+      n.recv_off.assign(n.nbr_rank.size() + 1, 0);
+      for (size_t i = 0; i < recv_counts.size(); ++i) n.recv_off[i + 1] = n.recv_off[i] + recv_counts[i];
+      n.mesh = nm;
+      CHECK(qdg_mesh_destroy(c.mesh));
+      c = std::move(n);
+      continue;
+    }
     qdg_chunk_refined* h = nullptr;
     CHECK(qdg_refine_chunk(c.nielem, c.nunk, c.nnode, c.inpoel.data(), c.x.data(), c.y.data(), c.z.data(),
                            c.gid.data(), c.tri_set.size(), c.tri.data(), c.tri_set.data(), c.nbr_rank.size(),

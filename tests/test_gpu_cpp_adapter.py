@@ -160,7 +160,7 @@ LEVEL2_EXE = os.path.join(ROOT, "tests", "cpp", "test_level2_driver")
 
 
 @pytest.mark.parametrize("nparts", [2, 3])
-def test_level2_cpp_driver_partition_halo_steps_remesh(tmp_path, nparts):
+def test_level2_cpp_driver_partition_halo_steps_remesh(tmp_path, nparts, remesh="host"):
     """tests/cpp/test_level2_driver.cpp: integration Level 2 from C++ through the C ABI alone --
     qdg_partition -> qdg_chunk_build -> qdg_mesh_from_chunk -> qdg_halo_setup -> steps in the DG
     chare's stage order (dg.ci:57-70) with qdg_halo_pack / qdg_halo_copy / qdg_halo_unpack,
@@ -184,8 +184,8 @@ def test_level2_cpp_driver_partition_halo_steps_remesh(tmp_path, nparts):
         f.write(tset.tobytes())
     out = tmp_path / "out.bin"
     n0, n1 = 3, 3
-    r = subprocess.run([LEVEL2_EXE, str(mesh), str(out), str(nparts), str(n0), str(n1)], capture_output=True,
-                       text=True, timeout=600)
+    r = subprocess.run([LEVEL2_EXE, str(mesh), str(out), str(nparts), str(n0), str(n1)] +
+                       (["device"] if remesh == "device" else []), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr
     raw = open(out, "rb").read()
     t_end, nd = struct.unpack_from("<dQ", raw, 0)
@@ -226,3 +226,9 @@ def test_level2_cpp_driver_partition_halo_steps_remesh(tmp_path, nparts):
     assert sorted(got) == list(range(om2.nelem))
     G = np.array([got[g] for g in range(om2.nelem)])
     assert np.abs(G - U).max() <= 1e-10 * max(1.0, np.abs(U).max())
+
+
+def test_level2_cpp_driver_with_the_device_remesh(tmp_path):
+    """the same C++ driver with its re-mesh done by qdg_mesh_refine_chunk (one call per rank, on the device) instead
+    of qdg_refine_chunk + qdg_mesh_from_chunk + qdg_state_transfer: same comparison with the oracle"""
+    test_level2_cpp_driver_partition_halo_steps_remesh(tmp_path, 3, remesh="device")
