@@ -1577,25 +1577,8 @@ extern "C" int qdg_state_transfer(qdg_mesh* from, qdg_mesh* to, const size_t* pa
   if (from->dm.ndofel || to->dm.ndofel)
     return fail("qdg_state_transfer: p-adaptive runs are not combined with mesh refinement "
                 "(DG::resizePostAMR does not carry m_ndof over either)");
-  qdg_ctx* ctx = to->ctx;
-  HIPCHK(hipSetDevice(ctx->device));
-  hipStream_t s = ctx->stream;
-  std::vector<int> par(to->ne), d2h(from->ne), h2d(from->ne);
-  for (size_t c = 0; c < to->ne; ++c) {
-    if (parent_of_child[c] == QDG_NO_ROW) { par[c] = -1; continue; }     // row left as it is
-    if (parent_of_child[c] >= from->ne) return fail("qdg_state_transfer: parent id out of range");
-    par[c] = (int)parent_of_child[c];
-  }
-  HIPCHK(hipMemcpy(d2h.data(), from->d2h.p, from->ne * sizeof(int), hipMemcpyDeviceToHost));
-  for (size_t d = 0; d < from->ne; ++d) h2d[d2h[d]] = (int)d;
-  DevBuf<int> dpar, dh2d;
-  HIPCHK(dpar.upload(par, s));
-  HIPCHK(dh2d.upload(h2d, s));
-  launch_state_transfer((int)to->ne, to->nprop, to->d2h.p, dpar.p, dh2d.p, from->Ucur, to->Ucur, s);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(s));
-  to->Unp = nullptr; to->Upending = nullptr;
-  return 0;
+  // (the parent list is converted and applied on the device: no host loop over the tets)
+  return qdg::dev_state_transfer(from, to, parent_of_child);
   QDG_CATCH
 }
 
@@ -1606,18 +1589,11 @@ extern "C" int qdg_state_migrate(qdg_mesh* from, const size_t* from_gid, qdg_mes
 {
   QDG_TRY
   if (!from || !to || !from_gid || !to_gid) return fail("qdg_state_migrate: null argument");
-  std::unordered_map<size_t, size_t> own;
-  own.reserve(from->nie * 2);
-  for (size_t e = 0; e < from->nie; ++e) own.emplace(from_gid[e], e);      // owned rows only
-  std::vector<size_t> par(to->ne, QDG_NO_ROW);
-  size_t n = 0;
-  for (size_t e = 0; e < to->nie; ++e) {
-    auto it = own.find(to_gid[e]);
-    if (it != own.end()) { par[e] = it->second; ++n; }
-  }
-  if (nmoved) *nmoved = n;
-  if (n == 0) return 0;
-  return qdg_state_transfer(from, to, par.data());
+  if (from->ctx != to->ctx) return fail("qdg_state_migrate: the two meshes must belong to one context");
+  if (from->nprop != to->nprop) return fail("qdg_state_migrate: row length differs");
+  if (from->dm.ndofel || to->dm.ndofel) return fail("qdg_state_migrate: p-adaptive runs are not combined with mesh refinement");
+  // (matched on the device: the source ids sorted once, a binary search per destination row)
+  return qdg::dev_state_migrate(from, from_gid, to, to_gid, nmoved);
   QDG_CATCH
 }
 

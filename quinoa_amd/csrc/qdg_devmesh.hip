@@ -1736,6 +1736,110 @@ extern "C" int qdg_mesh_refine_uniform(qdg_mesh* mesh, qdg_mesh** out, qdg_refin
 }
 
 // ======================================================================================
+// Device side of qdg_state_transfer / qdg_state_migrate: the parent (or source) row of every row of `to`
+// found on the device -- a conversion kernel for a caller-supplied list, a sort + binary search for the
+// match by global tet id -- instead of host loops and hash maps over all tets.
+namespace {
+int dev_sort_pairs64(uint64_t* ki, uint64_t* ko, uint32_t* vi, uint32_t* vo, size_t n, hipStream_t s);   // (below)
+__global__ void k_parent_convert(const size_t* __restrict__ par64, size_t n, size_t nfrom, int* __restrict__ par32,
+                                 int* __restrict__ err)
+{
+  const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  const size_t p = par64[c];
+  if (p == (size_t)-1) { par32[c] = -1; return; }            // QDG_NO_ROW: the row is left as it is
+  if (p >= nfrom) { *err = 1; par32[c] = -1; return; }
+  par32[c] = (int)p;
+}
+__global__ void k_iota_u32(uint32_t* p, size_t n)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = (uint32_t)i;
+}
+__global__ void k_match_gid(const uint64_t* __restrict__ skey, const uint32_t* __restrict__ sval, size_t nfrom,
+                            const uint64_t* __restrict__ to_gid, size_t nto, int* __restrict__ par,
+                            unsigned long long* __restrict__ count)
+{
+  const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool hit = false;
+  if (c < nto) {
+    const uint64_t g = to_gid[c];
+    size_t lo = 0, hi = nfrom;
+    while (lo < hi) { const size_t mid = (lo + hi) >> 1; if (skey[mid] < g) lo = mid + 1; else hi = mid; }
+    hit = lo < nfrom && skey[lo] == g;
+    par[c] = hit ? (int)sval[lo] : -1;
+  }
+  const unsigned long long b = __ballot(hit);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(count, (unsigned long long)__popcll(b));
+}
+}  // namespace
+
+namespace qdg {
+// rows [0, nrow) of `to` (device order) <- rows of `from` by the DEVICE parent list d_par (caller's numbering of
+// both meshes; -1: row left as it is)
+static int transfer_rows(qdg_mesh* from, qdg_mesh* to, size_t nrow, const int* d_par)
+{
+  hipStream_t s = to->ctx->stream;
+  Buf<int> h2d_from;
+  DHIP(h2d_from.alloc(from->ne));
+  k_invert_perm<<<nblk(from->ne), 256, 0, s>>>(from->d2h.p, from->ne, h2d_from.p);
+  launch_state_transfer((int)nrow, to->nprop, to->d2h.p, d_par, h2d_from.p, from->Ucur, to->Ucur, s);
+  DHIP(hipGetLastError());
+  DHIP(hipStreamSynchronize(s));
+  to->Unp = nullptr; to->Upending = nullptr;
+  return 0;
+}
+
+int dev_state_transfer(qdg_mesh* from, qdg_mesh* to, const size_t* parent_of_child)
+{
+  qdg_ctx* ctx = to->ctx;
+  DHIP(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  qdg::StreamScope scope(s);
+  const size_t n = to->ne;
+  Buf<size_t> p64;
+  Buf<int> p32, d_err;
+  DHIP(p64.alloc(n)); DHIP(p32.alloc(n)); DHIP(d_err.alloc(1));
+  DHIP(hipMemsetAsync(d_err.p, 0, sizeof(int), s));
+  DHIP(hipMemcpyAsync(p64.p, parent_of_child, n * sizeof(size_t), hipMemcpyHostToDevice, s));
+  k_parent_convert<<<nblk(n), 256, 0, s>>>(p64.p, n, from->ne, p32.p, d_err.p);
+  int herr = 0;
+  DHIP(hipMemcpyAsync(&herr, d_err.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  DHIP(hipStreamSynchronize(s));
+  if (herr) return fail("qdg_state_transfer: parent id out of range");
+  return transfer_rows(from, to, n, p32.p);
+}
+
+int dev_state_migrate(qdg_mesh* from, const size_t* from_gid, qdg_mesh* to, const size_t* to_gid, size_t* nmoved)
+{
+  qdg_ctx* ctx = to->ctx;
+  DHIP(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  qdg::StreamScope scope(s);
+  const size_t nf = from->nie, nt = to->nie;               // owned rows only
+  if (nf > (size_t)UINT32_MAX) return fail("qdg_state_migrate: chunk too large");
+  Buf<uint64_t> fk, fk2, tk;
+  Buf<uint32_t> fv, fv2;
+  Buf<int> par;
+  Buf<unsigned long long> cnt;
+  DHIP(fk.alloc(nf)); DHIP(fk2.alloc(nf)); DHIP(fv.alloc(nf)); DHIP(fv2.alloc(nf)); DHIP(tk.alloc(nt));
+  DHIP(par.alloc(nt)); DHIP(cnt.alloc(1));
+  DHIP(hipMemsetAsync(cnt.p, 0, sizeof(unsigned long long), s));
+  DHIP(hipMemcpyAsync(fk.p, from_gid, nf * 8, hipMemcpyHostToDevice, s));
+  DHIP(hipMemcpyAsync(tk.p, to_gid, nt * 8, hipMemcpyHostToDevice, s));
+  k_iota_u32<<<nblk(nf), 256, 0, s>>>(fv.p, nf);
+  if (int rc = dev_sort_pairs64(fk.p, fk2.p, fv.p, fv2.p, nf, s)) return rc;
+  k_match_gid<<<nblk(nt), 256, 0, s>>>(fk2.p, fv2.p, nf, tk.p, nt, par.p, cnt.p);
+  unsigned long long n = 0;
+  DHIP(hipMemcpyAsync(&n, cnt.p, sizeof n, hipMemcpyDeviceToHost, s));
+  DHIP(hipStreamSynchronize(s));
+  if (nmoved) *nmoved = (size_t)n;
+  if (n == 0) return 0;
+  return transfer_rows(from, to, nt, par.p);
+}
+}  // namespace qdg
+
+// ======================================================================================
 // The same for ONE RANK's chunk with its ghost layer (config 5 on a decomposition): what qdg_refine_chunk
 // derives on the host -- the children of the owned tets, the new ghost layer (children of old ghosts that
 // share a face with an owned child, grouped by owner, ordered by global child id 8 * gid(parent) + k), the
@@ -1849,7 +1953,7 @@ static int dev_scan_int(const int* in, int* out, size_t n, hipStream_t s)
   DHIP(hipStreamSynchronize(s));
   return 0;
 }
-static int dev_sort_pairs64(uint64_t* ki, uint64_t* ko, uint32_t* vi, uint32_t* vo, size_t n, hipStream_t s)
+int dev_sort_pairs64(uint64_t* ki, uint64_t* ko, uint32_t* vi, uint32_t* vo, size_t n, hipStream_t s)
 {
   size_t bytes = 0;
   DHIP(rocprim::radix_sort_pairs(nullptr, bytes, ki, ko, vi, vo, n, 0, 64, s));

@@ -136,4 +136,7 @@ namespace qdg {
 int mesh_alloc_state(qdg_mesh* m, int ntile);
 // qdg_devmesh.hip: the halo plan of a chunk whose handle keeps its connectivity (for its re-mesh)
 void keep_set_plan(qdg_mesh* m, size_t nnbr, const int32_t* nbr_rank, const size_t* recv_off);
+// qdg_devmesh.hip: device side of qdg_state_transfer / qdg_state_migrate
+int dev_state_transfer(qdg_mesh* from, qdg_mesh* to, const size_t* parent_of_child);
+int dev_state_migrate(qdg_mesh* from, const size_t* from_gid, qdg_mesh* to, const size_t* to_gid, size_t* nmoved);
 }  // namespace qdg
