@@ -1457,6 +1457,11 @@ struct qdg_mesh::Keep {
 
 namespace {
 void keep_free_fn(qdg_mesh::Keep* k) { delete k; }
+struct KeepOn {
+  qdg_ctx* c; int saved;
+  explicit KeepOn(qdg_ctx* ctx) : c(ctx), saved(ctx->opt.keep_connectivity) { c->opt.keep_connectivity = 1; }
+  ~KeepOn() { c->opt.keep_connectivity = saved; }
+};
 
 // tables of the 1:8 template (k_children's child order), filled once on the host by enumeration over
 // the ten node labels A B C D AB AC AD BC BD CD
@@ -1682,10 +1687,11 @@ extern "C" int qdg_mesh_refine_uniform(qdg_mesh* mesh, qdg_mesh** out, qdg_refin
   }
   qdg_mesh* nm = nullptr;
   // (the layout build consumes fd's FaceData; its connectivity moves into the new handle's Keep afterwards)
-  const int keep_opt = ctx->opt.keep_connectivity;
-  ctx->opt.keep_connectivity = 1;
-  const int rc = dev_build_layout(ctx, fd, bcface, &nm);
-  ctx->opt.keep_connectivity = keep_opt;
+  int rc = 0;
+  {
+    KeepOn keep_on(ctx);          // a re-meshed handle always keeps its connectivity (restored on every path)
+    rc = dev_build_layout(ctx, fd, bcface, &nm);
+  }
   if (rc) return rc;
   std::unique_ptr<qdg_mesh, int (*)(qdg_mesh*)> guard(nm, qdg_mesh_destroy);
   // ---- state: child <- parent, through the two device numberings ----
@@ -2148,10 +2154,11 @@ extern "C" int qdg_mesh_refine_chunk(qdg_mesh* mesh, qdg_mesh** out, qdg_chunk_r
     DHIP(hipStreamSynchronize(s));
   }
   qdg_mesh* nm = nullptr;
-  const int keep_opt = ctx->opt.keep_connectivity;
-  ctx->opt.keep_connectivity = 1;
-  const int rc = dev_build_layout(ctx, fd, bcface, &nm);
-  ctx->opt.keep_connectivity = keep_opt;
+  int rc = 0;
+  {
+    KeepOn keep_on(ctx);          // a re-meshed handle always keeps its connectivity (restored on every path)
+    rc = dev_build_layout(ctx, fd, bcface, &nm);
+  }
   if (rc) return rc;
   std::unique_ptr<qdg_mesh, int (*)(qdg_mesh*)> guard(nm, qdg_mesh_destroy);
   lap("layout");
