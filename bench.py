@@ -480,6 +480,14 @@ def self_launch(ngpus):
     sharing this process's stdout / stderr; returns the launcher's exit code."""
     import socket
     import subprocess
+    try:                                     # (counting devices does not initialise the GPU on this image)
+        import torch
+        have = torch.cuda.device_count()
+    except Exception:
+        have = None
+    if have is not None and have < ngpus:
+        sys.stderr.write("bench.py --gpus %d: this node exposes %d GPU(s)\n" % (ngpus, have))
+        return 2
     with socket.socket() as sk:               # a free rendezvous port on the loopback interface
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]

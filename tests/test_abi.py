@@ -66,6 +66,8 @@ def test_bench_gpus_n_starts_its_own_ranks(monkeypatch):
         return 7
 
     monkeypatch.setattr(subprocess, "call", fake_call)
+    import torch
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
     monkeypatch.delenv("WORLD_SIZE", raising=False)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
     with pytest.raises(SystemExit) as ex:
@@ -77,3 +79,9 @@ def test_bench_gpus_n_starts_its_own_ranks(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
     assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
     assert seen["env"].get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"
+    # a node with fewer GPUs than asked for: refused before anything is started
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    seen.clear()
+    with pytest.raises(SystemExit) as ex:
+        bench.main()
+    assert ex.value.code == 2 and not seen
