@@ -1,11 +1,12 @@
 """Sedov DG-P1 + Superbee on the reference's fixture for 150 CFL steps (the reference's own baseline
 stops after 20): GPU and oracle stay together step by step, i.e. the reference's quirks on this
 path (HLLC's NaN fall-through at the 8-orders-of-magnitude pressure jump, the max rule of dt) are
-the same in both over a long run, not only over the baseline's horizon."""
+the same in both over a long run, not only over the baseline's horizon.  Per-component tolerance 1e-12
+(measured 4e-15 after 150 steps; the time steps agree to 1e-12)."""
 import numpy as np
 import pytest
 
-from conftest import load_fixture
+from conftest import compflow_err, load_fixture
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -30,13 +31,14 @@ def test_sedov_150_steps_gpu_tracks_oracle(cases):
         for step in range(150):
             dtg = mesh.step(t)
             dto = orc.step(t, U, Lm, cfl=case["cfl"])
-            assert abs(dtg - dto) <= 1e-9 * dto, step
+            assert abs(dtg - dto) <= 1e-12 * dto, step
             t += dto
             if step % 25 == 24 or step == 149:
                 Ug = mesh.state_download()
                 fin = np.isfinite(U)
                 assert np.array_equal(fin, np.isfinite(Ug)), step
-                worst = max(worst, np.abs(np.where(fin, Ug - U, 0.0)).max() / max(1.0, np.abs(U[fin]).max()))
-        assert worst <= 1e-9
+                worst = max(worst, compflow_err(Ug, U, case["ndof"]))       # per component
+        # (measured, both DG-P1 kernels: 4e-15 after 150 steps, tools/long_sedov_probe.py)
+        assert worst <= 1e-12
     finally:
         mesh.close(); ctx.close()
