@@ -212,17 +212,21 @@ __global__ __launch_bounds__(256, (NDOF > 4 ? 1 : 2)) void k_rhs(DevMesh m, Phys
 // the in-place update is order independent.
 // Limiter.cpp:283-301: phi = min over the face points of f(phi_gp),
 // phi_gp = min(1, (uMax|uMin - u0) / (2 uNeg)), f(p) = max(0, max(min(2p,1), min(p,2))).
-// f is non-decreasing, so phi = f(min phi_gp): the smallest ratio a/b is tracked by
-// cross-multiplication (a, b >= 0) and divided once per component instead of once
-// per point (|uNeg| <= 1e-14 -> phi_gp = 1: skipped).
+// f is non-decreasing, so phi = f(min phi_gp).  All points with uNeg > 0 share the numerator
+// uMax - u0 and all points with uNeg < 0 share u0 - uMin, so the smallest phi_gp of either sign
+// sits at the LARGEST excursion of that sign: the point loop only tracks the largest positive and
+// the most negative uNeg (fmax / fmin drop a NaN excursion, as the reference's two comparisons do),
+// and the two candidates are compared by cross-multiplication (a, b >= 0) and divided once per
+// component (|uNeg| <= 1e-14 -> phi_gp = 1: not a candidate).  uNeg itself is formed as the
+// reference forms it, state - mean, cancellation included.
 template <int NDOF>
 __device__ __forceinline__ void superbee_phi(const Tables<NDOF>& T, const double (&u)[NCOMP][NDOF],
                                              const double* uMin, const double* uMax, double* phi)
 {
   constexpr int NGF = Tables<NDOF>::NGF;
-  double ra[NCOMP], rb[NCOMP];
+  double hi[NCOMP], lo[NCOMP];
 #pragma unroll
-  for (int c = 0; c < NCOMP; ++c) { ra[c] = 1.0; rb[c] = 1.0; }
+  for (int c = 0; c < NCOMP; ++c) { hi[c] = 0.0; lo[c] = 0.0; }
 #pragma unroll 1
   for (int lf = 0; lf < 4; ++lf)
 #pragma unroll
@@ -232,16 +236,22 @@ __device__ __forceinline__ void superbee_phi(const Tables<NDOF>& T, const double
 #pragma unroll
       for (int c = 0; c < NCOMP; ++c) {
         const double uNeg = s[c] - u[c][0];
-        const double a = (uNeg > 0.0) ? (uMax[c] - u[c][0]) : (u[c][0] - uMin[c]);
-        const double b = 2.0 * fabs(uNeg);
-        const bool take = (fabs(uNeg) > 1.0e-14) && (a * rb[c] < ra[c] * b);
-        ra[c] = take ? a : ra[c];
-        rb[c] = take ? b : rb[c];
+        hi[c] = fmax(hi[c], uNeg);
+        lo[c] = fmin(lo[c], uNeg);
       }
     }
 #pragma unroll
   for (int c = 0; c < NCOMP; ++c) {
-    const double pg = fmin(1.0, ra[c] * fast_rcp(rb[c]));
+    const double ap = uMax[c] - u[c][0], bp = 2.0 * hi[c];
+    const double an = u[c][0] - uMin[c], bn = -2.0 * lo[c];
+    double ra = 1.0, rb = 1.0;
+    const bool takep = (hi[c] > 1.0e-14) && (ap * rb < ra * bp);
+    ra = takep ? ap : ra;
+    rb = takep ? bp : rb;
+    const bool taken = (lo[c] < -1.0e-14) && (an * rb < ra * bn);
+    ra = taken ? an : ra;
+    rb = taken ? bn : rb;
+    const double pg = fmin(1.0, ra * fast_rcp(rb));
     phi[c] = fmax(0.0, fmax(fmin(2.0 * pg, 1.0), fmin(pg, 2.0)));
   }
 }
