@@ -219,40 +219,68 @@ __global__ __launch_bounds__(256, (NDOF > 4 ? 1 : 2)) void k_rhs(DevMesh m, Phys
 // and the two candidates are compared by cross-multiplication (a, b >= 0) and divided once per
 // component (|uNeg| <= 1e-14 -> phi_gp = 1: not a candidate).  uNeg itself is formed as the
 // reference forms it, state - mean, cancellation included.
+// one component at a time (short live ranges: the kernel's occupancy is bounded by its registers)
 template <int NDOF>
-__device__ __forceinline__ void superbee_phi(const Tables<NDOF>& T, const double (&u)[NCOMP][NDOF],
-                                             const double* uMin, const double* uMax, double* phi)
+__device__ __forceinline__ double superbee_phi1(const Tables<NDOF>& T, const double (&u)[NDOF], double uMin, double uMax)
 {
   constexpr int NGF = Tables<NDOF>::NGF;
-  double hi[NCOMP], lo[NCOMP];
-#pragma unroll
-  for (int c = 0; c < NCOMP; ++c) { hi[c] = 0.0; lo[c] = 0.0; }
+  double hi = 0.0, lo = 0.0;
 #pragma unroll 1
   for (int lf = 0; lf < 4; ++lf)
 #pragma unroll
     for (int ig = 0; ig < NGF; ++ig) {
-      double s[NCOMP];
-      state_from<NDOF>(u, T.fB[lf][ig], s);
+      const double* B = T.fB[lf][ig];
+      double a = u[0];
 #pragma unroll
-      for (int c = 0; c < NCOMP; ++c) {
-        const double uNeg = s[c] - u[c][0];
-        hi[c] = fmax(hi[c], uNeg);
-        lo[c] = fmin(lo[c], uNeg);
-      }
+      for (int k = 1; k < NDOF; ++k) a += u[k] * B[k];        // (state_from's order)
+      const double uNeg = a - u[0];
+      hi = fmax(hi, uNeg);
+      lo = fmin(lo, uNeg);
     }
+  const double ap = uMax - u[0], bp = 2.0 * hi;
+  const double an = u[0] - uMin, bn = -2.0 * lo;
+  double ra = 1.0, rb = 1.0;
+  const bool takep = (hi > 1.0e-14) && (ap * rb < ra * bp);
+  ra = takep ? ap : ra;
+  rb = takep ? bp : rb;
+  const bool taken = (lo < -1.0e-14) && (an * rb < ra * bn);
+  ra = taken ? an : ra;
+  rb = taken ? bn : rb;
+  const double pg = fmin(1.0, ra * fast_rcp(rb));
+  return fmax(0.0, fmax(fmin(2.0 * pg, 1.0), fmin(pg, 2.0)));
+}
+
+// Rows of a 256-row tile back to HBM in two coalesced passes of 128 rows through a 128-row LDS staging
+// area (half the LDS of tile_store_rows: the limiter kernels' occupancy).  All 256 threads call; the caller
+// guarantees that nobody still reads `lds` (a barrier has been passed since the last read).
+template <int NPROP>
+__device__ __forceinline__ void tile_store_rows_halves(double* __restrict__ U, int tile_e0, int nrows,
+                                                       double* __restrict__ lds, const double* r)
+{
+  const int tid = threadIdx.x;
 #pragma unroll
-  for (int c = 0; c < NCOMP; ++c) {
-    const double ap = uMax[c] - u[c][0], bp = 2.0 * hi[c];
-    const double an = u[c][0] - uMin[c], bn = -2.0 * lo[c];
-    double ra = 1.0, rb = 1.0;
-    const bool takep = (hi[c] > 1.0e-14) && (ap * rb < ra * bp);
-    ra = takep ? ap : ra;
-    rb = takep ? bp : rb;
-    const bool taken = (lo[c] < -1.0e-14) && (an * rb < ra * bn);
-    ra = taken ? an : ra;
-    rb = taken ? bn : rb;
-    const double pg = fmin(1.0, ra * fast_rcp(rb));
-    phi[c] = fmax(0.0, fmax(fmin(2.0 * pg, 1.0), fmin(pg, 2.0)));
+  for (int half = 0; half < 2; ++half) {
+    if (half) __syncthreads();                    // the first half has left the staging area
+    if ((tid >> 7) == half) {
+      double2* row = reinterpret_cast<double2*>(lds + (size_t)(tid & 127) * NPROP);
+#pragma unroll
+      for (int j = 0; j < NPROP / 2; ++j) row[j] = make_double2(r[2 * j], r[2 * j + 1]);
+    }
+    __syncthreads();
+    const int base = tile_e0 + half * 128;
+    const int left = nrows - base;
+    const int nvalid = (left < 0 ? 0 : (left < 128 ? left : 128)) * (NPROP / 2);
+    const double2* src = reinterpret_cast<const double2*>(lds);
+    double2* dst = reinterpret_cast<double2*>(U + (size_t)base * NPROP);
+#pragma unroll
+    for (int j = 0; j < NPROP / 4; ++j) {
+      const int i = j * 256 + tid;
+      if (i < nvalid) dst[i] = src[i];
+    }
+    if constexpr ((NPROP / 2) % 2 != 0) {         // 128 * NPROP/2 chunks over 256 threads: an odd half pass
+      const int i = (NPROP / 4) * 256 + tid;
+      if (tid < 128 && i < nvalid) dst[i] = src[i];
+    }
   }
 }
 
@@ -261,69 +289,70 @@ __global__ __launch_bounds__(256) void k_superbee(DevMesh m, double* __restrict_
 {
   if constexpr (NDOF > 1) {
     const Tables<NDOF>& T = tab<NDOF>();
-    constexpr int NGF = Tables<NDOF>::NGF;
     constexpr int NPROP = NCOMP * NDOF;
-    __shared__ double lds[256 * NPROP];
+    // first the tile's MEANS, [c][row] (10 KB), for the in-tile neighbours; later the staging area of the
+    // coalesced row stores (128 rows)
+    __shared__ double lds[128 * NPROP];
     const int tile_e0 = (m.blk0 + xcd_tile(blockIdx.x, gridDim.x)) * 256;
     const int e0 = tile_e0 + threadIdx.x;
     const bool active = e0 < m.nie;
     const int e = active ? e0 : m.nie - 1;
     const int stride = m.stride;
+    int nb[4];
+#pragma unroll
+    for (int lf = 0; lf < 4; ++lf) nb[lf] = m.nbr[(size_t)lf * stride + e];
     double u[NCOMP][NDOF];
     // the lane reads its own row directly (5.7 TB/s measured for that access, against 4.5 for the
-    // detour through LDS: tools/ubench_rowstream.hip); only the MEANS go to LDS, for the
-    // neighbours in the tile (93 -> 85 us at 1 M tets)
+    // detour through LDS: tools/ubench_rowstream.hip); only the MEANS go to LDS
     load_row<NPROP>(U, e, &u[0][0]);
 #pragma unroll
-    for (int c = 0; c < NCOMP; ++c) lds[(size_t)threadIdx.x * NPROP + c * NDOF] = u[c][0];
+    for (int c = 0; c < NCOMP; ++c) lds[c * 256 + threadIdx.x] = u[c][0];
     __syncthreads();
-    double uMin[NCOMP], uMax[NCOMP], phi[NCOMP];
+    double uMin[NCOMP], uMax[NCOMP];
 #pragma unroll
-    for (int c = 0; c < NCOMP; ++c) { uMin[c] = uMax[c] = u[c][0]; phi[c] = 1.0; }
+    for (int c = 0; c < NCOMP; ++c) uMin[c] = uMax[c] = u[c][0];
 #pragma unroll
     for (int lf = 0; lf < 4; ++lf) {
-      const int nb = m.nbr[(size_t)lf * stride + e];
-      if (nb < 0) continue;
-      const int r = nb - tile_e0;
+      if (nb[lf] < 0) continue;
+      const int r = nb[lf] - tile_e0;
       // in-tile neighbour: means from LDS (a ghost id may fall into the id range of a
       // ragged last tile: ghosts always come from global memory)
-      if (nb < m.nie && (unsigned)r < 256u) {
+      if (nb[lf] < m.nie && (unsigned)r < 256u) {
 #pragma unroll
         for (int c = 0; c < NCOMP; ++c) {
-          const double v = lds[(size_t)r * NPROP + c * NDOF];
+          const double v = lds[c * 256 + r];
           uMin[c] = fmin(uMin[c], v);
           uMax[c] = fmax(uMax[c], v);
         }
       } else {
 #pragma unroll
         for (int c = 0; c < NCOMP; ++c) {
-          const double v = U[fidx(c * NDOF, nb, NPROP)];
+          const double v = U[fidx(c * NDOF, nb[lf], NPROP)];
           uMin[c] = fmin(uMin[c], v);
           uMax[c] = fmax(uMax[c], v);
         }
       }
     }
-    superbee_phi<NDOF>(T, u, uMin, uMax, phi);
-    if (m.ndofel && m.ndofel[e] == 1) {    // pdg: P0 elements are not limited (Limiter.cpp:179-180)
-#pragma unroll
-      for (int c = 0; c < NCOMP; ++c) phi[c] = 1.0;
-    }
+    const bool p0row = m.ndofel && m.ndofel[e] == 1;   // pdg: P0 elements are not limited (Limiter.cpp:179-180)
     bool changed = false;
 #pragma unroll
-    for (int c = 0; c < NCOMP; ++c)
+    for (int c = 0; c < NCOMP; ++c) {
+      const double phi = p0row ? 1.0 : superbee_phi1<NDOF>(T, u[c], uMin[c], uMax[c]);
 #pragma unroll
       for (int k = 1; k < 4; ++k) {
-        const double v = phi[c] * u[c][k];
+        const double v = phi * u[c][k];
         changed = changed || (v != u[c][k]);
         u[c][k] = v;
       }
+    }
     if (active) halo_fold_row<NPROP>(m, e, &u[0][0]);      // (qdg_step_comm: the comlim pack, folded in)
     // A tile in which the limiter changed no value (phi = 1 or zero slopes on every row: uniform and smooth
     // regions) has nothing to write back -- the limiter works in place -- which halves this pass's traffic there.
+    // (The barrier inside is also the one that ends the reads of the means.)
     if (!__syncthreads_or(changed && active)) return;
     // Out-of-tile neighbours may be read from U while another tile has already
     // stored its limited rows: safe, Superbee never changes a mean.
-    tile_store_rows<NPROP>(U, tile_e0, m.nie, lds, &u[0][0]);
+    tile_store_rows_halves<NPROP>(U, tile_e0, m.nie, lds, &u[0][0]);
   }
 }
 
@@ -342,7 +371,9 @@ __global__ __launch_bounds__(256) void k_upd_superbee(DevMesh m, const double* _
   static_assert(NDOF == 4, "fused update + Superbee exists for DG-P1");
   const Tables<NDOF>& T = tab<NDOF>();
   constexpr int NPROP = NCOMP * NDOF, NCH = NPROP / 2;     // 16-byte chunks per row
-  __shared__ double lds[256 * NPROP];
+  // 32 KB instead of a whole tile of rows (42 KB): four workgroups per CU
+  __shared__ double stage[128 * NPROP];    // half a tile of rows: coalesced loads in, coalesced stores out
+  __shared__ double mean[NCOMP * 256];     // the tile's U1 means [c][row], for the in-tile neighbours
   __shared__ double sdtv[256];
   const int tid = threadIdx.x;
   const int tile_e0 = (m.blk0 + xcd_tile(blockIdx.x, gridDim.x)) * 256;
@@ -352,42 +383,53 @@ __global__ __launch_bounds__(256) void k_upd_superbee(DevMesh m, const double* _
   const int stride = m.stride;
   const double dt = dtp[0];
   sdtv[tid] = dt / m.vol[e];                       // the row's dt / vol, as k_rk forms it
-  __syncthreads();
-  // the tile's rows of U1 = U0 + dt R / L go to LDS in one coalesced pass over both arrays
-  {
-    const double2* su = reinterpret_cast<const double2*>(U0 + (size_t)tile_e0 * NPROP);
-    const double2* sr = reinterpret_cast<const double2*>(R + (size_t)tile_e0 * NPROP);
-    double2* dst = reinterpret_cast<double2*>(lds);
-    const int nvalid = (m.nie - tile_e0 < 256 ? m.nie - tile_e0 : 256) * NCH;
+  int nbr[4];
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) {
+  for (int lf = 0; lf < 4; ++lf) nbr[lf] = m.nbr[(size_t)lf * stride + e];
+  __syncthreads();
+  // the tile's rows of U1 = U0 + dt R / L pass through LDS half a tile at a time: one coalesced pass over
+  // both arrays, then every lane of that half takes its row
+  double u[NCOMP][NDOF];
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if (half) __syncthreads();                     // the first half's rows have been taken
+    const int base = tile_e0 + half * 128;
+    const int left = m.nie - base;
+    const int nvalid = (left < 0 ? 0 : (left < 128 ? left : 128)) * NCH;
+    const double2* su = reinterpret_cast<const double2*>(U0 + (size_t)base * NPROP);
+    const double2* sr = reinterpret_cast<const double2*>(R + (size_t)base * NPROP);
+    double2* dst = reinterpret_cast<double2*>(stage);
+#pragma unroll
+    for (int j = 0; j < NCH / 2; ++j) {
       const int i = j * 256 + tid;
       double2 v = make_double2(1.0, 1.0);
       if (i < nvalid) {
         const double2 a = su[i], b = sr[i];
         const int row = i / NCH, hi = (i - row * NCH) & 1;     // chunk holds modes (0,1) or (2,3)
-        const double dtv = sdtv[row];
+        const double dtv = sdtv[half * 128 + row];
         const double f0 = hi ? 10.0 / 3.0 : 1.0, f1 = hi ? 5.0 / 3.0 : 10.0;
         v = make_double2(a.x + dtv * f0 * b.x, a.y + dtv * f1 * b.y);
       }
       dst[i] = v;
     }
+    __syncthreads();
+    if ((tid >> 7) == half) lds_row<NPROP>(stage, tid & 127, &u[0][0]);
   }
-  __syncthreads();
-  double u[NCOMP][NDOF];
-  lds_row<NPROP>(lds, tid, &u[0][0]);
-  double uMin[NCOMP], uMax[NCOMP], phi[NCOMP];
 #pragma unroll
-  for (int c = 0; c < NCOMP; ++c) { uMin[c] = uMax[c] = u[c][0]; phi[c] = 1.0; }
+  for (int c = 0; c < NCOMP; ++c) mean[c * 256 + tid] = u[c][0];
+  __syncthreads();
+  double uMin[NCOMP], uMax[NCOMP];
+#pragma unroll
+  for (int c = 0; c < NCOMP; ++c) uMin[c] = uMax[c] = u[c][0];
 #pragma unroll
   for (int lf = 0; lf < 4; ++lf) {
-    const int nb = m.nbr[(size_t)lf * stride + e];
+    const int nb = nbr[lf];
     if (nb < 0) continue;
     const int rr = nb - tile_e0;
     if (nb < m.nie && (unsigned)rr < 256u) {     // (a ghost id may alias the ragged last tile)
 #pragma unroll
       for (int c = 0; c < NCOMP; ++c) {
-        const double v = lds[(size_t)rr * NPROP + c * NDOF];
+        const double v = mean[c * 256 + rr];
         uMin[c] = fmin(uMin[c], v); uMax[c] = fmax(uMax[c], v);
       }
     } else if (nb >= m.nie) {                   // ghost: the owner's U1 mean, already exchanged
@@ -405,13 +447,15 @@ __global__ __launch_bounds__(256) void k_upd_superbee(DevMesh m, const double* _
       }
     }
   }
-  superbee_phi<NDOF>(T, u, uMin, uMax, phi);
 #pragma unroll
-  for (int c = 0; c < NCOMP; ++c)
+  for (int c = 0; c < NCOMP; ++c) {
+    const double phi = superbee_phi1<NDOF>(T, u[c], uMin[c], uMax[c]);
 #pragma unroll
-    for (int k = 1; k < 4; ++k) u[c][k] = phi[c] * u[c][k];
+    for (int k = 1; k < 4; ++k) u[c][k] = phi * u[c][k];
+  }
   if (active) halo_fold_row<NPROP>(m, e, &u[0][0]);        // (qdg_step_comm: the comlim pack of stage 1, folded in)
-  tile_store_rows<NPROP>(Uout, tile_e0, m.nie, lds, &u[0][0]);
+  // (every lane has passed the barrier behind the means since it last read the staging area)
+  tile_store_rows_halves<NPROP>(Uout, tile_e0, m.nie, stage, &u[0][0]);
 }
 
 // send side of the same fusion: slab row j = U0[e] + dt * R[e] / L[e], e = send_elem[j]
