@@ -151,6 +151,12 @@ int qdg_device_pool_trim(size_t* released_bytes);
  * lives in it.  qdg_device_memory: free and total bytes of the context's device, bytes reserved this way. */
 int qdg_device_pool_reserve(qdg_ctx* ctx, size_t bytes);
 int qdg_device_memory(qdg_ctx* ctx, size_t* free_bytes, size_t* total_bytes, size_t* reserved_bytes);
+/* Device memory of the context's device from the same pool, for the buffers a host hands back in: the packed
+ * rows of qdg_state_rows_get / _put and qdg_halo_pack / _unpack (the message buffers of DG::comsol / comlim,
+ * src/Inciter/DG.cpp:1023-1086, on the device).  Memory of the runtime the library itself uses, which
+ * matters in a process that holds a second copy of the HIP runtime.  qdg_device_free(ctx, NULL) is a no-op. */
+int qdg_device_alloc(qdg_ctx* ctx, size_t bytes, void** out);
+int qdg_device_free(qdg_ctx* ctx, void* ptr);
 /* run all kernels of this context on an existing HIP stream (hipStream_t) */
 int qdg_ctx_set_stream(qdg_ctx* ctx, void* hip_stream);
 int qdg_ctx_synchronize(qdg_ctx* ctx);

@@ -288,6 +288,15 @@ class Context:
         """qdg_device_pool_reserve: one region from the driver now, the library's later allocations out of it"""
         _chk(lib().qdg_device_pool_reserve(self.h, C.c_size_t(int(nbytes))))
 
+    def device_alloc(self, nbytes):
+        """qdg_device_alloc: device pointer (int) to `nbytes` of this context's device, from the library's pool"""
+        p = C.c_void_p()
+        _chk(lib().qdg_device_alloc(self.h, C.c_size_t(int(nbytes)), C.byref(p)))
+        return p.value or 0
+
+    def device_free(self, ptr):
+        _chk(lib().qdg_device_free(self.h, C.c_void_p(ptr)))
+
     def set_stream(self, stream_ptr):
         _chk(lib().qdg_ctx_set_stream(self.h, C.c_void_p(stream_ptr)))
 

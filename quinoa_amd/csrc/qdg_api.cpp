@@ -241,6 +241,32 @@ extern "C" int qdg_device_memory(qdg_ctx* ctx, size_t* free_bytes, size_t* total
   QDG_CATCH
 }
 
+extern "C" int qdg_device_alloc(qdg_ctx* ctx, size_t bytes, void** out)
+{
+  QDG_TRY
+  if (!ctx || !out) return fail("qdg_device_alloc: null argument");
+  *out = nullptr;
+  if (bytes == 0) return 0;
+  HIPCHK(hipSetDevice(ctx->device));
+  // (no stream tag: the caller may use the buffer on any stream, so a recycled block waits for the device)
+  HIPCHK(qdg::dev_alloc(out, bytes));
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_device_free(qdg_ctx* ctx, void* ptr)
+{
+  QDG_TRY
+  if (!ctx) return fail("qdg_device_free: null ctx");
+  if (!ptr) return 0;
+  HIPCHK(hipSetDevice(ctx->device));
+  // the caller may have used the buffer on any stream: freed without a stream tag, the block waits for the
+  // device before it is handed out again (as hipFree would have)
+  qdg::dev_free(ptr);
+  return 0;
+  QDG_CATCH
+}
+
 extern "C" int qdg_ctx_set_stream(qdg_ctx* ctx, void* s)
 {
   QDG_TRY

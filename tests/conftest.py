@@ -53,3 +53,4 @@ def compflow_err(Ug, U, ndof):
     mom = max(mean[1:4].max(), 1e-3 * np.sqrt(mean[0] * mean[4]))
     scale = np.array([mean[0], mom, mom, mom, mean[4]])
     return float((np.abs(A - B).max(axis=(0, 2)) / scale).max())
+

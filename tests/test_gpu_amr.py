@@ -200,8 +200,7 @@ def test_config5_refine_then_recut_with_state_migration():
     part = partition.partition(g["coord"], g["inpoel"], 3, "rcb")
     chunks = [partition.build_chunk(g["coord"], g["inpoel"], g["sidesets"], part, 3, r) for r in range(3)]
     meshes = [build(ch) for ch in chunks]
-    hip = C.CDLL("libamdhip64.so")
-    buf = C.c_void_p()
+    buf = 0
     try:
         for m in meshes:
             m.state_initialize(0.0)
@@ -233,9 +232,9 @@ def test_config5_refine_then_recut_with_state_migration():
                     go, gn = co["gid"][:co["nielem"]], cn["gid"][:cn["nielem"]]
                     common, io, in_ = np.intersect1d(go, gn, return_indices=True)
                     if len(common):
-                        assert hip.hipMalloc(C.byref(buf), C.c_size_t(len(common) * 20 * 8)) == 0
-                        mo.state_rows_get(io, buf.value)
-                        mn.state_rows_put(in_, buf.value)
+                        buf = ctx.device_alloc(len(common) * 20 * 8)
+                        mo.state_rows_get(io, buf)
+                        mn.state_rows_put(in_, buf)
                     moved[r, q] = len(common)
                 else:
                     moved[r, q] = amr.state_migrate(mo, co["gid"], mn, cn["gid"])
@@ -255,8 +254,7 @@ def test_config5_refine_then_recut_with_state_migration():
             U = m.state_download().reshape(-1, 20)[:nie]
             assert np.abs(U - ref[ch["gid"][:nie]]).max() <= 1e-10 * np.abs(ref).max()
     finally:
-        if buf.value:
-            hip.hipFree(buf)
+        ctx.device_free(buf)
         for m in meshes:
             m.close()
         one.mesh.close(); ctx.close(); ctx1.close()
