@@ -479,7 +479,8 @@ int qdg_mesh_refine_uniform(qdg_mesh* mesh, qdg_mesh** refined_mesh, qdg_refined
  * qdg_refine_chunk derives them on the host -- without communication: both ranks of a pair get the same sets --
  * then the chunk build, qdg_halo_setup of the new handle and the state of the owned tets (child <- parent).
  * host_copy (may be NULL): gid[nunk], parent[nunk] (old local id), send lists, receive counts -- and with
- * copy_mesh != 0 connectivity, coordinates and side-set triangles too -- through qdg_chunk_refined_sizes / _get. */
+ * copy_mesh != 0 connectivity, coordinates and side-set triangles too -- through qdg_chunk_refined_sizes / _get.
+ * Limits: fewer than 65 536 neighbour ranks and global child ids below 2^48 (the device sorts owner << 48 | id). */
 int qdg_mesh_refine_chunk(qdg_mesh* mesh, qdg_mesh** refined_mesh, qdg_chunk_refined** host_copy, int copy_mesh);
 int qdg_refined_sizes(const qdg_refined* r, size_t* nelem, size_t* nnode, size_t* ntri);
 int qdg_refined_tri_sets(const qdg_refined* r, int32_t* tri_set);

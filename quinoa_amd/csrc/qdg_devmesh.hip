@@ -1988,6 +1988,7 @@ extern "C" int qdg_mesh_refine_chunk(qdg_mesh* mesh, qdg_mesh** out, qdg_chunk_r
   if (nunk > nie && (nnbr == 0 || mesh->nnbr != nnbr))
     return fail("qdg_mesh_refine_chunk: the chunk has ghosts: call qdg_halo_setup before the re-mesh");
   if (8 * nunk > (size_t)(INT32_MAX - 64) / 4) return fail("qdg_mesh_refine_chunk: refined chunk too large for 32-bit ids");
+  if (nnbr >= 65536) return fail("qdg_mesh_refine_chunk: more than 65535 neighbour ranks");   // (sort keys: owner << 48 | child id)
   DHIP(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
   qdg::StreamScope scope(s);
