@@ -1721,14 +1721,18 @@ extern "C" int qdg_mesh_refine_uniform(qdg_mesh* mesh, qdg_mesh** out, qdg_refin
       chk(hipSetDevice(dev));
       hipStream_t s2 = nullptr;
       chk(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
-      rp->inpoel.resize(4 * ne2); rp->x.resize(nn2); rp->y.resize(nn2); rp->z.resize(nn2); rp->tri.resize(3 * ntri2);
-      chk(hipMemcpyAsync(rp->inpoel.data(), nk->inpoel.p, 4 * ne2 * 8, hipMemcpyDeviceToHost, s2));
-      chk(hipMemcpyAsync(rp->x.data(), nk->x.p, nn2 * 8, hipMemcpyDeviceToHost, s2));
-      chk(hipMemcpyAsync(rp->y.data(), nk->y.p, nn2 * 8, hipMemcpyDeviceToHost, s2));
-      chk(hipMemcpyAsync(rp->z.data(), nk->z.p, nn2 * 8, hipMemcpyDeviceToHost, s2));
-      if (ntri2) chk(hipMemcpyAsync(rp->tri.data(), tri2->p, 3 * ntri2 * 8, hipMemcpyDeviceToHost, s2));
-      rp->parent.resize(ne2);
-      for (size_t c = 0; c < ne2; ++c) rp->parent[c] = c >> 3;
+      try {                                       // (nothing may leave a thread's function: the host arrays can fail to allocate)
+        rp->inpoel.resize(4 * ne2); rp->x.resize(nn2); rp->y.resize(nn2); rp->z.resize(nn2); rp->tri.resize(3 * ntri2);
+        chk(hipMemcpyAsync(rp->inpoel.data(), nk->inpoel.p, 4 * ne2 * 8, hipMemcpyDeviceToHost, s2));
+        chk(hipMemcpyAsync(rp->x.data(), nk->x.p, nn2 * 8, hipMemcpyDeviceToHost, s2));
+        chk(hipMemcpyAsync(rp->y.data(), nk->y.p, nn2 * 8, hipMemcpyDeviceToHost, s2));
+        chk(hipMemcpyAsync(rp->z.data(), nk->z.p, nn2 * 8, hipMemcpyDeviceToHost, s2));
+        if (ntri2) chk(hipMemcpyAsync(rp->tri.data(), tri2->p, 3 * ntri2 * 8, hipMemcpyDeviceToHost, s2));
+        rp->parent.resize(ne2);
+        for (size_t c = 0; c < ne2; ++c) rp->parent[c] = c >> 3;
+      } catch (const std::exception& ex) {
+        if (hc_raw->error.empty()) hc_raw->error = ex.what();
+      }
       chk(hipStreamSynchronize(s2));
       if (s2) chk(hipStreamDestroy(s2));
     });
