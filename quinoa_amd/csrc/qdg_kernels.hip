@@ -498,8 +498,17 @@ __global__ __launch_bounds__(BS) void k_weno(DevMesh m, double cweight,
   double r[NCOMP][NDOF];
   load_row<NPROP>(Uin, e, &r[0][0]);
   if constexpr (NDOF > 1) {
+    // the tile's gradient modes [row][c][3] go to LDS first (the area that later stages the rows): a
+    // neighbour inside the tile -- two thirds to three quarters of them in the Morton-ordered numbering --
+    // is read from there instead of through scattered global loads (the tiles cover ghost rows too)
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) stage[(threadIdx.x * NCOMP + c) * 3 + d] = r[c][1 + d];
+    __syncthreads();
     if (e < m.nie) {
       const int stride = m.stride;
+      const int t0 = blk * BS, tn = (m.ne - t0 < BS) ? m.ne - t0 : BS;    // rows [t0, t0 + tn) are in LDS
       int nb[4];
 #pragma unroll
       for (int lf = 0; lf < 4; ++lf) nb[lf] = m.nbr[(size_t)lf * stride + e];
@@ -512,7 +521,10 @@ __global__ __launch_bounds__(BS) void k_weno(DevMesh m, double cweight,
         for (int is = 1; is < 5; ++is) {
           const int n = nb[is - 1];
           g[is][0] = g[is][1] = g[is][2] = 0.0;
-          if (n >= 0) {
+          if (n >= 0 && (unsigned)(n - t0) < (unsigned)tn) {
+            const double* l = stage + ((n - t0) * NCOMP + c) * 3;
+            g[is][0] = l[0]; g[is][1] = l[1]; g[is][2] = l[2];
+          } else if (n >= 0) {
             // modes 1, 2, 3 of component c: doubles c*NDOF + 1 .. + 3 of the row; the row is
             // 16-byte aligned and c*NDOF is even, so the pair (2, 3) is a 16-byte load
             const double* pn = Uin + (size_t)n * NPROP + c * NDOF + 1;
@@ -538,6 +550,7 @@ __global__ __launch_bounds__(BS) void k_weno(DevMesh m, double cweight,
       }
     }
     {
+      __syncthreads();                            // the gradient modes in LDS have been read
       double2* row = reinterpret_cast<double2*>(stage + (size_t)threadIdx.x * NPROP);
 #pragma unroll
       for (int j = 0; j < NPROP / 2; ++j) row[j] = make_double2((&r[0][0])[2 * j], (&r[0][0])[2 * j + 1]);
