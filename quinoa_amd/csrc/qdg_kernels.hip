@@ -225,7 +225,7 @@ __device__ __forceinline__ double superbee_phi1(const Tables<NDOF>& T, const dou
 {
   constexpr int NGF = Tables<NDOF>::NGF;
   double hi = 0.0, lo = 0.0;
-#pragma unroll 1
+#pragma unroll
   for (int lf = 0; lf < 4; ++lf)
 #pragma unroll
     for (int ig = 0; ig < NGF; ++ig) {
