@@ -72,6 +72,15 @@ __device__ __forceinline__ void store_row(double* __restrict__ U, int e, const d
   }
 }
 
+// non-temporal 16-byte store (global_store_dwordx4 ... nt): rows that are written once per launch and read by a
+// later kernel.  (Non-temporal LOADS of streamed rows were measured and lose: the neighbour gathers of the same
+// launch live off those lines in the L2 -- profiles/r04_limiter_experiments.log.)
+__device__ __forceinline__ void store_nt(double2* p, double2 v)
+{
+  __builtin_nontemporal_store(v.x, &p->x);
+  __builtin_nontemporal_store(v.y, &p->y);
+}
+
 // ---- coalesced row I/O of a 256-tet tile through LDS -------------------------
 // The rows of a workgroup's 256 consecutive tets are one contiguous span of
 // 256*NPROP doubles.  These helpers move that span with unit-stride 16-byte

@@ -253,6 +253,15 @@ __device__ __forceinline__ double superbee_phi1(const Tables<NDOF>& T, const dou
 // Rows of a 256-row tile back to HBM in two coalesced passes of 128 rows through a 128-row LDS staging
 // area (half the LDS of tile_store_rows: the limiter kernels' occupancy).  All 256 threads call; the caller
 // guarantees that nobody still reads `lds` (a barrier has been passed since the last read).
+// The limited rows are written once and read by the next kernel only after this one has streamed gigabytes
+// through the L2: non-temporal stores keep them from displacing the rows of U0 / R that the out-of-tile
+// neighbour gathers of the same launch find there (k_upd_superbee 1116 -> 1096 us at 10.1 M tets, 127 -> 123 us
+// at 1 M; QDG_TEMPORAL_ROW_STORES restores plain stores for A/B runs).
+#ifndef QDG_TEMPORAL_ROW_STORES
+#define QDG_ROW_STORE(p, v) qdg::store_nt((p), (v))
+#else
+#define QDG_ROW_STORE(p, v) (*(p) = (v))
+#endif
 template <int NPROP>
 __device__ __forceinline__ void tile_store_rows_halves(double* __restrict__ U, int tile_e0, int nrows,
                                                        double* __restrict__ lds, const double* r)
@@ -275,11 +284,11 @@ __device__ __forceinline__ void tile_store_rows_halves(double* __restrict__ U, i
 #pragma unroll
     for (int j = 0; j < NPROP / 4; ++j) {
       const int i = j * 256 + tid;
-      if (i < nvalid) dst[i] = src[i];
+      if (i < nvalid) QDG_ROW_STORE(dst + i, src[i]);
     }
     if constexpr ((NPROP / 2) % 2 != 0) {         // 128 * NPROP/2 chunks over 256 threads: an odd half pass
       const int i = (NPROP / 4) * 256 + tid;
-      if (tid < 128 && i < nvalid) dst[i] = src[i];
+      if (tid < 128 && i < nvalid) QDG_ROW_STORE(dst + i, src[i]);
     }
   }
 }

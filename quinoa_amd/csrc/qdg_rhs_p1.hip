@@ -1091,7 +1091,14 @@ __global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1w(DevMesh m, Phys ph, doub
 #pragma unroll
     for (int j = 0; j < NPROP / 2; ++j) {
       const int i = j * BS + tid;
+      // non-temporal: the rows are read next by another kernel, after gigabytes of other traffic, and must not
+      // displace the partner rows that the cross-tile face tasks of this launch find in the L2 (RHS launch
+      // 1.54 -> 1.51 ms at 10.1 M tets; at 1 M the update + limiter kernel that follows gains 6 %)
+#ifndef QDG_TEMPORAL_ROW_STORES
+      if (i < nvalid) store_nt(dst + i, src[i]);
+#else
       if (i < nvalid) dst[i] = src[i];
+#endif
     }
   }
 
