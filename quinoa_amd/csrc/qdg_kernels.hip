@@ -572,7 +572,11 @@ __global__ __launch_bounds__(BS) void k_weno(DevMesh m, double cweight,
 #pragma unroll 5
       for (int j = 0; j < NPROP / 2; ++j) {
         const int i = j * BS + threadIdx.x;
+#ifndef QDG_TEMPORAL_ROW_STORES      // (non-temporal: qdg_devfn.hpp, store_nt)
+        if (i < nvalid) store_nt(dst + i, src[i]);
+#else
         if (i < nvalid) dst[i] = src[i];
+#endif
       }
     }
   } else {
