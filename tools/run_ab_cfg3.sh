@@ -1,5 +1,5 @@
 #!/bin/bash
-# config 3 at its size: default library vs a variant.  Usage: tools/run_r4y.sh OUTTAG NAME
+# config 3 at its size: default library vs a variant.  Usage: tools/run_ab_cfg3.sh OUTTAG NAME
 o=gpurun_out/$1; mkdir -p $o; name=$2
 for v in default $name; do
   if [ $v = default ]; then unset QDG_LIB; else export QDG_LIB=$PWD/quinoa_amd/lib/variants/$v/libqdg.so; fi
