@@ -961,7 +961,7 @@ __device__ __forceinline__ void rk_epilogue_rows(const double (&u)[NCOMP][4], co
 // A workgroup of 256 lanes owns a tile of TILE = 248 consecutive device rows (Morton-compact),
 // two workgroups per CU (2 x 79 KB of LDS), in three phases separated by two barriers:
 //  0. every load that depends on nothing goes out at kernel entry in one burst (the tet's own
-//     modal row, the task words of all rounds, round 0's face record, node ids, volume); the row
+//     modal row, the task words and partner-row ids of all rounds, round 0's face record, node ids, volume); the row
 //     is written to LDS in NODAL form, nod[vertex][c][tet], and STAYS in registers for the RK
 //     epilogue (re-read in phase 2 it misses the L2 at size: 160 B per tet of extra HBM reads);
 //  1. one lane per face task (face_task_lean): every face of the tile once, both tets of an
@@ -969,7 +969,7 @@ __device__ __forceinline__ void rk_epilogue_rows(const double (&u)[NCOMP][4], co
 //  2. one lane per tet (tet_volume_lean): accumulators -> modal R, volume term from the vertex
 //     states in LDS, source; WITH_DT: CFL sum -> vol/sum, block minimum (stage 0); FUSE_RK:
 //     Uout = a*Un + b*(U + dt*R/L) written instead of R (stages 1, 2); rows leave through LDS as
-//     coalesced 1-KiB wave stores.
+//     coalesced, non-temporal 1-KiB wave stores.
 // Round 3 measured the alternatives on this kernel (profiles/r03_p1_experiments.log): 384 / 320
 // lanes per tile get ONE workgroup per CU from the dispatcher (2.7 ms against 1.6 ms at 10.1 M
 // tets), 512 lanes need 128 registers (spills: scratch traffic costs more than the waves hide),
@@ -977,7 +977,9 @@ __device__ __forceinline__ void rk_epilogue_rows(const double (&u)[NCOMP][4], co
 // prefetching the next tile's rows into registers through the face rounds 2.1 ms (256 registers,
 // in-order vmcnt couples the prefetch to every later load) or by LDS-DMA into the accumulator
 // planes during phase 2 1.84 ms, the round-2 form of the face task (vertex states held across
-// the Gauss points, 206 registers, the row re-read in phase 2) 1.60-1.65 ms.
+// the Gauss points, 206 registers, the row re-read in phase 2) 1.60-1.65 ms.  Round 4 repeated the 160-row
+// experiment with a register-lean fused epilogue (three workgroups per CU for both instantiations): a wash
+// (profiles/r04_p1_experiments.log).
 template <bool WITH_DT, bool FUSE_RK, int PROB>
 __global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1w(DevMesh m, Phys ph, double t,
                                                         const double* __restrict__ U,
