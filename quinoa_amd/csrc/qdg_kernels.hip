@@ -1340,18 +1340,8 @@ __global__ __launch_bounds__(256) void k_superbee(DevMesh m, double* __restrict_
       const double v = U[at<NDOF>(m, nb, c)];
       uMin = fmin(uMin, v); uMax = fmax(uMax, v);
     }
-#pragma unroll 1
-    for (int lf = 0; lf < 4; ++lf)
-#pragma unroll
-      for (int ig = 0; ig < NGF; ++ig) {
-        const double uNeg = state<NDOF>(u, T.fB[lf][ig]) - u[0];
-        double pg;
-        if (uNeg > 1.0e-14)       pg = fmin(1.0, (uMax - u[0]) / (2.0 * uNeg));
-        else if (uNeg < -1.0e-14) pg = fmin(1.0, (uMin - u[0]) / (2.0 * uNeg));
-        else                      pg = 1.0;
-        pg = fmax(0.0, fmax(fmin(2.0 * pg, 1.0), fmin(pg, 2.0)));
-        phi = fmin(phi, pg);
-      }
+    // (one division per scalar instead of one per face point: superbee_phi1, above)
+    phi = superbee_phi1<NDOF>(T, u, uMin, uMax);
 #pragma unroll
     for (int k = 1; k < 4; ++k) U[at<NDOF>(m, e, c) + k] = phi * u[k];
   }
