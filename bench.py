@@ -44,7 +44,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH
 # kernels' vector-instruction counts against the chip's issue rate.  A wave64 fp64 instruction occupies its SIMD
 # for 4 cycles (tools/ubench_fp64.hip: 4.2 measured), so 1024 SIMDs at the 2.4 GHz peak clock issue at most
 # 614.4 G wave instructions per second.  Instructions per tet from the committed PMC passes (SQ_INSTS_VALU per
-# launch / tets: profiles/r03_nx119_pmc_per_launch.json, profiles/r03_cfg3_nx110_pmc_per_launch.json).
+# launch / tets; which files: profiles/pmc_index.json).
 VALU_ISSUE_PEAK_G = 1024 * 2.4 / 4.0
 
 
