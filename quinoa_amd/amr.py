@@ -73,10 +73,17 @@ class RefinedRun:
         self.ctx = ctx
         self.device_refine = device_refine
         self.resident = resident
+        self.coord, self.inpoel, self.sidesets = np.asarray(coord, dtype=np.float64), np.asarray(inpoel), sidesets
+        # keep_connectivity concerns THIS run's meshes only: the caller's context gets its setting back (a
+        # re-meshed handle inherits the kept arrays from its parent handle, not from the option)
+        keep0 = ctx.get_option("keep_connectivity") if resident else None
         if resident:
             ctx.set_option("keep_connectivity", 1)
-        self.coord, self.inpoel, self.sidesets = np.asarray(coord, dtype=np.float64), np.asarray(inpoel), sidesets
-        self.mesh = capi.mesh_from_connectivity(ctx, self.inpoel, self.coord, self.sidesets)
+        try:
+            self.mesh = capi.mesh_from_connectivity(ctx, self.inpoel, self.coord, self.sidesets)
+        finally:
+            if resident:
+                ctx.set_option("keep_connectivity", keep0)
         self.timings = []
         self.host_copy_s = None
 

@@ -558,6 +558,9 @@ class Mesh:
                                          tset.ctypes.data_as(c_i32p) if copy_mesh else None,
                                          soff.ctypes.data_as(c_szp), slist.ctypes.data_as(c_szp),
                                          rc.ctypes.data_as(c_szp)))
+        except BaseException:
+            new.close()                      # the new device mesh is not handed out: release it
+            raise
         finally:
             L.qdg_chunk_refined_destroy(h)
         new.nielem, new.nunk = nie2, nunk2

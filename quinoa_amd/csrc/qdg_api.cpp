@@ -311,6 +311,8 @@ extern "C" int qdg_ctx_set_option(qdg_ctx* ctx, const char* name, int value)
   if (!ctx || !name) return fail("qdg_ctx_set_option: null argument");
   int* p = option_slot(ctx, name);
   if (!p) return fail(std::string("qdg_ctx_set_option: unknown option '") + name + "'");
+  if (p == &ctx->opt.p1_rhs && value != 0 && value != 1)
+    return fail("qdg_ctx_set_option: p1_rhs is 0 (tile / face-task kernel) or 1 (element-centric, reproducible)");
   *p = value;
   return 0;
   QDG_CATCH
@@ -730,7 +732,6 @@ extern "C" int qdg_mesh_upload_gid(qdg_ctx* ctx, size_t nielem, size_t nunk, siz
   HIPCHK(m->task_nb.upload(h_task_nb, s)); HIPCHK(m->task_f.upload(h_task_f, s));
   dm.ntile = ntile; dm.ntile_inner = ntile_inner; dm.tile_row = m->tile_row.p; dm.task_stride = task_stride;
   dm.tile_rows = TILE;
-  dm.persistent = ctx->opt.p1_rhs >= 2 ? ctx->opt.p1_rhs : 0;
   dm.tile_off = m->tile_off.p; dm.task_a = m->task_a.p;
   dm.task_nb = m->task_nb.p; dm.task_f = m->task_f.p;
   dm.tgeo = nullptr;
@@ -860,9 +861,6 @@ static bool use_p1_fast(const qdg_mesh* mesh)
 // ds_add_f64) unless bitwise run-to-run reproducibility is requested (option "p1_rhs" = 1)
 static bool use_tile(const qdg_mesh* mesh)
 {
-  // (read at launch time: 2 = role-specialised persistent workgroups where a launch has at least two tiles
-  // per CU, 3 = always; DevMesh is passed to the kernels by value)
-  const_cast<qdg_mesh*>(mesh)->dm.persistent = mesh->ctx->opt.p1_rhs >= 2 ? mesh->ctx->opt.p1_rhs : 0;
   return mesh->ctx->opt.p1_rhs != 1 || mesh->dm.ndofel;      // p-adaptive DG exists in the tile kernel only
 }
 
@@ -1245,6 +1243,7 @@ extern "C" int qdg_state_device_ptr(qdg_mesh* mesh, void** dptr, size_t* stride)
   QDG_TRY
   if (!mesh || !dptr || !stride) return fail("qdg_state_device_ptr: null argument");
   *dptr = mesh->Ucur; *stride = mesh->stride;
+  mesh->slab_ready_for = nullptr;      // the caller may write the state through this pointer
   return 0;
   QDG_CATCH
 }
@@ -1786,6 +1785,7 @@ extern "C" int qdg_halo_copy(qdg_mesh* dst, size_t dst_row0, qdg_mesh* src, size
   const size_t w = slab_w(dst);
   HIPCHK(hipMemcpyAsync(dst->recv_ptr + dst_row0 * w, src->send_ptr + src_row0 * w, nrows * w * sizeof(double),
                         hipMemcpyDeviceToDevice, dst->ctx->stream));
+  dst->slab_ready_for = src->slab_ready_for = nullptr;    // a caller-driven exchange: qdg_step_comm packs afresh
   return 0;
   QDG_CATCH
 }
@@ -1798,6 +1798,7 @@ extern "C" int qdg_halo_use_buffers(qdg_mesh* mesh, void* send_dev, void* recv_d
     return fail("qdg_halo_use_buffers: null buffer");
   mesh->send_ptr = (double*)send_dev;
   mesh->recv_ptr = (double*)recv_dev;
+  mesh->slab_ready_for = nullptr;      // another send slab: nothing packed in it yet
   return 0;
   QDG_CATCH
 }
@@ -2085,8 +2086,10 @@ static int step_comm_stages(qdg_mesh* mesh, qdg_comm* comm, double t, double tle
   // limited send rows to the slab themselves, the DG-P1 tile kernel with the fused RK update the rows of the
   // new state.  Enabled for THIS call's launches only (DevMesh goes to the kernels by value).
   const bool can_fold = mesh->fold_slot.p && mesh->nnbr > 0;
-  const bool lim_folds = can_fold && ctx->cfg.limiter == QDG_LIMITER_SUPERBEEP1 && mesh->ndof > 1;
-  const bool rhs_folds = can_fold && use_p1_fast(mesh) && use_tile(mesh) && ctx->opt.p1_rhs < 2 && !mesh->dm.ndofel;
+  // (only the CompFlow Superbee kernels fold: tr::k_superbee of dg::Transport does not write the slab)
+  const bool lim_folds = can_fold && ctx->cfg.limiter == QDG_LIMITER_SUPERBEEP1 && mesh->ndof > 1 &&
+                         mesh->dm.pde == QDG_PDE_COMPFLOW;
+  const bool rhs_folds = can_fold && use_p1_fast(mesh) && use_tile(mesh) && !mesh->dm.ndofel;
   struct FoldScope {
     qdg_mesh* m;
     FoldScope(qdg_mesh* mm, bool on) : m(mm) { if (on) { m->dm.fold_slot = m->fold_slot.p; m->dm.fold_slab = m->send_ptr; } }

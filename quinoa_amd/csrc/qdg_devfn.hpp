@@ -707,86 +707,6 @@ __device__ __forceinline__ void flux_hllc_own(const double* fn, const double* so
   flx[4] = sv * u4 + e4;
 }
 
-// ---- the three Gauss points of a DG-P1 face side by side (k_rhs_p1r's face waves) ----------------
-// The same arithmetic as primitives() / flux_hllc_own(), statement by statement over the three points:
-// three independent dependency chains next to each other in program order.  A face wave of the
-// role-specialised kernel shares its SIMD with ONE other wave, where a dependent fp64 chain issues every
-// ~8 cycles (tools/ubench_fp64.hip) against 4.2 when independent work is available.
-#define QDG_G3 _Pragma("unroll") for (int g = 0; g < 3; ++g)
-struct Prim3 { double ir[3], p[3], a[3], vn[3]; };
-__device__ __forceinline__ void rcp3(const double (&x)[3], double (&r)[3])
-{
-  QDG_G3 r[g] = __builtin_amdgcn_rcp(x[g]);
-#if QDG_RCP_NR >= 1
-  QDG_G3 r[g] = fma(fma(-x[g], r[g], 1.0), r[g], r[g]);
-#endif
-#if QDG_RCP_NR >= 2
-  QDG_G3 r[g] = fma(fma(-x[g], r[g], 1.0), r[g], r[g]);
-#endif
-}
-__device__ __forceinline__ void sqrt3(const double (&x)[3], double (&out)[3])
-{
-  QDG_G3 out[g] = fast_sqrt(x[g]);
-}
-__device__ __forceinline__ void primitives3(const Phys& ph, const double* fn, const double (&s)[3][NCOMP], Prim3& q)
-{
-  double rho[3], m2[3], arg[3];
-  QDG_G3 rho[g] = s[g][0];
-  rcp3(rho, q.ir);
-  QDG_G3 m2[g] = s[g][1] * s[g][1] + s[g][2] * s[g][2] + s[g][3] * s[g][3];
-  QDG_G3 q.p[g] = (s[g][4] - 0.5 * m2[g] * q.ir[g] - ph.pstiff) * (ph.gamma - 1.0) - ph.pstiff;
-  QDG_G3 arg[g] = ph.gamma * (q.p[g] + ph.pstiff) * q.ir[g];
-  sqrt3(arg, q.a);
-  QDG_G3 q.vn[g] = (s[g][1] * fn[0] + s[g][2] * fn[1] + s[g][3] * fn[2]) * q.ir[g];
-}
-__device__ __forceinline__ void flux_hllc_own3(const double* fn, const double (&so)[3][NCOMP], const double (&sn)[3][NCOMP],
-                                               const Prim3& qo, const Prim3& qn, bool own_left, double (&flx)[3][NCOMP])
-{
-  double t0[3], rlr[3], t1[3], irlr1[3], vnroe[3], aroe[3], Sl[3], Sr[3], ml[3], mr[3], dm[3], idm[3], Sm[3], pStar[3];
-  QDG_G3 t0[g] = sn[g][0] * qo.ir[g];
-  sqrt3(t0, rlr);
-  QDG_G3 t1[g] = 1.0 + rlr[g];
-  rcp3(t1, irlr1);
-  QDG_G3 vnroe[g] = (qn.vn[g] * rlr[g] + qo.vn[g]) * irlr1[g];
-  QDG_G3 aroe[g] = (qn.a[g] * rlr[g] + qo.a[g]) * irlr1[g];
-  QDG_G3 Sl[g] = fmin(qo.vn[g] - qo.a[g], vnroe[g] - aroe[g]);
-  QDG_G3 Sr[g] = fmax(qn.vn[g] + qn.a[g], vnroe[g] + aroe[g]);
-  QDG_G3 ml[g] = so[g][0] * (Sl[g] - qo.vn[g]);
-  QDG_G3 mr[g] = sn[g][0] * (Sr[g] - qn.vn[g]);
-  QDG_G3 dm[g] = mr[g] - ml[g];
-  rcp3(dm, idm);
-  QDG_G3 Sm[g] = (mr[g] * qn.vn[g] - ml[g] * qo.vn[g] + qo.p[g] - qn.p[g]) * idm[g];
-  QDG_G3 pStar[g] = so[g][0] * (qo.vn[g] - Sl[g]) * (qo.vn[g] - Sm[g]) + qo.p[g];
-  bool left[3], star[3];
-  QDG_G3 {
-    const bool c1 = Sl[g] > 0.0;
-    const bool c2 = !c1 && (Sl[g] <= 0.0) && (Sm[g] > 0.0);
-    const bool c3 = !c1 && !c2 && (Sm[g] <= 0.0) && (Sr[g] >= 0.0);
-    const bool m1 = Sr[g] < 0.0;
-    const bool m2 = !m1 && (Sr[g] >= 0.0) && (Sm[g] < 0.0);
-    const bool m3 = !m1 && !m2 && (Sm[g] >= 0.0) && (Sl[g] <= 0.0);
-    left[g] = own_left ? (c1 || c2) : !(m1 || m2);
-    star[g] = own_left ? (c2 || c3) : (m2 || m3);
-  }
-  double S[3], vn[3], p[3], d[3], id[3], sv[3], dp[3], e4[3];
-  QDG_G3 { S[g] = left[g] ? Sl[g] : Sr[g]; vn[g] = left[g] ? qo.vn[g] : qn.vn[g]; p[g] = left[g] ? qo.p[g] : qn.p[g]; }
-  QDG_G3 d[g] = S[g] - Sm[g];
-  rcp3(d, id);
-  QDG_G3 id[g] = star[g] ? id[g] : 1.0;
-  QDG_G3 sv[g] = star[g] ? (S[g] - vn[g]) * id[g] * Sm[g] : vn[g];
-  QDG_G3 dp[g] = star[g] ? (pStar[g] - p[g]) * id[g] * Sm[g] + pStar[g] : p[g];
-  QDG_G3 e4[g] = star[g] ? ((pStar[g] * Sm[g] - p[g] * vn[g]) * id[g] + pStar[g]) * Sm[g] : p[g] * vn[g];
-  QDG_G3 {
-    const double u0 = left[g] ? so[g][0] : sn[g][0], u1 = left[g] ? so[g][1] : sn[g][1], u2 = left[g] ? so[g][2] : sn[g][2],
-                 u3 = left[g] ? so[g][3] : sn[g][3], u4 = left[g] ? so[g][4] : sn[g][4];
-    flx[g][0] = sv[g] * u0;
-    flx[g][1] = sv[g] * u1 + dp[g] * fn[0];
-    flx[g][2] = sv[g] * u2 + dp[g] * fn[1];
-    flx[g][3] = sv[g] * u3 + dp[g] * fn[2];
-    flx[g][4] = sv[g] * u4 + e4[g];
-  }
-}
-
 #define QDG_DISPATCH_PDG(m, CALL)                              \
   do {                                                         \
     if ((m).ndofel) { constexpr bool G = true; CALL; }         \

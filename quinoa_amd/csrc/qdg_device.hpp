@@ -84,8 +84,6 @@ struct DevMesh {
   // fold_slot[4 * (d - ninner) ...] (-1 = none); null: no folding
   const int* fold_slot;
   double* fold_slab;
-  int persistent;   // DG-P1 tile RHS: option p1_rhs when 2 (role-specialised persistent workgroups, k_rhs_p1r,
-                    // for launches of >= 2 tiles per CU) or 3 (always), else 0
   int ncomp;        // 5: CompFlow; dg::Transport: its number of scalars (rows of ncomp*ndof doubles)
   int pde;          // 0: CompFlow, 1: dg::Transport (QDG_PDE_*)
   // p-adaptive DG (scheme pdg): DG::m_ndof per device row, 1 or 4; null otherwise

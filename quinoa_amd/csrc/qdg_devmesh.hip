@@ -1194,7 +1194,6 @@ static int dev_build_layout(qdg_ctx* ctx, DevFD& fd, const std::vector<int>& bcf
   while (ntile_inner < ntile && std::min((size_t)(ntile_inner + 1) * TILE, nie) <= ninner) ++ntile_inner;
   dm.ntile = ntile; dm.ntile_inner = ntile_inner; dm.tile_row = m->tile_row.p; dm.task_stride = task_stride;
   dm.tile_rows = TILE;
-  dm.persistent = ctx->opt.p1_rhs >= 2 ? ctx->opt.p1_rhs : 0;
   dm.tile_off = m->tile_off.p; dm.task_a = m->task_a.p; dm.task_nb = m->task_nb.p; dm.task_f = m->task_f.p;
   dm.tgeo = nullptr;
   if (task_stride > 0 && ctx->cfg.ndof == 4) {
@@ -1797,6 +1796,7 @@ static int transfer_rows(qdg_mesh* from, qdg_mesh* to, size_t nrow, const int* d
   DHIP(hipGetLastError());
   DHIP(hipStreamSynchronize(s));
   to->Unp = nullptr; to->Upending = nullptr;
+  to->slab_ready_for = nullptr;        // the send slab no longer holds this state's rows (qdg_step_comm)
   return 0;
 }
 
@@ -1865,6 +1865,12 @@ __global__ void k_ghost_child_flag(const int* __restrict__ esuel2, size_t nown, 
   int f = 0;
   for (int q = 0; q < 4; ++q) { const int nb = esuel2[4 * c + q]; f |= (nb >= 0 && (size_t)nb < nown) ? 1 : 0; }
   flag[c - nown] = f;
+}
+// the sort keys below hold a global CHILD id 8 * gid + k in 48 bits: flag a parent id that does not fit
+__global__ void k_check_gid48(const uint64_t* __restrict__ gid, size_t n, int* __restrict__ err)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && gid[i] >= (1ull << 45)) *err = 1;
 }
 // keys of the new ghosts: (owner index << 48) | global child id; value = child index
 __global__ void k_ghost_keys(const int* __restrict__ flag, const int* __restrict__ pos, size_t nown, size_t nall,
@@ -2007,8 +2013,12 @@ extern "C" int qdg_mesh_refine_chunk(qdg_mesh* mesh, qdg_mesh** out, qdg_chunk_r
     const ChildTables& t = child_tables();
     DHIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_child), &t, sizeof t, 0, hipMemcpyHostToDevice, s));
     DHIP(hipMemsetAsync(d_err.p, 0, sizeof(int), s));
-    k_child_esuel<<<nblk(n4), 256, 0, s>>>(o.inpoel2.p, kp.esuel.p, n4, esuel2.p, d_err.p);
+    k_check_gid48<<<nblk(nunk), 256, 0, s>>>(kp.gid.p, nunk, d_err.p);
     int herr = 0;
+    DHIP(hipMemcpyAsync(&herr, d_err.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    DHIP(hipStreamSynchronize(s));
+    if (herr) return fail("qdg_mesh_refine_chunk: a global tet id is >= 2^45 (the children's ids 8 * gid + k must stay below 2^48)");
+    k_child_esuel<<<nblk(n4), 256, 0, s>>>(o.inpoel2.p, kp.esuel.p, n4, esuel2.p, d_err.p);
     DHIP(hipMemcpyAsync(&herr, d_err.p, sizeof(int), hipMemcpyDeviceToHost, s));
     DHIP(hipStreamSynchronize(s));
     if (herr) return fail("qdg_mesh_refine_chunk: a child face finds no partner across its parent's face");

@@ -256,12 +256,8 @@ __device__ __forceinline__ double superbee_phi1(const Tables<NDOF>& T, const dou
 // The limited rows are written once and read by the next kernel only after this one has streamed gigabytes
 // through the L2: non-temporal stores keep them from displacing the rows of U0 / R that the out-of-tile
 // neighbour gathers of the same launch find there (k_upd_superbee 1116 -> 1096 us at 10.1 M tets, 127 -> 123 us
-// at 1 M; QDG_TEMPORAL_ROW_STORES restores plain stores for A/B runs).
-#ifndef QDG_TEMPORAL_ROW_STORES
+// at 1 M).
 #define QDG_ROW_STORE(p, v) qdg::store_nt((p), (v))
-#else
-#define QDG_ROW_STORE(p, v) (*(p) = (v))
-#endif
 template <int NPROP>
 __device__ __forceinline__ void tile_store_rows_halves(double* __restrict__ U, int tile_e0, int nrows,
                                                        double* __restrict__ lds, const double* r)
@@ -572,11 +568,7 @@ __global__ __launch_bounds__(BS) void k_weno(DevMesh m, double cweight,
 #pragma unroll 5
       for (int j = 0; j < NPROP / 2; ++j) {
         const int i = j * BS + threadIdx.x;
-#ifndef QDG_TEMPORAL_ROW_STORES      // (non-temporal: qdg_devfn.hpp, store_nt)
-        if (i < nvalid) store_nt(dst + i, src[i]);
-#else
-        if (i < nvalid) dst[i] = src[i];
-#endif
+        if (i < nvalid) store_nt(dst + i, src[i]);      // (non-temporal: qdg_devfn.hpp, store_nt)
       }
     }
   } else {

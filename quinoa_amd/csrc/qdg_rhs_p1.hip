@@ -680,20 +680,15 @@ struct LyTile {            // planes [vertex][component][tet] over the whole til
   static constexpr int CS = TILE;
   __device__ static __forceinline__ int idx(int e, int v) { return v * NCOMP * TILE + e; }
 };
-struct LyBlk {             // the same planes per BLOCK of 62 tets, 4 blocks per tile: a wave of the role-specialised
-  static constexpr int BLK = 62, CS = BLK, VS = NCOMP * BLK, BSZ = 4 * VS;   // kernel owns its block's words
-  static_assert(4 * BLK == TILE || TILE != 248, "4 blocks of 62 tets = the 248-row tile");
-  __device__ static __forceinline__ int blk(int e) { return (e * 1058) >> 16; }          // e / 62 for e < 256
-  __device__ static __forceinline__ int idx(int e, int v) { const int b = blk(e); return b * BSZ + v * VS + (e - b * BLK); }
-};
 
-template <bool WITH_DT, int PROB, class LY = LyTile, bool ILP3 = false>
+template <bool WITH_DT, int PROB>
 __device__ __forceinline__ void face_task_lean(const DevMesh& m, const Phys& ph, double t,
                                                const double* __restrict__ U, double* __restrict__ nod,
                                                double* __restrict__ accN, double* __restrict__ sdelt,
                                                int a, const int* __restrict__ nbrow, int tile_e0,
                                                const double (&g4)[4])
 {
+  using LY = LyTile;
   constexpr int NDOF = 4, NGF = 3, NPROP = NCOMP * NDOF;
   constexpr bool HAS_DIRICHLET = (PROB == 3 || PROB == 4 || PROB == 0 || PROB == 7 || PROB == 10);
   const Tables<4>& T = c_tab4;
@@ -755,46 +750,6 @@ __device__ __forceinline__ void face_task_lean(const DevMesh& m, const Phys& ph,
   // 3-point rule: state at point g = B + V_h(g)/2, h(g) = (g+1)%3; vertex-weighted flux sums
   // W_j = A/18 (F_0+F_1+F_2) + A/6 F_g(j), g(j) = (j+2)%3   (Quadrature.cpp:261-339)
   double Fg[3][NCOMP], dsum = 0.0;
-  if constexpr (ILP3) {
-    // the three points side by side (see flux_hllc_own3): the same arithmetic per point
-    if (kind == TASK_BND) {
-#pragma unroll
-      for (int ig = 0; ig < NGF; ++ig) {
-        const double* so = Y[ig];
-        const double vn2 = refl * (so[1] * fn[0] + so[2] * fn[1] + so[3] * fn[2]);
-        X[ig][0] = so[0]; X[ig][1] = so[1] - vn2 * fn[0]; X[ig][2] = so[2] - vn2 * fn[1];
-        X[ig][3] = so[3] - vn2 * fn[2]; X[ig][4] = so[4];
-        if constexpr (HAS_DIRICHLET) {
-          if (bc == 1) {
-            double P[3];
-            face_point(gdir, lf, T.fs[ig][0], T.fs[ig][1], T.fs[ig][2], P);
-            prob_solution<PROB>(ph, P[0], P[1], P[2], t, X[ig]);
-          }
-        }
-      }
-    }
-    Prim3 qo, qn;
-    primitives3(ph, fn, Y, qo);
-    primitives3(ph, fn, X, qn);
-    if (WITH_DT) {
-#pragma unroll
-      for (int ig = 0; ig < NGF; ++ig) {
-        const double d_o = fabs(qo.vn[ig]) + qo.a[ig];
-        const double d_n = bnd ? 0.0 : fabs(qn.vn[ig]) + qn.a[ig];
-        const bool take_n = own_left ? (d_o < d_n) : !(d_n < d_o);
-        dsum += take_n ? d_n : d_o;
-      }
-    }
-    if (ph.flux == 1) {
-#pragma unroll
-      for (int ig = 0; ig < NGF; ++ig) {
-        const Prim a1{ qo.ir[ig], qo.p[ig], qo.a[ig], qo.vn[ig] }, a2{ qn.ir[ig], qn.p[ig], qn.a[ig], qn.vn[ig] };
-        flux_lf_q(fn, Y[ig], X[ig], a1, a2, Fg[ig]);
-      }
-    } else {
-      flux_hllc_own3(fn, Y, X, qo, qn, own_left, Fg);
-    }
-  } else {
 #pragma unroll
   for (int ig = 0; ig < NGF; ++ig) {
     double so[NCOMP], sn[NCOMP];
@@ -829,10 +784,7 @@ __device__ __forceinline__ void face_task_lean(const DevMesh& m, const Phys& ph,
     }
     if (ph.flux == 1) flux_lf_q(fn, so, sn, qo, qn, Fg[ig]);   // symmetric under the mirror image
     else flux_hllc_own(fn, so, sn, qo, qn, own_left, Fg[ig]);
-#ifndef QDG_FACE_ILP
     __builtin_amdgcn_sched_barrier(0);     // keep the three points in sequence (register pressure)
-#endif
-  }
   }
 
   // scatter the vertex-weighted flux sums: the own tet loses, the neighbour gains
@@ -1102,11 +1054,7 @@ __global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1w(DevMesh m, Phys ph, doub
       // non-temporal: the rows are read next by another kernel, after gigabytes of other traffic, and must not
       // displace the partner rows that the cross-tile face tasks of this launch find in the L2 (RHS launch
       // 1.54 -> 1.51 ms at 10.1 M tets; at 1 M the update + limiter kernel that follows gains 6 %)
-#ifndef QDG_TEMPORAL_ROW_STORES
       if (i < nvalid) store_nt(dst + i, src[i]);
-#else
-      if (i < nvalid) dst[i] = src[i];
-#endif
     }
   }
 
@@ -1121,364 +1069,6 @@ __global__ __launch_bounds__(TILE_BS, 2) void k_rhs_p1w(DevMesh m, Phys ph, doub
       for (int w = 1; w < (BS + 63) / 64; ++w) mn = fmin(mn, wmin[w]);
       blockmin[tile] = mn;
     }
-  }
-}
-
-// ------------------------------------------- DG-P1 RHS, role-specialised persistent workgroups
-// (round 4; option p1_rhs = 2).  ONE workgroup of 8 waves per CU walks over its share of the tiles.
-// Waves 0-3 are FACE waves: they run the face tasks of tile i (face_task_lean, the task lists of
-// k_rhs_p1w) back to back.  Waves 4-7 are STREAM waves, one block of 62 tets each: while the face
-// waves work on tile i they FINISH tile i-1 (accumulators -> modal row, scale, coalesced store of
-// the block's 62 rows through the block's own LDS words) and LOAD tile i+1 (rows of U [and Un], node
-// ids, volume, coordinates; vertex states to LDS; the volume term [+ source] and, for the fused RK
-// stages, the image of a*Un + b*U are computed from the row in registers and become the INITIAL
-// accumulators -- finishing a tile then needs no row: Uout = f_k * (face sums + G_k),
-// G_k = (a*Un + b*U)/f_k + volume term, f_k = b*dt*imf_k/vol).  LDS holds two tiles (2 x (vertex states
-// + accumulators) = 155 KB), hand-off by ONE workgroup barrier per tile.  Every SIMD hosts one face
-// wave (fp64 issue) and one stream wave (loads in flight for the whole face phase).
-// Reference work per face: src/PDE/Integrate/Surface.cpp:73-189; volume term Volume.cpp:54-111.
-constexpr int RBS = 512;                 // lanes of a role-specialised workgroup
-#ifndef QDG_P1R_ILP3
-#define QDG_P1R_ILP3 false      // the three Gauss points side by side: measured, no gain (profiles/r04_p1_experiments.log)
-#endif
-
-// volume term (+ source) of one tet from its four vertex states in registers: the arithmetic of
-// tet_volume_lean (which reads the same vertex states from LDS)
-template <int PROB>
-__device__ __forceinline__ void tet_volume_regs(const Phys& ph, double t, const double (&V)[4][NCOMP], double vol,
-                                                const ElemGeom& g, double (&acc)[NCOMP][4])
-{
-  constexpr int NDOF = 4;
-  const Tables<4>& T = c_tab4;
-  double ji[3][3];
-  inverse_jacobian(g, ji);
-  double SV[NCOMP], Fs[NCOMP][3];
-#pragma unroll
-  for (int c = 0; c < NCOMP; ++c) {
-    SV[c] = (V[0][c] + V[1][c]) + (V[2][c] + V[3][c]);
-    Fs[c][0] = Fs[c][1] = Fs[c][2] = 0.0;
-  }
-#pragma unroll
-  for (int ig = 0; ig < 5; ++ig) {
-    double s[NCOMP];
-#pragma unroll
-    for (int c = 0; c < NCOMP; ++c)
-      s[c] = (ig == 0) ? 0.25 * SV[c] : fma(1.0 / 3.0, V[(ig + 3) & 3][c], SV[c] * (1.0 / 6.0));
-    const double ir = fast_rcp(s[0]);
-    const double uu = s[1] * ir, vv = s[2] * ir, ww = s[3] * ir;
-    const double p = eos_pressure(ph, s[0], uu, vv, ww, s[4]);
-    const double wg = T.vw[ig];
-    const double h = s[4] + p;
-    Fs[0][0] += wg * s[1];            Fs[0][1] += wg * s[2];            Fs[0][2] += wg * s[3];
-    Fs[1][0] += wg * (s[1] * uu + p); Fs[1][1] += wg * (s[2] * uu);     Fs[1][2] += wg * (s[3] * uu);
-    Fs[2][0] += wg * (s[1] * vv);     Fs[2][1] += wg * (s[2] * vv + p); Fs[2][2] += wg * (s[3] * vv);
-    Fs[3][0] += wg * (s[1] * ww);     Fs[3][1] += wg * (s[2] * ww);     Fs[3][2] += wg * (s[3] * ww + p);
-    Fs[4][0] += wg * (uu * h);        Fs[4][1] += wg * (vv * h);        Fs[4][2] += wg * (ww * h);
-  }
-#pragma unroll
-  for (int c = 0; c < NCOMP; ++c) acc[c][0] = 0.0;
-#pragma unroll
-  for (int k = 1; k < NDOF; ++k) {
-    const double g0 = T.vdB[0][0][k], g1 = T.vdB[0][1][k], g2 = T.vdB[0][2][k];
-    const double dx = vol * (g0 * ji[0][0] + g1 * ji[1][0] + g2 * ji[2][0]);
-    const double dy = vol * (g0 * ji[0][1] + g1 * ji[1][1] + g2 * ji[2][1]);
-    const double dz = vol * (g0 * ji[0][2] + g1 * ji[1][2] + g2 * ji[2][2]);
-#pragma unroll
-    for (int c = 0; c < NCOMP; ++c) acc[c][k] = Fs[c][0] * dx + Fs[c][1] * dy + Fs[c][2] * dz;
-  }
-  if constexpr (prob_has_source<PROB>()) {
-#pragma unroll 1
-    for (int ig = 0; ig < 5; ++ig) {
-      const double xi = T.vc[ig][0], eta = T.vc[ig][1], zeta = T.vc[ig][2];
-      const double w0 = 1.0 - xi - eta - zeta;
-      double P[3], s[NCOMP];
-#pragma unroll
-      for (int d = 0; d < 3; ++d)
-        P[d] = g.p[0][d] * w0 + g.p[1][d] * xi + g.p[2][d] * eta + g.p[3][d] * zeta;
-      prob_src<PROB>(ph, P[0], P[1], P[2], t, s);
-      const double wt = T.vw[ig] * vol;
-#pragma unroll
-      for (int c = 0; c < NCOMP; ++c) {
-        const double ws = wt * s[c];
-        acc[c][0] += ws;
-#pragma unroll
-        for (int k = 1; k < NDOF; ++k) acc[c][k] += ws * T.vB[ig][k];
-      }
-    }
-  }
-}
-
-template <bool WITH_DT, bool FUSE_RK, int PROB>
-__global__ __launch_bounds__(RBS, 1) void k_rhs_p1r(DevMesh m, Phys ph, double t,
-                                                    const double* __restrict__ U, double* __restrict__ R,
-                                                    double* __restrict__ blockmin, double rk_a, double rk_b,
-                                                    const double* __restrict__ dtp,
-                                                    const double* __restrict__ Un, int ntile_run)
-{
-  constexpr int NDOF = 4, NPROP = NCOMP * NDOF, NR = 4, FBS = TILE_BS;
-  static_assert(TILE == 248 && TILE_BS == 256, "k_rhs_p1r: 4 blocks of 62 tets, 4 rounds of 256 task slots");
-  constexpr double imf[4] = { 1.0, 10.0, 10.0 / 3.0, 5.0 / 3.0 };
-  __shared__ __attribute__((aligned(16))) double nodS[2][TILE * NPROP];
-  __shared__ __attribute__((aligned(16))) double accS[2][TILE * NPROP];
-  __shared__ double sdeltS[WITH_DT ? 2 * TILE : 1];
-  __shared__ double wminS[WITH_DT ? 8 : 1];
-  const int tid = threadIdx.x;
-  const bool face = tid < FBS;
-  // this workgroup's tiles: XCD x owns the contiguous range of tiles xcd_tile() would give it; its
-  // workgroups stride through that range, so that the tiles in flight on an XCD are neighbours
-  constexpr int NXCD = 8;
-  const int nwg = gridDim.x, xcd = blockIdx.x % NXCD, jw = blockIdx.x / NXCD;
-  const int wgx = nwg / NXCD + (xcd < nwg % NXCD ? 1 : 0);             // workgroups on this XCD
-  const int per = ntile_run / NXCD, rem = ntile_run - per * NXCD;
-  const int x0 = m.blk0 + xcd * per + (xcd < rem ? xcd : rem), cnt = per + (xcd < rem ? 1 : 0);
-  const int ntl = (jw < cnt) ? (cnt - jw + wgx - 1) / wgx : 0;          // tiles of this workgroup
-  auto tile_of = [&](int i) { return x0 + jw + i * wgx; };
-
-  // ---- stream lanes: tet tl of block w ----
-  const int stid = tid - FBS, sw = stid >> 6, sl = stid & 63;
-  const int tl = LyBlk::BLK * sw + sl;
-  const bool slot = !face && sl < LyBlk::BLK;          // lane owns a tet slot of the tile
-
-  // the loads of a tile are REQUESTED at the top of a step and CONSUMED after the previous tile has been
-  // finished, so that their latency runs under that work; the node ids come one step earlier still (four
-  // loop-carried registers), so that the coordinate gathers go out with the rows
-  struct StreamRegs { double r[NCOMP][NDOF]; double un[NCOMP][NDOF]; double vol; ElemGeom g; };
-  auto tile_row = [&](int tile) {
-    const int tile_e0 = tile * TILE;
-    const int nloc = (m.nie - tile_e0 < TILE) ? m.nie - tile_e0 : TILE;
-    return tile_e0 + ((tl < nloc) ? tl : 0);
-  };
-  auto load_ids = [&](int tile, int (&in4)[4]) {
-    if (!slot) return;
-    const int erow = tile_row(tile);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) in4[i] = m.inpoel[(size_t)i * m.stride + erow];
-  };
-  auto load_issue = [&](int tile, const int (&in4)[4], StreamRegs& sr) {
-    if (!slot) return;
-    const int erow = tile_row(tile);
-    load_row<NPROP>(U, erow, &sr.r[0][0]);
-    if constexpr (FUSE_RK) load_row<NPROP>(Un, erow, &sr.un[0][0]);
-    sr.vol = m.vol[erow];
-    double q[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      load_row<4>(m.xyz4, in4[i], q);
-      sr.g.p[i][0] = q[0]; sr.g.p[i][1] = q[1]; sr.g.p[i][2] = q[2];
-    }
-  };
-  // vertex states and initial accumulators of tile `tile` into buffer `b`
-  auto load_consume = [&](int tile, int b, StreamRegs& sr) {
-    if (!slot) return;
-    const int tile_e0 = tile * TILE;
-    const int nloc = (m.nie - tile_e0 < TILE) ? m.nie - tile_e0 : TILE;
-    const bool act = tl < nloc;
-    double (&r)[NCOMP][NDOF] = sr.r;
-    const double vol = sr.vol;
-    double* nod = nodS[b];
-    double* accN = accS[b];
-    if (!act) {
-#pragma unroll
-      for (int c = 0; c < NCOMP; ++c) { r[c][0] = 1.0; r[c][1] = r[c][2] = r[c][3] = 0.0; }
-    }
-    // the image of the RK combination first: un <- (a*Un + b*U) / f_k (the two rows are dead after this)
-    if constexpr (FUSE_RK) {
-      const double bdtv = rk_b * dtp[0] / vol;
-#pragma unroll
-      for (int k = 0; k < NDOF; ++k) {
-        const double ifk = 1.0 / (bdtv * imf[k]);
-#pragma unroll
-        for (int c = 0; c < NCOMP; ++c) sr.un[c][k] = (rk_a * sr.un[c][k] + rk_b * r[c][k]) * ifk;
-      }
-    }
-    double V[4][NCOMP];
-#pragma unroll
-    for (int c = 0; c < NCOMP; ++c) {
-      const double a = r[c][0] - r[c][3];
-      V[0][c] = a - r[c][1] - r[c][2];
-      V[1][c] = a + r[c][1] - r[c][2];
-      V[2][c] = a + 2.0 * r[c][2];
-      V[3][c] = r[c][0] + 3.0 * r[c][3];
-#pragma unroll
-      for (int vx = 0; vx < 4; ++vx) nod[LyBlk::idx(tl, vx) + c * LyBlk::CS] = V[vx][c];
-    }
-    double G[NCOMP][NDOF];
-    if (act) {
-#ifndef QDG_P1R_KO_VOL
-      tet_volume_regs<PROB>(ph, t, V, vol, sr.g, G);
-#else
-#pragma unroll
-      for (int c = 0; c < NCOMP; ++c) G[c][0] = G[c][1] = G[c][2] = G[c][3] = sr.g.p[c & 3][c % 3];
-#endif
-      if constexpr (FUSE_RK) {
-#pragma unroll
-        for (int c = 0; c < NCOMP; ++c)
-#pragma unroll
-          for (int k = 0; k < NDOF; ++k) G[c][k] += sr.un[c][k];
-      }
-    } else {
-#pragma unroll
-      for (int c = 0; c < NCOMP; ++c) G[c][0] = G[c][1] = G[c][2] = G[c][3] = 0.0;
-    }
-    // the accumulators start at the vertex image of G: tet_face_sums maps (n0..n3) to
-    // (n0+n1+n2+n3, n1-n0, 2 n2-n0-n1, 3 n3-n0-n1-n2)
-#pragma unroll
-    for (int c = 0; c < NCOMP; ++c) {
-      const double n3 = 0.25 * (G[c][0] + G[c][3]);
-      const double T3 = G[c][0] - n3;
-      const double n2 = (G[c][2] + T3) * (1.0 / 3.0);
-      const double Q = T3 - n2;
-      const double n1 = 0.5 * (Q + G[c][1]), n0 = 0.5 * (Q - G[c][1]);
-      accN[LyBlk::idx(tl, 0) + c * LyBlk::CS] = n0;
-      accN[LyBlk::idx(tl, 1) + c * LyBlk::CS] = n1;
-      accN[LyBlk::idx(tl, 2) + c * LyBlk::CS] = n2;
-      accN[LyBlk::idx(tl, 3) + c * LyBlk::CS] = n3;
-    }
-    if (WITH_DT) sdeltS[b * TILE + tl] = 0.0;
-  };
-
-  // finish tile `tile` from buffer `b`: rows out; the block's minimum of vol / delt into wminS
-  auto finish_tile = [&](int tile, int b) {
-    if (face) return;
-    const int tile_e0 = tile * TILE;
-    const int nloc = (m.nie - tile_e0 < TILE) ? m.nie - tile_e0 : TILE;
-    const bool act = slot && tl < nloc;
-    double* nod = nodS[b];
-    const double* accN = accS[b];
-    double dte = DBL_MAX;
-    if (act) {
-      const double vol = m.vol[tile_e0 + tl];
-      [[maybe_unused]] double fk[NDOF] = { 1.0, 1.0, 1.0, 1.0 };
-      if constexpr (FUSE_RK) {
-        const double bdtv = rk_b * dtp[0] / vol;
-#pragma unroll
-        for (int k = 0; k < NDOF; ++k) fk[k] = bdtv * imf[k];
-      }
-      if (WITH_DT) dte = vol / sdeltS[b * TILE + tl];
-      // all accumulators are read before the first staging store: the block's rows, row-major, go over the
-      // block's own vertex-state words (nobody reads those any more), component by component
-      double n[NCOMP][4];
-#pragma unroll
-      for (int c = 0; c < NCOMP; ++c)
-#pragma unroll
-        for (int v = 0; v < 4; ++v) n[c][v] = accN[LyBlk::idx(tl, v) + c * LyBlk::CS];
-      double2* row = reinterpret_cast<double2*>(nod + (size_t)sw * LyBlk::BSZ + (size_t)sl * NPROP);
-#pragma unroll
-      for (int c = 0; c < NCOMP; ++c) {
-        const double n0 = n[c][0], n1 = n[c][1], n2 = n[c][2], n3 = n[c][3];
-        double o0 = (n0 + n1) + (n2 + n3), o1 = n1 - n0, o2 = 2.0 * n2 - n0 - n1, o3 = 3.0 * n3 - n0 - n1 - n2;
-        if constexpr (FUSE_RK) { o0 *= fk[0]; o1 *= fk[1]; o2 *= fk[2]; o3 *= fk[3]; }
-        row[2 * c] = make_double2(o0, o1);
-        row[2 * c + 1] = make_double2(o2, o3);
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    {
-      const int nrows = nloc - LyBlk::BLK * sw;                       // rows of this block that exist
-      const int nvalid = (nrows < 0 ? 0 : nrows > LyBlk::BLK ? LyBlk::BLK : nrows) * (NPROP / 2);
-      const double2* src = reinterpret_cast<const double2*>(nod + (size_t)sw * LyBlk::BSZ);
-      double2* dst = reinterpret_cast<double2*>(R + ((size_t)tile_e0 + (size_t)LyBlk::BLK * sw) * NPROP);
-#pragma unroll
-      for (int j = 0; j < NPROP / 2; ++j) {
-        const int i = j * 64 + sl;
-        if (i < nvalid) dst[i] = src[i];
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    if (WITH_DT) {
-      for (int off = 32; off > 0; off >>= 1) dte = fmin(dte, __shfl_down(dte, off, 64));
-      if (sl == 0) wminS[(b & 1) * 4 + sw] = dte;
-    }
-  };
-
-  // ---- prologue ----
-  int in4n[4] = { 0, 0, 0, 0 };                 // node ids of the tile the stream lanes load next
-  if (!face && ntl > 0) {
-    StreamRegs sr;
-    load_ids(tile_of(0), in4n);
-    load_issue(tile_of(0), in4n, sr);
-    if (ntl > 1) load_ids(tile_of(1), in4n);
-    load_consume(tile_of(0), 0, sr);
-  }
-  // the face lanes' task words, neighbour rows and first face record of tile 0
-  int ta[NR], tb[NR];
-  double gnx[4];
-  size_t slot0 = 0;
-  if (face && ntl > 0) {
-    slot0 = (size_t)tile_of(0) * (4 * FBS) + tid;
-#pragma unroll
-    for (int q = 0; q < NR; ++q) { ta[q] = m.task_a[slot0 + FBS * q]; tb[q] = m.task_nb[slot0 + FBS * q]; }
-    load_row<4>(m.tgeo, slot0, gnx);
-  }
-  __syncthreads();
-
-  // The two roles run their own loops (one workgroup barrier per step in each: s_barrier counts waves, and a
-  // wave is in one role for good) -- written as ONE loop with a role branch inside, the register allocator
-  // merges the live ranges of both bodies and spills (256 registers + 96 B of scratch against 200 / 228).
-  if (face) {
-#pragma unroll 1
-    for (int i = 0; i <= ntl; ++i) {
-      const int b = i & 1;
-      if (i < ntl) {
-        const int tile = tile_of(i);
-        const int tile_e0 = tile * TILE;
-        // the next tile's task words and neighbour rows are requested now and used one step later
-        int tn[NR] = { -1, -1, -1, -1 }, tnb[NR] = { 0, 0, 0, 0 };
-        size_t slotn = 0;
-        if (i + 1 < ntl) {
-          slotn = (size_t)tile_of(i + 1) * (4 * FBS) + tid;
-#pragma unroll
-          for (int q = 0; q < NR; ++q) { tn[q] = m.task_a[slotn + FBS * q]; tnb[q] = m.task_nb[slotn + FBS * q]; }
-        }
-#ifndef QDG_P1R_KO_FACE
-#pragma unroll 1
-        for (int q = 0; q < NR; ++q) {
-          const int a = (q == 0) ? ta[0] : (q == 1) ? ta[1] : (q == 2) ? ta[2] : ta[3];
-          if (a < 0) break;
-          const int nbr_row = (q == 0) ? tb[0] : (q == 1) ? tb[1] : (q == 2) ? tb[2] : tb[3];
-          const double g4[4] = { gnx[0], gnx[1], gnx[2], gnx[3] };
-          const int an_ = (q == 0) ? ta[1] : (q == 1) ? ta[2] : (q == 2) ? ta[3] : -1;
-          if (an_ >= 0) load_row<4>(m.tgeo, slot0 + (size_t)FBS * (q + 1), gnx);
-          face_task_lean<WITH_DT, PROB, LyBlk, QDG_P1R_ILP3>(m, ph, t, U, nodS[b], accS[b], sdeltS + (WITH_DT ? b * TILE : 0), a,
-                                               &nbr_row, tile_e0, g4);
-        }
-#endif
-        if (i + 1 < ntl) {
-#pragma unroll
-          for (int q = 0; q < NR; ++q) { ta[q] = tn[q]; tb[q] = tnb[q]; }
-          slot0 = slotn;
-          load_row<4>(m.tgeo, slot0, gnx);
-        }
-      }
-      // the minimum of the tile finished one step ago (its four block minima are in LDS since the last barrier)
-      if (WITH_DT && tid == 0 && i >= 2) {
-        const double* w = wminS + ((i - 2) & 1) * 4;
-        blockmin[tile_of(i - 2)] = fmin(fmin(w[0], w[1]), fmin(w[2], w[3]));
-      }
-      __syncthreads();
-    }
-  } else {
-#pragma unroll 1
-    for (int i = 0; i <= ntl; ++i) {
-      const int b = i & 1;
-#ifndef QDG_P1R_KO_STREAM
-      StreamRegs sr;
-      const bool more = i + 1 < ntl;
-      if (more) {
-        load_issue(tile_of(i + 1), in4n, sr);
-        if (i + 2 < ntl) load_ids(tile_of(i + 2), in4n);
-      }
-      if (i >= 1) finish_tile(tile_of(i - 1), 1 - b);
-      if (more) load_consume(tile_of(i + 1), 1 - b, sr);
-#endif
-      __syncthreads();
-    }
-  }
-  if (WITH_DT && tid == 0 && ntl >= 1) {
-    const double* w = wminS + ((ntl - 1) & 1) * 4;
-    blockmin[tile_of(ntl - 1)] = fmin(fmin(w[0], w[1]), fmin(w[2], w[3]));
   }
 }
 
@@ -1507,23 +1097,6 @@ void launch_rhs_p1(const DevMesh& m, const Phys& ph, double t, const double* U, 
   }
 }
 
-// one role-specialised workgroup per CU
-static int persistent_grid()
-{
-  static const int ncu = [] {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-      n = 256;
-    return n / 8 * 8;                    // a multiple of the XCD count
-  }();
-  return ncu;
-}
-// (launches of fewer than two tiles per workgroup keep the one-tile-per-workgroup kernel)
-static bool use_persistent(const DevMesh& m, int ntile_run)
-{
-  return m.persistent == 3 || (m.persistent == 2 && ntile_run >= 2 * persistent_grid());
-}
-
 // tile / face-task form of the P1 RHS; tiles [first, first+count) (count < 0: all).
 // Uniform order runs k_rhs_p1w, p-adaptive meshes (m.ndofel) k_rhs_p1t.  With with_dt the
 // launch that ends at the last tile also reduces the per-tile minima to the time step.
@@ -1535,14 +1108,7 @@ void launch_rhs_p1t(const DevMesh& m0, const Phys& ph, double t, const double* U
   DevMesh m = m0;
   m.blk0 = first;
   const int nb = count < 0 ? m.ntile - first : count;
-  if (nb > 0 && !m.ndofel && use_persistent(m, nb)) {
-    const int nwg = persistent_grid();
-    if (with_dt) {
-      QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1r<true, false, P><<<nwg, RBS, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr, nb)));
-    } else {
-      QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1r<false, false, P><<<nwg, RBS, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr, nb)));
-    }
-  } else if (nb > 0 && !m.ndofel) {
+  if (nb > 0 && !m.ndofel) {
     if (with_dt) {
       QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1w<true, false, P><<<nb, TILE_BS, 0, s>>>(m, ph, t, U, R, blockmin, 0.0, 0.0, nullptr, nullptr)));
     } else {
@@ -1568,10 +1134,6 @@ void launch_rhs_p1t_rk(const DevMesh& m0, const Phys& ph, double t, const double
   m.blk0 = first;
   const int nb = count < 0 ? m.ntile - first : count;
   if (nb <= 0) return;
-  if (!m.ndofel && use_persistent(m, nb)) {
-    QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1r<false, true, P><<<persistent_grid(), RBS, 0, s>>>(m, ph, t, U, Uout, nullptr, a, b, dt, Un, nb)));
-    return;
-  }
   if (!m.ndofel) {
     QDG_DISPATCH_PROB(ph.problem, (k_rhs_p1w<false, true, P><<<nb, TILE_BS, 0, s>>>(m, ph, t, U, Uout, nullptr, a, b, dt, Un)));
     return;

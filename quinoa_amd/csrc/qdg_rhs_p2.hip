@@ -303,11 +303,7 @@ __global__ __launch_bounds__(256, 2) void k_rhs_p2s(DevMesh m, Phys ph, double t
 #pragma unroll
     for (int j = 0; j < (TPB * NPROP / 2 + 255) / 256; ++j) {
       const int i = j * 256 + tid;
-#ifndef QDG_TEMPORAL_ROW_STORES      // (non-temporal: qdg_devfn.hpp, store_nt)
-      if (i < nvalid) store_nt(dst + i, src[i]);
-#else
-      if (i < nvalid) dst[i] = src[i];
-#endif
+      if (i < nvalid) store_nt(dst + i, src[i]);      // (non-temporal: qdg_devfn.hpp, store_nt)
     }
   }
   if (WITH_DT) {

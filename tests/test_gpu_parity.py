@@ -286,43 +286,6 @@ def test_element_centric_rhs_kernel_passes_the_same_golden_runs(cases, monkeypat
     test_time_stepping_matches_reference_golden("vortical_flow_dgp1_lf", cases)
 
 
-def test_role_specialised_persistent_rhs_kernel_passes_the_same_golden_runs(cases, monkeypatch):
-    """Option p1_rhs = 3 forces the role-specialised persistent DG-P1 kernel (k_rhs_p1r: face waves and
-    stream waves of one workgroup per CU, two tiles in LDS, the RK image folded into the initial
-    accumulators) on every launch, also on meshes of a few tiles: the same golden runs and operator checks
-    as the default tile kernel, plus a mesh with a ragged last tile and more tiles than workgroups on some XCDs."""
-    from quinoa_amd import capi, meshgen
-    monkeypatch.setattr(capi, "default_options", {"p1_rhs": 3})
-    test_time_stepping_matches_reference_golden("sedov_dgp1", cases)
-    test_operators_match_oracle("sedov_dgp1", cases)
-    test_time_stepping_matches_reference_golden("vortical_flow_dgp1", cases)
-    test_operators_match_oracle("vortical_flow_dgp1", cases)
-    test_time_stepping_matches_reference_golden("vortical_flow_dgp1_lf", cases)
-    test_final_state_matches_oracle_full_dof_vector(cases)
-    # 55^3 box: 4 026 tiles over 256 workgroups (15 or 16 tiles each), against the default kernel
-    ch = meshgen.kuhn_box(55, 55, 55)
-    kw = dict(flux="hllc", limiter="superbeep1", problem="sod_shocktube", gamma=1.4, cfl=0.3,
-              bc_extrapolate=[1, 2], bc_sym=[3, 4, 5, 6])
-    out = {}
-    for mode in (0, 2):
-        ctx = capi.Context(4, options={"p1_rhs": mode}, **kw)
-        mesh = capi.mesh_from_connectivity(ctx, ch["inpoel"], ch["coord"], ch["sidesets"])
-        try:
-            mesh.state_initialize(0.0)
-            U0 = mesh.state_download()
-            R = mesh.rhs(0.0, U0)
-            t = 0.0
-            for _ in range(4):
-                t += mesh.step(t)
-            out[mode] = (R, t, mesh.state_download())
-        finally:
-            mesh.close(); ctx.close()
-    a, b = out[0], out[2]
-    assert np.abs(a[0] - b[0]).max() <= 1e-12 * np.abs(a[0]).max()
-    assert abs(a[1] - b[1]) <= 1e-13 * a[1]
-    assert compflow_err(b[2], a[2], 4) <= 1e-11
-
-
 def test_element_centric_rhs_kernel_is_bitwise_reproducible(cases):
     """two runs of the same steps with p1_rhs = 1 give identical bits"""
     from quinoa_amd import capi, dgmesh, meshgen
