@@ -135,9 +135,13 @@ def cpu_baseline(budget_s=10.0, budget_all_s=5.0):
     return out
 
 
-def run_workload(args, rank, world, local_rank, dims, lengths, parts, steps, warmup, comm_kind, use_dist):
-    """One timed run of the Sod DG-P1 workload on the box `dims` (global hexes per axis) cut
-    into `parts`; returns the measurements of this rank's chunk (max/sum over ranks done)."""
+def run_workload(args, rank, world, local_rank, dims, lengths, parts, steps, warmup, comm_kind, use_dist, develop):
+    """One run of the DG-P1 workload on the box `dims` (global hexes per axis) cut into `parts`:
+    `warmup` untimed steps, `steps` timed steps from the initial state (the COLD-START reading),
+    `develop` untimed steps that let the flow develop, then the `steps` timed steps of the headline,
+    bracketed by barrier + synchronize, with nothing but the step in the loop; last, a short loop with
+    HIP events around every RHS launch, halo exchange and all-reduce (qdg_profile_*).  Returns the
+    measurements of this rank's chunk (max / sum over ranks done)."""
     import numpy as np
     import torch
     from quinoa_amd import capi, dg, meshgen
@@ -146,12 +150,13 @@ def run_workload(args, rank, world, local_rank, dims, lengths, parts, steps, war
     if self_halo:
         ch["nbr_rank"] = [0 for _ in ch["nbr_rank"]]
     nielem = int(ch["nielem"])
+    opts = {"graph_step": 0 if args.no_graph else 1}
     if args.workload == "sedov":     # config 4's physics (symmetry on x-min, y-min and the z faces)
         ctx = capi.Context(4, flux="hllc", limiter="superbeep1", problem="sedov_blastwave", gamma=1.4,
-                           cfl=0.3, bc_extrapolate=[2, 4], bc_sym=[1, 3, 5, 6], device=local_rank)
+                           cfl=0.3, bc_extrapolate=[2, 4], bc_sym=[1, 3, 5, 6], device=local_rank, options=opts)
     else:
         ctx = capi.Context(4, flux="hllc", limiter="superbeep1", problem="sod_shocktube", gamma=1.4,
-                           cfl=0.3, bc_extrapolate=[1, 2], bc_sym=[3, 4, 5, 6], device=local_rank)
+                           cfl=0.3, bc_extrapolate=[1, 2], bc_sym=[3, 4, 5, 6], device=local_rank, options=opts)
     # FaceData, geometry and the device layout of the chunk (with its ghost layer) are built on
     # the GPU: only connectivity, coordinates and side-set triangles cross PCIe
     # ... with the tets' global ids: faces oriented by global id, so the N-rank run takes the branches of the
@@ -191,17 +196,32 @@ def run_workload(args, rank, world, local_rank, dims, lengths, parts, steps, war
         if use_dist:
             torch.distributed.barrier()
 
+    def timed(n):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            drv.step(0.0)
+        sync()
+        return time.perf_counter() - t0
+
     for _ in range(warmup):
         drv.step(0.0)
-    sync()
+    el_cold = timed(steps) if develop > 0 else None        # the first steps after the initial discontinuity
+    t_flow = 0.0
+    for i in range(develop):                               # untimed: the flow develops
+        drv.step(0.0)
+        if (i & 255) == 255:
+            t_flow += 256 * drv.dt_taken()                  # (dt varies slowly: sampled, for the record only)
+    el = timed(steps)                                       # THE measurement: nothing but the step in the loop
+    # a second, short loop with events on the library's stream around every RHS launch, exchange and all-reduce
+    nprof = max(5, min(steps, 10))
     mesh.profile_enable(True)
-    t0 = time.perf_counter()
-    for _ in range(steps):
+    for _ in range(nprof):
         drv.step(0.0)
     sync()
-    el = time.perf_counter() - t0
-    nl, ms = mesh.profile_read()
+    pr = mesh.profile_read_all() if hasattr(mesh, "profile_read_all") else None
     mesh.profile_enable(False)
+    nl, ms = pr["rhs"]
     dt_last = drv.dt_taken()
     if not (dt_last > 0.0 and np.isfinite(dt_last)):
         raise SystemExit("invalid run: dt = %r" % dt_last)
@@ -211,21 +231,32 @@ def run_workload(args, rank, world, local_rank, dims, lengths, parts, steps, war
     ntet = nielem
     # what the transport itself reports: ranks in the RCCL communicator (ncclCommCount), this rank's device
     seen = None
+    graph = None
     if isinstance(comm, dg.RcclComm):
         seen = comm.comm.info()
+        st, ng, nrep, err = mesh.step_graph_status()
+        graph = {"state": {0: "not tried", 1: "in use", -1: "refused"}.get(st, st), "graphs": ng, "replays": nrep,
+                 "error": err or None}
     per_rank = [{"rank": rank, "tets": nielem, "ghost_tets": int(len(ch["gid"]) - nielem),
                  "neighbours": [int(r) for r in ch["nbr_rank"]], "device": local_rank,
-                 "rhs_avg_launch_ms": ms / max(nl, 1)}]
+                 "rhs_avg_launch_ms": ms / max(nl, 1),
+                 # the communication of a step where it happens (events around every exchange = pack + grouped
+                 # ncclSend / ncclRecv incl. the gaps in front of them, and around the dt all-reduce)
+                 "exchanges_per_step": pr["halo"][0] / nprof, "halo_ms_per_step": pr["halo"][1] / nprof,
+                 "allreduces_per_step": pr["allreduce"][0] / nprof,
+                 "allreduce_ms_per_step": pr["allreduce"][1] / nprof,
+                 "step_graph": graph}]
     if world > 1:
-        tt = torch.tensor([el, float(ntet)], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([el, float(ntet), el_cold or 0.0], dtype=torch.float64, device="cuda")
         mx = tt.clone(); torch.distributed.all_reduce(mx, op=torch.distributed.ReduceOp.MAX)
         sm = tt.clone(); torch.distributed.all_reduce(sm, op=torch.distributed.ReduceOp.SUM)
         el, ntet = float(mx[0]), int(round(float(sm[1])))
+        el_cold = float(mx[2]) if el_cold is not None else None
         gathered = [None] * world
         torch.distributed.all_gather_object(gathered, per_rank[0])
         per_rank = gathered
-    res = {"el": el, "ntet": ntet, "ntet_local": nielem, "avg_ms": ms / max(nl, 1), "launches": nl,
-           "alg": mesh.rhs_algorithmic_bytes(), "dt_last": dt_last, "drift": drift,
+    res = {"el": el, "el_cold": el_cold, "ntet": ntet, "ntet_local": nielem, "avg_ms": ms / max(nl, 1), "launches": nl,
+           "alg": mesh.rhs_algorithmic_bytes(), "dt_last": dt_last, "drift": drift, "develop": develop, "t_flow": t_flow,
            "backend": None if comm is None else comm.backend, "per_rank": per_rank,
            "ranks_seen_by_rccl": None if seen is None else seen[0]}
     mesh.close()
@@ -405,16 +436,7 @@ def config3_point(local_rank, nx=110, steps=20):
                        bc_dirichlet=[1, 2, 3, 4, 5, 6], device=local_rank)
     mesh = capi.mesh_from_connectivity(ctx, ch["inpoel"], ch["coord"], ch["sidesets"])
     mesh.state_initialize(0.0)
-    for _ in range(2):
-        mesh.step(0.0, want_dt=False)
-    ctx.synchronize()
-    mesh.profile_enable(True)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        mesh.step(0.0, want_dt=False)
-    ctx.synchronize()
-    el = (time.perf_counter() - t0) / steps
-    nl, ms = mesh.profile_read()
+    el, nl, ms = _time_single_chunk(ctx, mesh, steps, warm=2)
     alg = mesh.rhs_algorithmic_bytes()
     U = mesh.state_download()
     ok = bool(np.isfinite(U).all())
@@ -440,9 +462,36 @@ def config3_point(local_rank, nx=110, steps=20):
             "roofline_binding": binding}
 
 
-def config4_point(local_rank, nx=110, steps=20):
+def _time_single_chunk(ctx, mesh, steps, warm=2, develop=0):
+    """`warm` + `develop` untimed steps, `steps` timed steps with nothing but the step in the loop, then a short
+    loop with HIP events around the RHS launches; -> (seconds per step, profiled launches, their summed ms)
+    [+ seconds per step of the first `steps` steps when develop > 0]"""
+    def timed(n):
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            mesh.step(0.0, want_dt=False)
+        ctx.synchronize()
+        return (time.perf_counter() - t0) / n
+    for _ in range(warm):
+        mesh.step(0.0, want_dt=False)
+    cold = timed(steps) if develop > 0 else None
+    for _ in range(develop):
+        mesh.step(0.0, want_dt=False)
+    el = timed(steps)
+    mesh.profile_enable(True)
+    for _ in range(max(3, min(steps, 8))):
+        mesh.step(0.0, want_dt=False)
+    ctx.synchronize()
+    nl, ms = mesh.profile_read()
+    mesh.profile_enable(False)
+    return (el, nl, ms) if cold is None else (el, nl, ms, cold)
+
+
+def config4_point(local_rank, nx=110, steps=20, develop=2000):
     """One GPU's share of BASELINE config 4 (Sedov blast DG-P1 + Superbee, CFL 0.3, 64 M tets over
-    8 GPUs): nx^3 x 6 = 7 986 000 tets on this GPU, no halo (the 8-GPU run is `--gpus 8 --nx 110`)."""
+    8 GPUs): nx^3 x 6 = 7 986 000 tets on this GPU, no halo (the 8-GPU run is `--gpus 8 --nx 110`);
+    timed after `develop` untimed steps (the blast has left its corner), cold-start rate beside it."""
     import numpy as np
     from quinoa_amd import capi, meshgen
     ch = meshgen.kuhn_box(nx, nx, nx)
@@ -450,16 +499,9 @@ def config4_point(local_rank, nx=110, steps=20):
                        bc_sym=[1, 3, 5, 6], bc_extrapolate=[2, 4], device=local_rank)
     mesh = capi.mesh_from_connectivity(ctx, ch["inpoel"], ch["coord"], ch["sidesets"])
     mesh.state_initialize(0.0)
-    for _ in range(2):
-        mesh.step(0.0, want_dt=False)
-    ctx.synchronize()
-    mesh.profile_enable(True)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        mesh.step(0.0, want_dt=False)
-    ctx.synchronize()
-    el = (time.perf_counter() - t0) / steps
-    nl, ms = mesh.profile_read()
+    r = _time_single_chunk(ctx, mesh, steps, warm=2, develop=develop)
+    el, nl, ms = r[:3]
+    cold = r[3] if len(r) > 3 else None
     alg = mesh.rhs_algorithmic_bytes()
     U = mesh.state_download()
     ok = bool(np.isfinite(U).all())
@@ -467,12 +509,58 @@ def config4_point(local_rank, nx=110, steps=20):
     mesh.close(); ctx.close()
     ach = alg / (ms / nl * 1e-3) / 1e9
     return {"workload": "CompFlow Sedov blast wave DG-P1 + superbeep1, CFL 0.3, Kuhn-tet box %d^3 hexes = %d tets "
-                        "(one GPU's share of config 4), %d timed steps" % (nx, ne, steps),
+                        "(one GPU's share of config 4), %d timed steps after %d untimed ones" % (nx, ne, steps, develop),
             "tets_total": ne, "steps": steps, "value": ne * 3 / el / 1e6, "unit": "M element-updates/s",
             "ms_per_step": el * 1e3, "finite": ok,
+            "cold_start_M_per_s": None if cold is None else ne * 3 / cold / 1e6,
             "roofline": {"bound": "hbm", "kernel": "qdg::k_rhs_p1w", "achieved": ach, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "avg_launch_ms": ms / nl, "launches": nl,
                          "algorithmic_bytes_per_launch": alg, "traffic": None}}
+
+
+def real_mesh_point(local_rank, levels=(2, 3), steps=20, develop=500):
+    """A genuinely unstructured mesh: the reference's own 31 304-tet unit-cube fixture (unitcube_01_31k.exo of
+    its SlotCyl / Sod regression cases, kept as data in tests/golden/slot_cyl_dg.npz), refined 1:8 on the device
+    `levels` times (2.0 M / 16.0 M tets) -- valence, nodes per tet and tile surface are a mesh generator's, not
+    the Kuhn box's.  Sod DG-P1 + Superbee, CFL 0.3: step rate, RHS roofline fraction, face-task mix."""
+    import numpy as np
+    from quinoa_amd import capi
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "slot_cyl_dg.npz"))
+    coord, inpoel, tri = fx["coord"], fx["inpoel"], fx["ss_tri_1"]
+    # the fixture lists the whole boundary as one side set: split it by cube face (1 x=0, 2 x=1, 3 y=0, ...)
+    c = coord[tri].mean(axis=1)
+    sets = {}
+    for ax in range(3):
+        sets[2 * ax + 1] = tri[c[:, ax] < 1e-9]
+        sets[2 * ax + 2] = tri[c[:, ax] > 1.0 - 1e-9]
+    out = []
+    for lev in levels:
+        ctx = capi.Context(4, flux="hllc", limiter="superbeep1", problem="sod_shocktube", gamma=1.4, cfl=0.3,
+                           bc_extrapolate=[1, 2], bc_sym=[3, 4, 5, 6], device=local_rank,
+                           options={"keep_connectivity": 1})
+        mesh = capi.mesh_from_connectivity(ctx, inpoel, coord, sets)
+        for _ in range(lev):
+            new, _ref = mesh.refine_uniform(host_copy=False)
+            mesh.close()
+            mesh = new
+        mesh.state_initialize(0.0)
+        el, nl, ms, cold = _time_single_chunk(ctx, mesh, steps, warm=2, develop=develop)
+        ne = mesh.nielem
+        alg = mesh.rhs_algorithmic_bytes()
+        ls = mesh.layout_stats()
+        ok = bool(np.isfinite(mesh.state_download()).all())
+        mesh.close(); ctx.close()
+        ach = alg / (ms / nl * 1e-3) / 1e9
+        out.append({"tets_total": ne, "refinements_1_to_8": lev, "steps": steps, "untimed_steps_first": develop,
+                    "value": ne * 3 / el / 1e6, "unit": "M element-updates/s", "ms_per_step": el * 1e3,
+                    "cold_start_M_per_s": ne * 3 / cold / 1e6, "finite": ok,
+                    "face_tasks_per_tet": {"in_tile_evaluated_once": ls["in_tile"] / ne,
+                                           "to_other_tiles": ls["to_other_tiles"] / ne, "boundary": ls["boundary"] / ne},
+                    "roofline": {"bound": "hbm", "kernel": "qdg::k_rhs_p1w", "achieved": ach, "peak": HBM_PEAK_GBS,
+                                 "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "avg_launch_ms": ms / nl, "launches": nl,
+                                 "algorithmic_bytes_per_launch": alg, "traffic": None}})
+    return {"workload": "CompFlow Sod DG-P1 + superbeep1, CFL 0.3, on the reference's unstructured unit-cube mesh "
+                        "(31 304 tets, tests/golden/slot_cyl_dg.npz) refined 1:8 on the device", "points": out}
 
 
 def self_launch(ngpus):
@@ -506,6 +594,16 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--nx", type=int, default=55, help="hexes per direction PER GPU (weak scaling)")
+    ap.add_argument("--develop", type=int, default=4000,
+                    help="untimed steps between the cold-start timing and the headline timing, at --nx 55; other "
+                         "box sizes take the steps that reach the same flow time (x nx/55).  The Superbee kernel "
+                         "does not write back tiles it leaves unchanged, so the step is fastest right after the "
+                         "initial discontinuity: the headline is taken on the developed flow, the cold-start "
+                         "rate is reported beside it (0: headline = cold start, as before round 5)")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="multi-rank / self-halo runs: plain launches instead of qdg_step_comm's hipGraph replay")
+    ap.add_argument("--no-real-mesh", action="store_true",
+                    help="skip the point on the reference's unstructured 31 k-tet cube mesh refined to 2 M / 16 M tets")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", choices=["sod", "sedov"], default="sod",
                     help="physics of the DG-P1 run: the Sod shock tube of BASELINE config 2 (default, the "
@@ -564,16 +662,18 @@ def main():
     # ---- headline: weak scaling, NX^3 hexes per GPU ------------------------------------------
     parts = meshgen.parts_for(world) if not args.self_halo else (2, 1, 1)
     nx = args.nx
+    def develop_for(n):                     # the same flow time on a finer / coarser box
+        return int(round(args.develop * n / 55.0))
     w = run_workload(args, rank, world, local_rank, (nx * parts[0], nx * parts[1], nx * parts[2]),
                      (float(parts[0]), float(parts[1]), float(parts[2])), parts,
-                     args.steps, args.warmup, args.comm, use_dist)
+                     args.steps, args.warmup, args.comm, use_dist, develop_for(nx))
     # ---- north-star / strong-scaling point: fixed-size box cut across the ranks ---------------
     ns = None
     if not args.no_north_star and not args.self_halo:
         sx = args.strong_nx
         ns_steps, ns_warm = max(20, args.steps // 2), max(2, args.warmup // 2)   # >= 20 timed steps whatever --steps says
         ns = run_workload(args, rank, world, local_rank, (sx, sx, sx), (1.0, 1.0, 1.0), parts, ns_steps, ns_warm,
-                          args.comm, use_dist)
+                          args.comm, use_dist, develop_for(sx))
         ns["steps"], ns["warmup"] = ns_steps, ns_warm
 
     if rank == 0:
@@ -601,7 +701,10 @@ def main():
             "config": {"workload": ("CompFlow Euler Sedov blast wave DG-P1 (dgp1, HLLC, superbeep1, "
                                     if args.workload == "sedov" else
                                     "CompFlow Euler Sod shock-tube DG-P1 (dgp1, HLLC, superbeep1, ")
-                                   + "cfl 0.3), Kuhn-tet box %d^3 hexes per GPU" % nx,
+                                   + "cfl 0.3), Kuhn-tet box %d^3 hexes per GPU" % nx
+                                   + (", timed on the DEVELOPED flow: %d untimed steps first (flow time %.4f; the "
+                                      "cold-start rate of the first steps is rates.cold_start_M_per_s)"
+                                      % (w["develop"], w["t_flow"]) if w["develop"] else ", timed from the initial state"),
                        "tets_total": w["ntet"], "tets_per_gpu": w["ntet_local"],
                        "parallelism": "block decomposition %dx%dx%d, ghost-face halo" % parts
                                       + ("" if w["backend"] is None else ", transport " + w["backend"])
@@ -618,7 +721,10 @@ def main():
             # the RHS-only rate divides by the time of the RHS kernels alone; per time step = value / 3
             "rates": {"full_stage_M_per_s": w["ntet"] * 3 * args.steps / w["el"] / 1e6,
                       "rhs_only_M_per_s_rank0": w["ntet_local"] / (w["avg_ms"] * 1e-3) / 1e6,
-                      "per_time_step_M_per_s": w["ntet"] * args.steps / w["el"] / 1e6},
+                      "per_time_step_M_per_s": w["ntet"] * args.steps / w["el"] / 1e6,
+                      # the same K steps timed right after the initial discontinuity (almost every tile unchanged
+                      # by the limiter, nothing written back): the pre-round-5 headline
+                      "cold_start_M_per_s": None if w["el_cold"] is None else w["ntet"] * 3 * args.steps / w["el_cold"] / 1e6},
             # who ran: ranks in the RCCL communicator as RCCL counts them (ncclCommCount; None without RCCL),
             # and every rank's chunk, neighbours, device and own RHS launch time
             "ranks_seen_by_rccl": w["ranks_seen_by_rccl"], "per_rank": w["per_rank"],
@@ -638,9 +744,11 @@ def main():
                 "steps": ns["steps"], "warmup": ns["warmup"],
                 "value": ns["ntet"] * 3 * ns["steps"] / ns["el"] / 1e6, "unit": "M element-updates/s",
                 "ms_per_step": ns["el"] / ns["steps"] * 1e3,
+                "developed_flow": {"untimed_steps_first": ns["develop"], "flow_time": ns["t_flow"]},
                 "rates": {"full_stage_M_per_s": ns["ntet"] * 3 * ns["steps"] / ns["el"] / 1e6,
                           "rhs_only_M_per_s_rank0": ns["ntet_local"] / (ns["avg_ms"] * 1e-3) / 1e6,
-                          "per_time_step_M_per_s": ns["ntet"] * ns["steps"] / ns["el"] / 1e6},
+                          "per_time_step_M_per_s": ns["ntet"] * ns["steps"] / ns["el"] / 1e6,
+                          "cold_start_M_per_s": None if ns["el_cold"] is None else ns["ntet"] * 3 * ns["steps"] / ns["el_cold"] / 1e6},
                 "roofline": {"bound": "hbm", "kernel": "qdg::k_rhs_p1w on rank 0's chunk", "achieved": a2,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": f2, "avg_launch_ms": ns["avg_ms"],
                              "launches": ns["launches"], "algorithmic_bytes_per_launch": ns["alg"],
@@ -664,7 +772,9 @@ def main():
         if world == 1 and not args.no_config3 and not args.self_halo:
             out["config3_point"] = config3_point(local_rank, args.config3_nx)
         if world == 1 and not args.no_config4 and not args.self_halo:
-            out["config4_point"] = config4_point(local_rank)
+            out["config4_point"] = config4_point(local_rank, develop=args.develop // 2)
+        if world == 1 and not args.no_real_mesh and not args.self_halo:
+            out["real_mesh_point"] = real_mesh_point(local_rank)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

@@ -312,6 +312,14 @@ int qdg_state_device_ptr(qdg_mesh* mesh, void** dptr, size_t* stride);
 int qdg_halo_setup(qdg_mesh* mesh, size_t nnbr, const int32_t* nbr_rank,
                    const size_t* send_off, const size_t* send_elem,
                    const size_t* recv_off);
+/* Two ghost layers (chunks of qdg_chunk_build_depth(depth = 2) built by qdg_mesh_from_chunk[_gid]; after
+ * qdg_halo_setup with the plan's (rank, layer) entries): the first nghost1 ghost rows are layer 1.  From then on the
+ * limiter stages (qdg_stage_limit, qdg_step_comm) also limit those rows -- layer 2 completes their inputs -- and
+ * qdg_step_comm drops the exchange of the limited solution (DG::lim -> comlim, src/Inciter/DG.cpp:1262-1282):
+ * 3 exchanges + 1 all-reduce per SSP-RK3 step instead of 6 + 1.  A driver that calls the stages itself skips its
+ * second exchange of every stage.  Results equal the one-layer run's (the same limiter on the same inputs).
+ * nghost1 = 0 returns to one layer.  Not for p-adaptive runs, nor for meshes of qdg_mesh_upload. */
+int qdg_halo_set_depth(qdg_mesh* mesh, size_t nghost1);
 int qdg_halo_buffers(qdg_mesh* mesh, void** send_dev, void** recv_dev,
                      size_t* row_bytes);
 /* use caller-owned device memory for the slabs / the dt scalar (e.g. buffers a
@@ -349,6 +357,15 @@ int qdg_stage_dt_allreduce(qdg_mesh* mesh, qdg_comm* comm);
  * 3 x (exchange, limit, exchange, rhs [+dt, min over ranks], update); the dt
  * taken is read back (host sync) only when dt_taken != NULL */
 int qdg_step_comm(qdg_mesh* mesh, qdg_comm* comm, double t, double tleft, double* dt_taken);
+/* Context option "graph_step" = 1: qdg_step_comm records its launch sequence (compute kernels, RCCL send /
+ * receive / all-reduce kernels, ghost-row copy) once per buffer-rotation phase as a hipGraph and replays it with
+ * one hipGraphLaunch per time step (the reference's analogue: nothing -- Charm++ schedules entry methods one
+ * message at a time, src/Inciter/dg.ci:57-70).  Used where the step's kernels do not read t (Sod, Sedov, rotated
+ * Sod), for uniform-order runs, outside profiling; the first two steps of a mesh run plain (RCCL connects its
+ * peers lazily).  Where HIP or RCCL refuses the capture the plain launches stay in charge.  Status: state 0 not
+ * tried yet, 1 graphs in use, -1 refused (error text copied to `error`, any pointer may be NULL). */
+int qdg_step_graph_status(qdg_mesh* mesh, int32_t* state, int32_t* ngraphs, int64_t* nreplays, char* error,
+                          size_t error_len);
 
 /* -- measurement ---------------------------------------------------------- */
 /* When enabled, every launch of the RHS kernel inside qdg_stage_rhs_update is
@@ -357,10 +374,20 @@ int qdg_step_comm(qdg_mesh* mesh, qdg_comm* comm, double t, double tleft, double
  * their summed duration since the last read. */
 int qdg_profile_enable(qdg_mesh* mesh, int on);
 int qdg_profile_read(qdg_mesh* mesh, size_t* nlaunch, double* total_ms);
+/* The same events by kind -- [0] RHS launches, [1] halo exchanges (pack kernel + grouped ncclSend / ncclRecv, with
+ * the gaps in front of them: DG::comsol / comlim, src/Inciter/DG.cpp:1023-1086, 1266-1358), [2] dt all-reduces
+ * (contribute(min), DG.cpp:1428-1429) -- recorded inside qdg_step_comm, qdg_halo_exchange and
+ * qdg_stage_dt_allreduce while profiling is enabled: counts and summed milliseconds since the last read. */
+int qdg_profile_read_all(qdg_mesh* mesh, size_t count[3], double total_ms[3]);
 /* algorithmic bytes of one RHS launch: nielem * (16*5*ndof + 32) + 24*nnode
  * (read U once, write R once, 8 int32 indices per tet, node coordinates once;
  * SURVEY.md 8d) */
 int qdg_rhs_algorithmic_bytes(qdg_mesh* mesh, double* bytes);
+/* the face-task mix of the mesh's tile layout (DG-P1 tile kernel): counts[0] interior faces with both tets in
+ * one tile (evaluated once), [1] faces from a tile to another tile or to a ghost (evaluated by both sides),
+ * [2] physical-boundary faces, [3] tiles -- the figure that says how a mesh's numbering suits the kernel
+ * (what QDG_UPLOAD_STATS prints at build time) */
+int qdg_mesh_layout_stats(qdg_mesh* mesh, size_t counts[4]);
 
 /* -- host-side mesh-derived data (mirror of FaceData / DerivedData) ------- */
 int qdg_gen_esuel(size_t nelem, const size_t* inpoel, int* esuel);
@@ -400,8 +427,32 @@ int qdg_partition(size_t nelem, const size_t* inpoel, size_t nnode, const double
                   const double* z, int nparts, int method, int32_t* part);
 int qdg_chunk_build(size_t nelem, size_t nnode, const size_t* inpoel, const int* esuel,
                     const int32_t* part, int nparts, int rank, qdg_chunk** out);
+/* The same with TWO ghost layers (depth = 2; depth = 1 is the call above): behind the face-neighbour ghosts
+ * (layer 1) come the tets of other ranks that share a face with a layer-1 ghost (layer 2).  A rank then holds every
+ * input of the limiter of its layer-1 ghosts (src/PDE/Limiter.cpp:29-316 read a tet's face neighbours) and limits
+ * them itself, so the exchange of the LIMITED solution (DG::lim -> comlim, src/Inciter/DG.cpp:1262-1282) is not
+ * needed: 3 exchanges per time step instead of 6 (qdg_halo_set_depth).  The plan then has one ENTRY per
+ * (neighbour rank, layer): nnbr counts entries, nbr_rank[] lists the layer-1 entries (ranks ascending) followed
+ * by the layer-2 entries (ranks ascending; a rank can appear in both, or in layer 2 only), each with its send
+ * list and receive range as before; ghost rows = layer 1 (nghost1 rows, grouped by owner), then layer 2. */
+int qdg_chunk_build_depth(size_t nelem, size_t nnode, const size_t* inpoel, const int* esuel,
+                          const int32_t* part, int nparts, int rank, int depth, qdg_chunk** out);
 int qdg_chunk_sizes(const qdg_chunk* c, size_t* nielem, size_t* nunk, size_t* nnode, size_t* nnbr,
                     size_t* nsend);
+/* depth of the chunk, its number of layer-1 ghosts, the layer (1 / 2) of every plan entry (any pointer may be NULL) */
+int qdg_chunk_layers(const qdg_chunk* c, int32_t* depth, size_t* nghost1, int32_t* nbr_layer);
+/* The ghost layers and the halo plan ALONE, from the face adjacency esuel[4*nelem] of the tets around a rank's
+ * own (complete up to `depth` faces away from them), their owner ranks and global ids (NULL: the index): for a
+ * caller that assembles its chunk itself.  Tets are addressed by their index: ghost[nghost] = layer 1 (nghost1
+ * tets, by owner and global id), then layer 2; entries as for qdg_chunk_build_depth (recv_off / send_off
+ * [nentry + 1], send_elem[nsend] = owned tets). */
+typedef struct qdg_ghost_plan qdg_ghost_plan;
+int qdg_ghost_plan_build(size_t nelem, const int* esuel, const int32_t* owner, const size_t* gid, int rank,
+                         int depth, qdg_ghost_plan** out);
+int qdg_ghost_plan_sizes(const qdg_ghost_plan* p, size_t* nghost, size_t* nghost1, size_t* nentry, size_t* nsend);
+int qdg_ghost_plan_get(const qdg_ghost_plan* p, size_t* ghost, int32_t* entry_rank, int32_t* entry_layer,
+                       size_t* recv_off, size_t* send_off, size_t* send_elem);
+int qdg_ghost_plan_destroy(qdg_ghost_plan* p);
 /* copy-out (any pointer may be NULL): inpoel[4*nunk] local node ids, elem_gid[nunk],
  * node_gid[nnode], nbr_rank[nnbr], send_off[nnbr+1], send_elem[nsend] (local owned ids),
  * recv_off[nnbr+1] (ghost rows nielem + recv_off[i] ...) */
@@ -533,7 +584,9 @@ int qdg_dev_facedata(qdg_ctx* ctx, size_t nelem, size_t nnode, const size_t* inp
  * boundary faces regenerated from the side-set triangles (the order of qdg_bnd_faces), FaceData
  * and geometry (the arrays of qdg_dev_facedata), device order, numbering and face tasks (what
  * qdg_mesh_upload derives on the host) -- all on the device; only connectivity, coordinates and
- * the side-set triangles cross PCIe.  tri_set[i] is the side set id of triangle i.
+ * the side-set triangles cross PCIe.  tri_set[i] is the side set id of triangle i; a triangle listed in
+ * several side sets belongs to the one with the highest id, as in the reference's loader (the last writer of
+ * `faceside`, src/Inciter/Partitioner.cpp:358-364), and is integrated once (src/PDE/Integrate/Boundary.cpp:84-86).
  * (context option "host_layout" = 1: FaceData on the device, layout by qdg_mesh_upload, for
  * equivalence tests.) */
 int qdg_mesh_from_connectivity(qdg_ctx* ctx, size_t nelem, size_t nnode, const size_t* inpoel,

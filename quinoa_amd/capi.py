@@ -159,6 +159,14 @@ class FaceData:
         self.belem = self.belem[:nb]
 
 
+def gen_esuel(inpoel):
+    """qdg_gen_esuel: esuel[nelem, 4] (tet across local face lpofa[f], -1: none) of any tet connectivity"""
+    inp, pinp = _sz(np.asarray(inpoel).reshape(-1))
+    es = np.zeros(len(inp), dtype=np.int32)
+    _chk(lib().qdg_gen_esuel(C.c_size_t(len(inp) // 4), pinp, es.ctypes.data_as(c_i32p)))
+    return es.reshape(-1, 4)
+
+
 def gen_geoface(nfac, inpofa, coord):
     x, px = _f64(coord[:, 0]); y, py = _f64(coord[:, 1]); z, pz = _f64(coord[:, 2])
     inpofa, pf = _sz(inpofa)
@@ -492,6 +500,11 @@ class Mesh:
         _chk(lib().qdg_halo_setup(self.h, C.c_size_t(len(nbr_rank)), pn, psoff, pse, proff))
         self.send_off, self.recv_off = soff.astype(np.int64), roff.astype(np.int64)
 
+    def halo_set_depth(self, nghost1):
+        """qdg_halo_set_depth: the first nghost1 ghost rows are layer 1 of two ghost layers (the rank limits them
+        itself, no exchange of the limited solution); 0: one layer"""
+        _chk(lib().qdg_halo_set_depth(self.h, C.c_size_t(int(nghost1))))
+
     def halo_buffers(self):
         a, b, r = C.c_void_p(), C.c_void_p(), C.c_size_t()
         _chk(lib().qdg_halo_buffers(self.h, C.byref(a), C.byref(b), C.byref(r)))
@@ -581,6 +594,25 @@ class Mesh:
         n, ms = C.c_size_t(), C.c_double()
         _chk(lib().qdg_profile_read(self.h, C.byref(n), C.byref(ms)))
         return n.value, ms.value
+
+    def layout_stats(self):
+        """-> dict: face tasks of the tile layout (in_tile, to_other_tiles, boundary, tiles)"""
+        n = (C.c_size_t * 4)()
+        _chk(lib().qdg_mesh_layout_stats(self.h, n))
+        return {"in_tile": int(n[0]), "to_other_tiles": int(n[1]), "boundary": int(n[2]), "tiles": int(n[3])}
+
+    def profile_read_all(self):
+        """-> {"rhs": (launches, ms), "halo": (exchanges, ms), "allreduce": (calls, ms)} since the last read"""
+        n, ms = (C.c_size_t * 3)(), (C.c_double * 3)()
+        _chk(lib().qdg_profile_read_all(self.h, n, ms))
+        return {k: (int(n[i]), float(ms[i])) for i, k in enumerate(("rhs", "halo", "allreduce"))}
+
+    def step_graph_status(self):
+        """-> (state, graphs, replays, error text): qdg_step_comm's hipGraph replay (option graph_step)"""
+        st, ng, nr = C.c_int32(), C.c_int32(), C.c_int64()
+        buf = C.create_string_buffer(512)
+        _chk(lib().qdg_step_graph_status(self.h, C.byref(st), C.byref(ng), C.byref(nr), buf, C.c_size_t(512)))
+        return st.value, ng.value, nr.value, buf.value.decode()
 
     def rhs_algorithmic_bytes(self):
         b = C.c_double()

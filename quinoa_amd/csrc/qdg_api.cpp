@@ -299,6 +299,7 @@ static int* option_slot(qdg_ctx* ctx, const char* name)
     { "renumber", &qdg::Options::renumber },       { "host_layout", &qdg::Options::host_layout },
     { "orient_by_gid", &qdg::Options::orient_by_gid }, { "keep_pool", &qdg::Options::keep_pool },
     { "keep_connectivity", &qdg::Options::keep_connectivity },
+    { "graph_step", &qdg::Options::graph_step },
   };
   for (const auto& t : tab)
     if (std::strcmp(name, t.n) == 0) return &(ctx->opt.*(t.p));
@@ -742,6 +743,7 @@ extern "C" int qdg_mesh_upload_gid(qdg_ctx* ctx, size_t nielem, size_t nunk, siz
     dm.tgeo = m->tgeo.p;
   }
   dm.blk0 = 0; dm.ninner = (int)ninner; dm.ncomp = ncomp; dm.pde = ctx->cfg.pde;
+  dm.nlim = (int)nie; dm.row0 = 0;
   dm.ndofel = nullptr;
   if (ctx->cfg.pref) {
     HIPCHK(m->ndofel.alloc(ne)); HIPCHK(m->ndofel2.alloc(ne));
@@ -835,16 +837,20 @@ static int scratch(qdg_mesh* mesh)
   return 0;
 }
 
-static int run_limiter(qdg_mesh* mesh, double*& Ucur, double* Ualt_in)
+// owned_only: the stateless DGPDE-shaped call limits [0, nielem) as the reference does; the resident stages
+// also limit the layer-1 ghosts of a chunk with two ghost layers (DevMesh::nlim, qdg_halo_set_depth)
+static int run_limiter(qdg_mesh* mesh, double*& Ucur, double* Ualt_in, bool owned_only = false)
 {
   double* Ualt = Ualt_in;
   qdg_ctx* ctx = mesh->ctx;
   hipStream_t s = ctx->stream;
   if (mesh->ndof == 1) return 0;          // DG.cpp:1251: rdof > 1 only
+  DevMesh dm = mesh->dm;
+  if (owned_only) dm.nlim = dm.nie;
   if (ctx->cfg.limiter == QDG_LIMITER_SUPERBEEP1) {
-    launch_superbee(mesh->ndof, mesh->dm, Ucur, s);
+    launch_superbee(mesh->ndof, dm, Ucur, s);
   } else if (ctx->cfg.limiter == QDG_LIMITER_WENOP1) {
-    launch_weno(mesh->ndof, mesh->dm, ctx->ph.cweight, Ucur, Ualt, s);    // writes every row of Ualt
+    launch_weno(mesh->ndof, dm, ctx->ph.cweight, Ucur, Ualt, s);    // writes every row of Ualt
     std::swap(Ucur, Ualt);
   }
   HIPCHK(hipGetLastError());
@@ -950,7 +956,7 @@ extern "C" int qdg_limit(qdg_mesh* mesh, double* U_aos)
   if (int rc = scratch(mesh)) return rc;
   double* a = mesh->S1.p;
   if (int rc = host_to_planes(mesh, U_aos, a)) return rc;
-  if (int rc = run_limiter(mesh, a, mesh->S2.p)) return rc;
+  if (int rc = run_limiter(mesh, a, mesh->S2.p, true)) return rc;
   return planes_to_host(mesh, a, mesh->ne, U_aos, false);
   QDG_CATCH
 }
@@ -1311,7 +1317,7 @@ extern "C" int qdg_stage_dt_device_ptr(qdg_mesh* mesh, void** dptr)
 
 static const double RK[2][3] = { { 0.0, 3.0 / 4.0, 1.0 / 3.0 }, { 1.0, 1.0 / 4.0, 2.0 / 3.0 } };   // DG.cpp:39-40
 
-static int prof_begin(qdg_mesh* mesh, std::pair<hipEvent_t, hipEvent_t>** ev, bool cont = false)
+static int prof_begin(qdg_mesh* mesh, std::pair<hipEvent_t, hipEvent_t>** ev, bool cont = false, int kind = 0)
 {
   *ev = nullptr;
   if (!mesh->prof) return 0;
@@ -1321,8 +1327,10 @@ static int prof_begin(qdg_mesh* mesh, std::pair<hipEvent_t, hipEvent_t>** ev, bo
     HIPCHK(hipEventCreate(&b));
     mesh->ev.emplace_back(a, b);
     mesh->ev_cont.push_back(0);
+    mesh->ev_kind.push_back(0);
   }
   mesh->ev_cont[mesh->ev_used] = cont ? 1 : 0;
+  mesh->ev_kind[mesh->ev_used] = (char)kind;
   *ev = &mesh->ev[mesh->ev_used++];
   HIPCHK(hipEventRecord((*ev)->first, mesh->ctx->stream));
   return 0;
@@ -1694,6 +1702,7 @@ extern "C" int qdg_halo_setup(qdg_mesh* mesh, size_t nnbr, const int32_t* nbr_ra
     return fail("qdg_halo_setup: receive counts must add up to the number of ghost rows");
   if (send_off[nnbr] > (size_t)INT32_MAX / 64) return fail("qdg_halo_setup: send list too long");
   mesh->nnbr = nnbr;
+  mesh->nghost1 = 0; mesh->dm.nlim = (int)mesh->nie;      // a new plan: one ghost layer until qdg_halo_set_depth
   mesh->nbr_rank.assign(nbr_rank, nbr_rank + nnbr);
   mesh->send_off.assign(send_off, send_off + nnbr + 1);
   mesh->recv_off.assign(recv_off, recv_off + nnbr + 1);
@@ -1734,6 +1743,23 @@ extern "C" int qdg_halo_setup(qdg_mesh* mesh, size_t nnbr, const int32_t* nbr_ra
   HIPCHK(mesh->recv_slab.alloc(std::max<size_t>(1, mesh->nrecv * slab_w(mesh))));
   mesh->send_ptr = mesh->send_slab.p;
   mesh->recv_ptr = mesh->recv_slab.p;
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_halo_set_depth(qdg_mesh* mesh, size_t nghost1)
+{
+  QDG_TRY
+  MESH_ENTER("qdg_halo_set_depth");
+  if (nghost1 == 0) { mesh->nghost1 = 0; mesh->dm.nlim = (int)mesh->nie; return 0; }
+  if (nghost1 > mesh->ne - mesh->nie) return fail("qdg_halo_set_depth: more layer-1 ghosts than ghost rows");
+  if (!mesh->ghost_nbr)
+    return fail("qdg_halo_set_depth: the mesh holds no face neighbours of its ghost rows (build it with "
+                "qdg_mesh_from_chunk[_gid]; qdg_mesh_upload takes esuel of the owned tets only)");
+  if (mesh->dm.ndofel) return fail("qdg_halo_set_depth: p-adaptive DG runs with one ghost layer");
+  if (mesh->nnbr == 0) return fail("qdg_halo_set_depth: call qdg_halo_setup first");
+  mesh->nghost1 = nghost1;
+  mesh->dm.nlim = (int)(mesh->nie + nghost1);
   return 0;
   QDG_CATCH
 }
@@ -1957,7 +1983,32 @@ extern "C" int qdg_comm_destroy(qdg_comm* comm)
 }
 
 // pack, grouped send / receive into the ghost rows -- all enqueued on stream `s`
+static int exchange_on_impl(qdg_mesh* mesh, qdg_comm* comm, hipStream_t s, bool packed);
+static int exchange_upd_impl(qdg_mesh* mesh, qdg_comm* comm, hipStream_t s, double* out);
+
+// (with qdg_profile_enable: an event pair around the whole exchange -- pack kernel, RCCL kernel and the gaps
+// in front of them, which is what the exchange costs the step)
 static int exchange_on(qdg_mesh* mesh, qdg_comm* comm, hipStream_t s, bool packed = false)
+{
+  if (mesh->nnbr == 0) return 0;
+  std::pair<hipEvent_t, hipEvent_t>* ev;
+  if (int rc = prof_begin(mesh, &ev, false, 1)) return rc;
+  if (int rc = exchange_on_impl(mesh, comm, s, packed)) return rc;
+  if (ev) HIPCHK(hipEventRecord(ev->second, s));
+  return 0;
+}
+
+static int exchange_upd(qdg_mesh* mesh, qdg_comm* comm, hipStream_t s, double* out)
+{
+  if (mesh->nnbr == 0) return 0;
+  std::pair<hipEvent_t, hipEvent_t>* ev;
+  if (int rc = prof_begin(mesh, &ev, false, 1)) return rc;
+  if (int rc = exchange_upd_impl(mesh, comm, s, out)) return rc;
+  if (ev) HIPCHK(hipEventRecord(ev->second, s));
+  return 0;
+}
+
+static int exchange_on_impl(qdg_mesh* mesh, qdg_comm* comm, hipStream_t s, bool packed)
 {
   if (mesh->nnbr == 0) return 0;
   if (!comm) return fail("qdg_halo_exchange: null communicator");
@@ -1999,7 +2050,7 @@ static int exchange_on(qdg_mesh* mesh, qdg_comm* comm, hipStream_t s, bool packe
 // the comsol exchange of stage 1 when the stage-0 update is fused into the limiter:
 // the send rows U1 = U0 + dt R / L are formed by the pack kernel, the neighbours' rows
 // land in the ghost rows of `out`, the buffer the fused kernel is about to fill
-static int exchange_upd(qdg_mesh* mesh, qdg_comm* comm, hipStream_t s, double* out)
+static int exchange_upd_impl(qdg_mesh* mesh, qdg_comm* comm, hipStream_t s, double* out)
 {
   if (mesh->nnbr == 0) return 0;
   if (!comm) return fail("qdg_step_comm: null communicator");
@@ -2036,12 +2087,91 @@ extern "C" int qdg_stage_dt_allreduce(qdg_mesh* mesh, qdg_comm* comm)
   QDG_TRY
   MESH_ENTER("qdg_stage_dt_allreduce");
   if (!comm) return fail("qdg_stage_dt_allreduce: null communicator");
+  std::pair<hipEvent_t, hipEvent_t>* ev;
+  if (int rc = prof_begin(mesh, &ev, false, 2)) return rc;
   RCCLCHK(rccl_api()->AllReduce(mesh->dt_ptr, mesh->dt_ptr, 1, ncclDouble, ncclMin, comm->comm, s));
+  if (ev) HIPCHK(hipEventRecord(ev->second, s));
   return 0;
   QDG_CATCH
 }
 
 static int step_comm_stages(qdg_mesh* mesh, qdg_comm* comm, double t, double tleft, bool slab_ready);
+
+// ---- qdg_step_comm as a hipGraph (context option graph_step) --------------------------------------
+// The launch sequence of a step -- ~9 compute kernels, the RCCL send / receive and all-reduce kernels, the
+// ghost-row copy -- depends on nothing but WHICH of the three state buffers is current at entry (the
+// rotation has period two) and on the arguments t and tleft.  It is captured once per such entry state and
+// replayed with ONE hipGraphLaunch: the host enqueues one command per step instead of ~25, and the runtime
+// knows the whole dependency chain ahead of time.  Conditions: the RHS must not read t (Sod, Sedov and
+// rotated Sod: no source term, no analytic boundary state -- else every step has its own t and nothing can
+// be replayed), uniform order (the p-adaptive step has a host-visible phase), no profiling events.  RCCL sets
+// its peer connections up lazily inside the first exchanges, so the first two steps of a mesh run plain.
+// A capture that is refused (by HIP or by RCCL) leaves the plain path in charge; qdg_step_graph_status says why.
+static bool step_reads_t(const qdg_ctx* ctx)
+{
+  if (ctx->cfg.pde != QDG_PDE_COMPFLOW) return true;
+  return !(ctx->cfg.problem == QDG_PROBLEM_SOD_SHOCKTUBE || ctx->cfg.problem == QDG_PROBLEM_SEDOV_BLASTWAVE ||
+           ctx->cfg.problem == QDG_PROBLEM_ROTATED_SOD_SHOCKTUBE);
+}
+
+struct StepState {             // what step_comm_stages changes in the handle
+  double *Ucur, *Unp, *Upending, *carry_src; const double* slab_ready_for; bool skip_ghost_carry;
+  explicit StepState(const qdg_mesh* m) : Ucur(m->Ucur), Unp(m->Unp), Upending(m->Upending), carry_src(m->carry_src),
+                                          slab_ready_for(m->slab_ready_for), skip_ghost_carry(m->skip_ghost_carry) {}
+  void restore(qdg_mesh* m) const
+  {
+    m->Ucur = Ucur; m->Unp = Unp; m->Upending = Upending; m->carry_src = carry_src;
+    m->slab_ready_for = slab_ready_for; m->skip_ghost_carry = skip_ghost_carry;
+  }
+};
+
+// 1: the step was enqueued as a graph launch; 0: not applicable / refused, take the plain path; < 0: error
+static int step_comm_graph(qdg_mesh* mesh, qdg_comm* comm, double t, double tleft, bool slab_ready)
+{
+  qdg_ctx* ctx = mesh->ctx;
+  hipStream_t s = ctx->stream;
+  if (!ctx->opt.graph_step || mesh->graph_state < 0 || mesh->prof || mesh->dm.ndofel || step_reads_t(ctx)) return 0;
+  if (mesh->Unp || mesh->Upending) return 0;                 // a stage in flight: not the entry state of a step
+  if (mesh->graph_warm < 2) { ++mesh->graph_warm; return 0; }
+  for (const qdg_mesh::StepGraph& g : mesh->step_graphs)
+    if (g.ucur_in == mesh->Ucur && g.tleft == tleft && g.slab_ready_in == slab_ready) {
+      if (hipGraphLaunch(g.exec, s) != hipSuccess) return -1;
+      mesh->Ucur = g.ucur_out; mesh->Unp = nullptr; mesh->Upending = nullptr; mesh->carry_src = nullptr;
+      mesh->slab_ready_for = g.slab_ready_out;
+      ++mesh->graph_replays;
+      return 1;
+    }
+  if (mesh->step_graphs.size() >= 8) return 0;               // (tleft changes every step: the caller's last steps)
+  const StepState before(mesh);
+  auto refuse = [&](const std::string& why) {
+    mesh->graph_state = -1;
+    mesh->graph_error = why;
+    before.restore(mesh);
+    return 0;
+  };
+  hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed);
+  if (e != hipSuccess) return refuse(std::string("hipStreamBeginCapture: ") + hipGetErrorString(e));
+  const int rc = step_comm_stages(mesh, comm, t, tleft, slab_ready);
+  const std::string rc_msg = rc ? qdg_last_error() : "";
+  hipGraph_t graph = nullptr;
+  e = hipStreamEndCapture(s, &graph);
+  if (rc || e != hipSuccess || !graph) {
+    if (graph) (void)hipGraphDestroy(graph);
+    (void)hipGetLastError();
+    return refuse(rc ? "capture of the step: " + rc_msg : std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+  }
+  hipGraphExec_t exec = nullptr;
+  e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (e != hipSuccess || !exec) { (void)hipGetLastError(); return refuse(std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
+  mesh->step_graphs.push_back({ before.Ucur, t, tleft, slab_ready, exec, mesh->Ucur, mesh->slab_ready_for });
+  mesh->graph_state = 1;
+  // (nothing has run yet: the capture only recorded; the handle's state is already the state after the step)
+  if (hipGraphLaunch(exec, s) != hipSuccess) { before.restore(mesh); return -1; }
+  mesh->carry_src = nullptr;
+  ++mesh->graph_replays;
+  return 1;
+}
 
 extern "C" int qdg_step_comm(qdg_mesh* mesh, qdg_comm* comm, double t, double tleft, double* dt_taken)
 {
@@ -2054,7 +2184,9 @@ extern "C" int qdg_step_comm(qdg_mesh* mesh, qdg_comm* comm, double t, double tl
   // the skipped ghost-row carries below rely on every ghost row being received by the next exchange
   if (mesh->nnbr > 0 && mesh->nrecv != mesh->ne - mesh->nie)
     return fail("qdg_step_comm: the halo plan does not cover every ghost row");
-  const int rc = step_comm_stages(mesh, comm, t, tleft, slab_ready);
+  const int g = step_comm_graph(mesh, comm, t, tleft, slab_ready);
+  if (g < 0) return fail("qdg_step_comm: hipGraphLaunch failed");
+  const int rc = g == 1 ? 0 : step_comm_stages(mesh, comm, t, tleft, slab_ready);
   const double* ready_after = mesh->slab_ready_for;
   if (rc && mesh->carry_src && mesh->carry_src != mesh->Ucur) {
     // an exchange failed after an update whose ghost-row carry was skipped: do the carry now, so that
@@ -2087,8 +2219,11 @@ static int step_comm_stages(qdg_mesh* mesh, qdg_comm* comm, double t, double tle
   // new state.  Enabled for THIS call's launches only (DevMesh goes to the kernels by value).
   const bool can_fold = mesh->fold_slot.p && mesh->nnbr > 0;
   // (only the CompFlow Superbee kernels fold: tr::k_superbee of dg::Transport does not write the slab)
+  // Two ghost layers (qdg_halo_set_depth): the limiter also covers the layer-1 ghosts, whose inputs layer 2
+  // completes, so the exchange of the limited solution (comlim) is not needed -- 3 exchanges per step, not 6
+  const bool deep = mesh->nghost1 > 0;
   const bool lim_folds = can_fold && ctx->cfg.limiter == QDG_LIMITER_SUPERBEEP1 && mesh->ndof > 1 &&
-                         mesh->dm.pde == QDG_PDE_COMPFLOW;
+                         mesh->dm.pde == QDG_PDE_COMPFLOW && !deep;
   const bool rhs_folds = can_fold && use_p1_fast(mesh) && use_tile(mesh) && !mesh->dm.ndofel;
   struct FoldScope {
     qdg_mesh* m;
@@ -2104,7 +2239,7 @@ static int step_comm_stages(qdg_mesh* mesh, qdg_comm* comm, double t, double tle
     packed = false;
     if (pdg0) if (int rc = qdg_stage_pdg_propagate(mesh)) return rc;     // DG::lim: propagate_ndof
     if (!fused1) if (int rc = qdg_stage_limit(mesh)) return rc;          // DG::lim
-    if (limited || pdg0) if (int rc = exchange_on(mesh, comm, s, lim_folds && !pdg0)) return rc;   // -> comlim
+    if ((limited && !deep) || pdg0) if (int rc = exchange_on(mesh, comm, s, lim_folds && !pdg0)) return rc;   // -> comlim
     if (int rc = qdg_stage_rhs_dt(mesh, stage, t, tleft)) return rc;     // DG::dt, DG::solve
     if (stage == 0) if (int rc = qdg_stage_dt_allreduce(mesh, comm)) return rc;
     if (fuse && stage == 0) {
@@ -2112,6 +2247,10 @@ static int step_comm_stages(qdg_mesh* mesh, qdg_comm* comm, double t, double tle
       double* out = free_buf(mesh, mesh->Ucur, mesh->Unp);
       if (int rc = exchange_upd(mesh, comm, s, out)) return rc;
       if (int rc = stage0_update_and_limit(mesh)) return rc;
+      if (deep) {        // ... and the limiter of the layer-1 ghosts (their unlimited U1 has just been received)
+        launch_superbee_rows(mesh->ndof, mesh->dm, mesh->Ucur, (int)mesh->nie, (int)(mesh->nie + mesh->nghost1), s);
+        HIPCHK(hipGetLastError());
+      }
     } else {
       // stages 0, 1: the next stage starts by receiving the ghost rows of the new state
       mesh->skip_ghost_carry = stage < 2 && mesh->nnbr > 0;
@@ -2148,6 +2287,7 @@ extern "C" int qdg_profile_read(qdg_mesh* mesh, size_t* nlaunch, double* total_m
   double tot = 0.0;
   size_t nl = 0;
   for (size_t i = 0; i < mesh->ev_used; ++i) {
+    if (mesh->ev_kind[i] != 0) continue;
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, mesh->ev[i].first, mesh->ev[i].second));
     tot += ms;
@@ -2156,6 +2296,58 @@ extern "C" int qdg_profile_read(qdg_mesh* mesh, size_t* nlaunch, double* total_m
   *nlaunch = nl;
   *total_ms = tot;
   mesh->ev_used = 0;
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_profile_read_all(qdg_mesh* mesh, size_t count[3], double total_ms[3])
+{
+  QDG_TRY
+  MESH_ENTER("qdg_profile_read_all");
+  if (!count || !total_ms) return fail("qdg_profile_read_all: null argument");
+  HIPCHK(hipStreamSynchronize(s));
+  for (int k = 0; k < 3; ++k) { count[k] = 0; total_ms[k] = 0.0; }
+  for (size_t i = 0; i < mesh->ev_used; ++i) {
+    const int k = mesh->ev_kind[i];
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, mesh->ev[i].first, mesh->ev[i].second));
+    total_ms[k] += ms;
+    if (!mesh->ev_cont[i]) ++count[k];
+  }
+  mesh->ev_used = 0;
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_step_graph_status(qdg_mesh* mesh, int32_t* state, int32_t* ngraphs, int64_t* nreplays,
+                                     char* error, size_t error_len)
+{
+  QDG_TRY
+  if (!mesh) return fail("qdg_step_graph_status: null mesh");
+  if (state) *state = mesh->graph_state;
+  if (ngraphs) *ngraphs = (int32_t)mesh->step_graphs.size();
+  if (nreplays) *nreplays = mesh->graph_replays;
+  if (error && error_len) {
+    std::strncpy(error, mesh->graph_error.c_str(), error_len - 1);
+    error[error_len - 1] = 0;
+  }
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_mesh_layout_stats(qdg_mesh* mesh, size_t counts[4])
+{
+  QDG_TRY
+  MESH_ENTER("qdg_mesh_layout_stats");
+  if (!counts) return fail("qdg_mesh_layout_stats: null argument");
+  counts[0] = counts[1] = counts[2] = 0;
+  counts[3] = (size_t)mesh->dm.ntile;
+  std::vector<int> ta(mesh->task_a.n);
+  if (!ta.empty()) {
+    HIPCHK(hipMemcpyAsync(ta.data(), mesh->task_a.p, ta.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+  }
+  for (int a : ta) if (a >= 0) ++counts[TASK_KIND(a)];
   return 0;
   QDG_CATCH
 }

@@ -84,6 +84,10 @@ struct DevMesh {
   // fold_slot[4 * (d - ninner) ...] (-1 = none); null: no folding
   const int* fold_slot;
   double* fold_slab;
+  // limiter range: rows [row0 + 256 * blk0 ..., nlim).  nlim = nie, or nie + the chunk's layer-1 ghosts when the
+  // rank limits them itself (two ghost layers, qdg_halo_set_depth: their nbr rows are filled); 0 reads as nie
+  int nlim;
+  int row0;
   int ncomp;        // 5: CompFlow; dg::Transport: its number of scalars (rows of ncomp*ndof doubles)
   int pde;          // 0: CompFlow, 1: dg::Transport (QDG_PDE_*)
   // p-adaptive DG (scheme pdg): DG::m_ndof per device row, 1 or 4; null otherwise

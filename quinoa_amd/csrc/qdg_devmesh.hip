@@ -419,15 +419,20 @@ static int dev_bnd_faces(qdg_ctx* ctx, DevFD& fd, size_t ntri, const size_t* tri
   }
   std::sort(keys.begin(), keys.end(), [](const K& p, const K& q) {
     return p.a != q.a ? p.a < q.a : p.b != q.b ? p.b < q.b : p.c != q.c ? p.c < q.c : p.set < q.set; });
-  // The reference keeps one boundary face per side-set ENTRY (a triangle listed in two side sets is
-  // integrated once per set, src/Inciter/Partitioner.cpp:357-393); here a triangle gets one boundary
-  // face, so such input is refused instead of silently dropping a condition.
-  for (size_t i = 0; i + 1 < ntri; ++i)
-    if (keys[i].a == keys[i + 1].a && keys[i].b == keys[i + 1].b && keys[i].c == keys[i + 1].c)
-      return fail(keys[i].set == keys[i + 1].set
-                  ? "qdg_mesh_from_connectivity: a side-set triangle is listed twice"
-                  : "qdg_mesh_from_connectivity: a triangle is listed in two side sets (not supported "
-                    "by the device mesh build; use qdg_mesh_upload with the reference's bface)");
+  // A triangle listed in several side sets: the mesh loader's map from triangle to side set is filled set by
+  // set in ascending id (`faceside[tri] = s.first` over the std::map m_bface, src/Inciter/Partitioner.cpp:358-364,
+  // Partitioner.hpp:198), so the LAST set that lists a triangle owns it and the tet face is integrated once, with
+  // that set's condition (Boundary.cpp:84-86 then finds it in that set only).  The keys are sorted by (nodes,
+  // set): the last entry of every run of equal node triples stays (as qdg_bnd_faces does on the host).
+  {
+    size_t w = 0;
+    for (size_t i = 0; i < ntri; ++i) {
+      const bool last = i + 1 == ntri || keys[i].a != keys[i + 1].a || keys[i].b != keys[i + 1].b || keys[i].c != keys[i + 1].c;
+      if (last) keys[w++] = keys[i];
+    }
+    ntri = w;
+    keys.resize(ntri);
+  }
   std::sort(sets.begin(), sets.end());
   sets.erase(std::unique(sets.begin(), sets.end()), sets.end());
   if (sets.size() >= (1u << 20)) return fail("qdg_mesh_from_connectivity: too many side sets");
@@ -798,6 +803,21 @@ __global__ void k_layout_rows(size_t ne, int stride, const int* __restrict__ d2h
   }
 }
 
+// ghost rows [nie, ne): their face neighbours in device numbering (-1: none in this chunk).  Read only by the
+// limiter of a rank that limits its layer-1 ghosts itself (two ghost layers, qdg_halo_set_depth): every face
+// neighbour of such a ghost is in the chunk, so -1 there is a physical-boundary face, which the limiters skip
+// (Limiter.cpp:67-68, 212-213)
+__global__ void k_layout_ghost_nbr(size_t nie, size_t ne, int stride, const int* __restrict__ h2d,
+                                   const int* __restrict__ esuel, int* __restrict__ o_nbr)
+{
+  const size_t d = nie + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= ne) return;
+  for (int lf = 0; lf < 4; ++lf) {
+    const int nb = esuel[4 * d + lf];                 // (ghosts keep their rows: d2h[d] = d)
+    o_nbr[(size_t)lf * stride + d] = nb >= 0 ? h2d[nb] : -1;
+  }
+}
+
 __global__ void k_layout_nodes(size_t nnode, const int* __restrict__ nnew, const double* __restrict__ x,
                                const double* __restrict__ y, const double* __restrict__ z,
                                double* __restrict__ ox, double* __restrict__ oy, double* __restrict__ oz,
@@ -1116,6 +1136,8 @@ static int dev_build_layout(qdg_ctx* ctx, DevFD& fd, const std::vector<int>& bcf
   k_layout_rows<<<nblk(nie), 256, 0, s>>>(nie, (int)stride, m->d2h.p, h2d.p, fd.inpoel.p, fd.esuel.p, fd.esuf.p,
                                          rface.p, nnew.p, fmap.p, d_bc.p, fd.geoElem.p, m->inpoel.p, m->nbr.p,
                                          m->finfo.p, m->fid.p, m->vol.p, d_err.p);
+  if (ne > nie) k_layout_ghost_nbr<<<nblk(ne - nie), 256, 0, s>>>(nie, ne, (int)stride, h2d.p, fd.esuel.p, m->nbr.p);
+  m->ghost_nbr = true;
   const size_t nn1 = (size_t)std::max(ncount, 1), nf1 = (size_t)std::max(nfd, 1);
   HIPCHK(m->x.alloc(nn1)); HIPCHK(m->y.alloc(nn1)); HIPCHK(m->z.alloc(nn1)); HIPCHK(m->xyz4.alloc(4 * nn1));
   HIPCHK(m->farea.alloc(nf1)); HIPCHK(m->fnx.alloc(nf1)); HIPCHK(m->fny.alloc(nf1)); HIPCHK(m->fnz.alloc(nf1));
@@ -1202,6 +1224,7 @@ static int dev_build_layout(qdg_ctx* ctx, DevFD& fd, const std::vector<int>& bcf
     dm.tgeo = m->tgeo.p;
   }
   dm.blk0 = 0; dm.ninner = (int)ninner; dm.ncomp = ncomp; dm.pde = ctx->cfg.pde; dm.ndofel = nullptr;
+  dm.nlim = (int)nie; dm.row0 = 0;
   if (ctx->cfg.pref) {
     HIPCHK(m->ndofel.alloc(ne)); HIPCHK(m->ndofel2.alloc(ne));
     k_fill_i32<<<nblk(ne), 256, 0, s>>>(m->ndofel.p, ne, 4);

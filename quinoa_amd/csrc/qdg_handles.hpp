@@ -56,6 +56,8 @@ struct Options {
   int keep_pool = 0;     // 1: qdg_ctx_destroy of the last context keeps the device buffer cache
   int keep_connectivity = 0;  // 1: device-built meshes without ghosts keep connectivity, coordinates, esuel and
                               // boundary faces (caller's numbering) resident: qdg_mesh_refine_uniform needs them
+  int graph_step = 0;    // 1: qdg_step_comm replays its launch sequence (kernels + RCCL) as a hipGraph per
+                         // buffer-rotation phase; falls back to plain launches where capture is refused
 };
 }  // namespace qdg
 
@@ -103,6 +105,8 @@ struct qdg_mesh {
   qdg::DevBuf<int> ndofel, ndofel2;    // p-adaptive DG: DG::m_ndof per device row (+ Jacobi copy)
   qdg::DevBuf<double> fout;            // field output staging (allocated on first use)
   // halo
+  bool ghost_nbr = false;         // the nbr planes hold the ghost rows' neighbours too (device-built meshes)
+  size_t nghost1 = 0;             // > 0: two ghost layers, the rank limits its nghost1 layer-1 ghosts itself
   size_t nnbr = 0, nsend = 0, nrecv = 0;
   std::vector<int32_t> nbr_rank;
   std::vector<size_t> send_off, recv_off;
@@ -118,14 +122,28 @@ struct qdg_mesh {
   struct Keep;
   Keep* keep = nullptr;
   void (*keep_free)(Keep*) = nullptr;
-  // measurement: event pairs around the RHS kernel (cont: second part of a split launch)
+  // measurement: event pairs around the RHS kernel (cont: second part of a split launch) and, inside
+  // qdg_step_comm / qdg_halo_exchange / qdg_stage_dt_allreduce, around every exchange and all-reduce
+  // (ev_kind: 0 RHS launch, 1 halo exchange = pack + grouped send / receive, 2 dt all-reduce)
   bool prof = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
-  std::vector<char> ev_cont;
+  std::vector<char> ev_cont, ev_kind;
   size_t ev_used = 0;
+  // qdg_step_comm as a hipGraph (option graph_step): one executable graph per entry state
+  struct StepGraph {
+    const double* ucur_in; double t, tleft; bool slab_ready_in;
+    hipGraphExec_t exec;
+    double* ucur_out; const double* slab_ready_out;
+  };
+  std::vector<StepGraph> step_graphs;
+  int graph_state = 0;            // 0 not tried, 1 in use, -1 capture refused (graph_error says why)
+  int graph_warm = 0;             // plain steps taken (RCCL sets its connections up in the first ones)
+  long long graph_replays = 0;
+  std::string graph_error;
   ~qdg_mesh()
   {
     for (auto& e : ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (auto& g : step_graphs) (void)hipGraphExecDestroy(g.exec);
     if (keep && keep_free) keep_free(keep);
   }
 };

@@ -298,10 +298,11 @@ __global__ __launch_bounds__(256) void k_superbee(DevMesh m, double* __restrict_
     // first the tile's MEANS, [c][row] (10 KB), for the in-tile neighbours; later the staging area of the
     // coalesced row stores (128 rows)
     __shared__ double lds[128 * NPROP];
-    const int tile_e0 = (m.blk0 + xcd_tile(blockIdx.x, gridDim.x)) * 256;
+    // rows [row0, nlim): the owned tets, plus the layer-1 ghosts of a chunk with two ghost layers
+    const int tile_e0 = m.row0 + (m.blk0 + xcd_tile(blockIdx.x, gridDim.x)) * 256;
     const int e0 = tile_e0 + threadIdx.x;
-    const bool active = e0 < m.nie;
-    const int e = active ? e0 : m.nie - 1;
+    const bool active = e0 < m.nlim;
+    const int e = active ? e0 : m.nlim - 1;
     const int stride = m.stride;
     int nb[4];
 #pragma unroll
@@ -320,9 +321,9 @@ __global__ __launch_bounds__(256) void k_superbee(DevMesh m, double* __restrict_
     for (int lf = 0; lf < 4; ++lf) {
       if (nb[lf] < 0) continue;
       const int r = nb[lf] - tile_e0;
-      // in-tile neighbour: means from LDS (a ghost id may fall into the id range of a
-      // ragged last tile: ghosts always come from global memory)
-      if (nb[lf] < m.nie && (unsigned)r < 256u) {
+      // in-tile neighbour: means from LDS (a row beyond the limited range may fall into the id range of
+      // a ragged last tile: it always comes from global memory)
+      if (nb[lf] < m.nlim && (unsigned)r < 256u) {
 #pragma unroll
         for (int c = 0; c < NCOMP; ++c) {
           const double v = lds[c * 256 + r];
@@ -357,7 +358,7 @@ __global__ __launch_bounds__(256) void k_superbee(DevMesh m, double* __restrict_
     if (!__syncthreads_or(changed && active)) return;
     // Out-of-tile neighbours may be read from U while another tile has already
     // stored its limited rows: safe, Superbee never changes a mean.
-    tile_store_rows_halves<NPROP>(U, tile_e0, m.nie, lds, &u[0][0]);
+    tile_store_rows_halves<NPROP>(U, tile_e0, m.nlim, lds, &u[0][0]);
   }
 }
 
@@ -511,7 +512,7 @@ __global__ __launch_bounds__(BS) void k_weno(DevMesh m, double cweight,
 #pragma unroll
       for (int d = 0; d < 3; ++d) stage[(threadIdx.x * NCOMP + c) * 3 + d] = r[c][1 + d];
     __syncthreads();
-    if (e < m.nie) {
+    if (e < m.nlim) {
       const int stride = m.stride;
       const int t0 = blk * BS, tn = (m.ne - t0 < BS) ? m.ne - t0 : BS;    // rows [t0, t0 + tn) are in LDS
       int nb[4];
@@ -1316,7 +1317,7 @@ template <int NDOF>
 __global__ __launch_bounds__(256) void k_superbee(DevMesh m, double* __restrict__ U)
 {
   const int e = xcd_tile(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
-  if (e >= m.nie) return;
+  if (e >= m.nlim) return;
   if constexpr (NDOF > 1) {
     if (m.ndofel && m.ndofel[e] == 1) return;        // Limiter.cpp:179-180
     const int c = blockIdx.y;
@@ -1350,7 +1351,7 @@ __global__ __launch_bounds__(256) void k_weno(DevMesh m, double cweight, const d
   double r[NDOF];
   load<NDOF>(Uin, at<NDOF>(m, e, c), r);
   if constexpr (NDOF > 1) {
-    if (e < m.nie) {
+    if (e < m.nlim) {
       double g[5][3], wd[5], wtot = 0.0;
       int nb[4];
 #pragma unroll
@@ -1693,19 +1694,38 @@ void launch_rhs_rk(int ndof, const DevMesh& m, const Phys& ph, double t, const d
   QDG_DISPATCH_PROB(ph.problem, (k_rhs<1, P, 2><<<nb, 256, 0, s>>>(m, ph, t, U, Uout, nullptr, a, b, dt, Un)));
 }
 
+// the limiter's row range: [0, nlim) -- the owned tets and, with two ghost layers, the layer-1 ghosts
+static DevMesh lim_range(const DevMesh& m0)
+{
+  DevMesh m = m0;
+  if (m.nlim < m.nie) m.nlim = m.nie;
+  m.row0 = 0;
+  return m;
+}
+
 // 256-row blocks [first, first+count) (count < 0: all)
 void launch_superbee(int ndof, const DevMesh& m0, double* U, hipStream_t s, int first, int count)
 {
   if (m0.nie == 0 || ndof == 1) return;
-  if (m0.pde == 1) {
-    if (first == 0) QDG_DISPATCH_NDOF(ndof, (tr::k_superbee<N><<<dim3(nblk(m0.nie, 256), m0.ncomp), 256, 0, s>>>(m0, U)));
+  DevMesh m = lim_range(m0);
+  if (m.pde == 1) {
+    if (first == 0) QDG_DISPATCH_NDOF(ndof, (tr::k_superbee<N><<<dim3(nblk(m.nlim, 256), m.ncomp), 256, 0, s>>>(m, U)));
     return;
   }
-  DevMesh m = m0;
   m.blk0 = first;
-  const int nb = count < 0 ? (int)nblk(m.nie, 256) - first : count;
+  const int nb = count < 0 ? (int)nblk(m.nlim, 256) - first : count;
   if (nb <= 0) return;
   QDG_DISPATCH_NDOF(ndof, (k_superbee<N><<<nb, 256, 0, s>>>(m, U)));
+}
+
+// rows [row0, row1) only (CompFlow): the layer-1 ghosts behind the fused stage-0 update + limiter
+void launch_superbee_rows(int ndof, const DevMesh& m0, double* U, int row0, int row1, hipStream_t s)
+{
+  if (row1 <= row0 || ndof == 1 || m0.pde == 1) return;
+  DevMesh m = m0;
+  m.row0 = row0; m.nlim = row1; m.blk0 = 0;
+  m.fold_slot = nullptr; m.fold_slab = nullptr;
+  QDG_DISPATCH_NDOF(ndof, (k_superbee<N><<<nblk(row1 - row0, 256), 256, 0, s>>>(m, U)));
 }
 
 void launch_upd_superbee(const DevMesh& m, const double* dt, const double* U0, const double* R,
@@ -1723,10 +1743,11 @@ void launch_halo_pack_upd(const double* U0, const double* R, const double* dt, c
   k_halo_pack_upd<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(U0, R, dt, vol, send_elem, nsend, slab);
 }
 
-void launch_weno(int ndof, const DevMesh& m, double cweight, const double* Uin, double* Uout,
+void launch_weno(int ndof, const DevMesh& m0, double cweight, const double* Uin, double* Uout,
                  hipStream_t s)
 {
-  if (m.ne == 0 || ndof == 1) return;
+  if (m0.ne == 0 || ndof == 1) return;
+  const DevMesh m = lim_range(m0);
   if (m.pde == 1) {
     QDG_DISPATCH_NDOF(ndof, (tr::k_weno<N><<<dim3(nblk(m.ne, 256), m.ncomp), 256, 0, s>>>(m, cweight, Uin, Uout)));
     return;

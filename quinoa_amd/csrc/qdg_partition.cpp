@@ -120,22 +120,137 @@ extern "C" int qdg_partition(size_t nelem, const size_t* inpoel, size_t nnode, c
   QDG_CATCH
 }
 
+// ---------------------------------------------------------------------------------------
+// Ghost layers and halo plan of ONE rank from the face adjacency of a mesh (or of the part of a mesh around
+// the rank's tets), the owner rank of every tet and the tets' global ids.
+//
+//   layer 1 = tets of other ranks that share a face with an owned tet: what the DG chare keeps as ghosts
+//             (src/Inciter/DG.cpp:468-712);
+//   layer 2 (depth 2) = tets of other ranks, not in layer 1, that share a face with a layer-1 tet.  With it a
+//             rank holds every input of the limiter of its layer-1 ghosts (Limiter.cpp:29-316 read the face
+//             neighbours of a tet) and limits them ITSELF: the second exchange of every RK stage -- the limited
+//             solution, DG::lim -> comlim, DG.cpp:1262-1282 -- is not needed, a step has 3 exchanges instead of 6.
+//
+// A plan ENTRY is a (neighbour rank, layer) pair: the layer-1 entries by ascending rank, then the layer-2
+// entries by ascending rank; entry i has a send list (the owned tets in that rank's layer of THAT rank's plan,
+// ordered by global id) and a receive range of the ghost rows (that rank's tets in this rank's layer, ordered
+// by global id).  Both ranks of a pair derive matching lists without talking to each other.  Rank q's layer 2
+// holds my tet t iff t is not in q's layer 1 and some face neighbour g of t (mine or a third rank's) is: i.e.
+// owner(g) != q and g shares a face with a tet of q -- all within two faces of t, so the adjacency only has to
+// be complete that far around the owned tets.
+namespace {
+struct GhostPlan {
+  size_t nghost1 = 0;
+  std::vector<size_t> ghost;                     // tets of the layers: layer 1 (by owner, gid), then layer 2
+  std::vector<int32_t> entry_rank, entry_layer;
+  std::vector<size_t> recv_off, send_off, send_elem;
+};
+
+int ghost_plan(size_t nelem, const int* esuel, const int32_t* owner, const size_t* gid, int rank, int depth,
+               GhostPlan& gp, const char* who)
+{
+  auto gidof = [&](size_t e) { return gid ? gid[e] : e; };
+  std::vector<char> layer(nelem, 0);
+  using Pair = std::pair<int32_t, size_t>;        // (rank, tet)
+  std::vector<Pair> recv[2], send[2];
+  for (size_t e = 0; e < nelem; ++e) {
+    if (owner[e] != rank) continue;
+    for (int lf = 0; lf < 4; ++lf) {
+      const int nb = esuel[4 * e + lf];
+      if (nb < -1 || (nb >= 0 && (size_t)nb >= nelem)) return fail(std::string(who) + ": esuel entry out of range");
+      if (nb >= 0 && owner[nb] != rank) {
+        if (!layer[nb]) { layer[nb] = 1; recv[0].emplace_back(owner[nb], (size_t)nb); }
+        send[0].emplace_back(owner[nb], e);
+      }
+    }
+  }
+  if (depth >= 2) {
+    const size_t n1 = recv[0].size();
+    for (size_t i = 0; i < n1; ++i) {
+      const size_t g = recv[0][i].second;
+      for (int lf = 0; lf < 4; ++lf) {
+        const int nb = esuel[4 * g + lf];
+        if (nb >= 0 && owner[nb] != rank && !layer[nb]) { layer[nb] = 2; recv[1].emplace_back(owner[nb], (size_t)nb); }
+      }
+    }
+    // my tets in the layer 2 of rank q: not next to a tet of q, but next to a tet g (not q's) that is
+    for (size_t e = 0; e < nelem; ++e) {
+      if (owner[e] != rank) continue;
+      int32_t direct[4]; int nd = 0;
+      for (int lf = 0; lf < 4; ++lf) {
+        const int nb = esuel[4 * e + lf];
+        if (nb >= 0 && owner[nb] != rank) direct[nd++] = owner[nb];
+      }
+      for (int lf = 0; lf < 4; ++lf) {
+        const int g = esuel[4 * e + lf];
+        if (g < 0) continue;
+        for (int l2 = 0; l2 < 4; ++l2) {
+          const int a = esuel[4 * (size_t)g + l2];
+          if (a < 0) continue;
+          const int32_t q = owner[a];
+          if (q == rank || q == owner[g]) continue;          // g must be in q's layer 1: not q's own tet
+          bool isdirect = false;
+          for (int i = 0; i < nd; ++i) isdirect = isdirect || direct[i] == q;
+          if (!isdirect) send[1].emplace_back(q, e);
+        }
+      }
+    }
+  }
+  auto order = [&](std::vector<Pair>& v) {
+    std::sort(v.begin(), v.end(), [&](const Pair& p, const Pair& q) {
+      return p.first != q.first ? p.first < q.first : gidof(p.second) < gidof(q.second); });
+    v.erase(std::unique(v.begin(), v.end()), v.end());
+  };
+  gp.recv_off.assign(1, 0); gp.send_off.assign(1, 0);
+  for (int l = 0; l < (depth >= 2 ? 2 : 1); ++l) {
+    order(recv[l]); order(send[l]);
+    std::vector<int32_t> ranks;
+    for (const Pair& p : recv[l]) ranks.push_back(p.first);
+    for (const Pair& p : send[l]) ranks.push_back(p.first);
+    std::sort(ranks.begin(), ranks.end());
+    ranks.erase(std::unique(ranks.begin(), ranks.end()), ranks.end());
+    size_t i = 0, j = 0;
+    for (int32_t q : ranks) {
+      gp.entry_rank.push_back(q); gp.entry_layer.push_back(l + 1);
+      while (i < recv[l].size() && recv[l][i].first == q) { gp.ghost.push_back(recv[l][i].second); ++i; }
+      while (j < send[l].size() && send[l][j].first == q) { gp.send_elem.push_back(send[l][j].second); ++j; }
+      gp.recv_off.push_back(gp.ghost.size());
+      gp.send_off.push_back(gp.send_elem.size());
+      // (layer 1: a face joins the two tets, so both directions exist)
+      if (l == 0 && (gp.recv_off[gp.recv_off.size() - 2] == gp.recv_off.back() || gp.send_off[gp.send_off.size() - 2] == gp.send_off.back()))
+        return fail(std::string(who) + ": a rank receives from us but sends nothing (asymmetric esuel)");
+    }
+    if (l == 0) gp.nghost1 = gp.ghost.size();
+  }
+  return 0;
+}
+}  // namespace
+
 struct qdg_chunk {
-  size_t nielem = 0, nunk = 0, nnode = 0;
+  size_t nielem = 0, nunk = 0, nnode = 0, nghost1 = 0;
+  int depth = 1;
   std::vector<size_t> inpoel;     // [4*nunk] local node ids
   std::vector<size_t> elem_gid;   // [nunk]
   std::vector<size_t> node_gid;   // [nnode]
-  std::vector<int32_t> nbr_rank;  // ascending
+  std::vector<int32_t> nbr_rank;  // per plan entry: layer-1 entries (ranks ascending), then layer-2 entries
+  std::vector<int32_t> nbr_layer;
   std::vector<size_t> send_off, send_elem, recv_off;
 };
 
 extern "C" int qdg_chunk_build(size_t nelem, size_t nnode, const size_t* inpoel, const int* esuel,
                                const int32_t* part, int nparts, int rank, qdg_chunk** out)
 {
+  return qdg_chunk_build_depth(nelem, nnode, inpoel, esuel, part, nparts, rank, 1, out);
+}
+
+extern "C" int qdg_chunk_build_depth(size_t nelem, size_t nnode, const size_t* inpoel, const int* esuel,
+                                     const int32_t* part, int nparts, int rank, int depth, qdg_chunk** out)
+{
   QDG_TRY
   if (!inpoel || !part || !out) return fail("qdg_chunk_build: null argument");
   *out = nullptr;
   if (rank < 0 || rank >= nparts) return fail("qdg_chunk_build: rank outside [0, nparts)");
+  if (depth != 1 && depth != 2) return fail("qdg_chunk_build: depth must be 1 or 2");
   std::vector<int> own_esuel;
   if (!esuel) {                       // face adjacency of the whole mesh (FaceData.cpp:19-41 -> genEsuelTet)
     own_esuel.resize(4 * nelem);
@@ -143,6 +258,7 @@ extern "C" int qdg_chunk_build(size_t nelem, size_t nnode, const size_t* inpoel,
     esuel = own_esuel.data();
   }
   std::unique_ptr<qdg_chunk> c(new qdg_chunk);
+  c->depth = depth;
   // owned tets keep the input order (a serial run keeps the file's numbering too)
   std::vector<size_t> owned;
   for (size_t e = 0; e < nelem; ++e) {
@@ -150,46 +266,23 @@ extern "C" int qdg_chunk_build(size_t nelem, size_t nnode, const size_t* inpoel,
     if (part[e] == rank) owned.push_back(e);
   }
   if (owned.empty()) return fail("qdg_chunk_build: this rank owns no element");
-  // (neighbour rank, global tet id) pairs: what we receive (their tets) and what we send (ours)
-  std::vector<std::pair<int32_t, size_t>> recv, send;
-  for (size_t e : owned)
-    for (int lf = 0; lf < 4; ++lf) {
-      const int nb = esuel[4 * e + lf];
-      if (nb < -1 || (nb >= 0 && (size_t)nb >= nelem)) return fail("qdg_chunk_build: esuel entry out of range");
-      if (nb >= 0 && part[nb] != rank) {
-        recv.emplace_back(part[nb], (size_t)nb);
-        send.emplace_back(part[nb], e);
-      }
-    }
-  auto uniq = [](std::vector<std::pair<int32_t, size_t>>& v) {
-    std::sort(v.begin(), v.end());
-    v.erase(std::unique(v.begin(), v.end()), v.end());
-  };
   // both sides order a pair's tets by global id: the sender's list for q IS the order in which q
   // stores the ghosts it gets from us (DG.cpp:1023-1031 sends m_ghostData[q] in the order q's
   // m_ghost map expects)
-  uniq(recv); uniq(send);
-  for (const auto& r : recv) if (c->nbr_rank.empty() || c->nbr_rank.back() != r.first) c->nbr_rank.push_back(r.first);
-  const size_t nnbr = c->nbr_rank.size();
+  GhostPlan gp;
+  if (int rc = ghost_plan(nelem, esuel, part, nullptr, rank, depth, gp, "qdg_chunk_build")) return rc;
+  c->nbr_rank = gp.entry_rank; c->nbr_layer = gp.entry_layer;
+  c->recv_off = gp.recv_off; c->send_off = gp.send_off;
+  c->nghost1 = gp.nghost1;
   c->nielem = owned.size();
-  c->nunk = owned.size() + recv.size();
+  c->nunk = owned.size() + gp.ghost.size();
   c->elem_gid = owned;
-  c->recv_off.assign(nnbr + 1, 0); c->send_off.assign(nnbr + 1, 0);
-  {
-    size_t i = 0, j = 0;
-    for (size_t k = 0; k < nnbr; ++k) {
-      while (i < recv.size() && recv[i].first == c->nbr_rank[k]) { c->elem_gid.push_back(recv[i].second); ++i; }
-      c->recv_off[k + 1] = i;
-      while (j < send.size() && send[j].first == c->nbr_rank[k]) ++j;
-      c->send_off[k + 1] = j;
-    }
-    if (j != send.size()) return fail("qdg_chunk_build: a rank receives from us but sends nothing (asymmetric esuel)");
-  }
+  c->elem_gid.insert(c->elem_gid.end(), gp.ghost.begin(), gp.ghost.end());
   // global -> local ids
   std::vector<int> e_g2l(nelem, -1);
   for (size_t l = 0; l < c->nielem; ++l) e_g2l[owned[l]] = (int)l;
-  c->send_elem.resize(send.size());
-  for (size_t j = 0; j < send.size(); ++j) c->send_elem[j] = (size_t)e_g2l[send[j].second];
+  c->send_elem.resize(gp.send_elem.size());
+  for (size_t j = 0; j < gp.send_elem.size(); ++j) c->send_elem[j] = (size_t)e_g2l[gp.send_elem[j]];
   std::vector<int> n_g2l(nnode, -1);
   c->inpoel.resize(4 * c->nunk);
   for (size_t l = 0; l < c->nunk; ++l)
@@ -201,6 +294,65 @@ extern "C" int qdg_chunk_build(size_t nelem, size_t nnode, const size_t* inpoel,
     }
   c->nnode = c->node_gid.size();
   *out = c.release();
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_chunk_layers(const qdg_chunk* c, int32_t* depth, size_t* nghost1, int32_t* nbr_layer)
+{
+  QDG_TRY
+  if (!c) return fail("qdg_chunk_layers: null chunk");
+  if (depth) *depth = c->depth;
+  if (nghost1) *nghost1 = c->nghost1;
+  if (nbr_layer && !c->nbr_layer.empty()) std::memcpy(nbr_layer, c->nbr_layer.data(), c->nbr_layer.size() * sizeof(int32_t));
+  return 0;
+  QDG_CATCH
+}
+
+// the plan alone, for a caller that assembles its chunk itself (quinoa_amd/meshgen.py: the analytic block cut
+// of the synthetic box hands in the tets around its block): tets are addressed by their index in the arrays
+struct qdg_ghost_plan { GhostPlan gp; };
+
+extern "C" int qdg_ghost_plan_build(size_t nelem, const int* esuel, const int32_t* owner, const size_t* gid, int rank,
+                                    int depth, qdg_ghost_plan** out)
+{
+  QDG_TRY
+  if (!esuel || !owner || !out) return fail("qdg_ghost_plan_build: null argument");
+  *out = nullptr;
+  if (depth != 1 && depth != 2) return fail("qdg_ghost_plan_build: depth must be 1 or 2");
+  if (nelem > (size_t)INT32_MAX) return fail("qdg_ghost_plan_build: too many elements");
+  std::unique_ptr<qdg_ghost_plan> p(new qdg_ghost_plan);
+  if (int rc = ghost_plan(nelem, esuel, owner, gid, rank, depth, p->gp, "qdg_ghost_plan_build")) return rc;
+  *out = p.release();
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_ghost_plan_sizes(const qdg_ghost_plan* p, size_t* nghost, size_t* nghost1, size_t* nentry, size_t* nsend)
+{
+  QDG_TRY
+  if (!p || !nghost || !nghost1 || !nentry || !nsend) return fail("qdg_ghost_plan_sizes: null argument");
+  *nghost = p->gp.ghost.size(); *nghost1 = p->gp.nghost1; *nentry = p->gp.entry_rank.size(); *nsend = p->gp.send_elem.size();
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_ghost_plan_get(const qdg_ghost_plan* p, size_t* ghost, int32_t* entry_rank, int32_t* entry_layer,
+                                  size_t* recv_off, size_t* send_off, size_t* send_elem)
+{
+  QDG_TRY
+  if (!p) return fail("qdg_ghost_plan_get: null plan");
+  auto cp = [](auto* dst, const auto& v) { if (dst && !v.empty()) std::memcpy(dst, v.data(), v.size() * sizeof(v[0])); };
+  cp(ghost, p->gp.ghost); cp(entry_rank, p->gp.entry_rank); cp(entry_layer, p->gp.entry_layer);
+  cp(recv_off, p->gp.recv_off); cp(send_off, p->gp.send_off); cp(send_elem, p->gp.send_elem);
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_ghost_plan_destroy(qdg_ghost_plan* p)
+{
+  QDG_TRY
+  delete p;
   return 0;
   QDG_CATCH
 }

@@ -117,8 +117,12 @@ class RcclComm:
 
 
 class DGDriver:
-    def __init__(self, ctx, mesh, nbr_rank=(), send_lists=(), recv_counts=(), comm=None):
+    def __init__(self, ctx, mesh, nbr_rank=(), send_lists=(), recv_counts=(), comm=None, nghost1=0):
+        """nghost1 > 0: the chunk has two ghost layers (meshgen.kuhn_box_chunk / partition.build_chunk with
+        depth = 2; nbr_rank / send_lists / recv_counts per (rank, layer) entry): the rank limits its nghost1
+        layer-1 ghosts itself and the exchange of the limited solution (comlim) is dropped"""
         self.ctx, self.mesh = ctx, mesh
+        self.deep = nghost1 > 0
         self.comm = comm or SerialComm()
         self.nprop = mesh.nprop
         self.pref = bool(ctx.cfg.pref)
@@ -129,10 +133,14 @@ class DGDriver:
         self.rccl = isinstance(self.comm, RcclComm)
         if self.rccl:
             mesh.halo_setup(self.nbr_rank, send_lists, recv_counts)
+            if self.deep:
+                mesh.halo_set_depth(nghost1)
         if self.distributed:
             torch = self.comm.torch
             dev = torch.device("cuda", torch.cuda.current_device())
             mesh.halo_setup(self.nbr_rank, send_lists, recv_counts)
+            if self.deep:
+                mesh.halo_set_depth(nghost1)
             self.send_off, self.recv_off = mesh.send_off, mesh.recv_off
             ns, nr = mesh.halo_sizes()
             # doubles per slab row (nprop, + 1 for the tet's ndof with p-adaptive DG)
@@ -168,8 +176,8 @@ class DGDriver:
             self.exchange()                      # comsol (rows + ndof)
             if self.pref and stage == 0:
                 m.stage_pdg_propagate()          # DG::lim: propagate_ndof (+ zeroing of DG::solve)
-            m.stage_limit()
-            if self.limiter_active or (self.pref and stage == 0):
+            m.stage_limit()                      # (two ghost layers: also limits the layer-1 ghosts)
+            if (self.limiter_active and not self.deep) or (self.pref and stage == 0):
                 self.exchange()                  # comlim (a no-op copy without a limiter;
                                                  # with pdg it carries the propagated ndof)
             # rhs; at stage 0 it also yields the local dt (the reference computes
@@ -197,8 +205,12 @@ class LocalChunks:
         self.pref = bool(ctx.cfg.pref)
         self.limiter_active = ctx.cfg.limiter != 0 and ctx.ndof > 1
         self.soff, self.roff = [], []
+        # two ghost layers (chunks built with depth = 2): one plan entry per (rank, layer), no comlim exchange
+        self.deep = all(ch.get("depth", 1) == 2 for ch in chunks) and len(chunks) > 1
         for mesh, ch in zip(meshes, chunks):
             mesh.halo_setup(ch["nbr_rank"], ch["send_lists"], ch["recv_counts"])
+            if self.deep:
+                mesh.halo_set_depth(ch["nghost1"])
             self.soff.append(np.concatenate([[0], np.cumsum([len(s) for s in ch["send_lists"]])]).astype(np.int64))
             self.roff.append(np.concatenate([[0], np.cumsum(ch["recv_counts"])]).astype(np.int64))
 
@@ -206,8 +218,11 @@ class LocalChunks:
         for m in self.meshes:
             m.halo_pack()
         for r, ch in enumerate(self.chunks):
+            lay = ch.get("nbr_layer") or [1] * len(ch["nbr_rank"])
             for i, q in enumerate(ch["nbr_rank"]):
-                j = self.chunks[q]["nbr_rank"].index(r)
+                oth = self.chunks[q]
+                olay = oth.get("nbr_layer") or [1] * len(oth["nbr_rank"])
+                j = [k for k, (qq, ll) in enumerate(zip(oth["nbr_rank"], olay)) if qq == r and ll == lay[i]][0]
                 n = self.roff[r][i + 1] - self.roff[r][i]
                 assert n == self.soff[q][j + 1] - self.soff[q][j]
                 self.meshes[r].halo_copy_from(self.roff[r][i], self.meshes[q], self.soff[q][j], n)
@@ -225,7 +240,7 @@ class LocalChunks:
                     m.stage_pdg_propagate()
             for m in self.meshes:
                 m.stage_limit()
-            if self.limiter_active or (self.pref and stage == 0):
+            if (self.limiter_active and not self.deep) or (self.pref and stage == 0):
                 self.exchange()
             for m in self.meshes:
                 m.stage_rhs_dt(stage, t, tleft)

@@ -108,13 +108,16 @@ def _hex_tets(I, J, K, npx, npy):
 
 
 def kuhn_box_chunk(nx, ny, nz, lengths=(1.0, 1.0, 1.0), parts=(1, 1, 1), rank=0,
-                   jitter=0.2, seed=12345, shuffle_seed=67890):
+                   jitter=0.2, seed=12345, shuffle_seed=67890, depth=1):
     """Return one chunk of the box mesh as a dict:
       coord[nnode,3], inpoel[nunk,4] (local node ids; rows [0,nielem) owned,
       rows [nielem,nunk) ghosts grouped by neighbour rank), nielem,
       sidesets {id: triangles[n,3]} (local node ids, owned tets only),
       gid[nunk] global tet ids, nbr_rank[], send_lists[] (local tet ids per
       neighbour, ordered by global id), recv_counts[].
+    depth = 2: two ghost layers (qdg_chunk_build_depth's shape: nghost1 layer-1 ghosts, then layer 2; one plan
+    entry per (neighbour rank, layer): nbr_rank, nbr_layer, send_lists, recv_counts per entry); the mesh itself
+    and the owned tets' order are those of depth 1.
     """
     px, py, pz = parts
     nranks = px * py * pz
@@ -140,9 +143,46 @@ def kuhn_box_chunk(nx, ny, nz, lengths=(1.0, 1.0, 1.0), parts=(1, 1, 1), rank=0,
     ej0, ej1 = max(j0 - 1, 0), min(j1 + 1, ny)
     ek0, ek1 = max(k0 - 1, 0), min(k1 + 1, nz)
     nbr_rank, send_lists, recv_counts = [], [], []
+    nbr_layer, nghost1 = [], 0
     gho_gnode = np.zeros((0, 4), dtype=np.int64)
     gho_gid = np.zeros(0, dtype=np.int64)
-    if nranks > 1:
+    if nranks > 1 and depth == 2:
+        # two layers: the tets of the two outer hex layers of the block and of a two-hex ring around it (a face
+        # neighbour of a Kuhn tet lies in its own or in a face-adjacent hex), their face adjacency, and the
+        # library's ghost-plan builder (qdg_ghost_plan_build) on that -- the rule qdg_chunk_build_depth applies
+        from . import capi, partition
+        ei0, ei1 = max(i0 - 2, 0), min(i1 + 2, nx)
+        ej0, ej1 = max(j0 - 2, 0), min(j1 + 2, ny)
+        ek0, ek1 = max(k0 - 2, 0), min(k1 + 2, nz)
+        HI, HJ, HK = np.meshgrid(np.arange(ei0, ei1), np.arange(ej0, ej1), np.arange(ek0, ek1), indexing="ij")
+        HI, HJ, HK = HI.ravel(), HJ.ravel(), HK.ravel()
+        halo = ~((HI >= i0) & (HI < i1) & (HJ >= j0) & (HJ < j1) & (HK >= k0) & (HK < k1))
+        HI, HJ, HK = HI[halo], HJ[halo], HK[halo]
+
+        def blk2(v, ranges):
+            b = np.zeros_like(v)
+            for q, (lo, hi) in enumerate(ranges):
+                b[(v >= lo) & (v < hi)] = q
+            return b
+        h_owner = np.repeat(blk2(HI, bx) + px * (blk2(HJ, by) + py * blk2(HK, bz)), 6)
+        h_gnode = _hex_tets(HI, HJ, HK, npx, npy)
+        h_gid = ((HI + nx * (HJ + ny * HK))[:, None] * 6 + np.arange(6)[None, :]).reshape(-1)
+        own_hex = own_gid // 6
+        oi, oj, ok = own_hex % nx, (own_hex // nx) % ny, own_hex // (nx * ny)
+        near = (oi < i0 + 2) | (oi >= i1 - 2) | (oj < j0 + 2) | (oj >= j1 - 2) | (ok < k0 + 2) | (ok >= k1 - 2)
+        sidx2 = np.nonzero(near)[0]
+        c_gnode = np.concatenate([own_gnode[sidx2], h_gnode])
+        c_owner = np.concatenate([np.full(len(sidx2), rank, dtype=np.int64), h_owner])
+        c_gid = np.concatenate([own_gid[sidx2], h_gid])
+        fd_esuel = capi.gen_esuel(c_gnode)
+        pl = partition.ghost_plan(fd_esuel, c_owner, c_gid, rank, depth=2)
+        gsel = pl["ghost"] - len(sidx2)
+        assert (gsel >= 0).all()
+        gho_gnode, gho_gid = h_gnode[gsel], h_gid[gsel]
+        nbr_rank, nbr_layer, nghost1 = pl["nbr_rank"], pl["nbr_layer"], pl["nghost1"]
+        recv_counts = pl["recv_counts"]
+        send_lists = [sidx2[sl].astype(np.int64) for sl in pl["send_lists"]]
+    elif nranks > 1:
         HI, HJ, HK = np.meshgrid(np.arange(ei0, ei1), np.arange(ej0, ej1), np.arange(ek0, ek1),
                                  indexing="ij")
         HI, HJ, HK = HI.ravel(), HJ.ravel(), HK.ravel()
@@ -183,6 +223,7 @@ def kuhn_box_chunk(nx, ny, nz, lengths=(1.0, 1.0, 1.0), parts=(1, 1, 1), rank=0,
             recv_counts.append(int(np.sum(h_owner[gsel] == q)))
             cand = np.unique(pair_own[h_owner[pair_gho] == q])
             send_lists.append(cand[np.argsort(own_gid[cand])].astype(np.int64))
+        nbr_layer, nghost1 = [1] * len(nbr_rank), len(gho_gid)
 
     # ---- local nodes: the block's node box + extra ghost nodes, permuted ----
     bnx, bny, bnz = i1 - i0 + 1, j1 - j0 + 1, k1 - k0 + 1
@@ -240,6 +281,7 @@ def kuhn_box_chunk(nx, ny, nz, lengths=(1.0, 1.0, 1.0), parts=(1, 1, 1), rank=0,
     return {"coord": coord, "inpoel": inpoel.astype(np.int64), "nielem": nielem,
             "sidesets": sidesets, "gid": np.concatenate([own_gid, gho_gid]).astype(np.int64),
             "nbr_rank": nbr_rank, "send_lists": send_lists, "recv_counts": recv_counts,
+            "nbr_layer": nbr_layer, "nghost1": int(nghost1), "depth": int(depth) if nranks > 1 else 1,
             "ntet_global": nx * ny * nz * 6}
 
 

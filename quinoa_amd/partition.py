@@ -26,9 +26,42 @@ def partition(coord, inpoel, nparts, method="rcb"):
     return part
 
 
-def build_chunk(coord, inpoel, sidesets, part, nparts, rank, esuel=None):
+def ghost_plan(esuel, owner, gid, rank, depth=1):
+    """qdg_ghost_plan_build: ghost layers and halo plan of `rank` from the face adjacency of the tets around its
+    own, their owner ranks and global ids.  -> dict(ghost [tet indices: layer 1, then layer 2], nghost1,
+    nbr_rank, nbr_layer [per plan entry], send_lists [owned tet indices per entry], recv_counts)"""
+    L = capi.lib()
+    esuel = np.ascontiguousarray(esuel, dtype=np.int32).reshape(-1)
+    owner = np.ascontiguousarray(owner, dtype=np.int32)
+    g, pg = capi._sz(np.asarray(gid))
+    h = C.c_void_p()
+    capi._chk(L.qdg_ghost_plan_build(C.c_size_t(len(owner)), esuel.ctypes.data_as(capi.c_i32p),
+                                     owner.ctypes.data_as(capi.c_i32p), pg, C.c_int(int(rank)), C.c_int(int(depth)),
+                                     C.byref(h)))
+    try:
+        n = [C.c_size_t() for _ in range(4)]
+        capi._chk(L.qdg_ghost_plan_sizes(h, *[C.byref(v) for v in n]))
+        ng, ng1, nent, nsend = (int(v.value) for v in n)
+        ghost = np.zeros(max(ng, 1), dtype=np.uint64); selem = np.zeros(max(nsend, 1), dtype=np.uint64)
+        er = np.zeros(max(nent, 1), dtype=np.int32); el = np.zeros(max(nent, 1), dtype=np.int32)
+        roff = np.zeros(nent + 1, dtype=np.uint64); soff = np.zeros(nent + 1, dtype=np.uint64)
+        capi._chk(L.qdg_ghost_plan_get(h, ghost.ctypes.data_as(capi.c_szp), er.ctypes.data_as(capi.c_i32p),
+                                       el.ctypes.data_as(capi.c_i32p), roff.ctypes.data_as(capi.c_szp),
+                                       soff.ctypes.data_as(capi.c_szp), selem.ctypes.data_as(capi.c_szp)))
+    finally:
+        L.qdg_ghost_plan_destroy(h)
+    soff = soff.astype(np.int64); roff = roff.astype(np.int64)
+    return {"ghost": ghost[:ng].astype(np.int64), "nghost1": ng1, "nbr_rank": [int(r) for r in er[:nent]],
+            "nbr_layer": [int(r) for r in el[:nent]],
+            "send_lists": [selem[soff[i]:soff[i + 1]].astype(np.int64) for i in range(nent)],
+            "recv_counts": [int(roff[i + 1] - roff[i]) for i in range(nent)]}
+
+
+def build_chunk(coord, inpoel, sidesets, part, nparts, rank, esuel=None, depth=1):
     """One rank's chunk: dict(coord, inpoel, nielem, sidesets, gid, node_gid, nbr_rank,
-    send_lists, recv_counts) in local numbering (owned tets first, ghosts grouped by owner)."""
+    send_lists, recv_counts) in local numbering (owned tets first, ghosts grouped by owner).
+    depth = 2: two ghost layers (nghost1 rows of layer 1, then layer 2); the plan has one entry per
+    (neighbour rank, layer): nbr_rank / nbr_layer / send_lists / recv_counts per entry."""
     L = capi.lib()
     coord = np.asarray(coord, dtype=np.float64)
     inp, pinp = capi._sz(np.asarray(inpoel).reshape(-1))
@@ -38,9 +71,9 @@ def build_chunk(coord, inpoel, sidesets, part, nparts, rank, esuel=None):
         esuel = np.ascontiguousarray(esuel, dtype=np.int32)
         pes = esuel.ctypes.data_as(capi.c_i32p)
     h = C.c_void_p()
-    capi._chk(L.qdg_chunk_build(C.c_size_t(len(inp) // 4), C.c_size_t(coord.shape[0]), pinp, pes,
-                                part.ctypes.data_as(capi.c_i32p), C.c_int(int(nparts)), C.c_int(int(rank)),
-                                C.byref(h)))
+    capi._chk(L.qdg_chunk_build_depth(C.c_size_t(len(inp) // 4), C.c_size_t(coord.shape[0]), pinp, pes,
+                                      part.ctypes.data_as(capi.c_i32p), C.c_int(int(nparts)), C.c_int(int(rank)),
+                                      C.c_int(int(depth)), C.byref(h)))
     try:
         n = [C.c_size_t() for _ in range(5)]
         capi._chk(L.qdg_chunk_sizes(h, *[C.byref(v) for v in n]))
@@ -56,6 +89,9 @@ def build_chunk(coord, inpoel, sidesets, part, nparts, rank, esuel=None):
                                   ngid.ctypes.data_as(capi.c_szp), nbr.ctypes.data_as(capi.c_i32p),
                                   soff.ctypes.data_as(capi.c_szp), selem.ctypes.data_as(capi.c_szp),
                                   roff.ctypes.data_as(capi.c_szp)))
+        nlay = np.ones(max(nnbr, 1), dtype=np.int32)
+        ng1 = C.c_size_t()
+        capi._chk(L.qdg_chunk_layers(h, None, C.byref(ng1), nlay.ctypes.data_as(capi.c_i32p)))
     finally:
         L.qdg_chunk_destroy(h)
     ngid = ngid.astype(np.int64)
@@ -80,6 +116,7 @@ def build_chunk(coord, inpoel, sidesets, part, nparts, rank, esuel=None):
     soff = soff.astype(np.int64); roff = roff.astype(np.int64)
     return {"coord": coord[ngid], "inpoel": linp.astype(np.int64).reshape(-1, 4), "nielem": nielem,
             "sidesets": ss, "gid": egid.astype(np.int64), "node_gid": ngid,
-            "nbr_rank": [int(r) for r in nbr[:nnbr]],
+            "nbr_rank": [int(r) for r in nbr[:nnbr]], "nbr_layer": [int(r) for r in nlay[:nnbr]],
+            "depth": int(depth), "nghost1": int(ng1.value),
             "send_lists": [selem[soff[i]:soff[i + 1]].astype(np.int64) for i in range(nnbr)],
             "recv_counts": [int(roff[i + 1] - roff[i]) for i in range(nnbr)]}

@@ -218,3 +218,84 @@ def test_device_build_rejects_bad_chunks():
         m.close()
     finally:
         ctx.close()
+
+
+def test_overlapping_side_sets():
+    """A triangle listed in SEVERAL side sets belongs to the set with the highest id and is integrated once,
+    with that set's condition: the reference's loader fills its triangle -> set map set by set in ascending id
+    (`faceside[tri] = s.first`, src/Inciter/Partitioner.cpp:358-364 over the std::map m_bface, Partitioner.hpp:198)
+    and bndSurfInt finds the face in that one set (src/PDE/Integrate/Boundary.cpp:84-86).  An edge strip of the
+    x = 0 side (set 1, Dirichlet) is ALSO listed in set 7 (extrapolate), a strip of the x = 1 side (set 2,
+    Dirichlet) also in set 0 (extrapolate; lower id: loses).  The device build = qdg_mesh_upload with the
+    reference-style bface = the oracle <= 1e-10; the strips' assignment does matter; children of a doubly
+    listed face inherit its one set through the device re-mesh."""
+    from oracle import oracle as O
+    from quinoa_amd import capi, dgmesh, meshgen
+    ch = meshgen.kuhn_box(6, 5, 4)
+    coord, inpoel = ch["coord"], ch["inpoel"]
+    ss = {int(k): np.asarray(v) for k, v in ch["sidesets"].items()}
+    cy = coord[ss[1]].mean(axis=1)[:, 1]
+    ss[7] = ss[1][cy < 0.45]                       # the strip of x = 0 next to the edge y = 0
+    cy2 = coord[ss[2]].mean(axis=1)[:, 1]
+    ss[0] = ss[2][cy2 < 0.45]
+    assert 0 < len(ss[7]) < len(ss[1]) and 0 < len(ss[0]) < len(ss[2])
+    kw = dict(flux="hllc", limiter="nolimiter", problem="vortical_flow", gamma=5.0 / 3.0, alpha=0.1, beta=1.0, p0=10.0,
+              cfl=0.3)
+    bcs = dict(bc_dirichlet=[1, 2, 3, 4, 5, 6], bc_extrapolate=[7, 0], bc_sym=[])
+
+    def oracle_for(sidesets):
+        om = O.OracleMesh(coord, inpoel, sidesets)
+        cfg = O.make_cfg(4, flux="hllc", limiter="nolimiter", problem="vortical_flow", gamma=5.0 / 3.0, alpha=0.1,
+                         beta=1.0, p0=10.0)
+        return O.Oracle(om, cfg, bcs["bc_dirichlet"], bcs["bc_sym"], bcs["bc_extrapolate"])
+
+    orc = oracle_for(ss)
+    Lm = orc.lhs()
+    U = orc.initialize(Lm, 0.0)
+    t = 0.0
+    for _ in range(2):
+        t += orc.step(t, U, Lm, cfl=0.3)
+    R = orc.rhs(t, U)
+    # the assignment matters: with the x = 0 strip left to set 1 (Dirichlet) the residual differs
+    plain = {k: v for k, v in ss.items() if k not in (7, 0)}
+    Rp = oracle_for(plain).rhs(t, U)
+    assert np.abs(Rp - R).max() > 1e-6 * np.abs(R).max()
+    # ... and set 0 changes nothing (set 2 has the higher id)
+    no0 = {k: v for k, v in ss.items() if k != 0}
+    assert np.array_equal(oracle_for(no0).rhs(t, U), R)
+
+    ctx = capi.Context(4, options={"keep_connectivity": 1}, **kw, **bcs)
+    dev = capi.mesh_from_connectivity(ctx, inpoel, coord, ss)
+    host = dgmesh.upload(ctx, dgmesh.build_chunk(coord, inpoel, None, ss))
+    try:
+        Rd, Rh = dev.rhs(t, U), host.rhs(t, U)
+        scale = max(1.0, np.abs(R).max())
+        assert np.abs(Rd - R).max() <= 1e-10 * scale
+        assert np.abs(Rh - R).max() <= 1e-10 * scale
+        assert np.abs(Rd - Rh).max() <= 1e-12 * scale
+        # three resident steps: device-built mesh vs oracle
+        dev.state_upload(U)
+        Uo, to = U.copy(), t
+        for _ in range(3):
+            dtg = dev.step(to)
+            dto = orc.step(to, Uo, Lm, cfl=0.3)
+            assert abs(dtg - dto) <= 1e-12 * dto
+            to += dto
+        assert np.abs(dev.state_download() - Uo).max() <= 1e-10 * max(1.0, np.abs(Uo).max())
+        # the device re-mesh: children of the doubly listed faces carry the winning set
+        new, ref = dev.refine_uniform(host_copy=True)
+        try:
+            c2, i2, ss2, _par = ref.get()
+            assert sorted(ss2) == [1, 2, 3, 4, 5, 6, 7]            # set 0 owns no face
+            assert len(ss2[7]) == 4 * len(ss[7]) and len(ss2[1]) == 4 * (len(ss[1]) - len(ss[7]))
+            om2 = O.OracleMesh(c2, i2, ss2)
+            cfg = O.make_cfg(4, flux="hllc", limiter="nolimiter", problem="vortical_flow", gamma=5.0 / 3.0, alpha=0.1,
+                             beta=1.0, p0=10.0)
+            orc2 = O.Oracle(om2, cfg, bcs["bc_dirichlet"], bcs["bc_sym"], bcs["bc_extrapolate"])
+            U2 = orc2.initialize(orc2.lhs(), 0.0)
+            R2 = orc2.rhs(0.1, U2)
+            assert np.abs(new.rhs(0.1, U2) - R2).max() <= 1e-10 * max(1.0, np.abs(R2).max())
+        finally:
+            ref.close(); new.close()
+    finally:
+        dev.close(); host.close(); ctx.close()

@@ -92,25 +92,36 @@ def test_two_ranks_on_one_gpu_equal_single_chunk(tmp_path, pref, parts):
     assert n == ref.shape[0]
 
 
-def _self_halo_run(kind, out, pref=False, parts=(2, 1, 1)):
+def _self_halo_run(kind, out, pref=False, parts=(2, 1, 1), depth=1, graph=0, nstep=NSTEP):
     """chunk 0 of a cut whose neighbours are all this rank itself"""
     from quinoa_amd import capi, dg, dgmesh, meshgen
     nz = NZ if parts[2] == 1 else 2 * 5             # an even count for a cut along z
-    ch = meshgen.kuhn_box_chunk(NX, NY, nz, parts=parts, rank=0)
-    assert [len(s) for s in ch["send_lists"]] == list(ch["recv_counts"])   # segments line up
-    ck = dgmesh.build_chunk(ch["coord"], ch["inpoel"], ch["nielem"], ch["sidesets"])
-    ctx = capi.Context(4, cfl=0.3, device=0, pref=pref, tolref=0.1, **KW, **BC)
-    mesh = dgmesh.upload(ctx, ck)
+    ch = meshgen.kuhn_box_chunk(NX, NY, nz, parts=parts, rank=0, depth=depth)
+    ctx = capi.Context(4, cfl=0.3, device=0, pref=pref, tolref=0.1, options={"graph_step": graph}, **KW, **BC)
+    if depth == 1:
+        assert [len(s) for s in ch["send_lists"]] == list(ch["recv_counts"])   # segments line up
+        ck = dgmesh.build_chunk(ch["coord"], ch["inpoel"], ch["nielem"], ch["sidesets"])
+        mesh = dgmesh.upload(ctx, ck)
+        nie = ck.nielem
+    else:
+        # two ghost layers: the entries' send and receive counts differ (the rank is its own neighbour only in
+        # name), so every entry sends what it would receive: the first rows of its receive range's owners --
+        # any rows do for a transport test; the device-built mesh holds the ghost rows' neighbours
+        mesh = capi.mesh_from_connectivity(ctx, ch["inpoel"], ch["coord"], ch["sidesets"], nielem=ch["nielem"])
+        nie = ch["nielem"]
+        ch["send_lists"] = [np.resize(s, n) for s, n in zip(ch["send_lists"], ch["recv_counts"])]
     comm = dg.SelfComm() if kind == "copy" else \
         dg.RcclComm(ctx, rank=0, size=1, unique_id=capi.Comm.unique_id())
-    drv = dg.DGDriver(ctx, mesh, [0] * len(ch["nbr_rank"]), ch["send_lists"], ch["recv_counts"], comm)
+    drv = dg.DGDriver(ctx, mesh, [0] * len(ch["nbr_rank"]), ch["send_lists"], ch["recv_counts"], comm,
+                      nghost1=ch["nghost1"] if depth == 2 else 0)
     mesh.state_initialize(0.0)
     t = 0.0
-    for _ in range(NSTEP):
+    for _ in range(nstep):
         drv.step(t)
         t += drv.dt_taken()
     U = mesh.state_download().reshape(-1, 20)
-    np.savez(out, U=U, t=t, nie=ck.nielem, ndof=mesh.ndofel_get())
+    gs = mesh.step_graph_status() if kind != "copy" else (0, 0, 0, "")
+    np.savez(out, U=U, t=t, nie=nie, ndof=mesh.ndofel_get(), graph_state=gs[0], graph_replays=gs[2], graph_error=gs[3])
     mesh.close()
     if kind != "copy":
         comm.close()
@@ -139,8 +150,32 @@ def test_rccl_transport_self_halo(tmp_path, parts):
         assert err <= 1e-12, (kind, err)
 
 
-def _self_halo_run_spawn(_, kind, out, pref=False, parts=(2, 1, 1)):
-    _self_halo_run(kind, out, pref, parts)
+def _self_halo_run_spawn(_, kind, out, pref=False, parts=(2, 1, 1), depth=1, graph=0, nstep=NSTEP):
+    _self_halo_run(kind, out, pref, parts, depth, graph, nstep)
+
+
+@pytest.mark.parametrize("parts,depth", [((2, 1, 1), 1), ((2, 2, 2), 1), ((2, 2, 1), 2), ((2, 2, 2), 2)])
+def test_step_comm_as_a_hipgraph_and_with_two_ghost_layers(tmp_path, parts, depth):
+    """qdg_step_comm replayed as a hipGraph (context option graph_step; kernels + RCCL send / receive / all-reduce
+    captured once per buffer-rotation phase) and, depth 2, with two ghost layers (3 exchanges per step, the rank
+    limits its layer-1 ghosts; fused stage-0 update + limiter + the ghost rows' own limiter launch): the same
+    bits as plain launches, and the plan moved by a plain device copy through the per-stage Python driver
+    agrees to rounding.  NSTEP + 4 steps so that both rotation phases are replayed."""
+    import torch.multiprocessing as mp
+    outs = {}
+    for kind, graph in (("copy", 0), ("rccl", 0), ("rccl_graph", 1)):
+        outs[kind] = str(tmp_path / (kind + ".npz"))
+        mp.spawn(_self_halo_run_spawn, args=(kind.split("_")[0], outs[kind], False, parts, depth, graph, NSTEP + 4),
+                 nprocs=1, join=True)
+    a, b, g = (np.load(outs[k]) for k in ("copy", "rccl", "rccl_graph"))
+    assert int(a["nie"]) < a["U"].shape[0] and np.isfinite(a["U"]).all()
+    assert abs(float(a["t"]) - float(b["t"])) <= 1e-13 * float(a["t"])
+    assert np.abs(a["U"] - b["U"]).max() / np.abs(a["U"]).max() <= 1e-12
+    assert int(g["graph_state"]) == 1 and int(g["graph_replays"]) == NSTEP + 4 - 2, str(g["graph_error"])
+    assert abs(float(g["t"]) - float(b["t"])) <= 1e-13 * float(b["t"])    # (LDS-atomic order: rounding freedom)
+    nie = int(b["nie"])
+    # owned rows: identical launches in identical order (the tile kernel's LDS atomics leave rounding freedom)
+    assert np.abs(g["U"][:nie] - b["U"][:nie]).max() / np.abs(b["U"]).max() <= 1e-12
 
 
 def test_rccl_transport_self_halo_pdg(tmp_path):
