@@ -146,11 +146,15 @@ def run_workload(args, rank, world, local_rank, dims, lengths, parts, steps, war
     import torch
     from quinoa_amd import capi, dg, meshgen
     self_halo = args.self_halo
-    ch = meshgen.kuhn_box_chunk(dims[0], dims[1], dims[2], lengths=lengths, parts=parts, rank=rank)
+    # two ghost layers by default (a rank limits its layer-1 ghosts itself: 3 halo exchanges per step, not 6)
+    depth = args.halo_depth if (world > 1 or self_halo) else 1
+    ch = meshgen.kuhn_box_chunk(dims[0], dims[1], dims[2], lengths=lengths, parts=parts, rank=rank, depth=depth)
     if self_halo:
         ch["nbr_rank"] = [0 for _ in ch["nbr_rank"]]
+        # (the rank is its own neighbour in name only: every entry sends as many rows as it receives)
+        ch["send_lists"] = [np.resize(s_, n_) for s_, n_ in zip(ch["send_lists"], ch["recv_counts"])]
     nielem = int(ch["nielem"])
-    opts = {"graph_step": 0 if args.no_graph else 1}
+    opts = {"graph_step": 0 if args.no_graph else 1, "halo_depth": depth}
     if args.workload == "sedov":     # config 4's physics (symmetry on x-min, y-min and the z faces)
         ctx = capi.Context(4, flux="hllc", limiter="superbeep1", problem="sedov_blastwave", gamma=1.4,
                            cfl=0.3, bc_extrapolate=[2, 4], bc_sym=[1, 3, 5, 6], device=local_rank, options=opts)
@@ -171,7 +175,8 @@ def run_workload(args, rank, world, local_rank, dims, lengths, parts, steps, war
             comm = dg.RcclComm(ctx)
         else:
             comm = dg.TorchComm()
-    drv = dg.DGDriver(ctx, mesh, ch["nbr_rank"], ch["send_lists"], ch["recv_counts"], comm)
+    drv = dg.DGDriver(ctx, mesh, ch["nbr_rank"], ch["send_lists"], ch["recv_counts"], comm,
+                      nghost1=ch["nghost1"] if depth == 2 else 0)
     mesh.state_initialize(0.0)
 
     # outside the timed region: total mass and energy before / after the run.  Between
@@ -245,7 +250,9 @@ def run_workload(args, rank, world, local_rank, dims, lengths, parts, steps, war
                  "exchanges_per_step": pr["halo"][0] / nprof, "halo_ms_per_step": pr["halo"][1] / nprof,
                  "allreduces_per_step": pr["allreduce"][0] / nprof,
                  "allreduce_ms_per_step": pr["allreduce"][1] / nprof,
-                 "step_graph": graph}]
+                 "step_graph": graph,
+                 "halo_plan": dict(zip(("entries", "layer1_ghosts_limited_here", "packs_folded_into_producers"),
+                                       mesh.halo_info()))}]
     if world > 1:
         tt = torch.tensor([el, float(ntet), el_cold or 0.0], dtype=torch.float64, device="cuda")
         mx = tt.clone(); torch.distributed.all_reduce(mx, op=torch.distributed.ReduceOp.MAX)
@@ -257,7 +264,7 @@ def run_workload(args, rank, world, local_rank, dims, lengths, parts, steps, war
         per_rank = gathered
     res = {"el": el, "el_cold": el_cold, "ntet": ntet, "ntet_local": nielem, "avg_ms": ms / max(nl, 1), "launches": nl,
            "alg": mesh.rhs_algorithmic_bytes(), "dt_last": dt_last, "drift": drift, "develop": develop, "t_flow": t_flow,
-           "backend": None if comm is None else comm.backend, "per_rank": per_rank,
+           "backend": None if comm is None else comm.backend, "per_rank": per_rank, "halo_depth": depth,
            "ranks_seen_by_rccl": None if seen is None else seen[0]}
     mesh.close()
     if isinstance(comm, dg.RcclComm):
@@ -600,6 +607,10 @@ def main():
                          "does not write back tiles it leaves unchanged, so the step is fastest right after the "
                          "initial discontinuity: the headline is taken on the developed flow, the cold-start "
                          "rate is reported beside it (0: headline = cold start, as before round 5)")
+    ap.add_argument("--halo-depth", type=int, choices=[1, 2], default=2,
+                    help="ghost layers of a rank's chunk (N > 1, --self-halo): 2 (default) = the rank limits its "
+                         "layer-1 ghosts itself, 3 exchanges + 1 all-reduce per step; 1 = the reference's one layer, "
+                         "6 exchanges + 1 all-reduce")
     ap.add_argument("--no-graph", action="store_true",
                     help="multi-rank / self-halo runs: plain launches instead of qdg_step_comm's hipGraph replay")
     ap.add_argument("--no-real-mesh", action="store_true",
@@ -707,6 +718,7 @@ def main():
                                       % (w["develop"], w["t_flow"]) if w["develop"] else ", timed from the initial state"),
                        "tets_total": w["ntet"], "tets_per_gpu": w["ntet_local"],
                        "parallelism": "block decomposition %dx%dx%d, ghost-face halo" % parts
+                                      + (", two ghost layers (3 exchanges per step)" if w["halo_depth"] == 2 else "")
                                       + ("" if w["backend"] is None else ", transport " + w["backend"])
                                       + (" (SELF-HALO TEST: the neighbour is this rank)" if args.self_halo else ""),
                        "step": "SSP-RK3 time step = 3 x (halo, limiter, halo, [dt], rhs, update)"},

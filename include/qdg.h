@@ -168,6 +168,10 @@ int qdg_ctx_synchronize(qdg_ctx* ctx);
  *   "fused_update"  1 (default) stage-0 RK update fused with the Superbee limiter of stage 1
  *   "renumber"      1 (default) Morton order of the device rows; 0 keeps the caller's order
  *   "host_layout"   1: qdg_mesh_from_connectivity runs qdg_mesh_upload's host layout code (A/B)
+ *   "halo_depth"    2: chunks built from now on put the tets within TWO faces of a ghost last in the device order
+ *                   (default 1: within one face), so that the send rows of a two-layer halo plan
+ *                   (qdg_halo_set_depth) are trailing rows and their packs fold into the producing kernels
+ *   "graph_step"    1: qdg_step_comm replays its launches as a hipGraph (see qdg_step_graph_status)
  *   "orient_by_gid" 1 (default): meshes built with global tet ids (qdg_mesh_upload_gid, qdg_mesh_from_chunk_gid)
  *                   orient their faces by global id; 0: the chare-local rule of src/Inciter/DG.cpp:480-483
  *   "keep_connectivity" 1: meshes built on the device without ghosts keep their connectivity, coordinates, esuel
@@ -320,6 +324,10 @@ int qdg_halo_setup(qdg_mesh* mesh, size_t nnbr, const int32_t* nbr_rank,
  * second exchange of every stage.  Results equal the one-layer run's (the same limiter on the same inputs).
  * nghost1 = 0 returns to one layer.  Not for p-adaptive runs, nor for meshes of qdg_mesh_upload. */
 int qdg_halo_set_depth(qdg_mesh* mesh, size_t nghost1);
+/* the plan in use: its entries, the layer-1 ghosts the rank limits itself (0: one layer) and whether qdg_step_comm
+ * can fold the halo packs into the kernels that produce the rows (every send row among the trailing device rows:
+ * chunks built under context option "halo_depth" = 2 have that shape for two-layer plans); any pointer may be NULL */
+int qdg_halo_info(qdg_mesh* mesh, size_t* nentry, size_t* nghost1, int32_t* packs_folded);
 int qdg_halo_buffers(qdg_mesh* mesh, void** send_dev, void** recv_dev,
                      size_t* row_bytes);
 /* use caller-owned device memory for the slabs / the dt scalar (e.g. buffers a
@@ -501,6 +509,18 @@ int qdg_refine_chunk(size_t nielem, size_t nunk, size_t nnode, const size_t* inp
                      const double* y, const double* z, const size_t* gid, size_t ntri, const size_t* tri,
                      const int32_t* tri_set, size_t nnbr, const int32_t* nbr_rank,
                      const size_t* recv_counts, qdg_chunk_refined** out);
+/* The same for a chunk with `depth` ghost layers (depth = 1: the call above; depth = 2: qdg_chunk_build_depth's
+ * shape, nentry = the plan's (rank, layer) entries in order, recv_counts per entry).  The refined chunk's layers and
+ * plan follow the rule of qdg_chunk_build_depth on the children (owner of a child = its parent's, global id
+ * 8 * gid(parent) + k); its entries can differ from the old ones: qdg_chunk_refined_plan returns them (nentry,
+ * nghost1, nbr_rank[nentry], nbr_layer[nentry]; NULL pointers: sizes only), qdg_chunk_refined_get's send_off /
+ * recv_counts are sized by that nentry. */
+int qdg_refine_chunk_depth(size_t nielem, size_t nunk, size_t nnode, const size_t* inpoel, const double* x,
+                           const double* y, const double* z, const size_t* gid, size_t ntri, const size_t* tri,
+                           const int32_t* tri_set, size_t nentry, const int32_t* entry_rank,
+                           const size_t* recv_counts, int depth, qdg_chunk_refined** out);
+int qdg_chunk_refined_plan(const qdg_chunk_refined* c, size_t* nentry, size_t* nghost1, int32_t* nbr_rank,
+                           int32_t* nbr_layer);
 int qdg_chunk_refined_sizes(const qdg_chunk_refined* c, size_t* nielem, size_t* nunk, size_t* nnode,
                             size_t* ntri, size_t* nsend);
 int qdg_chunk_refined_get(const qdg_chunk_refined* c, size_t* inpoel, size_t* gid, size_t* parent,

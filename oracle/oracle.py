@@ -301,11 +301,16 @@ class Oracle:
                                     _p(m.y, c_f64p), _p(m.z, c_f64p), _p(m.geoFace, c_f64p),
                                     _p(m.geoElem, c_f64p), _p(U, c_f64p)))
 
-    def limit(self, U):
-        """In place, like the reference (src/Inciter/DG.cpp:1251-1260)."""
+    def limit(self, U, esuel=None, nrows=None):
+        """In place, like the reference (src/Inciter/DG.cpp:1251-1260).  esuel / nrows: the same limiter over the
+        first nrows rows with a caller-supplied esuel[4 * nrows] -- the multi-rank tests limit the layer-1 ghosts
+        of a chunk with two ghost layers this way (the limiters read esuel and the solution only,
+        src/PDE/Limiter.cpp:29-316)."""
         m = self.m
+        es = m.esuel if esuel is None else np.ascontiguousarray(esuel, dtype=np.int32).reshape(-1)
+        nr = self.nie if nrows is None else int(nrows)
         with self._Ndofel(self):
-            self.L_.orc_limit(C.byref(self.cfg), _p(m.esuel, c_i32p), C.c_int64(self.nie),
+            self.L_.orc_limit(C.byref(self.cfg), _p(es, c_i32p), C.c_int64(nr),
                               _p(m.inpoel.reshape(-1), c_i64p), _p(m.x, c_f64p), _p(m.y, c_f64p),
                               _p(m.z, c_f64p), _p(U, c_f64p))
         return U

@@ -150,16 +150,24 @@ def refine_chunk(ch):
     tset = np.ascontiguousarray(tset if ntri else np.zeros(1, np.int32), dtype=np.int32)
     nbr = list(ch["nbr_rank"])
     nnbr = len(nbr)
+    depth = int(ch.get("depth", 1))
     nb_a = np.ascontiguousarray(nbr or [0], dtype=np.int32)
     rc_a, prc = capi._sz(np.asarray(list(ch["recv_counts"]) or [0]))
     h = C.c_void_p()
-    capi._chk(L.qdg_refine_chunk(C.c_size_t(nie), C.c_size_t(nunk), C.c_size_t(nn), pinp, px, py, pz, pgid,
-                                 C.c_size_t(ntri), ptri, tset.ctypes.data_as(capi.c_i32p), C.c_size_t(nnbr),
-                                 nb_a.ctypes.data_as(capi.c_i32p), prc, C.byref(h)))
+    # (two ghost layers: qdg_refine_chunk_depth -- the refined chunk's plan entries are its own)
+    capi._chk(L.qdg_refine_chunk_depth(C.c_size_t(nie), C.c_size_t(nunk), C.c_size_t(nn), pinp, px, py, pz, pgid,
+                                       C.c_size_t(ntri), ptri, tset.ctypes.data_as(capi.c_i32p), C.c_size_t(nnbr),
+                                       nb_a.ctypes.data_as(capi.c_i32p), prc, C.c_int(depth), C.byref(h)))
     try:
         n = [C.c_size_t() for _ in range(5)]
         capi._chk(L.qdg_chunk_refined_sizes(h, *[C.byref(v) for v in n]))
         nie2, nunk2, nn2, ntri2, nsend = (int(v.value) for v in n)
+        ne_, ng1_ = C.c_size_t(), C.c_size_t()
+        capi._chk(L.qdg_chunk_refined_plan(h, C.byref(ne_), C.byref(ng1_), None, None))
+        nnbr, nghost1 = int(ne_.value), int(ng1_.value)
+        nb2 = np.zeros(max(1, nnbr), dtype=np.int32); nl2 = np.ones(max(1, nnbr), dtype=np.int32)
+        capi._chk(L.qdg_chunk_refined_plan(h, None, None, nb2.ctypes.data_as(capi.c_i32p), nl2.ctypes.data_as(capi.c_i32p)))
+        nbr = [int(v) for v in nb2[:nnbr]]
         inp2 = np.empty(4 * nunk2, dtype=np.uint64); gid2 = np.empty(nunk2, dtype=np.uint64)
         par = np.empty(nunk2, dtype=np.uint64)
         c2 = np.empty((3, nn2))
@@ -178,7 +186,8 @@ def refine_chunk(ch):
     soff = soff.view(np.int64); slist = slist.view(np.int64)
     new = {"coord": np.ascontiguousarray(c2.T), "inpoel": inp2.view(np.int64).reshape(-1, 4), "nielem": nie2,
            "sidesets": {int(s_): tri2[tset2 == s_] for s_ in ids if (tset2 == s_).any()},
-           "gid": gid2.view(np.int64), "nbr_rank": nbr,
+           "gid": gid2.view(np.int64), "nbr_rank": nbr, "nbr_layer": [int(v) for v in nl2[:nnbr]],
+           "depth": depth, "nghost1": nghost1,
            "send_lists": [slist[soff[i]:soff[i + 1]] for i in range(nnbr)],
            "recv_counts": [int(v) for v in rc2[:nnbr]]}
     return new, par.view(np.int64)

@@ -505,6 +505,12 @@ class Mesh:
         itself, no exchange of the limited solution); 0: one layer"""
         _chk(lib().qdg_halo_set_depth(self.h, C.c_size_t(int(nghost1))))
 
+    def halo_info(self):
+        """-> (plan entries, layer-1 ghosts limited by this rank, packs folded into the producing kernels?)"""
+        a, b, c = C.c_size_t(), C.c_size_t(), C.c_int32()
+        _chk(lib().qdg_halo_info(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, bool(c.value)
+
     def halo_buffers(self):
         a, b, r = C.c_void_p(), C.c_void_p(), C.c_size_t()
         _chk(lib().qdg_halo_buffers(self.h, C.byref(a), C.byref(b), C.byref(r)))

@@ -299,7 +299,7 @@ static int* option_slot(qdg_ctx* ctx, const char* name)
     { "renumber", &qdg::Options::renumber },       { "host_layout", &qdg::Options::host_layout },
     { "orient_by_gid", &qdg::Options::orient_by_gid }, { "keep_pool", &qdg::Options::keep_pool },
     { "keep_connectivity", &qdg::Options::keep_connectivity },
-    { "graph_step", &qdg::Options::graph_step },
+    { "graph_step", &qdg::Options::graph_step }, { "halo_depth", &qdg::Options::halo_depth },
   };
   for (const auto& t : tab)
     if (std::strcmp(name, t.n) == 0) return &(ctx->opt.*(t.p));
@@ -743,7 +743,7 @@ extern "C" int qdg_mesh_upload_gid(qdg_ctx* ctx, size_t nielem, size_t nunk, siz
     dm.tgeo = m->tgeo.p;
   }
   dm.blk0 = 0; dm.ninner = (int)ninner; dm.ncomp = ncomp; dm.pde = ctx->cfg.pde;
-  dm.nlim = (int)nie; dm.row0 = 0;
+  dm.nlim = (int)nie;
   dm.ndofel = nullptr;
   if (ctx->cfg.pref) {
     HIPCHK(m->ndofel.alloc(ne)); HIPCHK(m->ndofel2.alloc(ne));
@@ -771,14 +771,34 @@ extern "C" int qdg_mesh_destroy(qdg_mesh* mesh)
 
 // ---------------------------------------------------------------- helpers
 
-#define MESH_ENTER(name)                                         \
+// the ghost rows of the current state, where a qdg_step_comm left them in another buffer (carry_pending)
+static int flush_ghost_carry(qdg_mesh* mesh)
+{
+  double* src = mesh->carry_pending;
+  mesh->carry_pending = nullptr;
+  if (!src || src == mesh->Ucur || mesh->ne <= mesh->nie) return 0;
+  HIPCHK(hipMemcpyAsync(mesh->Ucur + mesh->nie * (size_t)mesh->nprop, src + mesh->nie * (size_t)mesh->nprop,
+                        (mesh->ne - mesh->nie) * (size_t)mesh->nprop * sizeof(double), hipMemcpyDeviceToDevice,
+                        mesh->ctx->stream));
+  return 0;
+}
+
+namespace qdg {
+int mesh_flush_carry(qdg_mesh* mesh) { return mesh && mesh->carry_pending ? flush_ghost_carry(mesh) : 0; }
+}  // namespace qdg
+
+#define MESH_ENTER_(name, flush)                                 \
   if (!mesh) return fail(name ": null mesh");                    \
   qdg_ctx* ctx = mesh->ctx;                                      \
   HIPCHK(hipSetDevice(ctx->device));                             \
   hipStream_t s = ctx->stream;                                   \
   qdg::StreamScope stream_scope_(s);                             \
+  if ((flush) && mesh->carry_pending) { if (int rcf_ = flush_ghost_carry(mesh)) return rcf_; } \
   mesh->slab_ready_for = nullptr;                                \
   (void)s
+#define MESH_ENTER(name) MESH_ENTER_(name, true)
+// (entry points that neither read nor move the state's ghost rows)
+#define MESH_ENTER_NOFLUSH(name) MESH_ENTER_(name, false)
 
 // host AoS (all ne rows) -> SoA planes `dst`
 static int ensure_aos(qdg_mesh* mesh)
@@ -1248,6 +1268,10 @@ extern "C" int qdg_state_device_ptr(qdg_mesh* mesh, void** dptr, size_t* stride)
 {
   QDG_TRY
   if (!mesh || !dptr || !stride) return fail("qdg_state_device_ptr: null argument");
+  if (mesh->carry_pending) {
+    HIPCHK(hipSetDevice(mesh->ctx->device));
+    if (int rc = flush_ghost_carry(mesh)) return rc;
+  }
   *dptr = mesh->Ucur; *stride = mesh->stride;
   mesh->slab_ready_for = nullptr;      // the caller may write the state through this pointer
   return 0;
@@ -1288,7 +1312,7 @@ extern "C" int qdg_stage_dt(qdg_mesh* mesh, double tleft)
 extern "C" int qdg_stage_dt_get(qdg_mesh* mesh, double* dt_host)
 {
   QDG_TRY
-  MESH_ENTER("qdg_stage_dt_get");
+  MESH_ENTER_NOFLUSH("qdg_stage_dt_get");
   if (!dt_host) return fail("qdg_stage_dt_get: null argument");
   HIPCHK(hipMemcpyAsync(dt_host, mesh->dt_ptr, sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
@@ -1721,21 +1745,21 @@ extern "C" int qdg_halo_setup(qdg_mesh* mesh, size_t nnbr, const int32_t* nbr_ra
   HIPCHK(mesh->send_elem.upload(se, s));
   // inverse of the send list for the packs folded into the producing kernels (qdg_step_comm): the slab rows
   // of every halo-adjacent device row.  Only where the plan has the shape the device order was built for --
-  // every send row among the trailing rows [ninner, nie), at most four slab rows per tet -- and not for
+  // every send row among the trailing rows [ninner, nie), at most FOLD_SLOTS slab rows per tet -- and not for
   // p-adaptive runs (their slab rows carry the ndof column)
   (void)mesh->fold_slot.alloc(0);
   mesh->slab_ready_for = nullptr;
   if (!mesh->dm.ndofel && mesh->nsend > 0) {
     const size_t ninner = (size_t)mesh->dm.ninner, nh = mesh->nie - ninner;
-    std::vector<int> slot(4 * std::max<size_t>(nh, 1), -1);
+    std::vector<int> slot(FOLD_SLOTS * std::max<size_t>(nh, 1), -1);
     bool ok = true;
     for (size_t j = 0; j < mesh->nsend && ok; ++j) {
       const size_t d = (size_t)se[j];
       if (d < ninner) { ok = false; break; }
-      int* sl = &slot[4 * (d - ninner)];
+      int* sl = &slot[FOLD_SLOTS * (d - ninner)];
       int q = 0;
-      while (q < 4 && sl[q] >= 0) ++q;
-      if (q == 4) ok = false; else sl[q] = (int)j;
+      while (q < FOLD_SLOTS && sl[q] >= 0) ++q;
+      if (q == FOLD_SLOTS) ok = false; else sl[q] = (int)j;
     }
     if (ok) HIPCHK(mesh->fold_slot.upload(slot, s));
   }
@@ -1760,6 +1784,17 @@ extern "C" int qdg_halo_set_depth(qdg_mesh* mesh, size_t nghost1)
   if (mesh->nnbr == 0) return fail("qdg_halo_set_depth: call qdg_halo_setup first");
   mesh->nghost1 = nghost1;
   mesh->dm.nlim = (int)(mesh->nie + nghost1);
+  return 0;
+  QDG_CATCH
+}
+
+extern "C" int qdg_halo_info(qdg_mesh* mesh, size_t* nentry, size_t* nghost1, int32_t* packs_folded)
+{
+  QDG_TRY
+  if (!mesh) return fail("qdg_halo_info: null mesh");
+  if (nentry) *nentry = mesh->nnbr;
+  if (nghost1) *nghost1 = mesh->nghost1;
+  if (packs_folded) *packs_folded = mesh->fold_slot.p ? 1 : 0;
   return 0;
   QDG_CATCH
 }
@@ -2136,7 +2171,7 @@ static int step_comm_graph(qdg_mesh* mesh, qdg_comm* comm, double t, double tlef
   for (const qdg_mesh::StepGraph& g : mesh->step_graphs)
     if (g.ucur_in == mesh->Ucur && g.tleft == tleft && g.slab_ready_in == slab_ready) {
       if (hipGraphLaunch(g.exec, s) != hipSuccess) return -1;
-      mesh->Ucur = g.ucur_out; mesh->Unp = nullptr; mesh->Upending = nullptr; mesh->carry_src = nullptr;
+      mesh->Ucur = g.ucur_out; mesh->Unp = nullptr; mesh->Upending = nullptr; mesh->carry_src = g.carry_out;
       mesh->slab_ready_for = g.slab_ready_out;
       ++mesh->graph_replays;
       return 1;
@@ -2164,11 +2199,10 @@ static int step_comm_graph(qdg_mesh* mesh, qdg_comm* comm, double t, double tlef
   e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
   (void)hipGraphDestroy(graph);
   if (e != hipSuccess || !exec) { (void)hipGetLastError(); return refuse(std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
-  mesh->step_graphs.push_back({ before.Ucur, t, tleft, slab_ready, exec, mesh->Ucur, mesh->slab_ready_for });
+  mesh->step_graphs.push_back({ before.Ucur, t, tleft, slab_ready, exec, mesh->Ucur, mesh->slab_ready_for, mesh->carry_src });
   mesh->graph_state = 1;
   // (nothing has run yet: the capture only recorded; the handle's state is already the state after the step)
   if (hipGraphLaunch(exec, s) != hipSuccess) { before.restore(mesh); return -1; }
-  mesh->carry_src = nullptr;
   ++mesh->graph_replays;
   return 1;
 }
@@ -2179,6 +2213,10 @@ extern "C" int qdg_step_comm(qdg_mesh* mesh, qdg_comm* comm, double t, double tl
   // (read before MESH_ENTER clears it: the slab still holds this state's send rows if the previous call on
   // this mesh was a qdg_step_comm whose last kernel packed them)
   const bool slab_ready = mesh && mesh->slab_ready_for && mesh->slab_ready_for == mesh->Ucur;
+  // (a ghost-row carry left pending by the previous qdg_step_comm is dropped: this step starts by receiving every
+  // ghost row -- except the p-adaptive step, whose first kernel reads them)
+  const bool drop_carry = mesh && !mesh->dm.ndofel && mesh->nnbr > 0 && mesh->nrecv == mesh->ne - mesh->nie && comm;
+  if (drop_carry) mesh->carry_pending = nullptr;
   MESH_ENTER("qdg_step_comm");
   if (!comm) return fail("qdg_step_comm: null communicator");
   // the skipped ghost-row carries below rely on every ghost row being received by the next exchange
@@ -2197,6 +2235,8 @@ extern "C" int qdg_step_comm(qdg_mesh* mesh, qdg_comm* comm, double t, double tl
     mesh->carry_src = nullptr;
     return fail(msg);
   }
+  // the last update's ghost-row carry is left to whoever looks at the ghost rows next (flush_ghost_carry)
+  if (!rc && mesh->carry_src && mesh->carry_src != mesh->Ucur) mesh->carry_pending = mesh->carry_src;
   mesh->carry_src = nullptr;
   if (rc) return rc;
   if (dt_taken) {
@@ -2246,14 +2286,12 @@ static int step_comm_stages(qdg_mesh* mesh, qdg_comm* comm, double t, double tle
       // update of stage 0 + comsol + limiter of stage 1 in one pass over the state
       double* out = free_buf(mesh, mesh->Ucur, mesh->Unp);
       if (int rc = exchange_upd(mesh, comm, s, out)) return rc;
+      // (two ghost layers: the same launch also limits the layer-1 ghosts, whose unlimited U1 has just arrived)
       if (int rc = stage0_update_and_limit(mesh)) return rc;
-      if (deep) {        // ... and the limiter of the layer-1 ghosts (their unlimited U1 has just been received)
-        launch_superbee_rows(mesh->ndof, mesh->dm, mesh->Ucur, (int)mesh->nie, (int)(mesh->nie + mesh->nghost1), s);
-        HIPCHK(hipGetLastError());
-      }
     } else {
-      // stages 0, 1: the next stage starts by receiving the ghost rows of the new state
-      mesh->skip_ghost_carry = stage < 2 && mesh->nnbr > 0;
+      // stages 0, 1: the next stage starts by receiving the ghost rows of the new state; stage 2: so does the
+      // next step -- the carry stays pending for any other reader (qdg_step_comm, flush_ghost_carry)
+      mesh->skip_ghost_carry = mesh->nnbr > 0 && (stage < 2 || !mesh->dm.ndofel);
       const bool by_kernel = mesh->Upending != nullptr;      // the fused RHS + RK kernel wrote the new state
       const int rc = qdg_stage_update(mesh, stage);
       mesh->skip_ghost_carry = false;
@@ -2281,7 +2319,7 @@ extern "C" int qdg_profile_enable(qdg_mesh* mesh, int on)
 extern "C" int qdg_profile_read(qdg_mesh* mesh, size_t* nlaunch, double* total_ms)
 {
   QDG_TRY
-  MESH_ENTER("qdg_profile_read");
+  MESH_ENTER_NOFLUSH("qdg_profile_read");
   if (!nlaunch || !total_ms) return fail("qdg_profile_read: null argument");
   HIPCHK(hipStreamSynchronize(s));
   double tot = 0.0;
@@ -2303,7 +2341,7 @@ extern "C" int qdg_profile_read(qdg_mesh* mesh, size_t* nlaunch, double* total_m
 extern "C" int qdg_profile_read_all(qdg_mesh* mesh, size_t count[3], double total_ms[3])
 {
   QDG_TRY
-  MESH_ENTER("qdg_profile_read_all");
+  MESH_ENTER_NOFLUSH("qdg_profile_read_all");
   if (!count || !total_ms) return fail("qdg_profile_read_all: null argument");
   HIPCHK(hipStreamSynchronize(s));
   for (int k = 0; k < 3; ++k) { count[k] = 0; total_ms[k] = 0.0; }
@@ -2338,7 +2376,7 @@ extern "C" int qdg_step_graph_status(qdg_mesh* mesh, int32_t* state, int32_t* ng
 extern "C" int qdg_mesh_layout_stats(qdg_mesh* mesh, size_t counts[4])
 {
   QDG_TRY
-  MESH_ENTER("qdg_mesh_layout_stats");
+  MESH_ENTER_NOFLUSH("qdg_mesh_layout_stats");
   if (!counts) return fail("qdg_mesh_layout_stats: null argument");
   counts[0] = counts[1] = counts[2] = 0;
   counts[3] = (size_t)mesh->dm.ntile;

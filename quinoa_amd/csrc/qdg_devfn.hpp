@@ -595,9 +595,9 @@ template <int NPROP>
 __device__ __forceinline__ void halo_fold_row(const DevMesh& m, int d, const double* row)
 {
   if (!m.fold_slot || d < m.ninner || d >= m.nie) return;
-  const int* sl = m.fold_slot + 4 * (size_t)(d - m.ninner);
+  const int* sl = m.fold_slot + FOLD_SLOTS * (size_t)(d - m.ninner);
 #pragma unroll 1
-  for (int q = 0; q < 4; ++q) {
+  for (int q = 0; q < FOLD_SLOTS; ++q) {
     const int j = sl[q];
     if (j < 0) break;
     store_row<NPROP>(m.fold_slab, j, row);

@@ -33,6 +33,7 @@
 namespace qdg {
 
 constexpr int NCOMP = 5;
+constexpr int FOLD_SLOTS = 8;     // slab rows a tet can appear in (one per (neighbour rank, ghost layer) entry that lists it)
 
 constexpr int ngfa(int ndof)   { return ndof == 1 ? 1 : ndof == 4 ? 3 : 6; }
 constexpr int ngvol(int ndof)  { return ndof == 1 ? 1 : ndof == 4 ? 5 : 11; }
@@ -80,14 +81,13 @@ struct DevMesh {
   int blk0;
   int ninner;
   // halo pack folded into the producing kernels (set by qdg_step_comm for its own launches only): a row
-  // d >= ninner that neighbours need is ALSO written to the send slab, at up to 4 slab rows
-  // fold_slot[4 * (d - ninner) ...] (-1 = none); null: no folding
+  // d >= ninner that neighbours need is ALSO written to the send slab, at up to FOLD_SLOTS slab rows
+  // fold_slot[FOLD_SLOTS * (d - ninner) ...] (-1 = none); null: no folding
   const int* fold_slot;
   double* fold_slab;
-  // limiter range: rows [row0 + 256 * blk0 ..., nlim).  nlim = nie, or nie + the chunk's layer-1 ghosts when the
-  // rank limits them itself (two ghost layers, qdg_halo_set_depth: their nbr rows are filled); 0 reads as nie
+  // limiter range: rows [0, nlim).  nlim = nie, or nie + the chunk's layer-1 ghosts when the rank limits them
+  // itself (two ghost layers, qdg_halo_set_depth: their nbr rows are filled); 0 reads as nie
   int nlim;
-  int row0;
   int ncomp;        // 5: CompFlow; dg::Transport: its number of scalars (rows of ncomp*ndof doubles)
   int pde;          // 0: CompFlow, 1: dg::Transport (QDG_PDE_*)
   // p-adaptive DG (scheme pdg): DG::m_ndof per device row, 1 or 4; null otherwise

@@ -652,15 +652,21 @@ __device__ __forceinline__ uint64_t spread21d(uint64_t v)
 
 // owned tets: Morton key of the centroid, bit 63 set for a tet with a ghost neighbour (those go
 // last, still in curve order: launches over the leading rows never touch the halo)
+// (two_hop: also the tets with a neighbour that has a ghost neighbour -- the send rows of a two-layer plan)
 __global__ void k_morton(const double* __restrict__ geoElem, size_t ne, const int* __restrict__ esuel, double lx,
                          double ly, double lz, double ext, uint64_t* __restrict__ key, uint32_t* __restrict__ val,
-                         int* __restrict__ ninner)
+                         int* __restrict__ ninner, int two_hop)
 {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   bool inner = false;
   if (e < ne) {
     bool halo = false;
-    for (int lf = 0; lf < 4; ++lf) halo = halo || esuel[4 * e + lf] >= (int)ne;
+    for (int lf = 0; lf < 4; ++lf) {
+      const int nb = esuel[4 * e + lf];
+      halo = halo || nb >= (int)ne;
+      if (two_hop && nb >= 0 && nb < (int)ne)
+        for (int l2 = 0; l2 < 4; ++l2) halo = halo || esuel[4 * (size_t)nb + l2] >= (int)ne;
+    }
     const double lo[3] = { lx, ly, lz };
     uint64_t k = 0;
 #pragma unroll
@@ -1062,7 +1068,7 @@ static int dev_build_layout(qdg_ctx* ctx, DevFD& fd, const std::vector<int>& bcf
   Buf<uint32_t> mval, mval2;
   DHIP(mkey.alloc(ne)); DHIP(mkey2.alloc(ne)); DHIP(mval.alloc(ne)); DHIP(mval2.alloc(ne));
   k_morton<<<nblk(nie), 256, 0, s>>>(fd.geoElem.p, nie, fd.esuel.p, lo[0], lo[1], lo[2], ext, mkey.p, mval.p,
-                                    d_count.p + 2);
+                                    d_count.p + 2, (ne > nie && ctx->opt.halo_depth == 2) ? 1 : 0);
   {
     size_t bytes = 0;
     DHIP(rocprim::radix_sort_pairs(nullptr, bytes, mkey.p, mkey2.p, mval.p, mval2.p, nie, 0, 64, s));
@@ -1224,7 +1230,7 @@ static int dev_build_layout(qdg_ctx* ctx, DevFD& fd, const std::vector<int>& bcf
     dm.tgeo = m->tgeo.p;
   }
   dm.blk0 = 0; dm.ninner = (int)ninner; dm.ncomp = ncomp; dm.pde = ctx->cfg.pde; dm.ndofel = nullptr;
-  dm.nlim = (int)nie; dm.row0 = 0;
+  dm.nlim = (int)nie;
   if (ctx->cfg.pref) {
     HIPCHK(m->ndofel.alloc(ne)); HIPCHK(m->ndofel2.alloc(ne));
     k_fill_i32<<<nblk(ne), 256, 0, s>>>(m->ndofel.p, ne, 4);
@@ -1812,6 +1818,8 @@ namespace qdg {
 static int transfer_rows(qdg_mesh* from, qdg_mesh* to, size_t nrow, const int* d_par)
 {
   hipStream_t s = to->ctx->stream;
+  if (int rc = mesh_flush_carry(from)) return rc;
+  if (int rc = mesh_flush_carry(to)) return rc;
   Buf<int> h2d_from;
   DHIP(h2d_from.alloc(from->ne));
   k_invert_perm<<<nblk(from->ne), 256, 0, s>>>(from->d2h.p, from->ne, h2d_from.p);
@@ -2015,6 +2023,9 @@ extern "C" int qdg_mesh_refine_chunk(qdg_mesh* mesh, qdg_mesh** out, qdg_chunk_r
     return fail("qdg_mesh_refine_chunk: the mesh keeps no connectivity / global ids on the device (context option "
                 "keep_connectivity = 1, built by qdg_mesh_from_chunk_gid)");
   if (mesh->dm.ndofel) return fail("qdg_mesh_refine_chunk: p-adaptive runs are not combined with mesh refinement");
+  if (mesh->nghost1 > 0)
+    return fail("qdg_mesh_refine_chunk: a chunk with two ghost layers re-meshes through qdg_refine_chunk_depth + "
+                "qdg_mesh_from_chunk_gid (the device form derives one ghost layer)");
   qdg_mesh::Keep& kp = *mesh->keep;
   if (kp.pending) kp.pending->join();
   const size_t nunk = kp.nelem, nie = kp.nie, nnode = kp.nnode, nb = kp.nbfac, nnbr = kp.nbr_rank.size();

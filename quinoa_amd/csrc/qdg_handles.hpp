@@ -56,6 +56,9 @@ struct Options {
   int keep_pool = 0;     // 1: qdg_ctx_destroy of the last context keeps the device buffer cache
   int keep_connectivity = 0;  // 1: device-built meshes without ghosts keep connectivity, coordinates, esuel and
                               // boundary faces (caller's numbering) resident: qdg_mesh_refine_uniform needs them
+  int halo_depth = 1;    // 2: chunks built from now on are meant for two ghost layers (qdg_halo_set_depth): the tets within
+                         // two faces of a ghost go last in the device order, so that every send row of the two-layer
+                         // plan is a trailing row and the packs can be folded into the producing kernels
   int graph_step = 0;    // 1: qdg_step_comm replays its launch sequence (kernels + RCCL) as a hipGraph per
                          // buffer-rotation phase; falls back to plain launches where capture is refused
 };
@@ -101,6 +104,9 @@ struct qdg_mesh {
   double* Upending = nullptr;     // output of a fused RHS+RK launch, adopted by qdg_stage_update
   bool skip_ghost_carry = false;  // set by qdg_step_comm around an update whose ghost rows are received next
   double* carry_src = nullptr;    // buffer that still holds the ghost rows of a skipped carry (qdg_step_comm's error path)
+  double* carry_pending = nullptr;  // after a qdg_step_comm: the buffer whose ghost rows belong to the current state;
+                                    // copied over by the next entry point that is not a qdg_step_comm (which
+                                    // starts by receiving every ghost row anyway)
   qdg::DevBuf<double> S1, S2;          // scratch of the stateless operators (allocated on first use)
   qdg::DevBuf<int> ndofel, ndofel2;    // p-adaptive DG: DG::m_ndof per device row (+ Jacobi copy)
   qdg::DevBuf<double> fout;            // field output staging (allocated on first use)
@@ -111,7 +117,7 @@ struct qdg_mesh {
   std::vector<int32_t> nbr_rank;
   std::vector<size_t> send_off, recv_off;
   qdg::DevBuf<int> send_elem;
-  qdg::DevBuf<int> fold_slot;     // [4 * (nie - ninner)] slab rows of every halo-adjacent row (-1 = none); empty: no folding
+  qdg::DevBuf<int> fold_slot;     // [FOLD_SLOTS * (nie - ninner)] slab rows of every halo-adjacent row (-1 = none); empty: no folding
   const double* slab_ready_for = nullptr;   // the state whose send rows the slab already holds (qdg_step_comm)
   qdg::DevBuf<double> send_slab, recv_slab;
   double* send_ptr = nullptr;     // slabs in use (own or caller-provided)
@@ -133,7 +139,7 @@ struct qdg_mesh {
   struct StepGraph {
     const double* ucur_in; double t, tleft; bool slab_ready_in;
     hipGraphExec_t exec;
-    double* ucur_out; const double* slab_ready_out;
+    double* ucur_out; const double* slab_ready_out; double* carry_out;
   };
   std::vector<StepGraph> step_graphs;
   int graph_state = 0;            // 0 not tried, 1 in use, -1 capture refused (graph_error says why)
@@ -152,6 +158,9 @@ struct qdg_mesh {
 namespace qdg {
 // qdg_api.cpp
 int mesh_alloc_state(qdg_mesh* m, int ntile);
+// ghost rows of the current state that a qdg_step_comm left in another buffer: copied over now (call before the
+// state's rows are read or replaced outside the entry points of qdg_api.cpp)
+int mesh_flush_carry(qdg_mesh* mesh);
 // qdg_devmesh.hip: the halo plan of a chunk whose handle keeps its connectivity (for its re-mesh)
 void keep_set_plan(qdg_mesh* m, size_t nnbr, const int32_t* nbr_rank, const size_t* recv_off);
 // qdg_devmesh.hip: device side of qdg_state_transfer / qdg_state_migrate

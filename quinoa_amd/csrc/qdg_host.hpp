@@ -72,4 +72,7 @@ struct qdg_chunk_refined {
   std::vector<size_t> tri, send_off, send_list, recv_counts;
   std::vector<int32_t> tri_set;
   rawvec<double> x, y, z;
+  // the plan's entries when they can differ from the caller's (two ghost layers, qdg_refine_chunk_depth)
+  std::vector<int32_t> nbr_rank, nbr_layer;
+  size_t nghost1 = 0;
 };

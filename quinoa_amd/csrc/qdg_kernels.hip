@@ -298,8 +298,8 @@ __global__ __launch_bounds__(256) void k_superbee(DevMesh m, double* __restrict_
     // first the tile's MEANS, [c][row] (10 KB), for the in-tile neighbours; later the staging area of the
     // coalesced row stores (128 rows)
     __shared__ double lds[128 * NPROP];
-    // rows [row0, nlim): the owned tets, plus the layer-1 ghosts of a chunk with two ghost layers
-    const int tile_e0 = m.row0 + (m.blk0 + xcd_tile(blockIdx.x, gridDim.x)) * 256;
+    // rows [0, nlim): the owned tets, plus the layer-1 ghosts of a chunk with two ghost layers
+    const int tile_e0 = (m.blk0 + xcd_tile(blockIdx.x, gridDim.x)) * 256;
     const int e0 = tile_e0 + threadIdx.x;
     const bool active = e0 < m.nlim;
     const int e = active ? e0 : m.nlim - 1;
@@ -382,12 +382,47 @@ __global__ __launch_bounds__(256) void k_upd_superbee(DevMesh m, const double* _
   __shared__ double mean[NCOMP * 256];     // the tile's U1 means [c][row], for the in-tile neighbours
   __shared__ double sdtv[256];
   const int tid = threadIdx.x;
-  const int tile_e0 = (m.blk0 + xcd_tile(blockIdx.x, gridDim.x)) * 256;
+  const int nown = (m.nie + 255) >> 8;           // tiles of owned rows; the workgroups behind them: layer-1 ghosts
+  const int tile = m.blk0 + xcd_tile(blockIdx.x, gridDim.x);
+  const int stride = m.stride;
+  const double dt = dtp[0];
+  if (tile >= nown) {
+    // Two ghost layers: the rank limits its layer-1 ghosts [nie, nlim) itself.  Their unlimited U1 rows are in
+    // Uout already (received); a neighbour's U1 mean comes from Uout if it is a ghost, else from U0 and R as
+    // below (the owned rows of Uout are being written by the other workgroups of this launch: never read here).
+    // One lane per row, the row rewritten in place (a few thousand rows: no staging)
+    const int g = m.nie + (tile - nown) * 256 + tid;
+    if (g >= m.nlim) return;
+    double u[NCOMP][NDOF];
+    load_row<NPROP>(Uout, g, &u[0][0]);
+    double uMin[NCOMP], uMax[NCOMP];
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c) uMin[c] = uMax[c] = u[c][0];
+#pragma unroll
+    for (int lf = 0; lf < 4; ++lf) {
+      const int nb = m.nbr[(size_t)lf * stride + g];
+      if (nb < 0) continue;
+      const double dtn = (nb < m.nie) ? dt / m.vol[nb] : 0.0;
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) {
+        const double v = (nb >= m.nie) ? Uout[fidx(c * NDOF, nb, NPROP)]
+                                       : U0[fidx(c * NDOF, nb, NPROP)] + dtn * 1.0 * R[fidx(c * NDOF, nb, NPROP)];
+        uMin[c] = fmin(uMin[c], v); uMax[c] = fmax(uMax[c], v);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c) {
+      const double phi = superbee_phi1<NDOF>(T, u[c], uMin[c], uMax[c]);
+#pragma unroll
+      for (int k = 1; k < 4; ++k) u[c][k] = phi * u[c][k];
+    }
+    store_row<NPROP>(Uout, g, &u[0][0]);
+    return;
+  }
+  const int tile_e0 = tile * 256;
   const int e0 = tile_e0 + tid;
   const bool active = e0 < m.nie;
   const int e = active ? e0 : m.nie - 1;
-  const int stride = m.stride;
-  const double dt = dtp[0];
   sdtv[tid] = dt / m.vol[e];                       // the row's dt / vol, as k_rk forms it
   int nbr[4];
 #pragma unroll
@@ -1699,7 +1734,6 @@ static DevMesh lim_range(const DevMesh& m0)
 {
   DevMesh m = m0;
   if (m.nlim < m.nie) m.nlim = m.nie;
-  m.row0 = 0;
   return m;
 }
 
@@ -1718,21 +1752,13 @@ void launch_superbee(int ndof, const DevMesh& m0, double* U, hipStream_t s, int 
   QDG_DISPATCH_NDOF(ndof, (k_superbee<N><<<nb, 256, 0, s>>>(m, U)));
 }
 
-// rows [row0, row1) only (CompFlow): the layer-1 ghosts behind the fused stage-0 update + limiter
-void launch_superbee_rows(int ndof, const DevMesh& m0, double* U, int row0, int row1, hipStream_t s)
-{
-  if (row1 <= row0 || ndof == 1 || m0.pde == 1) return;
-  DevMesh m = m0;
-  m.row0 = row0; m.nlim = row1; m.blk0 = 0;
-  m.fold_slot = nullptr; m.fold_slab = nullptr;
-  QDG_DISPATCH_NDOF(ndof, (k_superbee<N><<<nblk(row1 - row0, 256), 256, 0, s>>>(m, U)));
-}
-
 void launch_upd_superbee(const DevMesh& m, const double* dt, const double* U0, const double* R,
                          double* Uout, hipStream_t s)
 {
   if (m.nie == 0) return;
-  k_upd_superbee<4><<<nblk(m.nie, 256), 256, 0, s>>>(m, dt, U0, R, Uout);
+  // (+ one workgroup per 256 layer-1 ghosts of a chunk with two ghost layers: limited in the same launch)
+  const int nghost1 = m.nlim > m.nie ? m.nlim - m.nie : 0;
+  k_upd_superbee<4><<<nblk(m.nie, 256) + nblk(nghost1, 256), 256, 0, s>>>(m, dt, U0, R, Uout);
 }
 
 void launch_halo_pack_upd(const double* U0, const double* R, const double* dt, const double* vol,

@@ -37,7 +37,6 @@ void launch_rhs_p1t_rk(const DevMesh& m, const Phys& ph, double t, const double*
                        int first = 0, int count = -1);
 void launch_superbee(int ndof, const DevMesh& m, double* U, hipStream_t s, int first = 0,
                      int count = -1);
-void launch_superbee_rows(int ndof, const DevMesh& m, double* U, int row0, int row1, hipStream_t s);
 // stage-0 RK update fused with the Superbee limiter of stage 1 (DG-P1), and its halo pack
 void launch_upd_superbee(const DevMesh& m, const double* dt, const double* U0, const double* R,
                          double* Uout, hipStream_t s);

@@ -754,6 +754,144 @@ extern "C" int qdg_refine_chunk(size_t nielem, size_t nunk, size_t nnode, const 
   QDG_CATCH
 }
 
+// The same for a chunk with TWO ghost layers (qdg_chunk_build_depth(depth = 2); entries = the plan's (rank,
+// layer) entries in order, recv_counts per entry): all tets of the chunk are refined; the new layers and the new
+// plan come from the rule of qdg_chunk_build_depth (ghost_plan) applied to the children of the tets within two
+// faces of the old owned | ghost interface -- a child lies at least as many faces from a foreign child as its
+// parent from a foreign tet, so nothing farther in can enter a layer or a send list; owner of a child = owner of
+// its parent, global id 8 * gid(parent) + k.  No communication: every rank derives matching lists.
+extern "C" int qdg_refine_chunk_depth(size_t nielem, size_t nunk, size_t nnode, const size_t* inpoel,
+                                      const double* x, const double* y, const double* z, const size_t* gid,
+                                      size_t ntri, const size_t* tri, const int32_t* tri_set, size_t nentry,
+                                      const int32_t* entry_rank, const size_t* recv_counts, int depth,
+                                      qdg_chunk_refined** out)
+{
+  QDG_TRY
+  if (depth == 1) {
+    const int rc = qdg_refine_chunk(nielem, nunk, nnode, inpoel, x, y, z, gid, ntri, tri, tri_set, nentry, entry_rank,
+                                    recv_counts, out);
+    if (rc == 0) {
+      (*out)->nbr_rank.assign(entry_rank, entry_rank + nentry);
+      (*out)->nbr_layer.assign(nentry, 1);
+      (*out)->nghost1 = (*out)->nunk - (*out)->nielem;
+    }
+    return rc;
+  }
+  if (depth != 2) return fail("qdg_refine_chunk_depth: depth must be 1 or 2");
+  if (!inpoel || !x || !y || !z || !gid || !out || (ntri && (!tri || !tri_set)) || (nentry && (!entry_rank || !recv_counts)))
+    return fail("qdg_refine_chunk_depth: null argument");
+  *out = nullptr;
+  if (nielem == 0 || nielem > nunk) return fail("qdg_refine_chunk_depth: need 0 < nielem <= nunk");
+  size_t nghost = 0;
+  for (size_t i = 0; i < nentry; ++i) nghost += recv_counts[i];
+  if (nghost != nunk - nielem) return fail("qdg_refine_chunk_depth: receive counts do not add up to the ghost count");
+  for (size_t i = 0; i < 4 * nunk; ++i)
+    if (inpoel[i] >= nnode) return fail("qdg_refine_chunk_depth: inpoel entry out of range");
+  // side-set triangles that are faces of an owned tet (as qdg_refine_chunk)
+  std::vector<size_t> tri_in; std::vector<int32_t> set_in;
+  if (ntri) {
+    rawvec<FK> all(4 * nielem);
+    for (size_t e = 0; e < nielem; ++e)
+      for (int f = 0; f < 4; ++f)
+        all[4 * e + f] = fk_of(inpoel[4 * e + FACE_OF[f][0]], inpoel[4 * e + FACE_OF[f][1]], inpoel[4 * e + FACE_OF[f][2]], 4 * e + f);
+    fk_sort(all, nnode);
+    for (size_t t = 0; t < ntri; ++t) {
+      if (tri[3 * t] >= nnode || tri[3 * t + 1] >= nnode || tri[3 * t + 2] >= nnode) continue;
+      FK k = fk_of(tri[3 * t], tri[3 * t + 1], tri[3 * t + 2], 0);
+      auto it = std::lower_bound(all.begin(), all.end(), k, fk_less);
+      if (it != all.end() && fk_same(*it, k)) { tri_in.insert(tri_in.end(), tri + 3 * t, tri + 3 * t + 3); set_in.push_back(tri_set[t]); }
+    }
+  }
+  qdg_refined* rr = nullptr;
+  if (int rc = qdg_refine_uniform(nunk, nnode, inpoel, x, y, z, set_in.size(), tri_in.data(), &rr)) return rc;
+  std::unique_ptr<qdg_refined> r(rr);
+  if (32 * nunk > (size_t)INT32_MAX) return fail("qdg_refine_chunk_depth: chunk too large");
+  const rawvec<size_t>& i2 = r->inpoel;
+  const size_t nown = 8 * nielem;
+  // owner of every old tet: this rank = a value no neighbour has
+  const int32_t ME = INT32_MIN;
+  std::vector<int32_t> powner(nunk, ME);
+  { size_t o = nielem; for (size_t i = 0; i < nentry; ++i) for (size_t k = 0; k < recv_counts[i]; ++k) powner[o++] = entry_rank[i]; }
+  for (size_t i = 0; i < nentry; ++i) if (entry_rank[i] == ME) return fail("qdg_refine_chunk_depth: bad neighbour rank");
+  // the zone: all ghosts and the owned tets within two faces of one
+  std::vector<int> pes(4 * nunk);
+  if (int rc = qdg_gen_esuel(nunk, inpoel, pes.data())) return rc;
+  std::vector<char> zone(nunk, 0);
+  for (size_t e = nielem; e < nunk; ++e) zone[e] = 1;
+  for (int hop = 0; hop < 2; ++hop) {
+    std::vector<size_t> add;
+    for (size_t e = 0; e < nielem; ++e) {
+      if (zone[e]) continue;
+      for (int f = 0; f < 4; ++f) { const int nb = pes[4 * e + f]; if (nb >= 0 && zone[nb]) { add.push_back(e); break; } }
+    }
+    for (size_t e : add) zone[e] = 1;
+  }
+  std::vector<uint32_t> sub;                       // children of the zone's tets
+  for (size_t p = 0; p < nunk; ++p) if (zone[p]) for (int k = 0; k < 8; ++k) sub.push_back((uint32_t)(8 * p + k));
+  std::vector<size_t> sinp(4 * sub.size()), sgid(sub.size());
+  std::vector<int32_t> sown(sub.size());
+  for (size_t i = 0; i < sub.size(); ++i) {
+    const size_t e = sub[i];
+    for (int q = 0; q < 4; ++q) sinp[4 * i + q] = i2[4 * e + q];
+    sgid[i] = 8 * gid[r->parent[e]] + (e & 7);
+    sown[i] = powner[r->parent[e]];
+  }
+  std::vector<int> ses(4 * sub.size());
+  if (int rc = qdg_gen_esuel(sub.size(), sinp.data(), ses.data())) return rc;
+  GhostPlan gp;
+  if (int rc = ghost_plan(sub.size(), ses.data(), sown.data(), sgid.data(), ME, 2, gp, "qdg_refine_chunk_depth")) return rc;
+  std::unique_ptr<qdg_chunk_refined> c(new qdg_chunk_refined);
+  c->nielem = nown; c->nunk = nown + gp.ghost.size();
+  c->nbr_rank = gp.entry_rank; c->nbr_layer = gp.entry_layer; c->nghost1 = gp.nghost1;
+  const size_t ne2 = gp.entry_rank.size();
+  c->recv_counts.resize(ne2);
+  for (size_t i = 0; i < ne2; ++i) c->recv_counts[i] = gp.recv_off[i + 1] - gp.recv_off[i];
+  c->send_off = gp.send_off;
+  c->send_list.resize(gp.send_elem.size());
+  for (size_t j = 0; j < gp.send_elem.size(); ++j) c->send_list[j] = sub[gp.send_elem[j]];       // owned child = its new local id
+  std::vector<uint32_t> keep(c->nunk);
+  for (size_t e = 0; e < nown; ++e) keep[e] = (uint32_t)e;
+  for (size_t i = 0; i < gp.ghost.size(); ++i) keep[nown + i] = sub[gp.ghost[i]];
+  std::vector<int64_t> g2l(r->nnode, -1);
+  for (uint32_t e : keep) for (int i = 0; i < 4; ++i) g2l[i2[4 * (size_t)e + i]] = 0;
+  size_t nn = 0;
+  for (size_t n = 0; n < r->nnode; ++n) if (g2l[n] == 0) g2l[n] = (int64_t)nn++;
+  c->nnode = nn;
+  c->x.resize(nn); c->y.resize(nn); c->z.resize(nn);
+  for (size_t n = 0; n < r->nnode; ++n) if (g2l[n] >= 0) { c->x[g2l[n]] = r->x[n]; c->y[g2l[n]] = r->y[n]; c->z[g2l[n]] = r->z[n]; }
+  c->inpoel.resize(4 * c->nunk); c->gid.resize(c->nunk); c->parent.resize(c->nunk);
+  for (size_t k = 0; k < c->nunk; ++k) {
+    const size_t e = keep[k];
+    for (int i = 0; i < 4; ++i) c->inpoel[4 * k + i] = (size_t)g2l[i2[4 * e + i]];
+    c->gid[k] = 8 * gid[r->parent[e]] + (e & 7);
+    c->parent[k] = r->parent[e];
+  }
+  for (size_t t = 0; t < r->tri.size() / 3; ++t) {
+    const int64_t a = g2l[r->tri[3 * t]], b = g2l[r->tri[3 * t + 1]], d = g2l[r->tri[3 * t + 2]];
+    if (a >= 0 && b >= 0 && d >= 0) {
+      c->tri.push_back((size_t)a); c->tri.push_back((size_t)b); c->tri.push_back((size_t)d);
+      c->tri_set.push_back(set_in[t / 4]);
+    }
+  }
+  *out = c.release();
+  return 0;
+  QDG_CATCH
+}
+
+// the plan of a refined chunk: entries, layer-1 ghosts; nbr_rank / nbr_layer sized by *nentry (NULL: sizes only)
+extern "C" int qdg_chunk_refined_plan(const qdg_chunk_refined* c, size_t* nentry, size_t* nghost1, int32_t* nbr_rank,
+                                      int32_t* nbr_layer)
+{
+  QDG_TRY
+  if (!c) return fail("qdg_chunk_refined_plan: null handle");
+  if (nentry) *nentry = c->nbr_rank.size();
+  if (nghost1) *nghost1 = c->nghost1;
+  auto cp = [](auto* dst, const auto& v) { if (dst && !v.empty()) std::memcpy(dst, v.data(), v.size() * sizeof(v[0])); };
+  cp(nbr_rank, c->nbr_rank); cp(nbr_layer, c->nbr_layer);
+  return 0;
+  QDG_CATCH
+}
+
 extern "C" int qdg_chunk_refined_sizes(const qdg_chunk_refined* c, size_t* nielem, size_t* nunk, size_t* nnode,
                                        size_t* ntri, size_t* nsend)
 {

@@ -97,11 +97,14 @@ def test_config5_physics_refine_once_matches_oracle(ndof, limiter):
         run.mesh.close(); ctx.close()
 
 
-def test_config5_partitioned_chunks_refine_on_the_gpu():
+@pytest.mark.parametrize("depth", [1, 2])
+def test_config5_partitioned_chunks_refine_on_the_gpu(depth):
     """config 5 with a decomposition: 3 chunks on the GPU (dg.LocalChunks), 3 steps, every chunk
     refined by its own rank's logic (amr.refine_chunk) + re-uploaded + state handed over on the
     device (qdg_state_transfer across the two numberings, ghost rows included), 3 more steps;
-    equal to the single-chunk run across the same refinement (amr.RefinedRun)."""
+    equal to the single-chunk run across the same refinement (amr.RefinedRun).  depth 2: chunks with two
+    ghost layers (qdg_chunk_build_depth / qdg_refine_chunk_depth; device-built meshes, the ranks limit their
+    layer-1 ghosts themselves, one exchange per stage) before and after the re-mesh."""
     from quinoa_amd import amr, capi, dg, dgmesh, meshgen, partition
     g = meshgen.kuhn_box(6, 5, 4)
     kw = dict(flux="hllc", limiter="superbeep1", problem="sod_shocktube", gamma=1.4, cfl=0.3,
@@ -109,9 +112,12 @@ def test_config5_partitioned_chunks_refine_on_the_gpu():
     nparts = 3
     part = partition.partition(g["coord"], g["inpoel"], nparts, "rcb")
     ctx = capi.Context(4, **kw)
-    chunks = [partition.build_chunk(g["coord"], g["inpoel"], g["sidesets"], part, nparts, r) for r in range(nparts)]
+    chunks = [partition.build_chunk(g["coord"], g["inpoel"], g["sidesets"], part, nparts, r, depth=depth)
+              for r in range(nparts)]
 
     def upload(ch):
+        if depth == 2:      # (qdg_mesh_upload knows the owned tets' neighbours only)
+            return capi.mesh_from_connectivity(ctx, ch["inpoel"], ch["coord"], ch["sidesets"], nielem=ch["nielem"])
         return dgmesh.upload(ctx, dgmesh.build_chunk(ch["coord"], ch["inpoel"], ch["nielem"], ch["sidesets"]))
 
     meshes = [upload(ch) for ch in chunks]
@@ -122,6 +128,7 @@ def test_config5_partitioned_chunks_refine_on_the_gpu():
             m.state_initialize(0.0)
         one.mesh.state_initialize(0.0)
         drv = dg.LocalChunks(ctx, meshes, chunks)
+        assert drv.deep == (depth == 2)
         t = t1 = 0.0
         for _ in range(3):
             t += drv.step(t)
@@ -129,6 +136,7 @@ def test_config5_partitioned_chunks_refine_on_the_gpu():
         new_chunks, new_meshes = [], []
         for ch, m in zip(chunks, meshes):
             ch2, par = amr.refine_chunk(ch)
+            assert ch2["depth"] == depth
             # the re-mesh step of a rank: its refined chunk WITH the new ghost layer rebuilt on
             # the device from connectivity alone (qdg_mesh_from_chunk)
             m2 = capi.mesh_from_connectivity(ctx, ch2["inpoel"], ch2["coord"], ch2["sidesets"],
@@ -139,6 +147,7 @@ def test_config5_partitioned_chunks_refine_on_the_gpu():
         chunks, meshes = new_chunks, new_meshes
         one.refine()
         drv = dg.LocalChunks(ctx, meshes, chunks)
+        assert drv.deep == (depth == 2)
         for _ in range(3):
             t += drv.step(t)
             t1 += one.mesh.step(t1)

@@ -97,7 +97,8 @@ def _self_halo_run(kind, out, pref=False, parts=(2, 1, 1), depth=1, graph=0, nst
     from quinoa_amd import capi, dg, dgmesh, meshgen
     nz = NZ if parts[2] == 1 else 2 * 5             # an even count for a cut along z
     ch = meshgen.kuhn_box_chunk(NX, NY, nz, parts=parts, rank=0, depth=depth)
-    ctx = capi.Context(4, cfl=0.3, device=0, pref=pref, tolref=0.1, options={"graph_step": graph}, **KW, **BC)
+    ctx = capi.Context(4, cfl=0.3, device=0, pref=pref, tolref=0.1, options={"graph_step": graph, "halo_depth": depth},
+                       **KW, **BC)
     if depth == 1:
         assert [len(s) for s in ch["send_lists"]] == list(ch["recv_counts"])   # segments line up
         ck = dgmesh.build_chunk(ch["coord"], ch["inpoel"], ch["nielem"], ch["sidesets"])
@@ -121,7 +122,8 @@ def _self_halo_run(kind, out, pref=False, parts=(2, 1, 1), depth=1, graph=0, nst
         t += drv.dt_taken()
     U = mesh.state_download().reshape(-1, 20)
     gs = mesh.step_graph_status() if kind != "copy" else (0, 0, 0, "")
-    np.savez(out, U=U, t=t, nie=nie, ndof=mesh.ndofel_get(), graph_state=gs[0], graph_replays=gs[2], graph_error=gs[3])
+    np.savez(out, U=U, t=t, nie=nie, ndof=mesh.ndofel_get(), graph_state=gs[0], graph_replays=gs[2], graph_error=gs[3],
+             folded=mesh.halo_info()[2])
     mesh.close()
     if kind != "copy":
         comm.close()
@@ -172,6 +174,7 @@ def test_step_comm_as_a_hipgraph_and_with_two_ghost_layers(tmp_path, parts, dept
     assert abs(float(a["t"]) - float(b["t"])) <= 1e-13 * float(a["t"])
     assert np.abs(a["U"] - b["U"]).max() / np.abs(a["U"]).max() <= 1e-12
     assert int(g["graph_state"]) == 1 and int(g["graph_replays"]) == NSTEP + 4 - 2, str(g["graph_error"])
+    assert bool(b["folded"]) and bool(g["folded"])          # the packs ride in the producing kernels (depth 2 too)
     assert abs(float(g["t"]) - float(b["t"])) <= 1e-13 * float(b["t"])    # (LDS-atomic order: rounding freedom)
     nie = int(b["nie"])
     # owned rows: identical launches in identical order (the tile kernel's LDS atomics leave rounding freedom)

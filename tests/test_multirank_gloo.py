@@ -56,26 +56,26 @@ def _exchange(comm, drv, U, nielem):
     Um[nielem:nielem + n] = drv.recv_slab[:n * drv.nprop].numpy().reshape(n, drv.nprop)   # halo_unpack
 
 
-def _general_chunk(rank, world, method):
+def _general_chunk(rank, world, method, depth=1):
     """this rank's chunk of the global box mesh through the GENERAL decomposition
     (qdg_partition + qdg_chunk_build), as for a mesh read from a file"""
     from quinoa_amd import partition
     g = meshgen.kuhn_box(NX, NY, NZ)
     part = partition.partition(g["coord"], g["inpoel"], world, method)
-    ch = partition.build_chunk(g["coord"], g["inpoel"], g["sidesets"], part, world, rank)
+    ch = partition.build_chunk(g["coord"], g["inpoel"], g["sidesets"], part, world, rank, depth=depth)
     ch["gid"] = g["gid"][ch["gid"]]          # ids of the undivided generator mesh
     return ch
 
 
-def _rank_main(rank, world, port, parts, out):
+def _rank_main(rank, world, port, parts, out, depth=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         if isinstance(parts, str):
-            ch = _general_chunk(rank, world, parts)
+            ch = _general_chunk(rank, world, parts, depth)
         else:
-            ch = meshgen.kuhn_box_chunk(NX, NY, NZ, parts=parts, rank=rank)
+            ch = meshgen.kuhn_box_chunk(NX, NY, NZ, parts=parts, rank=rank, depth=depth)
         ck = dgmesh.build_chunk(ch["coord"], ch["inpoel"], ch["nielem"], ch["sidesets"])
         cm = O.ChunkMesh(ck.coord, ck.inpoel, ck.nielem, ck.esuel, ck.esuf, ck.inpofa, ck.geoFace,
                          ck.geoElem, ck.bface, ck.nbfac)
@@ -83,14 +83,22 @@ def _rank_main(rank, world, port, parts, out):
         comm = dg.TorchComm()
         drv = _CpuDriver(ch, 20)
         nie = ck.nielem
+        # two ghost layers: the rank limits its layer-1 ghosts itself (all their face neighbours are in the
+        # chunk; a free face of theirs is a physical-boundary face), and nothing is exchanged after the limiter
+        from quinoa_amd import capi
+        nlim = nie + ch["nghost1"] if depth == 2 else nie
+        esuel_all = capi.gen_esuel(ch["inpoel"])[:nlim] if depth == 2 else None
         Lm = orc.lhs()
         U = orc.initialize(Lm, 0.0)
         t = 0.0
         for _ in range(NSTEP):
             for stage in range(3):
                 _exchange(comm, drv, U, nie)          # comsol
-                orc.limit(U)
-                _exchange(comm, drv, U, nie)          # comlim
+                if depth == 2:
+                    orc.limit(U, esuel_all, nlim)
+                else:
+                    orc.limit(U)
+                    _exchange(comm, drv, U, nie)      # comlim
                 if stage == 0:
                     drv.dt_buf[0] = orc.dt(U) * CFL / 3.0
                     comm.allreduce_min(drv)           # contribute(min)
@@ -112,18 +120,21 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("parts", [(2, 1, 1), (2, 2, 1), (2, 2, 2), "rcb:2", "morton:3"])
-def test_two_rank_halo_run_equals_serial(tmp_path, parts):
+@pytest.mark.parametrize("parts,depth", [((2, 1, 1), 1), ((2, 2, 1), 1), ((2, 2, 2), 1), ("rcb:2", 1), ("morton:3", 1),
+                                         ((2, 2, 2), 2), ("rcb:3", 2)])
+def test_two_rank_halo_run_equals_serial(tmp_path, parts, depth):
     """2, 4 and 8 ranks: (2,2,2) is the decomposition of the 8-GPU bench run -- three
     face neighbours per rank, every pair's send list / receive range must match.  "rcb:2" /
     "morton:3": the same run on chunks cut by the general partitioner (qdg_partition +
-    qdg_chunk_build) instead of the box generator's own block cut."""
+    qdg_chunk_build) instead of the box generator's own block cut.  depth 2: chunks with two ghost layers
+    (one plan entry per (rank, layer), up to six per rank in the 2 x 2 x 2 cut), each rank limiting its layer-1
+    ghosts itself, ONE exchange per stage -- what bench.py runs on N > 1 GPUs."""
     if isinstance(parts, str):
         parts, world = parts.split(":")[0], int(parts.split(":")[1])
     else:
         world = parts[0] * parts[1] * parts[2]
     out = str(tmp_path / "rank%d.npz")
-    mp.spawn(_rank_main, args=(world, _free_port(), parts, out), nprocs=world, join=True)
+    mp.spawn(_rank_main, args=(world, _free_port(), parts, out, depth), nprocs=world, join=True)
     # serial oracle on the undivided mesh
     ch = meshgen.kuhn_box(NX, NY, NZ)
     om = O.OracleMesh(ch["coord"], ch["inpoel"], ch["sidesets"])

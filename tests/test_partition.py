@@ -202,3 +202,81 @@ def test_partitioned_sedov_pdg_matches_reference_pe4_goldens(cases):
         assert abs(t - float(fix[tag + "_time_last"][0])) <= 1e-12 * t
         assert (np.abs(got[:, oa] - gold[:6]) / scale).max() <= TOL
         assert np.array_equal(ndof[oa], gold[6].astype(np.int64))
+
+
+@pytest.mark.parametrize("parts", [(2, 1, 1), (2, 2, 1), (2, 2, 2), (3, 2, 1)])
+def test_two_ghost_layers_of_the_two_chunk_builders_agree(parts):
+    """Chunks with TWO ghost layers (the rank limits its layer-1 ghosts itself, 3 exchanges per step): the
+    analytic block cut (meshgen.kuhn_box_chunk(depth=2)) and the general builder (qdg_chunk_build_depth on the
+    undivided mesh with the same owners) produce the same layers and the same plan -- one entry per
+    (neighbour rank, layer), layer-1 entries first; every pair's send list is the other side's receive range,
+    tet by tet; the layer-1 prefix is the depth-1 chunk; layer 2 is exactly the set of foreign tets at face
+    distance two (checked against a breadth-first search on the undivided mesh)."""
+    from quinoa_amd import capi, meshgen, partition
+    NX, NY, NZ = 6, 5, 4
+    g = meshgen.kuhn_box(NX, NY, NZ)
+    world = parts[0] * parts[1] * parts[2]
+    chunks = [meshgen.kuhn_box_chunk(NX, NY, NZ, parts=parts, rank=r, depth=2) for r in range(world)]
+    one = [meshgen.kuhn_box_chunk(NX, NY, NZ, parts=parts, rank=r, depth=1) for r in range(world)]
+    owner = np.zeros(NX * NY * NZ * 6, dtype=np.int32)
+    for r, ch in enumerate(chunks):
+        owner[ch["gid"][:ch["nielem"]]] = r
+    part_g = owner[g["gid"]]
+    esuel = capi.gen_esuel(g["inpoel"])
+    gens = []
+    for r, ch in enumerate(chunks):
+        gen = partition.build_chunk(g["coord"], g["inpoel"], g["sidesets"], part_g, world, r, depth=2)
+        gen["gid"] = g["gid"][gen["gid"]]
+        gens.append(gen)
+        nie, n1 = ch["nielem"], ch["nghost1"]
+        assert ch["depth"] == 2 and gen["depth"] == 2
+        assert gen["nbr_rank"] == ch["nbr_rank"] and gen["nbr_layer"] == ch["nbr_layer"]
+        assert gen["recv_counts"] == ch["recv_counts"] and gen["nghost1"] == n1
+        assert ch["nbr_layer"] == sorted(ch["nbr_layer"])                   # layer-1 entries first
+        roff = np.concatenate([[0], np.cumsum(ch["recv_counts"])])
+        for i in range(len(ch["nbr_rank"])):
+            assert set(gen["gid"][nie + roff[i]:nie + roff[i + 1]]) == set(ch["gid"][nie + roff[i]:nie + roff[i + 1]])
+            assert set(gen["gid"][gen["send_lists"][i]]) == set(ch["gid"][ch["send_lists"][i]])
+            # a pair's tets are ordered by global id on both sides
+            seg = ch["gid"][nie + roff[i]:nie + roff[i + 1]]
+            assert (np.diff(seg) > 0).all() and (np.diff(ch["gid"][ch["send_lists"][i]]) > 0).all()
+        assert np.array_equal(ch["gid"][:nie + n1], one[r]["gid"])          # the depth-1 chunk is the prefix
+        # layers against a breadth-first search over the undivided mesh's face adjacency
+        mine = part_g == r
+        d1 = np.zeros(len(part_g), dtype=bool)
+        for e in np.nonzero(mine)[0]:
+            for nb in esuel[e]:
+                if nb >= 0 and not mine[nb]:
+                    d1[nb] = True
+        d2 = np.zeros(len(part_g), dtype=bool)
+        for e in np.nonzero(d1)[0]:
+            for nb in esuel[e]:
+                if nb >= 0 and not mine[nb] and not d1[nb]:
+                    d2[nb] = True
+        assert set(g["gid"][d1]) == set(ch["gid"][nie:nie + n1])
+        assert set(g["gid"][d2]) == set(ch["gid"][nie + n1:])
+    for fam in (chunks, gens):
+        for r, ch in enumerate(fam):
+            nie = ch["nielem"]
+            roff = np.concatenate([[0], np.cumsum(ch["recv_counts"])])
+            for i, (q, l) in enumerate(zip(ch["nbr_rank"], ch["nbr_layer"])):
+                o = fam[q]
+                j = [k for k, (qq, ll) in enumerate(zip(o["nbr_rank"], o["nbr_layer"])) if qq == r and ll == l]
+                assert len(j) == 1
+                assert np.array_equal(ch["gid"][nie + roff[i]:nie + roff[i + 1]], o["gid"][o["send_lists"][j[0]]])
+    if parts == (2, 2, 2):          # the edge-diagonal ranks appear in layer 2 only
+        assert any(l == 2 and q not in [qq for qq, ll in zip(c["nbr_rank"], c["nbr_layer"]) if ll == 1]
+                   for c in chunks for q, l in zip(c["nbr_rank"], c["nbr_layer"]))
+
+
+def test_depth_one_chunk_is_unchanged_by_the_depth_argument():
+    from quinoa_amd import meshgen, partition
+    g = meshgen.kuhn_box(5, 4, 3)
+    part = partition.partition(g["coord"], g["inpoel"], 3, "rcb")
+    a = partition.build_chunk(g["coord"], g["inpoel"], g["sidesets"], part, 3, 1)
+    b = partition.build_chunk(g["coord"], g["inpoel"], g["sidesets"], part, 3, 1, depth=1)
+    assert a["nbr_layer"] == [1] * len(a["nbr_rank"]) and a["nghost1"] == len(a["gid"]) - a["nielem"]
+    for k in ("gid", "inpoel", "coord"):
+        assert np.array_equal(a[k], b[k])
+    with pytest.raises(Exception):
+        partition.build_chunk(g["coord"], g["inpoel"], g["sidesets"], part, 3, 1, depth=3)
