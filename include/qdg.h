@@ -171,6 +171,8 @@ int qdg_ctx_synchronize(qdg_ctx* ctx);
  *   "halo_depth"    2: chunks built from now on put the tets within TWO faces of a ghost last in the device order
  *                   (default 1: within one face), so that the send rows of a two-layer halo plan
  *                   (qdg_halo_set_depth) are trailing rows and their packs fold into the producing kernels
+ *   "limiter_write_all" 1: the Superbee kernel writes back every tile (default: tiles it leaves unchanged are not
+ *                   written; results identical) -- the step rate of a flow developed everywhere, for measurement
  *   "graph_step"    1: qdg_step_comm replays its launches as a hipGraph (see qdg_step_graph_status)
  *   "orient_by_gid" 1 (default): meshes built with global tet ids (qdg_mesh_upload_gid, qdg_mesh_from_chunk_gid)
  *                   orient their faces by global id; 0: the chare-local rule of src/Inciter/DG.cpp:480-483

@@ -300,6 +300,7 @@ static int* option_slot(qdg_ctx* ctx, const char* name)
     { "orient_by_gid", &qdg::Options::orient_by_gid }, { "keep_pool", &qdg::Options::keep_pool },
     { "keep_connectivity", &qdg::Options::keep_connectivity },
     { "graph_step", &qdg::Options::graph_step }, { "halo_depth", &qdg::Options::halo_depth },
+    { "limiter_write_all", &qdg::Options::limiter_write_all },
   };
   for (const auto& t : tab)
     if (std::strcmp(name, t.n) == 0) return &(ctx->opt.*(t.p));
@@ -867,6 +868,7 @@ static int run_limiter(qdg_mesh* mesh, double*& Ucur, double* Ualt_in, bool owne
   if (mesh->ndof == 1) return 0;          // DG.cpp:1251: rdof > 1 only
   DevMesh dm = mesh->dm;
   if (owned_only) dm.nlim = dm.nie;
+  dm.lim_write_all = ctx->opt.limiter_write_all;
   if (ctx->cfg.limiter == QDG_LIMITER_SUPERBEEP1) {
     launch_superbee(mesh->ndof, dm, Ucur, s);
   } else if (ctx->cfg.limiter == QDG_LIMITER_WENOP1) {

@@ -88,6 +88,8 @@ struct DevMesh {
   // limiter range: rows [0, nlim).  nlim = nie, or nie + the chunk's layer-1 ghosts when the rank limits them
   // itself (two ghost layers, qdg_halo_set_depth: their nbr rows are filled); 0 reads as nie
   int nlim;
+  int lim_write_all;   // 1: the Superbee kernel writes every tile back, changed or not (context option
+                       // "limiter_write_all": the flow-independent lower bound of the limiter pass, for measurement)
   int ncomp;        // 5: CompFlow; dg::Transport: its number of scalars (rows of ncomp*ndof doubles)
   int pde;          // 0: CompFlow, 1: dg::Transport (QDG_PDE_*)
   // p-adaptive DG (scheme pdg): DG::m_ndof per device row, 1 or 4; null otherwise

@@ -59,6 +59,8 @@ struct Options {
   int halo_depth = 1;    // 2: chunks built from now on are meant for two ghost layers (qdg_halo_set_depth): the tets within
                          // two faces of a ghost go last in the device order, so that every send row of the two-layer
                          // plan is a trailing row and the packs can be folded into the producing kernels
+  int limiter_write_all = 0;  // 1: k_superbee writes back every tile (it normally skips tiles it leaves unchanged): the
+                              // rate of a flow that is developed EVERYWHERE, whatever the state; measurement only
   int graph_step = 0;    // 1: qdg_step_comm replays its launch sequence (kernels + RCCL) as a hipGraph per
                          // buffer-rotation phase; falls back to plain launches where capture is refused
 };

@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256) void k_superbee(DevMesh m, double* __restrict_
     // A tile in which the limiter changed no value (phi = 1 or zero slopes on every row: uniform and smooth
     // regions) has nothing to write back -- the limiter works in place -- which halves this pass's traffic there.
     // (The barrier inside is also the one that ends the reads of the means.)
-    if (!__syncthreads_or(changed && active)) return;
+    if (!__syncthreads_or((changed || m.lim_write_all) && active)) return;
     // Out-of-tile neighbours may be read from U while another tile has already
     // stored its limited rows: safe, Superbee never changes a mean.
     tile_store_rows_halves<NPROP>(U, tile_e0, m.nlim, lds, &u[0][0]);
