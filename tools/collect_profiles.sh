@@ -9,14 +9,14 @@ export TMPDIR=/tmp
 cd "${root:?}" || exit 1
 out=gpurun_out/${tag}_nx$nx
 mkdir -p $out
-timeout -k 10 900 python3 bench.py --nx $nx --no-north-star --no-amr --no-config3 --no-config4 > $out/bench.json 2> $out/bench.err
+timeout -k 10 900 python3 bench.py --nx $nx --no-north-star --no-amr --no-config3 --no-config4 --no-real-mesh > $out/bench.json 2> $out/bench.err
 tail -1 $out/bench.json | cut -c1-200
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --nx $nx --no-cpu-baseline --no-north-star --no-amr --no-config3 --no-config4 > $out/stats.log 2>&1
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --nx $nx --no-cpu-baseline --no-north-star --no-amr --no-config3 --no-config4 --no-real-mesh > $out/stats.log 2>&1
 cp $out/stats/*/*kernel_stats.csv $out/kernel_stats.csv
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "GRBM_GUI_ACTIVE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum"; do
   i=$((i+1))
-  timeout -k 10 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/pmc$i -- python3 bench.py --nx $nx --steps 3 --warmup 1 --no-cpu-baseline --no-north-star --no-amr --no-config3 --no-config4 > $out/pmc$i.log 2>&1 || echo "pmc pass $i failed"
+  timeout -k 10 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/pmc$i -- python3 bench.py --nx $nx --steps 3 --warmup 1 --develop 0 --no-cpu-baseline --no-north-star --no-amr --no-config3 --no-config4 --no-real-mesh > $out/pmc$i.log 2>&1 || echo "pmc pass $i failed"
 done
 python3 - <<PY
 import csv, glob, collections, json
@@ -41,7 +41,7 @@ if rhs:
         nl = cnt[(k, "FETCH_SIZE")]
         ker[k] = {"hbm_bytes_per_launch": b, "launches_counted": nl}
         tot += b * nl; n += nl
-    json.dump({"nx": $nx, "n_gpus": 1, "round": 4,
+    json.dump({"nx": $nx, "n_gpus": 1, "round": 5,
                "note": "x2 on FETCH_SIZE is the guide's calibration for 16-B-per-lane reads (what the RHS kernels issue); "
                        "other widths are uncalibrated, so for the gather-heavy kernels read this as an upper bound",
                "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes), per-launch means; "

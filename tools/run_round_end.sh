@@ -5,4 +5,4 @@ python -m pytest tests -m gpu -q > $o/pytest_all.log 2>&1; echo "rc $?" >> $o/py
 grep -q "^rc 0" $o/pytest_all.log || exit 1
 bash tools/collect_profiles.sh 55 $tag > $o/collect55.log 2>&1; tail -8 $o/collect55.log | cut -c1-200
 bash tools/collect_profiles.sh 119 $tag > $o/collect119.log 2>&1; tail -8 $o/collect119.log | cut -c1-200
-timeout -k 10 600 python bench.py > $o/bench_default.json 2> $o/bench_default.err; tail -1 $o/bench_default.json | cut -c1-400
+timeout -k 10 900 python bench.py > $o/bench_default.json 2> $o/bench_default.err; tail -1 $o/bench_default.json | cut -c1-400
