@@ -154,7 +154,7 @@ def run_workload(args, rank, world, local_rank, dims, lengths, parts, steps, war
         # (the rank is its own neighbour in name only: every entry sends as many rows as it receives)
         ch["send_lists"] = [np.resize(s_, n_) for s_, n_ in zip(ch["send_lists"], ch["recv_counts"])]
     nielem = int(ch["nielem"])
-    opts = {"graph_step": 0 if args.no_graph else 1, "halo_depth": depth}
+    opts = {"graph_step": 1 if args.graph else 0, "halo_depth": depth}
     if args.workload == "sedov":     # config 4's physics (symmetry on x-min, y-min and the z faces)
         ctx = capi.Context(4, flux="hllc", limiter="superbeep1", problem="sedov_blastwave", gamma=1.4,
                            cfl=0.3, bc_extrapolate=[2, 4], bc_sym=[1, 3, 5, 6], device=local_rank, options=opts)
@@ -617,8 +617,10 @@ def main():
                     help="ghost layers of a rank's chunk (N > 1, --self-halo): 2 (default) = the rank limits its "
                          "layer-1 ghosts itself, 3 exchanges + 1 all-reduce per step; 1 = the reference's one layer, "
                          "6 exchanges + 1 all-reduce")
-    ap.add_argument("--no-graph", action="store_true",
-                    help="multi-rank / self-halo runs: plain launches instead of qdg_step_comm's hipGraph replay")
+    ap.add_argument("--graph", action="store_true",
+                    help="multi-rank / self-halo runs: qdg_step_comm replays its launch sequence (kernels + RCCL) as a "
+                         "hipGraph (context option graph_step).  Measured on one GPU: <= 1 %% (the host is not the "
+                         "bottleneck), so plain launches are the default")
     ap.add_argument("--no-real-mesh", action="store_true",
                     help="skip the point on the reference's unstructured 31 k-tet cube mesh refined to 2 M / 16 M tets")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -48,12 +48,16 @@ struct Chunk {
   std::vector<size_t> inpoel, gid;                 // local node ids; global tet ids
   std::vector<double> x, y, z;
   std::vector<size_t> tri; std::vector<int32_t> tri_set;     // side-set triangles, local node ids
-  std::vector<int32_t> nbr_rank;
+  std::vector<int32_t> nbr_rank, nbr_layer;        // one plan entry per (neighbour rank, ghost layer)
+  size_t nghost1 = 0;                              // layer-1 ghosts (= all ghosts with one layer)
   std::vector<size_t> send_off, send_elem, recv_off;
   qdg_mesh* mesh = nullptr;
 };
 
 static bool g_device_remesh = false;    // 7th argument "device": the re-mesh by qdg_mesh_refine_chunk
+static int g_depth = 1;                 // 7th argument "deep": chunks with TWO ghost layers (qdg_chunk_build_depth,
+                                        // qdg_halo_set_depth, qdg_refine_chunk_depth): every rank limits its layer-1
+                                        // ghosts itself and the exchange of the limited solution (comlim) is dropped
 
 static void to_device(qdg_ctx* ctx, Chunk& c)
 {
@@ -62,6 +66,7 @@ static void to_device(qdg_ctx* ctx, Chunk& c)
                                 c.tri_set.size(), c.tri.data(), c.tri_set.data(), c.gid.data(), &c.mesh));
   CHECK(qdg_halo_setup(c.mesh, c.nbr_rank.size(), c.nbr_rank.data(), c.send_off.data(), c.send_elem.data(),
                        c.recv_off.data()));
+  if (g_depth == 2) CHECK(qdg_halo_set_depth(c.mesh, c.nghost1));
 }
 
 // DG::next -> comsol / DG::lim -> comlim: every chunk packs, rows travel, every chunk unpacks
@@ -71,7 +76,8 @@ static void exchange(std::vector<Chunk>& ch)
   for (size_t r = 0; r < ch.size(); ++r)
     for (size_t i = 0; i < ch[r].nbr_rank.size(); ++i) {
       Chunk& q = ch[(size_t)ch[r].nbr_rank[i]];
-      const size_t j = std::find(q.nbr_rank.begin(), q.nbr_rank.end(), (int32_t)r) - q.nbr_rank.begin();
+      size_t j = 0;                    // the other side's entry for (this rank, the same layer)
+      while (j < q.nbr_rank.size() && !(q.nbr_rank[j] == (int32_t)r && q.nbr_layer[j] == ch[r].nbr_layer[i])) ++j;
       const size_t n = ch[r].recv_off[i + 1] - ch[r].recv_off[i];
       if (j >= q.nbr_rank.size() || n != q.send_off[j + 1] - q.send_off[j]) { fprintf(stderr, "halo plan mismatch\n"); exit(1); }
       CHECK(qdg_halo_copy(ch[r].mesh, ch[r].recv_off[i], q.mesh, q.send_off[j], n));
@@ -85,8 +91,8 @@ static double step(std::vector<Chunk>& ch, double t)
   double dt = 0.0;
   for (int stage = 0; stage < 3; ++stage) {
     exchange(ch);                                              // next -> comsol
-    for (auto& c : ch) CHECK(qdg_stage_limit(c.mesh));         // lim
-    exchange(ch);                                              // -> comlim
+    for (auto& c : ch) CHECK(qdg_stage_limit(c.mesh));         // lim (two layers: the layer-1 ghosts too)
+    if (g_depth == 1) exchange(ch);                            // -> comlim
     for (auto& c : ch) CHECK(qdg_stage_rhs_dt(c.mesh, stage, t, 1e300));    // dt (stage 0), solve: rhs
     if (stage == 0) {                                          // contribute(min)
       dt = 1e300;
@@ -100,8 +106,9 @@ static double step(std::vector<Chunk>& ch, double t)
 
 int main(int argc, char** argv)
 {
-  if (argc != 6 && argc != 7) { fprintf(stderr, "usage: %s mesh.bin out.bin nparts nsteps_before nsteps_after [device]\n", argv[0]); return 2; }
+  if (argc != 6 && argc != 7) { fprintf(stderr, "usage: %s mesh.bin out.bin nparts nsteps_before nsteps_after [device|deep]\n", argv[0]); return 2; }
   g_device_remesh = argc == 7 && std::string(argv[6]) == "device";
+  g_depth = (argc == 7 && std::string(argv[6]) == "deep") ? 2 : 1;
   const int nparts = atoi(argv[3]), n0 = atoi(argv[4]), n1 = atoi(argv[5]);
   FILE* f = fopen(argv[1], "rb");
   if (!f) { perror("mesh"); return 2; }
@@ -127,6 +134,7 @@ int main(int argc, char** argv)
   qdg_ctx* ctx = nullptr;
   CHECK(qdg_ctx_create(&cfg, &ctx));
   if (g_device_remesh) CHECK(qdg_ctx_set_option(ctx, "keep_connectivity", 1));
+  if (g_depth == 2) CHECK(qdg_ctx_set_option(ctx, "halo_depth", 2));
 
   // ---- decomposition (Partitioner + the DG chare's ghost set-up) ---------------------------
   std::vector<int32_t> part(nelem);
@@ -136,12 +144,13 @@ int main(int argc, char** argv)
   for (int r = 0; r < nparts; ++r) {
     Chunk& c = ch[(size_t)r];
     qdg_chunk* h = nullptr;
-    CHECK(qdg_chunk_build(nelem, nnode, inpoel.data(), nullptr, part.data(), nparts, r, &h));
+    CHECK(qdg_chunk_build_depth(nelem, nnode, inpoel.data(), nullptr, part.data(), nparts, r, g_depth, &h));
     size_t nnbr = 0, nsend = 0;
     CHECK(qdg_chunk_sizes(h, &c.nielem, &c.nunk, &c.nnode, &nnbr, &nsend));
     c.inpoel.resize(4 * c.nunk); c.gid.resize(c.nunk);
     std::vector<size_t> node_gid(c.nnode);
-    c.nbr_rank.resize(nnbr); c.send_off.resize(nnbr + 1); c.send_elem.resize(nsend); c.recv_off.resize(nnbr + 1);
+    c.nbr_rank.resize(nnbr); c.nbr_layer.resize(nnbr); c.send_off.resize(nnbr + 1); c.send_elem.resize(nsend); c.recv_off.resize(nnbr + 1);
+    CHECK(qdg_chunk_layers(h, nullptr, &c.nghost1, c.nbr_layer.data()));
     CHECK(qdg_chunk_get(h, c.inpoel.data(), c.gid.data(), node_gid.data(), c.nbr_rank.data(), c.send_off.data(),
                         c.send_elem.data(), c.recv_off.data()));
     CHECK(qdg_chunk_destroy(h));
@@ -180,7 +189,7 @@ int main(int argc, char** argv)
       size_t ntri2 = 0, nsend = 0;
       CHECK(qdg_chunk_refined_sizes(h, &n.nielem, &n.nunk, &n.nnode, &ntri2, &nsend));
       n.gid.resize(n.nunk);
-      n.nbr_rank = c.nbr_rank;
+      n.nbr_rank = c.nbr_rank; n.nbr_layer = c.nbr_layer;
       n.send_off.resize(n.nbr_rank.size() + 1); n.send_elem.resize(nsend);
       CHECK(qdg_chunk_refined_get(h, nullptr, n.gid.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                                   n.send_off.data(), n.send_elem.data(), recv_counts.data()));
@@ -193,17 +202,22 @@ int main(int argc, char** argv)
       continue;
     }
     qdg_chunk_refined* h = nullptr;
-    CHECK(qdg_refine_chunk(c.nielem, c.nunk, c.nnode, c.inpoel.data(), c.x.data(), c.y.data(), c.z.data(),
-                           c.gid.data(), c.tri_set.size(), c.tri.data(), c.tri_set.data(), c.nbr_rank.size(),
-                           c.nbr_rank.data(), recv_counts.data(), &h));
+    CHECK(qdg_refine_chunk_depth(c.nielem, c.nunk, c.nnode, c.inpoel.data(), c.x.data(), c.y.data(), c.z.data(),
+                                 c.gid.data(), c.tri_set.size(), c.tri.data(), c.tri_set.data(), c.nbr_rank.size(),
+                                 c.nbr_rank.data(), recv_counts.data(), g_depth, &h));
     Chunk n;
     size_t ntri2 = 0, nsend = 0;
     CHECK(qdg_chunk_refined_sizes(h, &n.nielem, &n.nunk, &n.nnode, &ntri2, &nsend));
+    // (the refined chunk's plan entries are its own: with two layers they can differ from the old ones)
+    size_t nent2 = 0;
+    CHECK(qdg_chunk_refined_plan(h, &nent2, &n.nghost1, nullptr, nullptr));
+    n.nbr_rank.resize(nent2); n.nbr_layer.resize(nent2);
+    CHECK(qdg_chunk_refined_plan(h, nullptr, nullptr, n.nbr_rank.data(), n.nbr_layer.data()));
+    recv_counts.assign(nent2, 0);
     n.inpoel.resize(4 * n.nunk); n.gid.resize(n.nunk);
     std::vector<size_t> parent(n.nunk);
     n.x.resize(n.nnode); n.y.resize(n.nnode); n.z.resize(n.nnode);
     n.tri.resize(3 * ntri2); n.tri_set.resize(ntri2);
-    n.nbr_rank = c.nbr_rank;
     n.send_off.resize(n.nbr_rank.size() + 1); n.send_elem.resize(nsend);
     CHECK(qdg_chunk_refined_get(h, n.inpoel.data(), n.gid.data(), parent.data(), n.x.data(), n.y.data(), n.z.data(),
                                 n.tri.data(), n.tri_set.data(), n.send_off.data(), n.send_elem.data(),

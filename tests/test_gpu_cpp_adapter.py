@@ -185,7 +185,7 @@ def test_level2_cpp_driver_partition_halo_steps_remesh(tmp_path, nparts, remesh=
     out = tmp_path / "out.bin"
     n0, n1 = 3, 3
     r = subprocess.run([LEVEL2_EXE, str(mesh), str(out), str(nparts), str(n0), str(n1)] +
-                       (["device"] if remesh == "device" else []), capture_output=True, text=True, timeout=600)
+                       ([remesh] if remesh in ("device", "deep") else []), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr
     raw = open(out, "rb").read()
     t_end, nd = struct.unpack_from("<dQ", raw, 0)
@@ -226,6 +226,12 @@ def test_level2_cpp_driver_partition_halo_steps_remesh(tmp_path, nparts, remesh=
     assert sorted(got) == list(range(om2.nelem))
     G = np.array([got[g] for g in range(om2.nelem)])
     assert np.abs(G - U).max() <= 1e-10 * max(1.0, np.abs(U).max())
+
+
+def test_level2_cpp_driver_with_two_ghost_layers(tmp_path):
+    """the same C++ driver on chunks with TWO ghost layers (qdg_chunk_build_depth, qdg_halo_set_depth, one exchange
+    per stage, qdg_refine_chunk_depth for the re-mesh): same comparison with the oracle"""
+    test_level2_cpp_driver_partition_halo_steps_remesh(tmp_path, 3, remesh="deep")
 
 
 def test_level2_cpp_driver_with_the_device_remesh(tmp_path):
