@@ -554,6 +554,10 @@ int qdg_mesh_refine_uniform(qdg_mesh* mesh, qdg_mesh** refined_mesh, qdg_refined
  * host_copy (may be NULL): gid[nunk], parent[nunk] (old local id), send lists, receive counts -- and with
  * copy_mesh != 0 connectivity, coordinates and side-set triangles too -- through qdg_chunk_refined_sizes / _get.
  * Limits: fewer than 65 536 neighbour ranks and global child ids below 2^48 (the device sorts owner << 48 | id). */
+/* (A handle with two ghost layers -- qdg_halo_set_depth -- is re-meshed with two: the children within two faces of the
+ * old owned | ghost interface are cut out on the device, the rule of qdg_chunk_build_depth derives the new layers and
+ * plan from them, qdg_halo_setup + qdg_halo_set_depth of the new handle included; its plan entries:
+ * qdg_chunk_refined_plan.) */
 int qdg_mesh_refine_chunk(qdg_mesh* mesh, qdg_mesh** refined_mesh, qdg_chunk_refined** host_copy, int copy_mesh);
 int qdg_refined_sizes(const qdg_refined* r, size_t* nelem, size_t* nnode, size_t* ntri);
 int qdg_refined_tri_sets(const qdg_refined* r, int32_t* tri_set);

@@ -547,11 +547,12 @@ class Mesh:
         new.nielem = new.nunk = 8 * self.nielem
         return new, (Refined(r) if host_copy else None)
 
-    def refine_chunk(self, nbr_rank, copy_mesh=False):
-        """qdg_mesh_refine_chunk: the re-mesh of this rank's chunk WITH its ghost layer on the device (built by
-        mesh_from_connectivity(..., nielem, elem_gid) under keep_connectivity = 1, halo_setup done).  Returns
-        (new Mesh -- halo plan set up, owned state handed over --, chunk dict: nielem, gid, parent, nbr_rank,
-        send_lists, recv_counts [+ inpoel, coord, sidesets with copy_mesh])."""
+    def refine_chunk(self, nbr_rank=None, copy_mesh=False):
+        """qdg_mesh_refine_chunk: the re-mesh of this rank's chunk WITH its ghost layer(s) on the device (built by
+        mesh_from_connectivity(..., nielem, elem_gid) under keep_connectivity = 1, halo_setup [+ halo_set_depth]
+        done).  Returns (new Mesh -- halo plan set up, owned state handed over --, chunk dict: nielem, gid, parent,
+        nbr_rank, nbr_layer, nghost1, depth, send_lists, recv_counts [+ inpoel, coord, sidesets with copy_mesh]).
+        (nbr_rank is ignored: the refined chunk's plan entries come back from the library.)"""
         L = lib()
         new = Mesh.__new__(Mesh)
         new.ctx, new.nprop, new.h = self.ctx, self.nprop, C.c_void_p()
@@ -561,7 +562,11 @@ class Mesh:
             n = [C.c_size_t() for _ in range(5)]
             _chk(L.qdg_chunk_refined_sizes(h, *[C.byref(v) for v in n]))
             nie2, nunk2, nn2, ntri2, nsend = (int(v.value) for v in n)
-            nnbr = len(nbr_rank)
+            ne_, ng1_ = C.c_size_t(), C.c_size_t()
+            _chk(L.qdg_chunk_refined_plan(h, C.byref(ne_), C.byref(ng1_), None, None))
+            nnbr, nghost1 = int(ne_.value), int(ng1_.value)
+            nb2 = np.zeros(max(1, nnbr), dtype=np.int32); nl2 = np.ones(max(1, nnbr), dtype=np.int32)
+            _chk(L.qdg_chunk_refined_plan(h, None, None, nb2.ctypes.data_as(c_i32p), nl2.ctypes.data_as(c_i32p)))
             gid = np.empty(nunk2, dtype=np.uint64); par = np.empty(nunk2, dtype=np.uint64)
             soff = np.zeros(nnbr + 1, dtype=np.uint64); slist = np.zeros(max(1, nsend), dtype=np.uint64)
             rc = np.zeros(max(1, nnbr), dtype=np.uint64)
@@ -584,7 +589,10 @@ class Mesh:
             L.qdg_chunk_refined_destroy(h)
         new.nielem, new.nunk = nie2, nunk2
         soff = soff.astype(np.int64)
-        ch = {"nielem": nie2, "gid": gid.view(np.int64), "parent": par.view(np.int64), "nbr_rank": list(nbr_rank),
+        layers = [int(v) for v in nl2[:nnbr]]
+        ch = {"nielem": nie2, "gid": gid.view(np.int64), "parent": par.view(np.int64),
+              "nbr_rank": [int(v) for v in nb2[:nnbr]], "nbr_layer": layers, "nghost1": nghost1,
+              "depth": 2 if 2 in layers else 1,
               "send_lists": [slist[soff[i]:soff[i + 1]].astype(np.int64) for i in range(nnbr)],
               "recv_counts": [int(v) for v in rc[:nnbr]]}
         if copy_mesh:

@@ -1933,6 +1933,44 @@ __global__ void k_send_keys(const uint64_t* __restrict__ gkey, const uint32_t* _
   }
   skey[i] = k; sval[i] = v;
 }
+// ---- two ghost layers: the tets within two faces of the owned | ghost interface ("zone") and their children ----
+// one hop of the zone: an owned tet joins when a neighbour is in it (in -> out: no race)
+__global__ void k_zone_hop(const int* __restrict__ esuel, size_t nie, size_t nunk, const int* __restrict__ in, int* __restrict__ out)
+{
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nunk) return;
+  int z = e >= nie ? 1 : in[e];
+  if (!z)
+    for (int f = 0; f < 4; ++f) { const int nb = esuel[4 * e + f]; z |= (nb >= 0 && in[nb]) ? 1 : 0; }
+  out[e] = z;
+}
+// the zone's children as a mesh of their own: adjacency in subset numbering (8 * ppos[parent] + k; -1 outside),
+// owner rank (mine: INT32_MIN), global child id, child index in the refined chunk
+__global__ void k_zone_children(size_t nunk, size_t nie, const int* __restrict__ zone, const int* __restrict__ ppos,
+                                const int* __restrict__ esuel2, const uint64_t* __restrict__ gid_p,
+                                const size_t* __restrict__ recv_off, const int32_t* __restrict__ entry_rank, int nentry,
+                                int* __restrict__ s_esuel, int32_t* __restrict__ s_owner, uint64_t* __restrict__ s_gid,
+                                uint32_t* __restrict__ s_child)
+{
+  const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= 8 * nunk) return;
+  const size_t p = c >> 3;
+  if (!zone[p]) return;
+  const size_t i = 8 * (size_t)ppos[p] + (c & 7);
+  for (int f = 0; f < 4; ++f) {
+    const int d = esuel2[4 * c + f];
+    s_esuel[4 * i + f] = (d >= 0 && zone[d >> 3]) ? 8 * ppos[d >> 3] + (d & 7) : -1;
+  }
+  int32_t ow = INT32_MIN;
+  if (p >= nie) {
+    const size_t g = p - nie;
+    int en = 0;
+    while (en + 1 < nentry && g >= recv_off[en + 1]) ++en;
+    ow = entry_rank[en];
+  }
+  s_owner[i] = ow; s_gid[i] = 8 * gid_p[p] + (c & 7); s_child[i] = (uint32_t)c;
+}
+
 __global__ void k_mark_unique(const uint64_t* __restrict__ skey, size_t n, int* __restrict__ flag)
 {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2023,12 +2061,11 @@ extern "C" int qdg_mesh_refine_chunk(qdg_mesh* mesh, qdg_mesh** out, qdg_chunk_r
     return fail("qdg_mesh_refine_chunk: the mesh keeps no connectivity / global ids on the device (context option "
                 "keep_connectivity = 1, built by qdg_mesh_from_chunk_gid)");
   if (mesh->dm.ndofel) return fail("qdg_mesh_refine_chunk: p-adaptive runs are not combined with mesh refinement");
-  if (mesh->nghost1 > 0)
-    return fail("qdg_mesh_refine_chunk: a chunk with two ghost layers re-meshes through qdg_refine_chunk_depth + "
-                "qdg_mesh_from_chunk_gid (the device form derives one ghost layer)");
   qdg_mesh::Keep& kp = *mesh->keep;
   if (kp.pending) kp.pending->join();
-  const size_t nunk = kp.nelem, nie = kp.nie, nnode = kp.nnode, nb = kp.nbfac, nnbr = kp.nbr_rank.size();
+  const size_t nunk = kp.nelem, nie = kp.nie, nnode = kp.nnode, nb = kp.nbfac;
+  size_t nnbr = kp.nbr_rank.size();
+  const bool deep = mesh->nghost1 > 0;            // two ghost layers: the new layers and plan by the shared rule, below
   if (nunk > nie && (nnbr == 0 || mesh->nnbr != nnbr))
     return fail("qdg_mesh_refine_chunk: the chunk has ghosts: call qdg_halo_setup before the re-mesh");
   if (8 * nunk > (size_t)(INT32_MAX - 64) / 4) return fail("qdg_mesh_refine_chunk: refined chunk too large for 32-bit ids");
@@ -2070,7 +2107,7 @@ extern "C" int qdg_mesh_refine_chunk(qdg_mesh* mesh, qdg_mesh** out, qdg_chunk_r
   Buf<uint64_t> gkey, gkey2;
   Buf<uint32_t> gval, gval2;
   size_t ng = 0;
-  if (ngc) {
+  if (ngc && !deep) {
     DHIP(gflag.alloc(ngc + 1)); DHIP(gpos.alloc(ngc + 1));
     DHIP(hipMemsetAsync(gflag.p + ngc, 0, sizeof(int), s));
     k_ghost_child_flag<<<nblk(ngc), 256, 0, s>>>(esuel2.p, nown, nall, gflag.p);
@@ -2082,7 +2119,56 @@ extern "C" int qdg_mesh_refine_chunk(qdg_mesh* mesh, qdg_mesh** out, qdg_chunk_r
   }
   DHIP(gkey.alloc(ng)); DHIP(gkey2.alloc(ng)); DHIP(gval.alloc(ng)); DHIP(gval2.alloc(ng));
   std::vector<size_t> new_recv(nnbr, 0), send_off(nnbr + 1, 0), send_list;
-  if (ng) {
+  std::vector<int32_t> new_rank(kp.nbr_rank), new_layer(nnbr, 1);
+  size_t new_nghost1 = 0;
+  if (deep) {
+    // Two ghost layers.  The rule of qdg_chunk_build_depth (qdg_ghost_plan_build) applied to the children of the
+    // tets within two faces of the old interface -- nothing farther in can enter a layer or a send list (a child lies
+    // at least as many faces from a foreign child as its parent from a foreign tet).  That set is surface-sized: it
+    // is cut out on the device, its adjacency / owners / global ids go to the host, and the plan comes back.
+    Buf<int> za, zb, ppos;
+    DHIP(za.alloc(nunk + 1)); DHIP(zb.alloc(nunk + 1)); DHIP(ppos.alloc(nunk + 1));
+    DHIP(hipMemsetAsync(za.p, 0, (nunk + 1) * sizeof(int), s));
+    DHIP(hipMemsetAsync(zb.p, 0, (nunk + 1) * sizeof(int), s));
+    k_zone_hop<<<nblk(nunk), 256, 0, s>>>(kp.esuel.p, nie, nunk, za.p, zb.p);      // the ghosts
+    k_zone_hop<<<nblk(nunk), 256, 0, s>>>(kp.esuel.p, nie, nunk, zb.p, za.p);      // + owned tets next to one
+    k_zone_hop<<<nblk(nunk), 256, 0, s>>>(kp.esuel.p, nie, nunk, za.p, zb.p);      // + their owned neighbours
+    DHIP(hipMemcpyAsync(za.p, zb.p, nunk * sizeof(int), hipMemcpyDeviceToDevice, s));
+    if (int rc = dev_scan_int(za.p, ppos.p, nunk + 1, s)) return rc;
+    int nz = 0;
+    DHIP(hipMemcpyAsync(&nz, ppos.p + nunk, sizeof(int), hipMemcpyDeviceToHost, s));
+    DHIP(hipStreamSynchronize(s));
+    const size_t nsub = 8 * (size_t)nz;
+    Buf<int> s_es; Buf<int32_t> s_ow, d_er; Buf<uint64_t> s_gid; Buf<uint32_t> s_ch;
+    DHIP(s_es.alloc(4 * nsub)); DHIP(s_ow.alloc(nsub)); DHIP(s_gid.alloc(nsub)); DHIP(s_ch.alloc(nsub)); DHIP(d_er.alloc(nnbr));
+    DHIP(hipMemcpyAsync(d_er.p, kp.nbr_rank.data(), nnbr * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    k_zone_children<<<nblk(nall), 256, 0, s>>>(nunk, nie, za.p, ppos.p, esuel2.p, kp.gid.p, d_roff.p, d_er.p, (int)nnbr,
+                                              s_es.p, s_ow.p, s_gid.p, s_ch.p);
+    std::vector<int> h_es(4 * nsub); std::vector<int32_t> h_ow(nsub); std::vector<size_t> h_gid(nsub); std::vector<uint32_t> h_ch(nsub);
+    DHIP(hipMemcpyAsync(h_es.data(), s_es.p, 4 * nsub * sizeof(int), hipMemcpyDeviceToHost, s));
+    DHIP(hipMemcpyAsync(h_ow.data(), s_ow.p, nsub * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    DHIP(hipMemcpyAsync(h_gid.data(), s_gid.p, nsub * 8, hipMemcpyDeviceToHost, s));
+    DHIP(hipMemcpyAsync(h_ch.data(), s_ch.p, nsub * 4, hipMemcpyDeviceToHost, s));
+    DHIP(hipStreamSynchronize(s));
+    qdg_ghost_plan* gp = nullptr;
+    if (int rc = qdg_ghost_plan_build(nsub, h_es.data(), h_ow.data(), h_gid.data(), INT32_MIN, 2, &gp)) return rc;
+    std::unique_ptr<qdg_ghost_plan, int (*)(qdg_ghost_plan*)> gpg(gp, qdg_ghost_plan_destroy);
+    size_t nsend = 0, nent = 0;
+    if (int rc = qdg_ghost_plan_sizes(gp, &ng, &new_nghost1, &nent, &nsend)) return rc;
+    std::vector<size_t> gh(std::max<size_t>(ng, 1)), roff(nent + 1), se(std::max<size_t>(nsend, 1));
+    new_rank.assign(nent, 0); new_layer.assign(nent, 0); send_off.assign(nent + 1, 0);
+    if (int rc = qdg_ghost_plan_get(gp, gh.data(), new_rank.data(), new_layer.data(), roff.data(), send_off.data(), se.data())) return rc;
+    nnbr = nent;
+    new_recv.assign(nent, 0);
+    for (size_t i = 0; i < nent; ++i) new_recv[i] = roff[i + 1] - roff[i];
+    send_list.resize(nsend);
+    for (size_t j = 0; j < nsend; ++j) send_list[j] = h_ch[se[j]];        // an owned child's index is its new local id
+    std::vector<uint32_t> gchild(std::max<size_t>(ng, 1));
+    for (size_t i = 0; i < ng; ++i) gchild[i] = h_ch[gh[i]];
+    DHIP(gval2.alloc(ng));
+    if (ng) DHIP(hipMemcpyAsync(gval2.p, gchild.data(), ng * 4, hipMemcpyHostToDevice, s));
+    DHIP(hipStreamSynchronize(s));
+  } else if (ng) {
     k_ghost_keys<<<nblk(ngc), 256, 0, s>>>(gflag.p, gpos.p, nown, nall, nie, kp.gid.p, d_roff.p, (int)nnbr, gkey.p, gval.p);
     if (int rc = dev_sort_pairs64(gkey.p, gkey2.p, gval.p, gval2.p, ng, s)) return rc;
     std::vector<uint64_t> hk(ng);
@@ -2190,6 +2276,7 @@ extern "C" int qdg_mesh_refine_chunk(qdg_mesh* mesh, qdg_mesh** out, qdg_chunk_r
     DHIP(hipMemcpyAsync(hc->gid.data(), fd.gid.p, nkept * 8, hipMemcpyDeviceToHost, s));
     DHIP(hipMemcpyAsync(hc->parent.data(), par_out.p, nkept * 8, hipMemcpyDeviceToHost, s));
     hc->send_off = send_off; hc->send_list = send_list; hc->recv_counts = new_recv;
+    hc->nbr_rank = new_rank; hc->nbr_layer = new_layer; hc->nghost1 = deep ? new_nghost1 : ng;
     if (copy_mesh) {
       hc->inpoel.resize(4 * nkept); hc->x.resize((size_t)nn2); hc->y.resize((size_t)nn2); hc->z.resize((size_t)nn2);
       hc->tri.resize(3 * ntri2); hc->tri_set.resize(ntri2);
@@ -2215,7 +2302,8 @@ extern "C" int qdg_mesh_refine_chunk(qdg_mesh* mesh, qdg_mesh** out, qdg_chunk_r
   {
     std::vector<size_t> roff(nnbr + 1, 0);
     for (size_t q = 0; q < nnbr; ++q) roff[q + 1] = roff[q] + new_recv[q];
-    if (int rc2 = qdg_halo_setup(nm, nnbr, kp.nbr_rank.data(), send_off.data(), send_list.data(), roff.data())) return rc2;
+    if (int rc2 = qdg_halo_setup(nm, nnbr, new_rank.data(), send_off.data(), send_list.data(), roff.data())) return rc2;
+    if (deep) if (int rc2 = qdg_halo_set_depth(nm, new_nghost1)) return rc2;
   }
   // ---- state of the owned tets: child <- parent (ghost rows arrive with the next exchange) ----
   {

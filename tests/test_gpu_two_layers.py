@@ -150,3 +150,77 @@ def test_set_depth_is_refused_where_it_cannot_work():
         dev.halo_set_depth(0)
     finally:
         host.close(); dev.close(); ctx.close()
+
+
+@pytest.mark.parametrize("cut", ["2x2x1", "rcb:3"])
+def test_device_remesh_of_chunks_with_two_ghost_layers(cut):
+    """qdg_mesh_refine_chunk on handles with two ghost layers (keep_connectivity, halo_depth = 2): the refined
+    chunk's layers and plan come from the rule of qdg_chunk_build_depth applied to the children around the old
+    interface -- the same global ids, plan entries, send lists and receive counts as qdg_refine_chunk_depth on the
+    host; the new handles keep limiting their layer-1 ghosts (3 exchanges per step) and the run equals the single
+    chunk across the same refinement; a second re-mesh from the new handles works too."""
+    from quinoa_amd import amr, capi, dg, meshgen
+    dims = (6, 6, 4)
+    kw = dict(flux="hllc", limiter="superbeep1", problem="sod_shocktube", gamma=1.4, cfl=0.3,
+              bc_sym=[3, 4, 5, 6], bc_extrapolate=[1, 2])
+    if cut.startswith("rcb"):
+        parts, general = None, ("rcb", int(cut.split(":")[1]))
+    else:
+        parts, general = tuple(int(v) for v in cut.split("x")), None
+    chunks, _ = _chunks(dims, parts, 2, general)
+    ctx = capi.Context(4, options={"keep_connectivity": 1, "halo_depth": 2}, **kw)
+    meshes = [capi.mesh_from_connectivity(ctx, c["inpoel"], c["coord"], c["sidesets"], nielem=c["nielem"],
+                                          elem_gid=c["gid"]) for c in chunks]
+    one = meshgen.kuhn_box(*dims)
+    ctx1 = capi.Context(4, **kw)
+    run = amr.RefinedRun(ctx1, one["coord"], one["inpoel"], one["sidesets"])
+    try:
+        for m in meshes:
+            m.state_initialize(0.0)
+        run.mesh.state_initialize(0.0)
+        drv = dg.LocalChunks(ctx, meshes, chunks)
+        assert drv.deep
+        t = t1 = 0.0
+        for _ in range(2):
+            t += drv.step(t)
+            t1 += run.mesh.step(t1)
+        for level in range(2):
+            new_meshes, new_chunks = [], []
+            for c, m in zip(chunks, meshes):
+                host, _par = amr.refine_chunk(c)
+                m2, plan = m.refine_chunk()
+                assert plan["depth"] == 2 and plan["nghost1"] == host["nghost1"] and plan["nielem"] == host["nielem"]
+                assert plan["nbr_rank"] == host["nbr_rank"] and plan["nbr_layer"] == host["nbr_layer"]
+                assert plan["recv_counts"] == host["recv_counts"]
+                assert np.array_equal(plan["gid"], host["gid"])
+                for a, b in zip(plan["send_lists"], host["send_lists"]):
+                    assert np.array_equal(a, b)
+                assert m2.halo_info()[1] == plan["nghost1"]
+                m.close()
+                # (the next level's host cross-check needs the refined chunk's mesh: take the host's)
+                host["gid"] = plan["gid"]
+                new_meshes.append(m2); new_chunks.append(host)
+            meshes, chunks = new_meshes, new_chunks
+            run.refine()
+            drv = dg.LocalChunks(ctx, meshes, chunks)
+            assert drv.deep
+            for _ in range(2):
+                t += drv.step(t)
+                t1 += run.mesh.step(t1)
+            assert abs(t - t1) <= 1e-12 * t1
+            # single-chunk reference: child 8 * e + k of the generator's tet with global id gid(e): the chunks'
+            # global child ids are 8 * gid + k, the single chunk numbers its children 8 * (local e) + k
+            ref = run.mesh.state_download().reshape(-1, 20)
+            gmap = one["gid"] if level == 0 else gmap_next
+            gchild = (8 * np.asarray(gmap)[:, None] + np.arange(8)).reshape(-1)
+            glob = np.zeros((len(gchild), 20))
+            glob[gchild] = ref
+            gmap_next = gchild
+            for c, m in zip(chunks, meshes):
+                nie = c["nielem"]
+                U = m.state_download().reshape(-1, 20)[:nie]
+                assert compflow_err(U.reshape(-1), glob[c["gid"][:nie]].reshape(-1), 4) <= TOL, level
+    finally:
+        for m in meshes:
+            m.close()
+        run.mesh.close(); ctx.close(); ctx1.close()
