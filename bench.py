@@ -422,6 +422,42 @@ def amr_partitioned(local_rank, g, nparts, steps, host_path=True, reserve=False)
     return out
 
 
+def amr_one_rank(local_rank, nx, parts=(2, 1, 1), rank=0, depth=2):
+    """What ONE rank of a decomposition spends on a re-mesh, measured with only that rank's chunk on the GPU (as in a
+    one-process-per-GPU run: the other chunks' buffers do not compete for this device's memory): the rank's chunk of
+    the nx^3 box cut into `parts`, with `depth` ghost layers, built on the device with its halo plan, state
+    initialised; then qdg_mesh_refine_chunk -- refinement, new ghost layer(s) and halo plan, chunk build with ghosts,
+    halo set-up, owned state: one call, nothing uploaded."""
+    import numpy as np
+    from quinoa_amd import capi, meshgen
+    ch = meshgen.kuhn_box_chunk(nx, nx, nx, parts=parts, rank=rank, depth=depth)
+    ctx = capi.Context(4, flux="hllc", limiter="superbeep1", problem="sod_shocktube", gamma=1.4, cfl=0.3,
+                       bc_extrapolate=[1, 2], bc_sym=[3, 4, 5, 6], device=local_rank,
+                       options={"keep_connectivity": 1, "halo_depth": depth})
+    ctx.reserve_device_memory(int(0.6 * ctx.device_memory()[0]))
+    mesh = capi.mesh_from_connectivity(ctx, ch["inpoel"], ch["coord"], ch["sidesets"], nielem=ch["nielem"],
+                                       elem_gid=ch["gid"])
+    mesh.halo_setup(ch["nbr_rank"], ch["send_lists"], ch["recv_counts"])
+    if depth == 2:
+        mesh.halo_set_depth(ch["nghost1"])
+    mesh.state_initialize(0.0)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    m2, plan = mesh.refine_chunk()
+    ctx.synchronize()
+    t_dev = time.perf_counter() - t0
+    mesh.close()
+    ok = bool(np.isfinite(m2.state_download()[:20 * plan["nielem"]]).all())
+    out = {"cut": "%dx%dx%d, rank %d, %d ghost layer(s)" % (parts + (rank, depth)),
+           "owned_tets_before": int(ch["nielem"]), "ghost_tets_before": int(len(ch["gid"]) - ch["nielem"]),
+           "owned_tets_after": int(plan["nielem"]), "ghost_tets_after": int(len(plan["gid"]) - plan["nielem"]),
+           "plan_entries_after": list(zip(plan["nbr_rank"], plan["nbr_layer"])),
+           "remesh_device_ms": t_dev * 1e3, "finite": ok, "memory_reserved_ahead": True,
+           "note": "qdg_mesh_refine_chunk of ONE rank's chunk, alone on the GPU, from a reserved memory region"}
+    m2.close(); ctx.close()
+    return out
+
+
 def _amr_single(nx, steps, ne0, ne1, ms0, ms1, th, tr, tt, ok):
     return {"workload": "Sod DG-P1 + Superbee, %d^3 box: %d steps, uniform 1:8 refinement, %d steps" % (nx, steps, steps),
             "tets_before": ne0, "tets_after": ne1, "ms_per_step_before": ms0, "ms_per_step_after": ms1,
@@ -788,11 +824,10 @@ def main():
                                                                     with_partition=False, reserve=False)
             out["amr_point"]["at_north_star_size"] = amr_point(local_rank, nx=args.strong_nx, steps=5,
                                                                with_partition=False, reserve=True)
-            # ... and on a decomposition of that box: 2 chunks of 5.06 M owned tets -> 40.4 M each (device path)
-            from quinoa_amd import meshgen as _mg
-            out["amr_point"]["on_a_decomposition_at_north_star_size"] = amr_partitioned(
-                local_rank, _mg.kuhn_box(args.strong_nx, args.strong_nx, args.strong_nx), nparts=2, steps=2,
-                host_path=False, reserve=True)
+            # ... and what one rank of a decomposition of that box spends: rank 0 of a 2x1x1 cut, 5.06 M owned tets ->
+            # 40.4 M, alone on the GPU (round 4 kept both 40 M-tet chunks of the cut on the one device, so the second
+            # chunk's re-mesh paid the driver for memory: not a rank's figure)
+            out["amr_point"]["one_rank_of_a_decomposition_at_north_star_size"] = amr_one_rank(local_rank, args.strong_nx)
         if world == 1 and not args.no_config3 and not args.self_halo:
             out["config3_point"] = config3_point(local_rank, args.config3_nx)
         if world == 1 and not args.no_config4 and not args.self_halo:

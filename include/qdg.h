@@ -489,6 +489,15 @@ int qdg_refine_uniform(size_t nelem, size_t nnode, const size_t* inpoel, const d
 int qdg_refined_get(const qdg_refined* r, size_t* nnode, size_t* inpoel, size_t* parent,
                     double* x, double* y, double* z, size_t* tri);
 int qdg_refined_destroy(qdg_refined* r);
+/* Uniform 8:1 derefinement, the inverse of the above, for a mesh that is a uniform refinement in this library's order
+ * (children 8 e + k, old nodes before the midpoints, child triangles 4 t + k): what the reference's Refiner does for
+ * `uniform_derefine` at t0 (src/Inciter/Refiner.cpp:395-408, AMR/refinement.hpp:726-800; its t0ref goldens of uniform ->
+ * uniform_derefine -> uniform hold the original mesh again after that step).  Result through qdg_refined_get: nelem/8
+ * tets, the old nodes, ntri/4 triangles; parent[p] = 8 p (the first child of coarse tet p).  Any other input is
+ * refused.  The reference's DG scheme never removes tets at t > 0 (src/Inciter/DG.cpp:1597-1605 handles added tets
+ * only), so there is no reference for the solution transfer: qdg_mesh_derefine_uniform offers two. */
+int qdg_derefine_uniform(size_t nelem, size_t nnode, const size_t* inpoel, const double* x, const double* y,
+                         const double* z, size_t ntri, const size_t* tri, qdg_refined** out);
 /* The same refinement computed on the context's GPU (one radix sort of the edge keys and two
  * scans) and copied back: identical arrays, for meshes whose host-side refinement time matters. */
 int qdg_refine_uniform_device(qdg_ctx* ctx, size_t nelem, size_t nnode, const size_t* inpoel,
@@ -559,6 +568,15 @@ int qdg_mesh_refine_uniform(qdg_mesh* mesh, qdg_mesh** refined_mesh, qdg_refined
  * plan from them, qdg_halo_setup + qdg_halo_set_depth of the new handle included; its plan entries:
  * qdg_chunk_refined_plan.) */
 int qdg_mesh_refine_chunk(qdg_mesh* mesh, qdg_mesh** refined_mesh, qdg_chunk_refined** host_copy, int copy_mesh);
+/* The inverse for a resident chunk without ghosts whose kept connectivity is a uniform refinement in this library's
+ * order (qdg_derefine_uniform): 8 children -> their parent, on the device; the coarse boundary faces follow from the
+ * refined ones (same side sets), then the general device build.  There is no reference for the solution of a removed
+ * tet (src/Inciter/DG.cpp:1597-1605 handles added tets only): policy QDG_DEREF_FIRST_CHILD gives a parent the row of its
+ * first child -- the exact inverse of the reference's row copy child <- parent, so refinement followed by derefinement
+ * returns every DOF --, QDG_DEREF_MEAN the volume-weighted mean of the children's means with zero higher-order DOFs
+ * (conservative).  The new handle keeps its connectivity (it can be refined again). */
+enum { QDG_DEREF_FIRST_CHILD = 0, QDG_DEREF_MEAN = 1 };
+int qdg_mesh_derefine_uniform(qdg_mesh* mesh, int policy, qdg_mesh** coarse_mesh);
 int qdg_refined_sizes(const qdg_refined* r, size_t* nelem, size_t* nnode, size_t* ntri);
 int qdg_refined_tri_sets(const qdg_refined* r, int32_t* tri_set);
 /* The child mesh need not come from qdg_refine_*: ANY conforming tetrahedron mesh with a parent

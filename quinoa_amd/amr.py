@@ -48,6 +48,38 @@ def refine_uniform(coord, inpoel, sidesets, ctx=None):
     return np.ascontiguousarray(c2.T), inp2.view(np.int64).reshape(-1, 4), ss2, par.view(np.int64)
 
 
+def derefine_uniform(coord, inpoel, sidesets):
+    """qdg_derefine_uniform: the inverse of refine_uniform for a mesh in its order (children 8 e + k, old nodes first,
+    child triangles 4 t + k per side set) -> coord[nnode_old, 3], inpoel[ne / 8, 4], sidesets {id: tri[n / 4, 3]}"""
+    L = capi.lib()
+    coord = np.asarray(coord, dtype=np.float64)
+    inp, pinp = capi._sz(np.asarray(inpoel).reshape(-1))
+    ne, nn = len(inp) // 4, coord.shape[0]
+    x, px = capi._f64(coord[:, 0]); y, py = capi._f64(coord[:, 1]); z, pz = capi._f64(coord[:, 2])
+    ids = sorted(sidesets or {})
+    tri = np.concatenate([np.asarray(sidesets[s]).reshape(-1, 3) for s in ids]) if ids else np.zeros((0, 3))
+    tset = np.concatenate([np.full(len(sidesets[s]), s, np.int64) for s in ids]) if ids else np.zeros(0, np.int64)
+    tri, ptri = capi._sz(tri.reshape(-1) if len(tset) else np.zeros(3))
+    h = C.c_void_p()
+    capi._chk(L.qdg_derefine_uniform(C.c_size_t(ne), C.c_size_t(nn), pinp, px, py, pz, C.c_size_t(len(tset)), ptri,
+                                     C.byref(h)))
+    try:
+        n2 = C.c_size_t()
+        capi._chk(L.qdg_refined_get(h, C.byref(n2), None, None, None, None, None, None))
+        n2 = int(n2.value)
+        inp2 = np.empty(ne // 2, dtype=np.uint64)
+        c2 = np.empty((3, n2))
+        tri2 = np.zeros(max(1, 3 * (len(tset) // 4)), dtype=np.uint64)
+        capi._chk(L.qdg_refined_get(h, None, inp2.ctypes.data_as(capi.c_szp), None, c2[0].ctypes.data_as(capi.c_f64p),
+                                    c2[1].ctypes.data_as(capi.c_f64p), c2[2].ctypes.data_as(capi.c_f64p),
+                                    tri2.ctypes.data_as(capi.c_szp)))
+    finally:
+        L.qdg_refined_destroy(h)
+    tri2 = tri2[:3 * (len(tset) // 4)].view(np.int64).reshape(-1, 3)
+    tset2 = tset[::4]
+    return np.ascontiguousarray(c2.T), inp2.view(np.int64).reshape(-1, 4), {int(s): tri2[tset2 == s] for s in ids}
+
+
 def state_transfer(mesh_from, mesh_to, parent):
     par, ppar = capi._sz(parent)
     capi._chk(capi.lib().qdg_state_transfer(mesh_from.h, mesh_to.h, ppar))

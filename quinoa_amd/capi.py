@@ -547,6 +547,17 @@ class Mesh:
         new.nielem = new.nunk = 8 * self.nielem
         return new, (Refined(r) if host_copy else None)
 
+    def derefine_uniform(self, policy="first_child"):
+        """qdg_mesh_derefine_uniform: the 8:1 coarsening of this resident chunk (no ghosts; its kept connectivity must
+        be a uniform refinement in the library's order) on the device.  policy "first_child": a parent takes its first
+        child's row (the inverse of the reference's row copy child <- parent); "mean": the volume-weighted mean of
+        the children's means, higher-order DOFs zero.  Returns the new Mesh; this mesh stays valid until closed."""
+        new = Mesh.__new__(Mesh)
+        new.ctx, new.nprop, new.h = self.ctx, self.nprop, C.c_void_p()
+        _chk(lib().qdg_mesh_derefine_uniform(self.h, C.c_int({"first_child": 0, "mean": 1}[policy]), C.byref(new.h)))
+        new.nielem = new.nunk = self.nielem // 8
+        return new
+
     def refine_chunk(self, nbr_rank=None, copy_mesh=False):
         """qdg_mesh_refine_chunk: the re-mesh of this rank's chunk WITH its ghost layer(s) on the device (built by
         mesh_from_connectivity(..., nielem, elem_gid) under keep_connectivity = 1, halo_setup [+ halo_set_depth]

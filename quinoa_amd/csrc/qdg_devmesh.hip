@@ -1774,6 +1774,180 @@ extern "C" int qdg_mesh_refine_uniform(qdg_mesh* mesh, qdg_mesh** out, qdg_refin
 }
 
 // ======================================================================================
+// Uniform 8:1 derefinement of a resident chunk without ghosts: the inverse of qdg_mesh_refine_uniform for a handle
+// whose kept connectivity IS a uniform refinement in this library's order (qdg_derefine_uniform states the rule and
+// the reference lines).  Coarse tets from the children's first nodes, structure verified on the device; the coarse
+// boundary faces from the refined handle's boundary faces (a child triangle with exactly one old node, the corner of
+// its parent triangle, names that triangle through the end points of its two midpoints; same side set); then the
+// general build.  The reference's DG has no solution transfer for removed tets (src/Inciter/DG.cpp:1597-1605 handles
+// added tets only), so the state of a coarse tet is, by `policy`,
+//   QDG_DEREF_FIRST_CHILD  the row of its first child -- the exact inverse of the reference's row copy child <- parent
+//                          (a refinement followed by this derefinement returns every DOF);
+//   QDG_DEREF_MEAN         the volume-weighted mean of its children's means, higher-order DOFs zero (conservative).
+namespace {
+__global__ void k_derefine(const uint64_t* __restrict__ ip, size_t np, size_t nnode, uint64_t* __restrict__ out,
+                           unsigned long long* __restrict__ mm, int* __restrict__ err)
+{
+  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= np) return;
+  const uint64_t* c = ip + 32 * p;
+  const uint64_t A = c[0], B = c[4], C = c[8], D = c[12];
+  const uint64_t AB = c[1], AC = c[2], AD = c[3], BC = c[5], BD = c[7], CD = c[11];
+  const uint64_t want[8][4] = { { A, AB, AC, AD }, { B, BC, AB, BD }, { C, AC, BC, CD }, { D, AD, CD, BD },
+                                { BC, CD, AC, BD }, { AB, BD, AC, AD }, { AB, BC, AC, BD }, { AC, BD, CD, AD } };
+  bool ok = true;
+  for (int k = 0; k < 8; ++k)
+    for (int i = 0; i < 4; ++i) ok = ok && c[4 * k + i] == want[k][i] && c[4 * k + i] < nnode;
+  if (!ok) { *err = 1; return; }
+  out[4 * p] = A; out[4 * p + 1] = B; out[4 * p + 2] = C; out[4 * p + 3] = D;
+  unsigned long long hi = A > B ? A : B; hi = C > hi ? C : hi; hi = D > hi ? D : hi;
+  unsigned long long lo = AB < AC ? AB : AC; lo = AD < lo ? AD : lo; lo = BC < lo ? BC : lo; lo = BD < lo ? BD : lo; lo = CD < lo ? CD : lo;
+  atomicMax(mm, hi); atomicMin(mm + 1, lo);
+}
+// end points of every midpoint node (all parents of an edge write the same pair)
+__global__ void k_midpoint_ends(const uint64_t* __restrict__ ip, size_t np, size_t ncoarse, uint32_t* __restrict__ ends)
+{
+  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= np) return;
+  const uint64_t* c = ip + 32 * p;
+  const uint64_t V[4] = { c[0], c[4], c[8], c[12] };
+  const uint64_t M[6] = { c[1], c[2], c[3], c[5], c[7], c[11] };
+  const int E[6][2] = { {0, 1}, {0, 2}, {0, 3}, {1, 2}, {1, 3}, {2, 3} };
+  for (int k = 0; k < 6; ++k) {
+    ends[2 * (M[k] - ncoarse)] = (uint32_t)V[E[k][0]];
+    ends[2 * (M[k] - ncoarse) + 1] = (uint32_t)V[E[k][1]];
+  }
+}
+// a refined boundary face with exactly one old node -> its parent triangle (else ~0)
+__global__ void k_parent_tris(const uint64_t* __restrict__ tri, size_t nb, size_t ncoarse, const uint32_t* __restrict__ ends,
+                              uint64_t* __restrict__ out)
+{
+  const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nb) return;
+  const uint64_t q[3] = { tri[3 * b], tri[3 * b + 1], tri[3 * b + 2] };
+  int nc = 0, ic = 0;
+  for (int i = 0; i < 3; ++i) if (q[i] < ncoarse) { ++nc; ic = i; }
+  out[3 * b] = out[3 * b + 1] = out[3 * b + 2] = ~0ull;
+  if (nc != 1) return;
+  const uint64_t a = q[ic], m1 = q[(ic + 1) % 3], m2 = q[(ic + 2) % 3];
+  const uint32_t *e1 = ends + 2 * (m1 - ncoarse), *e2 = ends + 2 * (m2 - ncoarse);
+  out[3 * b] = a;
+  out[3 * b + 1] = e1[0] == a ? e1[1] : e1[0];
+  out[3 * b + 2] = e2[0] == a ? e2[1] : e2[0];
+}
+__global__ void k_derefine_state(size_t np, int nprop, int ndof, int policy, const int* __restrict__ d2h_c,
+                                 const int* __restrict__ h2d_f, const double* __restrict__ vol_f,
+                                 const double* __restrict__ Uf, double* __restrict__ Uc)
+{
+  const size_t d = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= np) return;
+  const size_t p = (size_t)d2h_c[d];
+  if (policy == 0) {
+    const size_t r = (size_t)h2d_f[8 * p];
+    for (int i = 0; i < nprop; ++i) Uc[d * nprop + i] = Uf[r * nprop + i];
+    return;
+  }
+  double vs = 0.0;
+  for (int k = 0; k < 8; ++k) vs += vol_f[h2d_f[8 * p + k]];
+  for (int i = 0; i < nprop; ++i) {
+    double v = 0.0;
+    if (i % ndof == 0) {
+      for (int k = 0; k < 8; ++k) { const size_t r = (size_t)h2d_f[8 * p + k]; v += vol_f[r] * Uf[r * nprop + i]; }
+      v /= vs;
+    }
+    Uc[d * nprop + i] = v;
+  }
+}
+}  // namespace
+
+extern "C" int qdg_mesh_derefine_uniform(qdg_mesh* mesh, int policy, qdg_mesh** out)
+{
+  QDG_TRY
+  if (!mesh || !out) return fail("qdg_mesh_derefine_uniform: null argument");
+  *out = nullptr;
+  if (policy != QDG_DEREF_FIRST_CHILD && policy != QDG_DEREF_MEAN) return fail("qdg_mesh_derefine_uniform: unknown policy");
+  qdg_ctx* ctx = mesh->ctx;
+  if (!mesh->keep) return fail("qdg_mesh_derefine_uniform: the mesh keeps no connectivity on the device (context option keep_connectivity = 1)");
+  if (mesh->ne != mesh->nie) return fail("qdg_mesh_derefine_uniform: chunks with ghosts are not derefined here");
+  if (mesh->dm.ndofel) return fail("qdg_mesh_derefine_uniform: p-adaptive runs are not combined with mesh refinement");
+  qdg_mesh::Keep& kp = *mesh->keep;
+  if (kp.pending) kp.pending->join();
+  const size_t nelem = kp.nelem, nnode = kp.nnode, nb = kp.nbfac;
+  if (nelem == 0 || nelem % 8 != 0) return fail("qdg_mesh_derefine_uniform: the number of tets is not a multiple of 8");
+  const size_t np = nelem / 8;
+  DHIP(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  qdg::StreamScope scope(s);
+  if (int rc = mesh_flush_carry(mesh)) return rc;
+  DevFD fd;
+  fd.nelem = fd.nie = np;
+  Buf<unsigned long long> d_mm;
+  Buf<int> d_err;
+  DHIP(fd.inpoel.alloc(4 * np)); DHIP(d_mm.alloc(2)); DHIP(d_err.alloc(1));
+  {
+    const unsigned long long init[2] = { 0ull, ~0ull };
+    DHIP(hipMemcpyAsync(d_mm.p, init, sizeof init, hipMemcpyHostToDevice, s));
+    DHIP(hipMemsetAsync(d_err.p, 0, sizeof(int), s));
+  }
+  k_derefine<<<nblk(np), 256, 0, s>>>(kp.inpoel.p, np, nnode, fd.inpoel.p, d_mm.p, d_err.p);
+  unsigned long long hmm[2]; int herr = 0;
+  DHIP(hipMemcpyAsync(hmm, d_mm.p, sizeof hmm, hipMemcpyDeviceToHost, s));
+  DHIP(hipMemcpyAsync(&herr, d_err.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  DHIP(hipStreamSynchronize(s));
+  if (herr) return fail("qdg_mesh_derefine_uniform: the kept connectivity is not a uniform refinement in the order of "
+                        "qdg_refine_uniform (eight children per tet, 8 e + k)");
+  const size_t ncoarse = (size_t)hmm[0] + 1;
+  if (hmm[1] < ncoarse) return fail("qdg_mesh_derefine_uniform: a midpoint node is numbered before a corner node");
+  fd.nnode = ncoarse;
+  DHIP(fd.x.alloc(ncoarse)); DHIP(fd.y.alloc(ncoarse)); DHIP(fd.z.alloc(ncoarse));
+  DHIP(hipMemcpyAsync(fd.x.p, kp.x.p, ncoarse * 8, hipMemcpyDeviceToDevice, s));
+  DHIP(hipMemcpyAsync(fd.y.p, kp.y.p, ncoarse * 8, hipMemcpyDeviceToDevice, s));
+  DHIP(hipMemcpyAsync(fd.z.p, kp.z.p, ncoarse * 8, hipMemcpyDeviceToDevice, s));
+  // ---- coarse side-set triangles from the refined boundary faces (a surface-sized detour through the host) ----
+  std::vector<size_t> tri; std::vector<int32_t> tset;
+  if (nb) {
+    Buf<uint32_t> ends; Buf<uint64_t> ptri;
+    DHIP(ends.alloc(2 * (nnode - ncoarse))); DHIP(ptri.alloc(3 * nb));
+    k_midpoint_ends<<<nblk(np), 256, 0, s>>>(kp.inpoel.p, np, ncoarse, ends.p);
+    k_parent_tris<<<nblk(nb), 256, 0, s>>>(kp.tri.p, nb, ncoarse, ends.p, ptri.p);
+    std::vector<uint64_t> h(3 * nb);
+    DHIP(hipMemcpyAsync(h.data(), ptri.p, 3 * nb * 8, hipMemcpyDeviceToHost, s));
+    DHIP(hipStreamSynchronize(s));
+    for (size_t b = 0; b < nb; ++b)
+      if (h[3 * b] != ~0ull) { tri.push_back(h[3 * b]); tri.push_back(h[3 * b + 1]); tri.push_back(h[3 * b + 2]); tset.push_back(kp.fset[b]); }
+  }
+  {
+    SortedFaces sf;
+    if (int rc = dev_esuel_by_sort(ctx, fd, sf)) return rc;
+  }
+  if (int rc = dev_bnd_faces(ctx, fd, tset.size(), tri.data(), tset.data())) return rc;
+  if (int rc = dev_faces_geometry(ctx, fd, nullptr)) return rc;
+  if (fd.nonpos_vol) return fail("qdg_mesh_derefine_uniform: non-positive parent volume");
+  std::vector<int> bcface;
+  if (int rc = bc_of_faces(ctx, fd, bcface)) return rc;
+  qdg_mesh* nm = nullptr;
+  int rc = 0;
+  {
+    KeepOn keep_on(ctx);
+    rc = dev_build_layout(ctx, fd, bcface, &nm);
+  }
+  if (rc) return rc;
+  std::unique_ptr<qdg_mesh, int (*)(qdg_mesh*)> guard(nm, qdg_mesh_destroy);
+  {
+    Buf<int> h2d_from;
+    DHIP(h2d_from.alloc(mesh->ne));
+    k_invert_perm<<<nblk(mesh->ne), 256, 0, s>>>(mesh->d2h.p, mesh->ne, h2d_from.p);
+    k_derefine_state<<<nblk(np), 256, 0, s>>>(np, nm->nprop, nm->ndof, policy, nm->d2h.p, h2d_from.p, mesh->vol.p, mesh->Ucur, nm->Ucur);
+    DHIP(hipGetLastError());
+    DHIP(hipStreamSynchronize(s));
+    nm->Unp = nullptr; nm->Upending = nullptr;
+  }
+  *out = guard.release();
+  return 0;
+  QDG_CATCH
+}
+
+// ======================================================================================
 // Device side of qdg_state_transfer / qdg_state_migrate: the parent (or source) row of every row of `to`
 // found on the device -- a conversion kernel for a caller-supplied list, a sort + binary search for the
 // match by global tet id -- instead of host loops and hash maps over all tets.

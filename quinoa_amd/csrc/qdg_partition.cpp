@@ -121,6 +121,64 @@ extern "C" int qdg_partition(size_t nelem, const size_t* inpoel, size_t nnode, c
 }
 
 // ---------------------------------------------------------------------------------------
+// Uniform 8:1 derefinement: the inverse of qdg_refine_uniform, for a mesh that IS a uniform refinement in this
+// library's order (children 8 e + k of parent e, refine_one_to_eight's child list: (A,AB,AC,AD), (B,BC,AB,BD),
+// (C,AC,BC,CD), (D,AD,CD,BD) and the four tets of the inner octahedron; old nodes before the edge midpoints; child
+// triangles 4 t + k of boundary triangle t).  What the reference's Refiner does for `uniform_derefine` at t0
+// (src/Inciter/Refiner.cpp:395-408 -> AMR::mesh_adapter_t::uniform_derefinement, AMR/mesh_adapter.cpp; parents restored
+// from their children, AMR/refinement.hpp:726-800): its t0ref goldens of uniform -> uniform_derefine -> uniform hold
+// the original mesh again after the derefinement step (tests/golden/t0ref_gauss_hump_udu.npz).  The parent is
+// (A, B, C, D) = the first node of children 0-3; the structure of all eight children is verified.
+extern "C" int qdg_derefine_uniform(size_t nelem, size_t nnode, const size_t* inpoel, const double* x, const double* y,
+                                    const double* z, size_t ntri, const size_t* tri, qdg_refined** out)
+{
+  QDG_TRY
+  if (!inpoel || !x || !y || !z || !out || (ntri && !tri)) return fail("qdg_derefine_uniform: null argument");
+  *out = nullptr;
+  if (nelem == 0 || nelem % 8 != 0) return fail("qdg_derefine_uniform: the number of tets is not a multiple of 8");
+  if (ntri % 4 != 0) return fail("qdg_derefine_uniform: the number of boundary triangles is not a multiple of 4");
+  const size_t np = nelem / 8;
+  std::unique_ptr<qdg_refined> r(new qdg_refined);
+  r->inpoel.resize(4 * np); r->parent.resize(np);
+  size_t ncoarse = 0;
+  for (size_t p = 0; p < np; ++p) {
+    const size_t* c = inpoel + 32 * p;
+    for (size_t i = 0; i < 32; ++i) if (c[i] >= nnode) return fail("qdg_derefine_uniform: inpoel entry out of range");
+    const size_t A = c[0], B = c[4], C = c[8], D = c[12];
+    const size_t AB = c[1], AC = c[2], AD = c[3], BC = c[5], BD = c[7], CD = c[11];
+    const size_t want[8][4] = { { A, AB, AC, AD }, { B, BC, AB, BD }, { C, AC, BC, CD }, { D, AD, CD, BD },
+                                { BC, CD, AC, BD }, { AB, BD, AC, AD }, { AB, BC, AC, BD }, { AC, BD, CD, AD } };
+    for (int k = 0; k < 8; ++k)
+      for (int i = 0; i < 4; ++i)
+        if (c[4 * k + i] != want[k][i])
+          return fail("qdg_derefine_uniform: tets " + std::to_string(8 * p) + "... are not the eight children of one tet "
+                      "in the order of qdg_refine_uniform");
+    r->inpoel[4 * p] = A; r->inpoel[4 * p + 1] = B; r->inpoel[4 * p + 2] = C; r->inpoel[4 * p + 3] = D;
+    r->parent[p] = 8 * p;                       // (its first child: where a row copy takes the parent's state from)
+    ncoarse = std::max({ ncoarse, A + 1, B + 1, C + 1, D + 1 });
+  }
+  // the old nodes come first: every midpoint id lies behind every corner id
+  for (size_t p = 0; p < np; ++p) {
+    const size_t* c = inpoel + 32 * p;
+    const size_t mid[6] = { c[1], c[2], c[3], c[5], c[7], c[11] };
+    for (size_t m : mid) if (m < ncoarse) return fail("qdg_derefine_uniform: a midpoint node is numbered before a corner node");
+  }
+  r->nnode = ncoarse;
+  r->x.assign(x, x + ncoarse); r->y.assign(y, y + ncoarse); r->z.assign(z, z + ncoarse);
+  r->tri.resize(3 * (ntri / 4));
+  for (size_t t = 0; t < ntri / 4; ++t) {
+    const size_t* q = tri + 12 * t;             // (a,ab,ac), (b,bc,ab), (c,ac,bc), (ab,bc,ac)
+    if (q[1] != q[5] || q[2] != q[7] || q[4] != q[8] || q[9] != q[1] || q[10] != q[4] || q[11] != q[2])
+      return fail("qdg_derefine_uniform: boundary triangles " + std::to_string(4 * t) + "... are not the four children of one triangle");
+    r->tri[3 * t] = q[0]; r->tri[3 * t + 1] = q[3]; r->tri[3 * t + 2] = q[6];
+    if (q[0] >= ncoarse || q[3] >= ncoarse || q[6] >= ncoarse) return fail("qdg_derefine_uniform: boundary triangle corner is a midpoint");
+  }
+  *out = r.release();
+  return 0;
+  QDG_CATCH
+}
+
+// ---------------------------------------------------------------------------------------
 // Ghost layers and halo plan of ONE rank from the face adjacency of a mesh (or of the part of a mesh around
 // the rank's tets), the owner rank of every tet and the tets' global ids.
 //

@@ -105,7 +105,30 @@ def read_diag(path):
     return np.array(rows)
 
 
+def make_udu():
+    """The reference's t0 mesh sequence uniform -> uniform_derefine -> uniform (-> uniform_derefine -> uniform):
+    the meshes its regression test amr_t0ref_ud(ud)u_trans_dg compares after every initial refinement step
+    (mesh_refinement/t0ref/gauss_hump_dg_uniform_deref_t0ref.std.e-s.{0..5}.1.0, CMakeLists.txt:108-160) ->
+    tests/golden/t0ref_gauss_hump_udu.npz: s{k}_coord, s{k}_inpoel, s{k}_ss_ids, s{k}_ss_tri_{id}.  Pins the uniform
+    derefinement (qdg_derefine_uniform, qdg_mesh_derefine_uniform): stage 2 is the initial mesh again."""
+    d = os.path.join(REF, "mesh_refinement", "t0ref")
+    out = {}
+    for k in range(6):
+        coord, tet, ss = read_mesh(os.path.join(d, "gauss_hump_dg_uniform_deref_t0ref.std.e-s.%d.1.0" % k))
+        out["s%d_coord" % k] = coord
+        out["s%d_inpoel" % k] = tet.astype(np.int32)
+        out["s%d_ss_ids" % k] = np.array(sorted(ss), dtype=np.int64)
+        for sid, tri in ss.items():
+            out["s%d_ss_tri_%d" % (k, sid)] = tri.astype(np.int32)
+    path = os.path.join(HERE, "t0ref_gauss_hump_udu.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "udu":
+        make_udu()
+        return
     with open(os.path.join(HERE, "cases.json")) as fh:
         cases = json.load(fh)
     only = set(sys.argv[1:])

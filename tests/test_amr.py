@@ -4,6 +4,8 @@ DG regression case with t>0 refinement: tests/regression/inciter/mesh_refinement
 gauss_hump.q (dg::Transport, DG-P0, uniform refinement every 5 of 10 steps, 112 -> 896 -> 7 168
 tets) and its committed goldens gauss_hump_u_trans_pe1_u0.0.std.e-s.{0,1,2}.1.0 + gauss_hump_dg.std.
 Host code + CPU oracle only."""
+import os
+
 import numpy as np
 import pytest
 
@@ -261,3 +263,52 @@ def test_refinement_of_a_chunk_with_two_ghost_layers(parts):
         for e in range(nie + n1, len(c["gid"])):
             assert not any(nb >= 0 and nb < nie for nb in es[e])
             assert any(nb >= nie and lay[nb] == 1 for nb in es[e])
+
+
+def _udu():
+    f = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "t0ref_gauss_hump_udu.npz"))
+    st = []
+    for k in range(6):
+        ss = {int(s): f["s%d_ss_tri_%d" % (k, s)].astype(np.int64) for s in f["s%d_ss_ids" % k]}
+        st.append((f["s%d_coord" % k], f["s%d_inpoel" % k].astype(np.int64), ss))
+    return st
+
+
+def _tri_keys(ss):
+    return {s: set(map(tuple, np.sort(np.asarray(t), axis=1).tolist())) for s, t in ss.items()}
+
+
+def test_uniform_derefinement_reproduces_the_reference_t0_sequence():
+    """The reference's initial-refinement sequence uniform -> uniform_derefine -> uniform (-> again), the meshes its
+    regression test amr_t0ref_ud(ud)u_trans_dg compares after every step
+    (mesh_refinement/t0ref/gauss_hump_dg_uniform_deref_t0ref.std.e-s.{0..5}.1.0: 955 -> 7 640 -> 955 -> 7 640 ...
+    tets; after the derefinement the reference holds the initial mesh again, array for array).  qdg_refine_uniform of
+    stage 0 gives stage 1's tets; qdg_derefine_uniform of that gives stage 2 = stage 0 EXACTLY (connectivity,
+    coordinates, side sets); refined again = stage 3; and once more.  Meshes that are no uniform refinement in the
+    library's order are refused."""
+    st = _udu()
+    for a, b in ((2, 0), (4, 0), (3, 1), (5, 1)):                  # the reference's own data
+        assert np.array_equal(st[a][0], st[b][0]) and np.array_equal(st[a][1], st[b][1])
+    c, i, s = st[0]
+    for cycle in range(2):
+        c1, i1, s1, par = amr.refine_uniform(c, i, s)
+        gc, gi, gs = st[2 * cycle + 1]
+        assert i1.shape == gi.shape and c1.shape == gc.shape
+        # the same tets (their four points) as the reference's refined mesh, and the same side-set surfaces
+        key = lambda cc, ii: np.sort(np.round(cc[ii].mean(axis=1) * 1e12).astype(np.int64).view([("", np.int64)] * 3).reshape(-1))
+        assert np.array_equal(key(c1, i1), key(gc, gi))
+        assert {k: len(v) for k, v in s1.items()} == {k: len(v) for k, v in gs.items()}
+        c2, i2, s2 = amr.derefine_uniform(c1, i1, s1)
+        gc2, gi2, gs2 = st[2 * cycle + 2] if 2 * cycle + 2 < 6 else st[0]
+        assert np.array_equal(i2, gi2) and np.array_equal(c2, gc2)          # the initial mesh again, exactly
+        assert _tri_keys(s2) == _tri_keys(gs2)
+        c, i, s = c2, i2, s2
+    # the reference's OWN refined mesh (stage 1: its children and their local node order are this library's) goes
+    # back to the reference's own derefined mesh (stage 2) through qdg_derefine_uniform, array for array
+    c2, i2, _ = amr.derefine_uniform(st[1][0], st[1][1], {})
+    assert np.array_equal(i2, st[2][1]) and np.array_equal(c2, st[2][0])
+    # not a refinement in the library's order: refused
+    with pytest.raises(Exception):
+        amr.derefine_uniform(st[1][0], st[1][1][::-1].copy(), {})
+    with pytest.raises(Exception):
+        amr.derefine_uniform(st[0][0], st[0][1][:952], {})

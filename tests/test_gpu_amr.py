@@ -470,3 +470,73 @@ def test_device_resident_chunk_remesh_equals_the_host_path():
         for m in A + B + allm:
             m.close()
         one.mesh.close(); ctxa.close(); ctxb.close(); ctx1.close()
+
+
+def test_device_derefinement_is_the_inverse_of_the_device_refinement():
+    """qdg_mesh_derefine_uniform (8 children -> their parent, on the device): refine -> derefine gives back the
+    original mesh -- the handle computes BITWISE what the original handle computes (lhs, rhs, dt, steps with the
+    reproducible DG-P1 kernel) -- and, with policy first_child, every DOF of the state (the inverse of the
+    reference's row copy child <- parent, DG.cpp:1597-1605); policy mean conserves mass and energy of a state that
+    has evolved on the refined mesh.  On the reference's own t0 sequence mesh (uniform -> uniform_derefine -> uniform,
+    tests/golden/t0ref_gauss_hump_udu.npz) with its three side sets."""
+    import os
+    from quinoa_amd import capi, meshgen
+    f = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "t0ref_gauss_hump_udu.npz"))
+    ss = {int(s): f["s0_ss_tri_%d" % s].astype(np.int64) for s in f["s0_ss_ids"]}
+    cases = [(meshgen.kuhn_box(5, 4, 3), dict(bc_sym=[3, 4, 5, 6], bc_extrapolate=[1, 2])),
+             ({"coord": f["s0_coord"], "inpoel": f["s0_inpoel"].astype(np.int64), "sidesets": ss},
+              dict(bc_sym=[1], bc_extrapolate=[2, 3]))]
+    kw = dict(flux="hllc", limiter="superbeep1", problem="sod_shocktube", gamma=1.4, cfl=0.3)
+    for g, bc in cases:
+        ctx = capi.Context(4, options={"keep_connectivity": 1, "p1_rhs": 1}, **kw, **bc)
+        m0 = capi.mesh_from_connectivity(ctx, g["inpoel"], g["coord"], g["sidesets"])
+        m1 = m2 = m3 = None
+        try:
+            m0.state_initialize(0.0)
+            t = 0.0
+            for _ in range(2):
+                t += m0.step(t)
+            U0 = m0.state_download()
+            m1, _ = m0.refine_uniform(host_copy=False)
+            assert m1.nielem == 8 * m0.nielem
+            m2 = m1.derefine_uniform("first_child")
+            assert m2.nielem == m0.nielem
+            assert np.array_equal(m2.state_download(), U0)                       # every DOF back
+            assert np.array_equal(m2.lhs(), m0.lhs())
+            assert np.array_equal(m2.rhs(t, U0), m0.rhs(t, U0)) and m2.dt(U0) == m0.dt(U0)
+            for _ in range(2):
+                assert m2.step(t) == m0.step(t)
+            assert np.array_equal(m2.state_download(), m0.state_download())
+            # it can be refined again (it keeps its connectivity), and that handle derefined again
+            m3, _ = m2.refine_uniform(host_copy=False)
+            assert m3.nielem == 8 * m0.nielem
+            # conservation of the mean policy: evolve on the refined mesh, coarsen, compare the totals
+            for _ in range(2):
+                m1.step(t)
+            U1 = m1.state_download().reshape(-1, 20)
+            v1 = m1.lhs().reshape(-1, 20)[:, 0]                                  # L(e, 0) = vol_e (Mass.cpp:25-73)
+            mc = m1.derefine_uniform("mean")
+            try:
+                Uc = mc.state_download().reshape(-1, 20)
+                vc = mc.lhs().reshape(-1, 20)[:, 0]
+                for c in (0, 4, 8, 12, 16):
+                    a, b = (U1[:, c] * v1).sum(), (Uc[:, c] * vc).sum()
+                    assert abs(a - b) <= 1e-13 * max(1.0, abs(a))
+                assert np.abs(Uc[:, [1, 2, 3, 5, 6, 7]]).max() == 0.0
+                assert abs(vc.sum() - v1.sum()) <= 1e-13 * v1.sum()
+            finally:
+                mc.close()
+        finally:
+            for m in (m0, m1, m2, m3):
+                if m is not None:
+                    m.close()
+            ctx.close()
+    # a mesh that is no uniform refinement is refused
+    g = meshgen.kuhn_box(4, 2, 2)
+    ctx = capi.Context(4, options={"keep_connectivity": 1}, **kw, bc_sym=[3, 4, 5, 6], bc_extrapolate=[1, 2])
+    m = capi.mesh_from_connectivity(ctx, g["inpoel"], g["coord"], g["sidesets"])
+    try:
+        with pytest.raises(capi.QdgError):
+            m.derefine_uniform()
+    finally:
+        m.close(); ctx.close()
