@@ -325,8 +325,27 @@ def amr_point(local_rank, nx=32, steps=20, with_partition=True, resident=True, r
     U = run.mesh.state_download()
     ne1 = run.mesh.nielem
     ok = bool(np.isfinite(U).all())
+    deref = None
+    if resident:
+        # ... and back: config 5's "deref" -- the 8:1 coarsening of the refined chunk on the device
+        # (qdg_mesh_derefine_uniform, conservative means), then `steps` steps on the coarse mesh again
+        del U
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        mc = run.mesh.derefine_uniform("mean")
+        ctx.synchronize()
+        t_deref = time.perf_counter() - t0
+        run.mesh.close()
+        run.mesh = mc
+        ms2 = advance(steps) * 1e3
+        deref = {"derefine_total_ms": t_deref * 1e3, "tets_after": int(mc.nielem), "ms_per_step_after": ms2,
+                 "finite": bool(np.isfinite(mc.state_download()).all()),
+                 "note": "qdg_mesh_derefine_uniform: coarse connectivity from the children, boundary faces from the refined "
+                         "ones, general device build (face sort), parent state = volume-weighted mean of its children"}
     run.mesh.close(); ctx.close()
     out = _amr_single(nx, steps, ne0, ne1, ms0, ms1, th, tr, tt, ok)
+    if deref is not None:
+        out["derefine"] = deref
     if resident:
         out["remesh_total_ms"] = (th + tr + tt) * 1e3
         out["steps_of_new_mesh_per_remesh"] = (th + tr + tt) * 1e3 / ms1

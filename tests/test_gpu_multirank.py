@@ -211,7 +211,7 @@ def test_other_orders_and_weno_across_the_halo(tmp_path, ndof, limiter):
         assert np.abs(d["U"] - ref[d["gid"]]).max() / np.abs(ref).max() <= 1e-10, r
 
 
-def _run_rccl(rank, world, port, parts, out):
+def _run_rccl(rank, world, port, parts, out, depth=1, graph=0):
     """one rank per GPU, the PRODUCT transport: libqdg's own RCCL calls (qdg_step_comm) between
     different devices; torch.distributed (nccl) only carries the RCCL id"""
     import torch
@@ -223,31 +223,39 @@ def _run_rccl(rank, world, port, parts, out):
     torch.cuda.set_device(rank)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
     try:
-        ch = meshgen.kuhn_box_chunk(NX, NY, NZ, parts=parts, rank=rank)
-        ck = dgmesh.build_chunk(ch["coord"], ch["inpoel"], ch["nielem"], ch["sidesets"])
-        ctx = capi.Context(4, cfl=0.3, device=rank, **KW, **BC)
-        mesh = dgmesh.upload(ctx, ck)
+        ch = meshgen.kuhn_box_chunk(NX, NY, NZ, parts=parts, rank=rank, depth=depth)
+        ctx = capi.Context(4, cfl=0.3, device=rank, options={"halo_depth": depth, "graph_step": graph}, **KW, **BC)
+        if depth == 2:          # what bench.py --gpus N runs: device-built chunk, global ids, two ghost layers
+            mesh = capi.mesh_from_connectivity(ctx, ch["inpoel"], ch["coord"], ch["sidesets"], nielem=ch["nielem"],
+                                               elem_gid=ch["gid"])
+        else:
+            mesh = dgmesh.upload(ctx, dgmesh.build_chunk(ch["coord"], ch["inpoel"], ch["nielem"], ch["sidesets"]))
+        nie = ch["nielem"]
         comm = dg.RcclComm(ctx)
         assert comm.comm.info() == (world, rank, rank)     # ncclCommCount / UserRank / CuDevice
-        drv = dg.DGDriver(ctx, mesh, ch["nbr_rank"], ch["send_lists"], ch["recv_counts"], comm)
+        drv = dg.DGDriver(ctx, mesh, ch["nbr_rank"], ch["send_lists"], ch["recv_counts"], comm,
+                          nghost1=ch["nghost1"] if depth == 2 else 0)
         mesh.state_initialize(0.0)
         t = 0.0
-        for _ in range(NSTEP):
+        for _ in range(NSTEP):          # (graph: steps 3 and 4 are captured and launched as graphs)
             drv.step(t)
             t += drv.dt_taken()
-        U = mesh.state_download().reshape(-1, 20)[:ck.nielem]
-        np.savez(out % rank, gid=ch["gid"][:ck.nielem], U=U, t=t, nnbr=len(ch["nbr_rank"]))
+        U = mesh.state_download().reshape(-1, 20)[:nie]
+        np.savez(out % rank, gid=ch["gid"][:nie], U=U, t=t, nnbr=len(ch["nbr_rank"]), graph=mesh.step_graph_status()[0])
         mesh.close(); comm.close(); ctx.close()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("parts", [(2, 1, 1), (2, 2, 1), (2, 2, 2)])
-def test_rccl_between_two_gpus_equals_single_chunk(tmp_path, parts):
+@pytest.mark.parametrize("parts,depth,graph", [((2, 1, 1), 1, 0), ((2, 2, 1), 1, 0), ((2, 2, 2), 1, 0),
+                                               ((2, 1, 1), 2, 0), ((2, 2, 2), 2, 0), ((2, 1, 1), 2, 1)])
+def test_rccl_between_two_gpus_equals_single_chunk(tmp_path, parts, depth, graph):
     """RcclComm / qdg_step_comm -- what `bench.py --gpus N` runs -- across DIFFERENT devices vs the
     single-chunk run, for every cut the visible device count allows: (2,1,1) one neighbour per rank,
-    (2,2,1) two, (2,2,2) three (the 8-GPU bench's decomposition).  Needs a lease with that many GPUs:
-    skipped on the one-GPU test box (torch.cuda.device_count() does not initialise the GPU)."""
+    (2,2,1) two, (2,2,2) three (the 8-GPU bench's decomposition); depth 2 = the bench's default (device-built
+    chunks with global ids and two ghost layers: up to nine (rank, layer) plan entries per rank, 3 exchanges per
+    step), graph 1 = the step replayed as a hipGraph on every rank (bench.py --graph).  Needs a lease with that
+    many GPUs: skipped on the one-GPU test box (torch.cuda.device_count() does not initialise the GPU)."""
     import torch
     import torch.multiprocessing as mp
     world = parts[0] * parts[1] * parts[2]
@@ -256,12 +264,15 @@ def test_rccl_between_two_gpus_equals_single_chunk(tmp_path, parts):
     out1 = str(tmp_path / "single%d.npz")
     out2 = str(tmp_path / "rank%d.npz")
     mp.spawn(_run, args=(1, 0, (1, 1, 1), out1, False), nprocs=1, join=True)
-    mp.spawn(_run_rccl, args=(world, _free_port(), parts, out2), nprocs=world, join=True)
+    mp.spawn(_run_rccl, args=(world, _free_port(), parts, out2, depth, graph), nprocs=world, join=True)
     s = np.load(out1 % 0)
     ref = np.zeros((NX * NY * NZ * 6, 20))
     ref[s["gid"]] = s["U"]
     for r in range(world):
         d = np.load(out2 % r)
-        assert int(d["nnbr"]) == sum(1 for p in parts if p > 1)
+        if depth == 1:
+            assert int(d["nnbr"]) == sum(1 for p in parts if p > 1)
+        if graph:
+            assert int(d["graph"]) == 1
         assert abs(float(d["t"]) - float(s["t"])) <= 1e-12 * float(s["t"])
         assert np.abs(d["U"] - ref[d["gid"]]).max() / np.abs(ref).max() <= 1e-10, r
