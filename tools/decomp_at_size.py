@@ -7,7 +7,9 @@ global ids after a few CFL steps.  What the 8-GPU runs of the north-star box (11
 Faces are oriented by global tet id in both runs (qdg_mesh_from_chunk_gid, context option orient_by_gid;
 round 4) unless the last argument is "local" (the chare-local rule, src/Inciter/DG.cpp:480-483: the runs
 then differ where HLLC falls through to the stored right state).
-Usage: python tools/decomp_at_size.py NX PX PY PZ [sod|sedov] [steps] [gid|local]"""
+An 8th argument 2 runs the decomposition with TWO ghost layers (round 5: every rank limits its layer-1 ghosts itself,
+one exchange per stage; up to nine (rank, layer) plan entries per rank in a 2x2x2 cut).
+Usage: python tools/decomp_at_size.py NX PX PY PZ [sod|sedov] [steps] [gid|local] [depth]"""
 import os
 import sys
 import time
@@ -20,6 +22,7 @@ nx = int(sys.argv[1]); parts = tuple(int(a) for a in sys.argv[2:5])
 work = sys.argv[5] if len(sys.argv) > 5 else "sod"
 steps = int(sys.argv[6]) if len(sys.argv) > 6 else 3
 orient = sys.argv[7] if len(sys.argv) > 7 else "gid"
+depth = int(sys.argv[8]) if len(sys.argv) > 8 else 1
 kw = dict(flux="hllc", limiter="superbeep1", gamma=1.4, cfl=0.3)
 if work == "sedov":
     kw.update(problem="sedov_blastwave", bc_extrapolate=[2, 4], bc_sym=[1, 3, 5, 6])
@@ -28,21 +31,23 @@ else:
 nr = parts[0] * parts[1] * parts[2]
 ntet = 6 * nx ** 3
 t0 = time.perf_counter()
-ctx = capi.Context(4, **kw)
+ctx = capi.Context(4, options={"halo_depth": depth}, **kw)
 chunks, meshes = [], []
 for r in range(nr):
-    c = meshgen.kuhn_box_chunk(nx, nx, nx, parts=parts, rank=r)
+    c = meshgen.kuhn_box_chunk(nx, nx, nx, parts=parts, rank=r, depth=depth)
     m = capi.mesh_from_connectivity(ctx, c["inpoel"], c["coord"], c["sidesets"], nielem=c["nielem"],
                                     elem_gid=c["gid"] if orient == "gid" else None)
     # keep only what the comparison and the halo plan need
-    chunks.append({k: c[k] for k in ("nielem", "gid", "nbr_rank", "send_lists", "recv_counts")})
+    chunks.append({k: c[k] for k in ("nielem", "gid", "nbr_rank", "nbr_layer", "nghost1", "depth", "send_lists", "recv_counts")})
     meshes.append(m)
-    print("chunk %d: %d owned + %d ghost tets, %d neighbours  (%.0f s)" % (
-        r, c["nielem"], len(c["gid"]) - c["nielem"], len(c["nbr_rank"]), time.perf_counter() - t0), flush=True)
+    print("chunk %d: %d owned + %d ghost tets (%d in layer 1), %d plan entries, packs folded: %s  (%.0f s)" % (
+        r, c["nielem"], len(c["gid"]) - c["nielem"], c["nghost1"], len(c["nbr_rank"]), "-", time.perf_counter() - t0), flush=True)
     del c
 for m in meshes:
     m.state_initialize(0.0)
 drv = dg.LocalChunks(ctx, meshes, chunks)
+assert drv.deep == (depth == 2)
+print("halo plans:", [m.halo_info() for m in meshes], flush=True)
 t, dts = 0.0, []
 for _ in range(steps):
     dt = drv.step(t); dts.append(dt); t += dt
@@ -82,9 +87,9 @@ if bad.any():
 # per component: the largest difference over all tets and DOFs relative to that component's own magnitude
 comp = [float(np.abs(U1[:, 4 * c:4 * c + 4] - ref[gid1][:, 4 * c:4 * c + 4]).max() / max(1e-300, np.abs(U1[:, 4 * c]).max()))
         for c in range(5)]
-print("nx %d (%d tets) %s in %dx%dx%d chunks vs single chunk after %d steps, faces oriented by %s: max |dU| / max|U| = %.2e, "
+print("nx %d (%d tets) %s in %dx%dx%d chunks with %d ghost layer(s) vs single chunk after %d steps, faces oriented by %s: max |dU| / max|U| = %.2e, "
       "per component (rho, rho*u, rho*v, rho*w, rho*E) %s, tets off by > 1e-10: %d, |dt - dt1| / dt1 = %.1e  (%.0f s)"
-      % ((nx, ntet, work) + parts + (steps, "global id" if orient == "gid" else "chunk-local id", err,
+      % ((nx, ntet, work) + parts + (depth, steps, "global id" if orient == "gid" else "chunk-local id", err,
                                      " ".join("%.1e" % v for v in comp), int(bad.sum()),
                                      max(abs(a - b) / b for a, b in zip(dts, dts1)), time.perf_counter() - t0)), flush=True)
 m1.close(); ctx.close(); ctx1.close()
