@@ -372,7 +372,9 @@ int qdg_step_comm(qdg_mesh* mesh, qdg_comm* comm, double t, double tleft, double
  * one hipGraphLaunch per time step (the reference's analogue: nothing -- Charm++ schedules entry methods one
  * message at a time, src/Inciter/dg.ci:57-70).  Used where the step's kernels do not read t (Sod, Sedov, rotated
  * Sod), for uniform-order runs, outside profiling; the first two steps of a mesh run plain (RCCL connects its
- * peers lazily).  Where HIP or RCCL refuses the capture the plain launches stay in charge.  Status: state 0 not
+ * peers lazily).  A graph is reused for calls with the SAME tleft (it is a kernel argument of the recorded dt
+ * reduction): pass a constant (e.g. 1e300) while the end time is more than a step away and the true remainder only for
+ * the last steps -- those run as plain launches (at most 8 graphs are kept per mesh).  Where HIP or RCCL refuses the capture the plain launches stay in charge.  Status: state 0 not
  * tried yet, 1 graphs in use, -1 refused (error text copied to `error`, any pointer may be NULL). */
 int qdg_step_graph_status(qdg_mesh* mesh, int32_t* state, int32_t* ngraphs, int64_t* nreplays, char* error,
                           size_t error_len);
